@@ -1,0 +1,903 @@
+"""CPU oracle for the PyDESeq2 ``deseq2()`` -> Wald hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy *restatement* of the reference algorithm
+(owkin/PyDESeq2 v0.5.3).  It exists to check the HIP engine in
+``pydeseq2_amd`` and to provide the ``cpu_baseline`` leg of ``bench.py``.
+Nothing under ``pydeseq2_amd/`` may import it: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do.
+
+Parity pinning
+--------------
+* every per-gene routine here is checked against the *unmodified* reference
+  functions (imported from ``/root/reference`` through an on-disk shim) on
+  seeded inputs by ``tests/golden/make_golden.py``; the resulting vectors are
+  committed as ``tests/golden/*.npz`` and re-checked by
+  ``tests/test_oracle_golden.py`` on every run;
+* the end-to-end orchestration is checked against the reference's own
+  R-DESeq2 fixtures (``tests/data/{single_factor,multi_factor,continuous,wide}``,
+  copied to ``tests/golden/r_*``) at the reference's own tolerances.
+
+Third-party arithmetic the reference delegates to (and so does this oracle):
+scipy 1.15.3 ``optimize.minimize(method="L-BFGS-B")``, ``special.gammaln``,
+``special.polygamma``, ``stats.norm/f``; numpy 2.2.6 ``linalg``.
+
+All ``file:line`` citations are relative to the reference tree
+(``pydeseq2/...``).  Conventions follow the reference: ``counts`` is
+samples x genes, natural-log LFCs, dispersions ``alpha`` with
+``var = mu + alpha mu^2``.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.optimize import minimize
+from scipy.special import gammaln, polygamma
+from scipy.stats import f as f_dist
+from scipy.stats import norm, trim_mean
+
+# --------------------------------------------------------------------------
+# a1/a2  size factors: median of ratios          preprocessing.py:31-102
+# --------------------------------------------------------------------------
+
+
+def logmeans_and_filter(counts: np.ndarray):
+    """Gene-wise mean of log counts and the finite-mean mask (preprocessing.py:31-56)."""
+    with np.errstate(divide="ignore"):
+        lc = np.log(counts)
+    lm = lc.mean(0)
+    return lm, ~np.isinf(lm)
+
+
+def size_factors_ratio(counts: np.ndarray):
+    """Median-of-ratios size factors (preprocessing.py:59-102, dds.py:692-708).
+
+    Returns (size_factors[N], normed_counts[N,G], logmeans[G], filtered[G]).
+    """
+    lm, keep = logmeans_and_filter(counts)
+    with np.errstate(divide="ignore"):
+        lc = np.log(counts)
+    ratios = lc[:, keep] - lm[keep]
+    sf = np.exp(np.median(ratios, axis=1))
+    return sf, counts / sf[:, None], lm, keep
+
+
+# --------------------------------------------------------------------------
+# a3/a4  method-of-moments initial dispersions    utils.py:814-885, dds.py:1140-1162
+# --------------------------------------------------------------------------
+
+
+def _ols_fit_predict(X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """Least-squares fitted values X (X^+ Y) (sklearn LinearRegression(fit_intercept=False))."""
+    coef, *_ = np.linalg.lstsq(X, Y, rcond=None)
+    return X @ coef
+
+
+def rough_dispersions(normed: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """Rough dispersion from OLS residuals (utils.py:814-853)."""
+    n, p = X.shape
+    if n == p:
+        raise ValueError(
+            "The number of samples and the number of design variables are "
+            "equal, i.e., there are no replicates to estimate the "
+            "dispersion. Please use a design with fewer variables."
+        )
+    yhat = np.maximum(_ols_fit_predict(X, normed), 1)
+    a = (((normed - yhat) ** 2 - yhat) / ((n - p) * yhat**2)).sum(0)
+    return np.maximum(a, 0)
+
+
+def moments_dispersions(normed: np.ndarray, sf: np.ndarray) -> np.ndarray:
+    """Moments dispersion (utils.py:856-885)."""
+    normed = normed[:, ~(normed == 0).all(axis=0)]
+    s_mean_inv = (1 / np.asarray(sf)).mean()
+    mu = normed.mean(0)
+    sigma = normed.var(0, ddof=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.nan_to_num((sigma - s_mean_inv * mu) / mu**2)
+
+
+def mom_dispersions(normed, X, sf, min_disp, max_disp):
+    """clip(min(rough, moments)) (dds.py:1149-1162)."""
+    return np.clip(
+        np.minimum(rough_dispersions(normed, X), moments_dispersions(normed, sf)),
+        min_disp,
+        max_disp,
+    )
+
+
+# --------------------------------------------------------------------------
+# a5  linear-model mu_hat                         utils.py:682-715
+# --------------------------------------------------------------------------
+
+
+def lin_reg_mu(counts, sf, X, min_mu):
+    """mu_hat = max(sf * OLS-fit(counts/sf), min_mu) for all genes (utils.py:682-715)."""
+    return np.maximum(sf[:, None] * _ols_fit_predict(X, counts / sf[:, None]), min_mu)
+
+
+# --------------------------------------------------------------------------
+# NB negative log-likelihood                      utils.py:163-270
+# --------------------------------------------------------------------------
+
+
+def nb_nll(counts, mu, alpha: float) -> float:
+    """Scalar-alpha branch of utils.nb_nll (utils.py:216-234)."""
+    n = len(counts)
+    a1 = 1 / alpha
+    logbinom = gammaln(counts + a1) - gammaln(counts + 1) - gammaln(a1)
+    return n * a1 * np.log(alpha) + (
+        -logbinom + (counts + a1) * np.log(a1 + mu) - counts * np.log(mu)
+    ).sum()
+
+
+def dnb_nll(counts, mu, alpha: float) -> float:
+    """d nll / d alpha (utils.py:237-270)."""
+    a1 = 1 / alpha
+    return -(
+        a1**2
+        * (
+            polygamma(0, a1)
+            - polygamma(0, counts + a1)
+            + np.log(1 + mu * alpha)
+            + (counts - mu) / (mu + a1)
+        ).sum()
+    )
+
+
+def vec_nb_nll(counts, mu, alpha):
+    """NLL over a grid of alpha (1-D mu) or of mu (2-D mu) (grid_search.py:7-51)."""
+    n = len(counts)
+    a1 = 1 / alpha
+    logbinom = gammaln(counts[:, None] + a1) - gammaln(counts + 1)[:, None] - gammaln(a1)
+    if mu.ndim == 1:
+        return n * a1 * np.log(alpha) + (
+            -logbinom
+            + (counts[:, None] + a1) * np.log(mu[:, None] + a1)
+            - (counts * np.log(mu))[:, None]
+        ).sum(0)
+    return n * a1 * np.log(alpha) + (
+        -logbinom + (counts[:, None] + a1) * np.log(mu + a1) - (counts[:, None] * np.log(mu))
+    ).sum(0)
+
+
+# --------------------------------------------------------------------------
+# a6/a7  dispersion MLE / MAP                     utils.py:441-564, grid_search.py:54-142
+# --------------------------------------------------------------------------
+
+
+def grid_fit_alpha(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
+                   cr_reg=True, prior_reg=False, grid_length=100) -> float:
+    """Two-level 1-D grid search; returns log(alpha) (grid_search.py:54-142)."""
+    lo, hi = np.log(min_disp), np.log(max_disp)
+    grid = np.linspace(lo, hi, grid_length)
+
+    def loss(la):
+        alpha = np.exp(la)
+        W = mu[:, None] / (1 + mu[:, None] * alpha)
+        reg = 0
+        if cr_reg:
+            reg = reg + 0.5 * np.linalg.slogdet(
+                (X.T[:, :, None] * W).transpose(2, 0, 1) @ X
+            )[1]
+        if prior_reg:
+            reg = reg + (np.log(alpha) - np.log(alpha_hat)) ** 2 / (2 * prior_disp_var)
+        return vec_nb_nll(counts, mu, alpha) + reg
+
+    ll = loss(grid)
+    k = np.argmin(ll)
+    delta = grid[1] - grid[0]
+    fine = np.linspace(grid[k] - delta, grid[k] + delta, grid_length)
+    ll = loss(fine)
+    return fine[np.argmin(ll)]
+
+
+def alpha_mle_gene(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
+                   cr_reg=True, prior_reg=False, return_info=False):
+    """One gene's dispersion fit by L-BFGS-B in log(alpha) (utils.py:441-564).
+
+    On ``success == False`` the grid search is called with the reference's six
+    positional arguments only, i.e. *without* the prior (utils.py:556-564).
+    """
+    la_hat = np.log(alpha_hat)
+
+    def loss(la):
+        alpha = np.exp(la)
+        reg = 0
+        if cr_reg:
+            W = mu / (1 + mu * alpha)
+            reg += 0.5 * np.linalg.slogdet((X.T * W) @ X)[1]
+        if prior_reg:
+            reg += (la - la_hat) ** 2 / (2 * prior_disp_var)
+        return nb_nll(counts, mu, alpha) + reg
+
+    def dloss(la):
+        alpha = np.exp(la)
+        rg = 0
+        if cr_reg:
+            W = mu / (1 + mu * alpha)
+            dW = -(W**2)
+            rg += (0.5 * (np.linalg.inv((X.T * W) @ X) * ((X.T * dW) @ X)).sum()) * alpha
+        if prior_reg:
+            rg += (la - la_hat) / prior_disp_var
+        return alpha * dnb_nll(counts, mu, alpha) + rg
+
+    res = minimize(
+        lambda x: loss(x[0]),
+        x0=np.asarray([la_hat]),
+        jac=lambda x: np.asarray([dloss(x[0])]),
+        method="L-BFGS-B",
+        bounds=[(np.log(min_disp), np.log(max_disp))],
+    )
+    if res.success:
+        out = np.exp(res.x[0])
+    else:
+        out = np.exp(grid_fit_alpha(counts, X, mu, alpha_hat, min_disp, max_disp))
+    if return_info:
+        return out, bool(res.success), res
+    return out, bool(res.success)
+
+
+def _alpha_chunk(args):
+    counts, X, mu, ah, min_disp, max_disp, pv, cr, pr = args
+    with np.errstate(all="ignore"):
+        out = [
+            alpha_mle_gene(counts[:, j], X, mu[:, j], ah[j], min_disp, max_disp, pv, cr, pr)
+            for j in range(counts.shape[1])
+        ]
+    return np.array([o[0] for o in out]), np.array([o[1] for o in out], dtype=bool)
+
+
+def _run_chunks(fn, chunks, n_jobs):
+    if n_jobs is None or n_jobs <= 1 or len(chunks) <= 1:
+        return [fn(c) for c in chunks]
+    from joblib import Parallel, delayed
+
+    return Parallel(n_jobs=n_jobs, backend="loky")(delayed(fn)(c) for c in chunks)
+
+
+def alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
+              cr_reg=True, prior_reg=False, n_jobs=1, chunk=256):
+    """All genes (default_inference.py:126-161).  Returns (alpha[G], converged[G])."""
+    G = counts.shape[1]
+    chunks = [
+        (counts[:, s:s + chunk], X, mu[:, s:s + chunk], alpha_hat[s:s + chunk], min_disp,
+         max_disp, prior_disp_var, cr_reg, prior_reg)
+        for s in range(0, G, chunk)
+    ]
+    res = _run_chunks(_alpha_chunk, chunks, n_jobs)
+    if not res:
+        return np.zeros(0), np.zeros(0, dtype=bool)
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+# --------------------------------------------------------------------------
+# a10/a11  IRLS NB-GLM fit                        utils.py:273-438, grid_search.py:145-221
+# --------------------------------------------------------------------------
+
+
+def grid_fit_beta(counts, sf, X, disp, min_mu=0.5, grid_length=60, min_beta=-30, max_beta=30):
+    """2-D two-level grid search on beta (p == 2 only) (grid_search.py:145-221)."""
+    xg = np.linspace(min_beta, max_beta, grid_length)
+    yg = np.linspace(min_beta, max_beta, grid_length)
+    ll = np.zeros((grid_length, grid_length))
+
+    def loss(beta):
+        mu = np.maximum(sf[:, None] * np.exp(X @ beta.T), min_mu)
+        return vec_nb_nll(counts, mu, disp) + 0.5 * (1e-6 * beta**2).sum(1)
+
+    for i, x in enumerate(xg):
+        ll[i, :] = loss(np.array([[x, y] for y in yg]))
+    k = np.unravel_index(np.argmin(ll, axis=None), ll.shape)
+    delta = xg[1] - xg[0]
+    fx = np.linspace(xg[k[0]] - delta, xg[k[0]] + delta, grid_length)
+    fy = np.linspace(yg[k[1]] - delta, yg[k[1]] + delta, grid_length)
+    for i, x in enumerate(fx):
+        ll[i, :] = loss(np.array([[x, y] for y in fy]))
+    k = np.unravel_index(np.argmin(ll, axis=None), ll.shape)
+    return np.array([fx[k[0]], fy[k[1]]])
+
+
+def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta):
+    """L-BFGS-B (+ grid for p<=2) rescue when IRLS diverges (utils.py:374-413)."""
+    p = X.shape[1]
+    ridge = np.diag(np.repeat(1e-6, p))
+
+    def f(beta):
+        mu_ = np.maximum(sf * np.exp(X @ beta), min_mu)
+        return nb_nll(counts, mu_, disp) + 0.5 * (ridge @ beta**2).sum()
+
+    def df(beta):
+        mu_ = np.maximum(sf * np.exp(X @ beta), min_mu)
+        return -X.T @ counts + ((1 / disp + counts) * mu_ / (1 / disp + mu_)) @ X + ridge @ beta
+
+    res = minimize(f, beta_init, jac=df, method="L-BFGS-B", bounds=[(min_beta, max_beta)] * p)
+    beta = res.x
+    if not res.success and p <= 2:
+        beta = grid_fit_beta(counts, sf, X, disp)
+    return beta, bool(res.success)
+
+
+def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=30, maxiter=250,
+         return_iters=False):
+    """NB log-link GLM by IRLS for all genes at once (utils.py:273-438).
+
+    Vectorised over genes with a per-gene ``active`` mask so every gene runs
+    exactly the reference's scalar ``while dev_ratio > beta_tol`` loop.
+    Returns (beta[G,p], mu[N,G] (UNclamped), H[N,G], converged[G]).
+    """
+    counts = np.asarray(counts, dtype=float)
+    N, G = counts.shape
+    p = X.shape[1]
+    disp = np.asarray(disp, dtype=float)
+    ridge = np.diag(np.repeat(1e-6, p))
+    with np.errstate(divide="ignore"):
+        if np.linalg.matrix_rank(X) == p:  # utils.py:349-353
+            Q, R = np.linalg.qr(X)
+            beta_init = np.linalg.solve(R, Q.T @ np.log(counts / sf[:, None] + 0.1))
+        else:  # utils.py:354-357
+            beta_init = np.zeros((p, G))
+            beta_init[0] = np.log(counts / sf[:, None]).mean(0)
+    beta = beta_init.copy()  # p x G
+    mu = np.maximum(sf[:, None] * np.exp(X @ beta), min_mu)
+    dev = np.full(G, 1000.0)
+    ratio = np.ones(G)
+    iters = np.zeros(G, dtype=int)
+    converged = np.ones(G, dtype=bool)
+    active = ratio > beta_tol
+    while active.any():
+        idx = np.nonzero(active)[0]
+        m = mu[:, idx]
+        W = m / (1.0 + m * disp[idx])
+        z = np.log(m / sf[:, None]) + (counts[:, idx] - m) / m
+        H = np.einsum("ni,ng,nj->gij", X, W, X) + ridge
+        rhs = np.einsum("ni,ng->gi", X, W * z)
+        bh = np.linalg.solve(H, rhs[:, :, None])[:, :, 0]  # len(idx) x p
+        iters[idx] += 1
+        bad = (np.abs(bh) > max_beta).any(1) | (iters[idx] >= maxiter)
+        for k in np.nonzero(bad)[0]:
+            g = idx[k]
+            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], beta_init[:, g], min_mu,
+                                   min_beta, max_beta)
+            beta[:, g] = b
+            mu[:, g] = np.maximum(sf * np.exp(X @ b), min_mu)
+            converged[g] = ok
+            active[g] = False
+        good = ~bad
+        gi = idx[good]
+        if gi.size:
+            beta[:, gi] = bh[good].T
+            mu[:, gi] = np.maximum(sf[:, None] * np.exp(X @ beta[:, gi]), min_mu)
+            old = dev[gi]
+            dev[gi] = np.array([-2 * nb_nll(counts[:, g], mu[:, g], disp[g]) for g in gi])
+            ratio[gi] = np.abs(dev[gi] - old) / (np.abs(dev[gi]) + 0.1)
+            active[gi] = ratio[gi] > beta_tol
+    # hat diagonals with the CLAMPED mu (utils.py:427-433)
+    W = mu / (1.0 + mu * disp)
+    Hm = np.einsum("ni,ng,nj->gij", X, W, X) + ridge
+    Hinv = np.linalg.inv(Hm)
+    h = np.einsum("ni,gij,nj->ng", X, Hinv, X)
+    Hd = np.sqrt(W) * h * np.sqrt(W)
+    mu_out = sf[:, None] * np.exp(X @ beta)  # UNclamped (utils.py:435-437)
+    if return_iters:
+        return beta.T.copy(), mu_out, Hd, converged, iters
+    return beta.T.copy(), mu_out, Hd, converged
+
+
+# --------------------------------------------------------------------------
+# a8  dispersion trend                            default_inference.py:200-230, dds.py:1199-1299
+# --------------------------------------------------------------------------
+
+
+def trend_gamma_glm(cov: np.ndarray, targets: np.ndarray):
+    """2-coefficient gamma GLM disp ~ a0 + a1*cov (default_inference.py:200-230)."""
+    A = np.column_stack([np.ones_like(cov), cov])
+
+    def loss(c):
+        mu = A @ c
+        return np.nanmean(targets / mu + np.log(mu), axis=0)
+
+    def grad(c):
+        mu = A @ c
+        return -np.nanmean(((targets / mu - 1)[:, None] * A) / mu[:, None], axis=0)
+
+    with np.errstate(all="ignore"):
+        res = minimize(loss, x0=np.array([1.0, 1.0]), jac=grad, method="L-BFGS-B",
+                       bounds=[(1e-12, np.inf)])
+    return res.x, A @ res.x, bool(res.success)
+
+
+def mean_trend(genewise: np.ndarray, min_disp: float) -> float:
+    """Trimmed-mean trend (dds.py:1277-1299). ``genewise`` may contain NaN (zero genes)."""
+    with np.errstate(invalid="ignore"):
+        sel = genewise[genewise > 10 * min_disp]
+    return float(trim_mean(sel, proportiontocut=0.001))
+
+
+def fit_parametric_trend(genewise_nz: np.ndarray, normed_means_nz: np.ndarray):
+    """Iterated gamma-GLM trend over non-zero genes (dds.py:1199-1275).
+
+    Returns (coeffs[2] or None on failure, n_outer_iterations).
+    """
+    with np.errstate(divide="ignore"):
+        cov_all = 1 / normed_means_nz
+    ok = ~(np.isinf(cov_all) | np.isnan(cov_all))  # dds.py:1225-1231
+    sel = np.nonzero(ok)[0]
+    old = np.array([0.1, 0.1])
+    coeffs = np.array([1.0, 1.0])
+    n_it = 0
+    while (coeffs > 1e-10).all() and (np.log(np.abs(coeffs / old)) ** 2).sum() >= 1e-6:
+        old = coeffs
+        coeffs, pred, conv = trend_gamma_glm(cov_all[sel], genewise_nz[sel])
+        n_it += 1
+        if not conv or (coeffs <= 1e-10).any():
+            return None, n_it
+        r = genewise_nz[sel] / pred
+        sel = sel[~((r < 1e-4) | (r >= 15))]
+    return coeffs, n_it
+
+
+# --------------------------------------------------------------------------
+# a9  dispersion prior                            dds.py:840-884, utils.py:1210-1227
+# --------------------------------------------------------------------------
+
+
+def mean_absolute_deviation(x):
+    c = np.median(x)
+    return np.median(np.abs(x - c)) / norm.ppf(0.75)
+
+
+def dispersion_prior(genewise_nz, fitted_nz, N, p, min_disp):
+    """(squared_logres, prior_disp_var) (dds.py:866-884)."""
+    res = np.log(genewise_nz) - np.log(fitted_nz)
+    above = genewise_nz >= 100 * min_disp
+    sq = mean_absolute_deviation(res[above]) ** 2
+    return sq, np.maximum(sq - polygamma(1, (N - p) / 2), 0.25)
+
+
+# --------------------------------------------------------------------------
+# a12  Cook's distances                           utils.py:567-679, 888-960, dds.py:986-1040
+# --------------------------------------------------------------------------
+
+
+def design_cells(X: np.ndarray):
+    """Group samples by identical design rows: (cell_id[N], cell_size[n_cells])."""
+    _, inv, cnt = np.unique(X, axis=0, return_inverse=True, return_counts=True)
+    return np.asarray(inv).reshape(-1), cnt
+
+
+def trimmed_mean(x, trim=0.1, axis=0):
+    s = np.sort(x, axis=axis)
+    n = x.shape[axis]
+    nt = math.floor(n * trim)
+    return np.take(s, np.arange(nt, n - nt), axis).mean(axis)
+
+
+def _trimfn(n):
+    return 2 if n >= 23.5 else 1 if n >= 3.5 else 0
+
+
+def trimmed_cell_variance(normed, cell_id):
+    """max over cells of scaled trimmed variance (utils.py:602-650)."""
+    ratios = (1 / 3, 1 / 4, 1 / 8)
+    scales = (2.04, 1.86, 1.51)
+    levels = np.unique(cell_id)
+    sq = np.zeros_like(normed)
+    for lv in levels:
+        m = cell_id == lv
+        t = ratios[_trimfn(m.sum())]
+        sq[m, :] = normed[m, :] - trimmed_mean(normed[m, :], trim=t, axis=0)[None, :]
+    sq **= 2
+    var = np.zeros((len(levels), normed.shape[1]))
+    for i, lv in enumerate(levels):
+        m = cell_id == lv
+        k = _trimfn(m.sum())
+        var[i, :] = scales[k] * trimmed_mean(sq[m, :], trim=ratios[k], axis=0)
+    return var.max(axis=0)
+
+
+def robust_mom_disp(normed, X):
+    """Trimmed method-of-moments dispersion, floor 0.04 (utils.py:914-960)."""
+    cid, cnt = design_cells(X)
+    three = cnt[cid] >= 3
+    if three.any():
+        v = trimmed_cell_variance(normed[three, :], cid[three])
+    else:
+        rm = trimmed_mean(normed, trim=0.125, axis=0)
+        v = 1.51 * trimmed_mean((normed - rm) ** 2, trim=0.125, axis=0)
+    m = normed.mean(0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = (v - m) / m**2
+    return np.maximum(a, 0.04)
+
+
+def cooks_distance(counts, normed, X, mu, H):
+    """Cook's distances for non-zero genes (dds.py:1001-1028)."""
+    p = X.shape[1]
+    a = robust_mom_disp(normed, X)
+    V = mu + a[None, :] * mu**2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (counts - mu) ** 2 / V / p * (H / (1 - H) ** 2)
+
+
+# --------------------------------------------------------------------------
+# a14  Wald test                                  utils.py:718-811
+# --------------------------------------------------------------------------
+
+
+def wald_test(X, disp, lfc, mu, ridge, contrast, lfc_null=0.0, alt_hypothesis=None):
+    """Wald statistics for all genes (utils.py:718-811, default_inference.py:163-198).
+
+    ``lfc`` is G x p, ``mu`` N x G.  Returns (pvalue[G], stat[G], se[G]).
+    """
+    G = lfc.shape[0]
+    W = mu / (1 + mu * disp[None, :])
+    M = np.einsum("ni,ng,nj->gij", X, W, X)
+    pv = np.full(G, np.nan)
+    st = np.full(G, np.nan)
+    se = np.full(G, np.nan)
+    for g in range(G):
+        if not np.isfinite(M[g]).all():
+            continue
+        Hc = np.linalg.inv(M[g] + ridge) @ contrast
+        s = np.sqrt(Hc.T @ M[g] @ Hc)
+        b = lfc[g]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if alt_hypothesis is None:
+                t = float(contrast @ (b - lfc_null) / s)
+                q = 2 * norm.sf(np.abs(t))
+            elif alt_hypothesis == "greater":
+                t = contrast @ np.fmax((b - lfc_null) / s, 0)
+                q = norm.sf(t)
+            elif alt_hypothesis == "less":
+                t = contrast @ np.fmin((b - lfc_null) / s, 0)
+                q = norm.sf(np.abs(t))
+            elif alt_hypothesis == "greaterAbs":
+                t = contrast @ (np.sign(b) * np.fmax((np.abs(b) - lfc_null) / s, 0))
+                q = 2 * norm.sf(np.abs(t))
+            elif alt_hypothesis == "lessAbs":
+                ta = contrast @ np.fmax((b + abs(lfc_null)) / s, 0)
+                pa = norm.sf(ta)
+                tb = contrast @ np.fmin((b - abs(lfc_null)) / s, 0)
+                pb = norm.sf(np.abs(tb))
+                t = min(ta, tb, key=abs)
+                q = max(pa, pb)
+            else:
+                raise KeyError(alt_hypothesis)
+        pv[g], st[g], se[g] = q, t, s
+    return pv, st, se
+
+
+# --------------------------------------------------------------------------
+# orchestration                                   dds.py:516-562, 1042-1110, 1301-1458; ds.py:303-360
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class DeseqResult:
+    """Field names follow the reference's AnnData schema."""
+
+    size_factors: np.ndarray = None
+    normed_means: np.ndarray = None
+    non_zero: np.ndarray = None
+    mom_dispersions: np.ndarray = None
+    mu_hat: np.ndarray = None
+    genewise_dispersions: np.ndarray = None
+    genewise_converged: np.ndarray = None
+    trend_coeffs: np.ndarray = None
+    disp_function_type: str = "parametric"
+    mean_disp: float = None
+    fitted_dispersions: np.ndarray = None
+    squared_logres: float = None
+    prior_disp_var: float = None
+    MAP_dispersions: np.ndarray = None
+    MAP_converged: np.ndarray = None
+    outlier_genes: np.ndarray = None
+    dispersions: np.ndarray = None
+    LFC: np.ndarray = None
+    LFC_converged: np.ndarray = None
+    mu_LFC: np.ndarray = None
+    hat_diagonals: np.ndarray = None
+    cooks: np.ndarray = None
+    replaced: np.ndarray = None
+    refitted: np.ndarray = None
+    new_all_zeroes: np.ndarray = None
+    replace_cooks: np.ndarray = None
+    cooks_outlier: np.ndarray = None
+    pvalue: np.ndarray = None
+    stat: np.ndarray = None
+    lfcSE: np.ndarray = None
+    timings: dict = field(default_factory=dict)
+
+
+def _fit_genewise(counts_nz, normed_nz, sf, X, min_mu, min_disp, max_disp, beta_tol, n_jobs):
+    """MoM -> mu_hat -> genewise alpha on non-zero genes (dds.py:713-797)."""
+    mom = mom_dispersions(normed_nz, X, sf, min_disp, max_disp)
+    n_cells = len(np.unique(X, axis=0))
+    if n_cells == X.shape[1]:  # dds.py:747-756
+        mu_hat = lin_reg_mu(counts_nz, sf, X, min_mu)
+    else:  # dds.py:757-765
+        _, mu_hat, _, _ = irls(counts_nz, sf, X, mom, min_mu, beta_tol)
+    gw, conv = alpha_mle(counts_nz, X, mu_hat, mom, min_disp, max_disp, n_jobs=n_jobs)
+    return mom, mu_hat, np.clip(gw, min_disp, max_disp), conv
+
+
+def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0,
+           refit_cooks=True, min_replicates=7, beta_tol=1e-8, fit_type="parametric",
+           lfc_null=0.0, alt_hypothesis=None, n_jobs=1, keep_layers=True):
+    """End-to-end restatement of ``DeseqDataSet.deseq2()`` + ``DeseqStats.run_wald_test()``.
+
+    Follows dds.py:516-562 step by step, then ds.py:303-360.  ``counts`` is
+    N x G non-negative integers, ``X`` the N x p design matrix (intercept first).
+    """
+    import time
+
+    counts = np.asarray(counts)
+    X = np.asarray(X, dtype=float)
+    N, G = counts.shape
+    p = X.shape[1]
+    max_disp = max(max_disp, N)  # dds.py:312
+    if contrast is None:
+        contrast = np.zeros(p)
+        contrast[-1] = 1.0
+    r = DeseqResult()
+    T = r.timings
+    t0 = time.perf_counter()
+
+    # -- size factors (dds.py:692-708)
+    sf, normed, _, _ = size_factors_ratio(counts)
+    r.size_factors = sf
+    r.normed_means = normed.mean(0)
+    T["size_factors"] = time.perf_counter() - t0
+
+    # -- genewise dispersions (dds.py:713-797)
+    t = time.perf_counter()
+    nz = ~(counts == 0).all(axis=0)
+    nzi = np.nonzero(nz)[0]
+    r.non_zero = nz
+    c_nz = counts[:, nzi]
+    mom, mu_hat, gw, gconv = _fit_genewise(c_nz, normed[:, nzi], sf, X, min_mu, min_disp,
+                                           max_disp, beta_tol, n_jobs)
+    r.mom_dispersions = _scatter(G, nzi, mom)
+    r.genewise_dispersions = _scatter(G, nzi, gw)
+    r.genewise_converged = _scatter(G, nzi, gconv.astype(float))
+    if keep_layers:
+        r.mu_hat = _scatter2(N, G, nzi, mu_hat)
+    T["genewise"] = time.perf_counter() - t
+
+    # -- trend (dds.py:799-838)
+    t = time.perf_counter()
+    coeffs = None
+    if fit_type == "parametric":
+        coeffs, _ = fit_parametric_trend(gw, r.normed_means[nzi])
+        if coeffs is None:
+            warnings.warn("The dispersion trend curve fitting did not converge. "
+                          "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
+    if coeffs is not None:
+        r.trend_coeffs = coeffs
+        r.disp_function_type = "parametric"
+        fitted = np.full(G, np.nan)
+        fitted[nzi] = coeffs[0] + coeffs[1] / r.normed_means[nzi]
+    else:
+        r.disp_function_type = "mean"
+        r.mean_disp = mean_trend(r.genewise_dispersions, min_disp)
+        fitted = np.full(G, r.mean_disp)
+    r.fitted_dispersions = fitted
+    T["trend"] = time.perf_counter() - t
+
+    # -- prior (dds.py:840-884)
+    r.squared_logres, r.prior_disp_var = dispersion_prior(gw, fitted[nzi], N, p, min_disp)
+    r.prior_disp_var = float(r.prior_disp_var)
+
+    # -- MAP (dds.py:886-935)
+    t = time.perf_counter()
+    mp, mconv = alpha_mle(c_nz, X, mu_hat, fitted[nzi], min_disp, max_disp,
+                          prior_disp_var=r.prior_disp_var, cr_reg=True, prior_reg=True,
+                          n_jobs=n_jobs)
+    r.MAP_dispersions = _scatter(G, nzi, np.clip(mp, min_disp, max_disp))
+    r.MAP_converged = _scatter(G, nzi, mconv.astype(float))
+    disp = r.MAP_dispersions.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out_g = np.log(r.genewise_dispersions) > np.log(fitted) + 2 * np.sqrt(r.squared_logres)
+    disp[out_g] = r.genewise_dispersions[out_g]
+    r.outlier_genes = out_g
+    r.dispersions = disp
+    T["MAP"] = time.perf_counter() - t
+
+    # -- LFC (dds.py:937-984)
+    t = time.perf_counter()
+    beta, mu, Hd, lconv = irls(c_nz, sf, X, disp[nzi], min_mu, beta_tol)
+    r.LFC = _rows(G, p, nzi, beta)
+    r.LFC_converged = _scatter(G, nzi, lconv.astype(float))
+    T["LFC"] = time.perf_counter() - t
+
+    # -- Cook's (dds.py:986-1040)
+    t = time.perf_counter()
+    ck_nz = cooks_distance(c_nz, normed[:, nzi], X, mu, Hd)
+    cooks = _scatter2(N, G, nzi, ck_nz)
+    if keep_layers:
+        r.mu_LFC, r.hat_diagonals, r.cooks = mu, Hd, cooks
+    T["cooks"] = time.perf_counter() - t
+
+    # -- refit (dds.py:1042-1064, 1301-1458)
+    t = time.perf_counter()
+    cutoff = f_dist.ppf(0.99, p, N - p)
+    cid, cnt = design_cells(X)
+    r.replaced = np.zeros(G, dtype=bool)
+    r.refitted = np.zeros(G, dtype=bool)
+    r.new_all_zeroes = np.zeros(G, dtype=bool)
+    replace_cooks = None
+    if refit_cooks:
+        replaceable = cnt[cid] >= min_replicates
+        if replaceable.sum() > 0:
+            with np.errstate(invalid="ignore"):
+                idx = cooks > cutoff
+            r.replaced = idx.any(axis=0)
+            if r.replaced.sum() > 0:
+                rp = np.nonzero(r.replaced)[0]
+                sub = counts[:, rp].copy()
+                tbm = trimmed_mean(sub / sf[:, None], trim=0.2, axis=0)
+                repl = (tbm[:, None] * sf[None, :]).astype(int).T  # truncation, dds.py:1344-1352
+                m = replaceable[:, None] & idx[:, rp]
+                sub[m] = repl[m]
+                naz = (sub == 0).all(axis=0)
+                r.new_all_zeroes[rp[naz]] = True
+                r.refitted[rp[~naz]] = True
+                if naz.sum() > 0:  # dds.py:1380-1383
+                    r.normed_means[rp[naz]] = 0
+                    r.LFC[rp[naz], :] = 0
+                if r.refitted.sum() > 0:
+                    rf = rp[~naz]
+                    s_c = sub[:, ~naz]
+                    s_n = s_c / sf[:, None]
+                    _, s_mu, s_gw, _ = _fit_genewise(s_c, s_n, sf, X, min_mu, min_disp,
+                                                     max_disp, beta_tol, 1)
+                    s_means = s_n.mean(0)
+                    if r.disp_function_type == "parametric":
+                        s_fit = r.trend_coeffs[0] + r.trend_coeffs[1] / s_means
+                    else:
+                        s_fit = np.full(len(rf), r.mean_disp)
+                    s_map, _ = alpha_mle(s_c, X, s_mu, s_fit, min_disp, max_disp,
+                                         prior_disp_var=r.prior_disp_var, cr_reg=True,
+                                         prior_reg=True, n_jobs=1)
+                    s_disp = np.clip(s_map, min_disp, max_disp)
+                    s_out = np.log(s_gw) > np.log(s_fit) + 2 * np.sqrt(r.squared_logres)
+                    s_disp[s_out] = s_gw[s_out]
+                    s_beta, _, _, _ = irls(s_c, sf, X, s_disp, min_mu, beta_tol)
+                    r.normed_means[rf] = s_means
+                    r.LFC[rf, :] = s_beta
+                    r.genewise_dispersions[rf] = s_gw
+                    r.fitted_dispersions[rf] = s_fit
+                    r.dispersions[rf] = s_disp
+                    replace_cooks = cooks.copy()
+                    for col in rf:
+                        replace_cooks[replaceable, col] = 0.0
+    r.replace_cooks = replace_cooks if keep_layers else None
+    T["refit"] = time.perf_counter() - t
+
+    # -- cooks_outlier (dds.py:1066-1110)
+    use_for_max = cnt[cid] >= 3
+    src = replace_cooks if (refit_cooks and r.refitted.sum() > 0 and replace_cooks is not None) else cooks
+    with np.errstate(invalid="ignore"):
+        co = (src[use_for_max, :] > cutoff).any(axis=0)
+    if co.any():
+        pos = cooks[:, co].argmax(0)
+        cc = counts[:, co]
+        co[co] = (cc > cc[pos, np.arange(len(pos))]).sum(0) < 3
+    r.cooks_outlier = co
+
+    # -- Wald (ds.py:303-360)
+    t = time.perf_counter()
+    with np.errstate(invalid="ignore", over="ignore"):
+        mu_w = np.exp(X @ r.LFC.T) * sf[:, None]
+    ridge = np.diag(np.repeat(1e-6, p))
+    pv, st, se = wald_test(X, r.dispersions, r.LFC, mu_w, ridge, np.asarray(contrast, float),
+                           np.log(2) * lfc_null, alt_hypothesis)
+    if refit_cooks and r.replaced.sum() > 0:
+        z = r.new_all_zeroes
+        se[z], st[z], pv[z] = 0.0, 0.0, 1.0
+    r.pvalue, r.stat, r.lfcSE = pv, st, se
+    T["wald"] = time.perf_counter() - t
+    T["total"] = time.perf_counter() - t0
+    return r
+
+
+def _scatter(G, idx, v):
+    out = np.full(G, np.nan)
+    out[idx] = v
+    return out
+
+
+def _scatter2(N, G, idx, v):
+    out = np.full((N, G), np.nan)
+    out[:, idx] = v
+    return out
+
+
+def _rows(G, p, idx, v):
+    out = np.full((G, p), np.nan)
+    out[idx, :] = v
+    return out
+
+
+# --------------------------------------------------------------------------
+# DeseqStats.summary() tail                       ds.py:266-286, 486-550
+# --------------------------------------------------------------------------
+
+
+def bh_adjust(p):
+    """Benjamini-Hochberg (scipy.stats.false_discovery_control(method='bh'))."""
+    p = np.asarray(p, dtype=float)
+    m = len(p)
+    order = np.argsort(p)
+    ps = p[order] * m / np.arange(1, m + 1)
+    ps = np.minimum.accumulate(ps[::-1])[::-1]
+    out = np.empty(m)
+    out[order] = np.clip(ps, 0, 1)
+    return out
+
+
+def p_value_adjustment(pvalue):
+    """BH over non-NaN p-values (ds.py:529-542)."""
+    padj = np.full(len(pvalue), np.nan)
+    ok = ~np.isnan(pvalue)
+    if ok.any():
+        padj[ok] = bh_adjust(pvalue[ok])
+    return padj
+
+
+# --------------------------------------------------------------------------
+# synthetic inputs                                SURVEY.md §8(d) / BASELINE.md §3
+# --------------------------------------------------------------------------
+
+
+def make_design(kind: str, N: int, rng: np.random.Generator) -> np.ndarray:
+    """Design matrices for the benchmark configs (intercept + treatment-coded factors)."""
+    def bal(levels):
+        v = np.arange(N) % levels
+        rng.shuffle(v)
+        return v
+
+    def dummies(v, levels):
+        return np.stack([(v == k).astype(float) for k in range(1, levels)], axis=1)
+
+    cols = [np.ones((N, 1))]
+    if kind == "2level":
+        cols.append(dummies(np.arange(N) % 2, 2))
+    elif kind == "3factor":  # 2/3/5 levels -> p = 8
+        for lv in (2, 3, 5):
+            cols.append(dummies(bal(lv), lv))
+    elif kind == "mixed":  # 2 + 4 levels + 3 continuous -> p = 8
+        for lv in (2, 4):
+            cols.append(dummies(bal(lv), lv))
+        cols.append(rng.normal(size=(N, 3)))
+    else:
+        raise KeyError(kind)
+    return np.concatenate(cols, axis=1)
+
+
+def synth_counts(G: int, N: int, design: str = "2level", seed: int = 0):
+    """Synthetic NB counts as specified in SURVEY.md §8(d).  Returns (counts int64 N x G, X)."""
+    rng = np.random.default_rng(seed)
+    X = make_design(design, N, rng)
+    p = X.shape[1]
+    beta = np.zeros((p, G))
+    beta[0] = rng.normal(4, 2, G)
+    beta[1] = rng.normal(0, 1, G) * (rng.random(G) < 0.3)
+    for j in range(2, p):
+        cont = design == "mixed" and j >= p - 3
+        beta[j] = rng.normal(0, 0.2 if cont else 0.5, G)
+    disp = 4 / np.maximum(2.0 ** beta[0], 1e-3) + 0.1
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * 2.0 ** (X @ beta)
+    size = 1 / disp
+    counts = rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu))
+    return counts.astype(np.int64), X
+
+
+def default_n_jobs() -> int:
+    return os.cpu_count() or 1

@@ -1,0 +1,170 @@
+"""The oracle (oracle/nbglm_oracle.py) against (i) vectors produced by the unmodified
+reference kernels (tests/golden/kat_*.npz, see make_golden.py) and (ii) the reference's
+own R-DESeq2 fixtures at the reference's own tolerances (tests/test_pydeseq2.py:932-942)."""
+import numpy as np
+import pytest
+
+from oracle import nbglm_oracle as orc
+from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design
+
+CASES = ["p2", "p4", "p8"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_size_factors_and_mom(case):
+    k = load_kat(case)
+    sf, normed, lm, filt = orc.size_factors_ratio(k["counts"])
+    assert_close(sf, k["sf"], 1e-13, what="sf")
+    assert_close(normed, k["normed"], 1e-13, what="normed")
+    assert (filt == k["filtered"]).all()
+    assert_close(orc.rough_dispersions(k["normed"], k["X"]), k["rough"], 1e-9, 1e-13, "rough")
+    assert_close(orc.moments_dispersions(k["normed"], k["sf"]), k["moments"], 1e-12, 1e-15, "mom")
+    assert_close(orc.mom_dispersions(k["normed"], k["X"], k["sf"], 1e-8, max(10, len(sf))),
+                 k["mom"], 1e-9, 0, "clip(min)")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lin_mu_and_irls(case):
+    k = load_kat(case)
+    assert_close(orc.lin_reg_mu(k["counts"], k["sf"], k["X"], 0.5), k["lin_mu"], 1e-10, 0, "lin_mu")
+    b, mu, H, conv = orc.irls(k["counts"], k["sf"], k["X"], k["mom"], 0.5, 1e-8)
+    assert (conv == k["irls_conv"]).all()
+    assert_close(b, k["irls_beta"], 1e-8, 1e-10, "irls beta")
+    assert_close(mu, k["irls_mu"], 1e-8, 1e-10, "irls mu")
+    assert_close(H, k["irls_H"], 1e-8, 1e-12, "irls H")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_alpha_mle(case):
+    k = load_kat(case)
+    N = k["counts"].shape[0]
+    a, c = orc.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, max(10, N))
+    assert (c == k["gw_conv"]).all()
+    assert_close(a, k["gw_alpha"], 1e-9, 0, "genewise alpha")
+    a, c = orc.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["fitted"], 1e-8, max(10, N),
+                         prior_disp_var=float(k["prior_var"]), cr_reg=True, prior_reg=True)
+    assert (c == k["map_conv"]).all()
+    assert_close(a, k["map_alpha"], 1e-9, 0, "MAP alpha")
+    for g in range(len(k["grid_alpha"])):
+        la = orc.grid_fit_alpha(k["counts"][:, g], k["X"], k["mu_hat"][:, g], k["mom"][g], 1e-8,
+                                max(10, N))
+        assert abs(la - k["grid_alpha"][g]) < 1e-12
+    nll = [orc.nb_nll(k["counts"][:, g], k["mu_hat"][:, g], np.clip(k["gw_alpha"][g], 1e-8, max(10, N)))
+           for g in range(k["counts"].shape[1])]
+    assert_close(nll, k["nll"], 1e-14, 0, "nll")
+
+
+def test_grid_beta():
+    k = load_kat("p2")
+    disp = np.clip(k["map_alpha"], 1e-8, 40)
+    for g in range(len(k["grid_beta"])):
+        b = orc.grid_fit_beta(k["counts"][:, g], k["sf"], k["X"], disp[g])
+        assert np.abs(b - k["grid_beta"][g]).max() < 1e-12
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_trend_cooks_wald(case):
+    k = load_kat(case)
+    N = k["counts"].shape[0]
+    gwc = np.clip(k["gw_alpha"], 1e-8, max(10, N))
+    means = k["normed"].mean(0)
+    coeffs, pred, conv = orc.trend_gamma_glm(1 / means, gwc)
+    assert conv == bool(k["trend_conv"])
+    assert_close(coeffs, k["trend_coeffs"], 1e-10, 0, "trend coeffs")
+    assert_close(orc.robust_mom_disp(k["normed"], k["X"]), k["robust_disp"], 1e-11, 0, "robust")
+    assert_close(orc.trimmed_mean(k["normed"], 0.2, axis=0), k["trim_mean_02"], 1e-13, 0, "tm")
+    assert abs(orc.mean_absolute_deviation(np.log(gwc) - np.log(k["fitted"])) - k["mad"]) < 1e-13
+    disp = np.clip(k["map_alpha"], 1e-8, max(10, N))
+    mu_w = np.exp(k["X"] @ k["lfc_beta"].T) * k["sf"][:, None]
+    ridge = np.diag(np.repeat(1e-6, k["X"].shape[1]))
+    for alt, null in ((None, 0.0), ("greater", 0.5), ("less", -0.5), ("greaterAbs", 0.5),
+                      ("lessAbs", 0.5)):
+        tag = alt or "none"
+        p, s, se = orc.wald_test(k["X"], disp, k["lfc_beta"], mu_w, ridge, k["contrast"],
+                                 np.log(2) * null, alt)
+        assert_close(se, k[f"wald_se_{tag}"], 1e-11, 0, f"se {tag}")
+        assert_close(s, k[f"wald_stat_{tag}"], 1e-10, 1e-14, f"stat {tag}")
+        assert_close(p, k[f"wald_p_{tag}"], 1e-9, 1e-300, f"p {tag}")
+
+
+# ---------------------------------------------------------------- R fixtures, end to end
+
+
+def _run_r_case(which, factors, continuous=(), with_outliers=False, **kw):
+    counts, meta = load_dataset(which)
+    if with_outliers:  # tests/test_pydeseq2.py:452-456
+        counts.loc["sample1", "gene1"] = 2000
+        counts.loc["sample11", "gene7"] = 1000
+        meta.loc["sample1", "condition"] = "C"
+    X, names = treatment_design(meta, factors, continuous)
+    return counts, X, names
+
+
+def _check_res(res, counts, r_res, contrast_idx, tol):
+    l2 = res.LFC[:, contrast_idx] / np.log(2)
+    assert max_rel_err(l2, r_res["log2FoldChange"].to_numpy()) < tol
+    p = res.pvalue.copy()
+    p[res.cooks_outlier] = np.nan
+    assert max_rel_err(p, r_res["pvalue"].to_numpy()) < tol
+
+
+def test_r_single_factor():
+    counts, X, names = _run_r_case("synthetic", ["condition"])
+    res = orc.deseq2(counts.to_numpy(), X, contrast=[0, 1])
+    r_sf = r_csv("single_factor", "r_test_size_factors.csv")["x"].to_numpy()
+    np.testing.assert_array_almost_equal(res.size_factors, r_sf, decimal=6)
+    _check_res(res, counts, r_csv("single_factor", "r_test_res.csv"), 1, 0.02)
+    r_disp = r_csv("single_factor", "r_test_dispersions.csv")["x"].to_numpy()
+    assert max_rel_err(res.dispersions, r_disp) < 0.02
+    padj = orc.p_value_adjustment(np.where(res.cooks_outlier, np.nan, res.pvalue))
+    r_noif = r_csv("single_factor", "r_test_res_no_independent_filtering.csv")
+    assert max_rel_err(padj, r_noif["padj"].to_numpy()) < 0.02
+
+
+@pytest.mark.parametrize("alt,null", [("greater", 0.5), ("less", -0.5), ("greaterAbs", 0.5),
+                                      ("lessAbs", 0.5)])
+def test_r_alt_hypothesis(alt, null):
+    counts, X, _ = _run_r_case("synthetic", ["condition"])
+    res = orc.deseq2(counts.to_numpy(), X, contrast=[0, 1], lfc_null=null, alt_hypothesis=alt)
+    r_res = r_csv("single_factor", f"r_test_res_{alt}.csv")
+    # same comparisons as the reference's test (tests/test_pydeseq2.py:209-226)
+    p = np.where(res.cooks_outlier, np.nan, res.pvalue)
+    assert (np.isnan(p) == r_res["pvalue"].isna().to_numpy()).all()
+    assert max_rel_err(res.LFC[:, 1] / np.log(2), r_res["log2FoldChange"].to_numpy()) < 0.02
+    st = np.abs(res.stat) if alt == "lessAbs" else res.stat
+    r_st = r_res["stat"].to_numpy()
+    nzs = r_st != 0
+    assert np.max(np.abs(r_st[nzs] - st[nzs]) / np.abs(r_st[nzs])) < 0.02
+    assert ((st != 0) == nzs).all()
+    assert max_rel_err(p[nzs], r_res["pvalue"].to_numpy()[nzs]) < 0.02
+
+
+@pytest.mark.parametrize("with_outliers", [False, True])
+def test_r_multi_factor(with_outliers):
+    counts, X, names = _run_r_case("synthetic", ["group", "condition"], with_outliers=with_outliers)
+    ci = names.index("condition[T.B]")
+    c = np.zeros(len(names))
+    c[ci] = 1
+    res = orc.deseq2(counts.to_numpy(), X, contrast=c)
+    fn = "r_test_res_outliers.csv" if with_outliers else "r_test_res.csv"
+    _check_res(res, counts, r_csv("multi_factor", fn), ci, 0.04)
+
+
+@pytest.mark.parametrize("with_outliers", [False, True])
+def test_r_continuous(with_outliers):
+    counts, X, names = _run_r_case("continuous", ["group", "condition"], ["measurement"],
+                                   with_outliers=with_outliers)
+    c = np.zeros(len(names))
+    c[-1] = 1
+    res = orc.deseq2(counts.to_numpy(), X, contrast=c)
+    fn = "r_test_res_outliers.csv" if with_outliers else "r_test_res.csv"
+    _check_res(res, counts, r_csv("continuous", fn), len(names) - 1, 0.04)
+
+
+def test_r_wide():
+    counts, X, names = _run_r_case("wide", ["group", "condition"])
+    ci = names.index("condition[T.B]")
+    c = np.zeros(len(names))
+    c[ci] = 1
+    res = orc.deseq2(counts.to_numpy(), X, contrast=c)
+    _check_res(res, counts, r_csv("wide", "r_test_res.csv"), ci, 0.02)

@@ -1,0 +1,206 @@
+/* deseq_hip.h — C ABI of libdeseq_hip.so, the MI355X (gfx950) engine for the
+ * PyDESeq2 `DeseqDataSet.deseq2()` -> Wald hot path.
+ *
+ * Boundary.  PyDESeq2's plug-in point for this path is the abstract class
+ * `pydeseq2.inference.Inference` (pydeseq2/inference.py:9-362); its default
+ * implementation is `DefaultInference` (pydeseq2/default_inference.py:14-264), which
+ * fans each method out to one joblib task per gene.  Every `dsq_inf_*` function below
+ * replaces exactly one of those methods (cited per function) with host pointers in and
+ * out, so a binding is a thin ctypes/cffi stub.  The `dsq_dev_*`
+ * functions expose the same stages on device-resident buffers for a fused pipeline that
+ * keeps counts / mu / hat-diagonals in HBM between stages (pydeseq2_amd/pipeline.py).
+ *
+ * Conventions
+ *   - plain C, no exceptions: every function returns 0 on success, a negative dsq_status
+ *     on failure; dsq_last_error(ctx) returns a message for the last failure.
+ *   - matrices are described by (pointer, layout): DSQ_SAMPLE_MAJOR is the reference's
+ *     N x G C-order array (element (n,g) at n*G+g); DSQ_GENE_MAJOR is G x N C-order
+ *     (= the F-ordered N x G arrays the reference gets from `mu_hat_.T`,
+ *     default_inference.py:81,119-124).  Device-resident gene-major buffers have a row
+ *     pitch `ldn` (elements), a multiple of 16.
+ *   - counts are non-negative integers < 2^31 (int32 or int64 storage); everything else
+ *     is IEEE double.  Natural-log fold changes, dispersion alpha with var = mu + alpha mu^2.
+ *   - N = samples, G = genes, P = design columns (1..DSQ_MAX_P).
+ *   - statistical non-convergence is NOT an error: it is reported in the `converged`
+ *     arrays exactly like the reference does.
+ */
+#ifndef DESEQ_HIP_H
+#define DESEQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSQ_MAX_P 12
+
+typedef struct dsq_ctx dsq_ctx;
+
+enum dsq_status {
+    DSQ_OK = 0,
+    DSQ_ERR_HIP = -1,       /* a HIP runtime call failed (message has the HIP error string) */
+    DSQ_ERR_ARG = -2,       /* bad argument (P out of range, N == P, null pointer, ...) */
+    DSQ_ERR_RANGE = -3,     /* a count does not fit int32 or is negative */
+    DSQ_ERR_NOMEM = -4
+};
+
+enum dsq_layout { DSQ_SAMPLE_MAJOR = 0, DSQ_GENE_MAJOR = 1 };
+enum dsq_count_type { DSQ_I32 = 0, DSQ_I64 = 1 };
+/* alternative hypotheses of utils.wald_test (pydeseq2/utils.py:778-806) */
+enum dsq_alt { DSQ_ALT_NONE = 0, DSQ_ALT_GREATER_ABS = 1, DSQ_ALT_LESS_ABS = 2,
+               DSQ_ALT_GREATER = 3, DSQ_ALT_LESS = 4 };
+
+/* ------------------------------------------------------------------ context */
+int dsq_create(int device_id, dsq_ctx** out);
+void dsq_destroy(dsq_ctx* ctx);
+const char* dsq_last_error(const dsq_ctx* ctx);
+/* name (<= name_len bytes), compute units, total device memory, gcnArchName */
+int dsq_device_info(dsq_ctx* ctx, char* name, int name_len, int* cu_count, size_t* mem_bytes,
+                    char* arch, int arch_len);
+int dsq_sync(dsq_ctx* ctx);
+/* HIP-event stopwatch on the context's stream (used by bench.py for kernel timing) */
+int dsq_timer_start(dsq_ctx* ctx);
+int dsq_timer_stop(dsq_ctx* ctx, float* elapsed_ms);
+
+/* ------------------------------------------------------------------ device memory */
+int dsq_malloc(dsq_ctx* ctx, size_t bytes, void** dptr);
+int dsq_free(dsq_ctx* ctx, void* dptr);
+int dsq_memset(dsq_ctx* ctx, void* dptr, int value, size_t bytes);
+int dsq_h2d(dsq_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dsq_d2h(dsq_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* pitched copies: `rows` rows of `row_bytes`, pitches in bytes */
+int dsq_h2d_2d(dsq_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+               size_t row_bytes, size_t rows);
+int dsq_d2h_2d(dsq_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+               size_t row_bytes, size_t rows);
+
+/* ================================================================== Inference-level API
+ * Host pointers in, host pointers out; stateless between calls (safe for the re-entrant
+ * use by DeseqDataSet._refit_without_outliers, dds.py:1392-1408).
+ * design[N*P] is the row-major design matrix (obsm["design_matrix"].values).          */
+
+/* Inference.lin_reg_mu (inference.py:13-44; DefaultInference.lin_reg_mu
+ * default_inference.py:58-81 -> utils.fit_lin_mu utils.py:682-715).
+ * mu_out: G x N gene-major (caller returns its transpose view). */
+int dsq_inf_lin_reg_mu(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                       const double* size_factors, const double* design, int N, int G, int P,
+                       double min_mu, double* mu_out);
+
+/* Inference.irls (inference.py:46-119; default_inference.py:83-124 -> utils.irls_solver
+ * utils.py:273-438).  beta_out[G*P]; mu_out, hat_out: G x N gene-major; converged[G].
+ * `optimizer` of the reference is fixed to "L-BFGS-B" semantics (bounded). */
+int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                 const double* size_factors, const double* design, const double* disp, int N,
+                 int G, int P, double min_mu, double beta_tol, double min_beta, double max_beta,
+                 int maxiter, double* beta_out, double* mu_out, double* hat_out,
+                 uint8_t* converged);
+
+/* Inference.alpha_mle (inference.py:121-178; default_inference.py:126-161 ->
+ * utils.fit_alpha_mle utils.py:441-564, grid_search.grid_fit_alpha grid_search.py:54-142).
+ * mu given in `mu_layout`; prior_disp_var ignored unless prior_reg. */
+int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                      const double* design, const double* mu, int mu_layout,
+                      const double* alpha_hat, int N, int G, int P, double min_disp,
+                      double max_disp, double prior_disp_var, int cr_reg, int prior_reg,
+                      double* alpha_out, uint8_t* converged);
+
+/* Inference.wald_test (inference.py:180-235; default_inference.py:163-198 ->
+ * utils.wald_test utils.py:718-811).  lfc[G*P] natural log; ridge[P*P]; contrast[P];
+ * lfc_null already multiplied by ln 2 by the caller (ds.py:345). */
+int dsq_inf_wald_test(dsq_ctx* ctx, const double* design, const double* disp, const double* lfc,
+                      const double* mu, int mu_layout, const double* ridge,
+                      const double* contrast, double lfc_null, int alt, int N, int G, int P,
+                      double* pvals, double* stats, double* se);
+
+/* Inference.fit_rough_dispersions (inference.py:237-259; utils.py:814-853) and
+ * Inference.fit_moments_dispersions (inference.py:261-282; utils.py:856-885) on
+ * normalised counts (double, `layout`).  Returns DSQ_ERR_ARG when N == P (the reference
+ * raises ValueError, utils.py:839-844). */
+int dsq_inf_fit_rough_dispersions(dsq_ctx* ctx, const double* normed, int layout,
+                                  const double* design, int N, int G, int P, double* alpha_out);
+int dsq_inf_fit_moments_dispersions(dsq_ctx* ctx, const double* normed, int layout,
+                                    const double* size_factors, int N, int G, double* alpha_out);
+
+/* Loss and gradient of the 2-coefficient gamma GLM of
+ * Inference.dispersion_trend_gamma_glm (inference.py:284-308; default_inference.py:200-230):
+ *   loss = mean(t/m + log m), m = a0 + a1*cov ; grad as default_inference.py:213-217.
+ * cov/targets are device pointers (n entries); used by the host L-BFGS-B driver. */
+int dsq_dev_trend_loss_grad(dsq_ctx* ctx, const double* d_cov, const double* d_targets,
+                            const uint8_t* d_keep, int n, double a0, double a1, double* loss,
+                            double* grad2);
+
+/* ================================================================== device-resident stage API
+ * All pointers are device pointers unless named h_*.  Gene-major rows have pitch ldn.
+ * Xt and pinvXt are [P][ldx] (design transposed; rows of (X^T X)^-1 X^T). */
+
+/* counts (host layout as uploaded) -> int32 gene-major [G][ldn]; *h_bad set to 1 if a value
+ * is negative or >= 2^31 */
+int dsq_dev_counts_to_gene_major(dsq_ctx* ctx, const void* d_src, int count_type, int layout,
+                                 int N, int G, int32_t* d_dst, int ldn, int* h_bad);
+int dsq_dev_f64_to_gene_major(dsq_ctx* ctx, const double* d_src, int layout, int N, int G,
+                              double* d_dst, int ldn);
+
+/* preprocessing.deseq2_norm_fit (preprocessing.py:31-56): logmeans[G] (-inf if any zero),
+ * nonzero[G] = any(count > 0) (dds.py:729) */
+int dsq_dev_logmeans(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, double* d_logmeans,
+                     uint8_t* d_nonzero);
+/* preprocessing.deseq2_norm_transform (preprocessing.py:59-102): per-sample median over the
+ * genes with finite logmeans (and d_gene_mask[g] != 0 if given) of log(count) - logmeans.
+ * d_counts_sm: sample-major counts [N][G] of `count_type`; d_work: N*G doubles scratch. */
+int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                         const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
+                         double* d_size_factors);
+/* utils.fit_rough_dispersions + fit_moments_dispersions + dds.py:1157-1162 and
+ * var["_normed_means"] (dds.py:708) */
+int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp,
+                double max_disp, double* d_normed_mean, double* d_rough, double* d_moments,
+                double* d_mom);
+int dsq_dev_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf,
+                   const double* d_Xt, const double* d_pinvXt, int ldx, int N, int G, int P,
+                   double min_mu, double* d_mu);
+/* d_nfev may be null.  alpha is NOT clipped (the caller clips, dds.py:792-794). */
+int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn,
+                      const double* d_Xt, int ldx, int N, int G, int P, const double* d_alpha_hat,
+                      double min_disp, double max_disp, double prior_disp_var, int cr_reg,
+                      int prior_reg, double* d_alpha, uint8_t* d_converged, int32_t* d_nfev);
+/* d_mu / d_hat may be null.  d_iters may be null. */
+int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                 const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank,
+                 const double* d_disp, double min_mu, double beta_tol, double min_beta,
+                 double max_beta, int maxiter, double* d_beta, double* d_mu, double* d_hat,
+                 uint8_t* d_converged, int32_t* d_iters);
+/* Cook's distances (dds.py:986-1040) with the robust trimmed dispersion
+ * (utils.py:914-960) + the per-gene ingredients of _replace_outliers / cooks_outlier
+ * (dds.py:1325-1326, 1083-1101).  d_cell_offsets/index: samples grouped by design cell
+ * (cells with >= 3 replicates); whole != 0: no such cell.  d_flags[N]: bit0 cell >= 3,
+ * bit1 cell >= min_replicates.  d_cooks may be null. */
+int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_mu,
+                  const double* d_hat, const int32_t* d_cell_offsets, const int32_t* d_cell_index,
+                  int n_cells, int whole, int max_cell, const uint8_t* d_flags, int N, int G, int P,
+                  double cutoff, double* d_cooks, double* d_robust_disp, uint8_t* d_any_all,
+                  uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above);
+/* Outlier replacement (dds.py:1329-1358) for the genes listed in d_gene_idx[n_sel]:
+ * writes new int32 gene-major rows d_y_out[n_sel][ldn] where samples with
+ * cooks > cutoff in replaceable cells get int(trimmed_mean(normed, 0.2) * sf). */
+int dsq_dev_replace_outliers(dsq_ctx* ctx, const int32_t* d_y, const double* d_cooks, int ldn,
+                             const double* d_sf, const uint8_t* d_flags, const int32_t* d_gene_idx,
+                             int n_sel, int N, double cutoff, int32_t* d_y_out,
+                             uint8_t* d_all_zero);
+/* d_mu may be null (then mu = sf * exp(X beta) is recomputed, ds.py:320-324) */
+int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, const double* d_Xt,
+                 int ldx, int N, int G, int P, const double* d_disp, const double* d_beta,
+                 const double* h_ridge, const double* h_contrast, double lfc_null, int alt,
+                 double* d_pvals, double* d_stats, double* d_se);
+/* row gathers for the refit sub-problem: dst[k][:] = src[idx[k]][:] */
+int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int32_t* d_idx,
+                            int n_idx, int ncols, double* d_dst);
+int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx,
+                            int n_idx, int ncols, int32_t* d_dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESEQ_HIP_H */

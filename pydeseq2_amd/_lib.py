@@ -1,0 +1,247 @@
+"""ctypes binding of libdeseq_hip.so (C ABI in include/deseq_hip.h).
+
+The shared library is the product: there is NO CPU fallback.  If it is missing or no
+MI355X is visible, loading / context creation raises and every op fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeseq_hip.so")
+
+DSQ_MAX_P = 12
+SAMPLE_MAJOR, GENE_MAJOR = 0, 1
+I32, I64 = 0, 1
+ALT = {None: 0, "greaterAbs": 1, "lessAbs": 2, "greater": 3, "less": 4}
+
+c_void_p, c_int, c_double, c_size_t = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_vp = c_void_p
+
+
+class DsqError(RuntimeError):
+    """A libdeseq_hip call failed (HIP error, bad argument, out of memory)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libdeseq_hip.so and declare every prototype of include/deseq_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsqError(
+            f"{LIB_PATH} not found: build it with `make -C pydeseq2_amd/csrc` "
+            "(or __graft_entry__.build()).  pydeseq2_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+
+    def proto(name, *argtypes, res=c_int):
+        fn = getattr(lib, name)
+        fn.argtypes = list(argtypes)
+        fn.restype = res
+        return fn
+
+    proto("dsq_create", c_int, C.POINTER(_vp))
+    proto("dsq_destroy", _vp, res=None)
+    proto("dsq_last_error", _vp, res=C.c_char_p)
+    proto("dsq_device_info", _vp, C.c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_size_t), C.c_char_p, c_int)
+    proto("dsq_sync", _vp)
+    proto("dsq_timer_start", _vp)
+    proto("dsq_timer_stop", _vp, C.POINTER(C.c_float))
+    proto("dsq_malloc", _vp, c_size_t, C.POINTER(_vp))
+    proto("dsq_free", _vp, _vp)
+    proto("dsq_memset", _vp, _vp, c_int, c_size_t)
+    proto("dsq_h2d", _vp, _vp, _vp, c_size_t)
+    proto("dsq_d2h", _vp, _vp, _vp, c_size_t)
+    proto("dsq_h2d_2d", _vp, _vp, c_size_t, _vp, c_size_t, c_size_t, c_size_t)
+    proto("dsq_d2h_2d", _vp, _vp, c_size_t, _vp, c_size_t, c_size_t, c_size_t)
+    # Inference level
+    proto("dsq_inf_lin_reg_mu", _vp, _vp, c_int, c_int, _vp, _vp, c_int, c_int, c_int, c_double, _vp)
+    proto("dsq_inf_irls", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double, c_double,
+          c_double, c_double, c_int, _vp, _vp, _vp, _vp)
+    proto("dsq_inf_alpha_mle", _vp, _vp, c_int, c_int, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_double,
+          c_double, c_double, c_int, c_int, _vp, _vp)
+    proto("dsq_inf_wald_test", _vp, _vp, _vp, _vp, _vp, c_int, _vp, _vp, c_double, c_int, c_int, c_int,
+          c_int, _vp, _vp, _vp)
+    proto("dsq_inf_fit_rough_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, c_int, _vp)
+    proto("dsq_inf_fit_moments_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    proto("dsq_dev_trend_loss_grad", _vp, _vp, _vp, _vp, c_int, c_double, c_double, C.POINTER(c_double),
+          C.POINTER(c_double))
+    # device-resident stages
+    proto("dsq_dev_counts_to_gene_major", _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_int, C.POINTER(c_int))
+    proto("dsq_dev_f64_to_gene_major", _vp, _vp, c_int, c_int, c_int, _vp, c_int)
+    proto("dsq_dev_logmeans", _vp, _vp, c_int, c_int, c_int, _vp, _vp)
+    proto("dsq_dev_size_factors", _vp, _vp, c_int, c_int, c_int, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_mom", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, c_double,
+          _vp, _vp, _vp, _vp)
+    proto("dsq_dev_lin_mu", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, _vp)
+    proto("dsq_dev_alpha_mle", _vp, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_int, _vp, c_double,
+          c_double, c_double, c_int, c_int, _vp, _vp, _vp)
+    proto("dsq_dev_irls", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, _vp, c_double,
+          c_double, c_double, c_double, c_int, _vp, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_cooks", _vp, _vp, c_int, _vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, c_int, c_int,
+          c_int, c_double, _vp, _vp, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_replace_outliers", _vp, _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_double, _vp, _vp)
+    proto("dsq_dev_wald", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, _vp, _vp, _vp,
+          c_double, c_int, _vp, _vp, _vp)
+    proto("dsq_dev_gather_rows_f64", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    proto("dsq_dev_gather_rows_i32", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    _lib = lib
+    return lib
+
+
+EXPORTS = [
+    "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_timer_start",
+    "dsq_timer_stop", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
+    "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
+    "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad",
+    "dsq_dev_counts_to_gene_major", "dsq_dev_f64_to_gene_major", "dsq_dev_logmeans",
+    "dsq_dev_size_factors", "dsq_dev_mom", "dsq_dev_lin_mu", "dsq_dev_alpha_mle", "dsq_dev_irls",
+    "dsq_dev_cooks", "dsq_dev_replace_outliers", "dsq_dev_wald", "dsq_dev_gather_rows_f64",
+    "dsq_dev_gather_rows_i32",
+]
+
+
+def ptr(a):
+    """Raw pointer of a numpy array (None -> NULL) or pass a device pointer (int) through."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a
+
+
+class Context:
+    """One HIP device context + stream (dsq_ctx).  Raises DsqError if no GPU is usable."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.dsq_create(int(device), C.byref(h))
+        if rc != 0 or not h.value:
+            raise DsqError(
+                f"dsq_create(device={device}) failed (rc={rc}): no usable MI355X / HIP runtime. "
+                "pydeseq2_amd runs on the GPU only."
+            )
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.dsq_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            msg = self.lib.dsq_last_error(self.h).decode(errors="replace")
+            if rc == -2:
+                raise ValueError(msg)
+            raise DsqError(f"{name} failed (rc={rc}): {msg}")
+
+    # ---- info / timing
+    def device_info(self):
+        name, arch = C.create_string_buffer(256), C.create_string_buffer(256)
+        cu, mem = c_int(), c_size_t()
+        self.call("dsq_device_info", name, 256, C.byref(cu), C.byref(mem), arch, 256)
+        return dict(name=name.value.decode(), arch=arch.value.decode(), cu_count=cu.value, mem_bytes=mem.value)
+
+    def sync(self):
+        self.call("dsq_sync")
+
+    def timer_start(self):
+        self.call("dsq_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.call("dsq_timer_stop", C.byref(ms))
+        return float(ms.value)
+
+    # ---- memory
+    def malloc(self, nbytes: int) -> int:
+        p = _vp()
+        self.call("dsq_malloc", c_size_t(int(nbytes)), C.byref(p))
+        return p.value
+
+    def free(self, dptr):
+        if dptr:
+            self.call("dsq_free", _vp(dptr))
+
+    def memset(self, dptr, value, nbytes):
+        self.call("dsq_memset", _vp(dptr), int(value), c_size_t(int(nbytes)))
+
+    def h2d(self, dptr, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self.call("dsq_h2d", _vp(dptr), _vp(arr.ctypes.data), c_size_t(arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, dptr):
+        assert arr.flags.c_contiguous
+        self.call("dsq_d2h", _vp(arr.ctypes.data), _vp(dptr), c_size_t(arr.nbytes))
+        return arr
+
+    def d2h_rows(self, dptr, rows, cols, ld, dtype=np.float64):
+        """Pitched device matrix [rows][ld] -> contiguous host [rows][cols]."""
+        out = np.empty((rows, cols), dtype=dtype)
+        isz = out.itemsize
+        self.call("dsq_d2h_2d", _vp(out.ctypes.data), c_size_t(cols * isz), _vp(dptr), c_size_t(ld * isz),
+                  c_size_t(cols * isz), c_size_t(rows))
+        return out
+
+    def h2d_rows(self, dptr, arr: np.ndarray, ld):
+        arr = np.ascontiguousarray(arr)
+        rows, cols = arr.shape
+        isz = arr.itemsize
+        self.call("dsq_h2d_2d", _vp(dptr), c_size_t(ld * isz), _vp(arr.ctypes.data), c_size_t(cols * isz),
+                  c_size_t(cols * isz), c_size_t(rows))
+
+
+class DeviceArray:
+    """Owning handle of a device allocation (1-D or pitched 2-D)."""
+
+    def __init__(self, ctx: Context, shape, dtype, ld=None):
+        self.ctx = ctx
+        self.shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        self.dtype = np.dtype(dtype)
+        self.ld = ld if ld is not None else (self.shape[-1] if len(self.shape) > 1 else None)
+        n = self.shape[0] * (self.ld if len(self.shape) > 1 else 1)
+        self.nbytes = int(n) * self.dtype.itemsize
+        self.ptr = ctx.malloc(self.nbytes)
+
+    @classmethod
+    def from_host(cls, ctx, arr, ld=None):
+        arr = np.ascontiguousarray(arr)
+        self = cls(ctx, arr.shape, arr.dtype, ld)
+        if arr.ndim == 2 and self.ld != arr.shape[1]:
+            ctx.h2d_rows(self.ptr, arr, self.ld)
+        else:
+            ctx.h2d(self.ptr, arr)
+        return self
+
+    def to_host(self):
+        if len(self.shape) == 2 and self.ld != self.shape[1]:
+            return self.ctx.d2h_rows(self.ptr, self.shape[0], self.shape[1], self.ld, self.dtype)
+        out = np.empty(self.shape, dtype=self.dtype)
+        return self.ctx.d2h(out, self.ptr)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,570 @@
+// dsq_capi.hip — the C ABI of libdeseq_hip.so (see include/deseq_hip.h).
+// Host-side glue only: context, device memory, argument checks, staging of host arrays
+// into the gene-major device layout, kernel launches, copy-back.  No math lives here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/deseq_hip.h"
+#include "dsq_launch.h"
+
+struct dsq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_scratch = nullptr;  // 8 KiB of device scratch (scalars, trend partials)
+    int32_t* d_counter = nullptr; // IRLS fallback counter
+    std::string err;
+};
+
+namespace {
+
+constexpr size_t kScratchBytes = 16 * 1024;
+
+int fail(dsq_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define DSQ_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, DSQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+#define DSQ_CHECK_ARG(cond, msg)                          \
+    do {                                                  \
+        if (!(cond)) return fail(ctx, DSQ_ERR_ARG, msg);  \
+    } while (0)
+
+inline int pad16(int n) { return (n + 15) & ~15; }
+
+// RAII device buffer for the Inference-level calls
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T>
+    T* as() { return (T*)p; }
+};
+
+// Householder QR of the N x P design (row-major) -> Xt [P][ldx], pinvXt [P][ldx] =
+// rows of R^-1 Q^T (the reference's beta_init = solve(R, Q^T y), utils.py:350-352, and
+// sklearn's least-squares fit, utils.py:711-713 / 846-848), full_rank flag
+// (numpy.linalg.matrix_rank(X) == P, utils.py:349).
+void design_factor(const double* X, int N, int P, int ldx, std::vector<double>& Xt,
+                   std::vector<double>& pinvXt, int& full_rank) {
+    Xt.assign((size_t)P * ldx, 0.0);
+    pinvXt.assign((size_t)P * ldx, 0.0);
+    for (int n = 0; n < N; ++n)
+        for (int j = 0; j < P; ++j) Xt[(size_t)j * ldx + n] = X[(size_t)n * P + j];
+    // A (column-major copy), Q accumulated explicitly as N x P (thin)
+    std::vector<double> A((size_t)N * P), R((size_t)P * P, 0.0);
+    for (int n = 0; n < N; ++n)
+        for (int j = 0; j < P; ++j) A[(size_t)j * N + n] = X[(size_t)n * P + j];
+    // modified Gram-Schmidt with re-orthogonalisation (P <= 12, N >> P): Q in A, R upper
+    for (int j = 0; j < P; ++j) {
+        double* aj = &A[(size_t)j * N];
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < j; ++i) {
+                const double* qi = &A[(size_t)i * N];
+                long double s = 0.0L;
+                for (int n = 0; n < N; ++n) s += (long double)qi[n] * aj[n];
+                const double sd = (double)s;
+                R[(size_t)i * P + j] += sd;
+                for (int n = 0; n < N; ++n) aj[n] -= sd * qi[n];
+            }
+        }
+        long double nn = 0.0L;
+        for (int n = 0; n < N; ++n) nn += (long double)aj[n] * aj[n];
+        const double nrm = std::sqrt((double)nn);
+        R[(size_t)j * P + j] = nrm;
+        if (nrm > 0.0)
+            for (int n = 0; n < N; ++n) aj[n] /= nrm;
+    }
+    double rmax = 0.0;
+    for (int j = 0; j < P; ++j) rmax = std::fmax(rmax, std::fabs(R[(size_t)j * P + j]));
+    full_rank = 1;
+    const double tol = rmax * (double)(N > P ? N : P) * 2.220446049250313e-16;
+    for (int j = 0; j < P; ++j)
+        if (!(std::fabs(R[(size_t)j * P + j]) > tol)) full_rank = 0;
+    if (!full_rank) return;
+    // pinv = R^-1 Q^T : back substitution per sample
+    for (int n = 0; n < N; ++n) {
+        double b[DSQ_MAX_P];
+        for (int j = 0; j < P; ++j) b[j] = A[(size_t)j * N + n];
+        for (int i = P - 1; i >= 0; --i) {
+            double s = b[i];
+            for (int k = i + 1; k < P; ++k) s -= R[(size_t)i * P + k] * b[k];
+            b[i] = s / R[(size_t)i * P + i];
+        }
+        for (int j = 0; j < P; ++j) pinvXt[(size_t)j * ldx + n] = b[j];
+    }
+}
+
+struct DesignDev {
+    DevBuf Xt, pinv;
+    int ldx = 0, full_rank = 1;
+};
+
+int upload_design(dsq_ctx* ctx, const double* design, int N, int P, DesignDev& D) {
+    D.ldx = pad16(N);
+    std::vector<double> Xt, pinv;
+    design_factor(design, N, P, D.ldx, Xt, pinv, D.full_rank);
+    DSQ_HIP(D.Xt.alloc(Xt.size() * sizeof(double)));
+    DSQ_HIP(D.pinv.alloc(pinv.size() * sizeof(double)));
+    DSQ_HIP(hipMemcpyAsync(D.Xt.p, Xt.data(), Xt.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(D.pinv.p, pinv.data(), pinv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    return DSQ_OK;
+}
+
+// host counts -> device int32 gene-major [G][ldn]
+int upload_counts(dsq_ctx* ctx, const void* counts, int count_type, int layout, int N, int G, DevBuf& y,
+                  int ldn) {
+    const size_t esz = count_type == DSQ_I64 ? 8 : 4;
+    DevBuf raw;
+    DSQ_HIP(raw.alloc((size_t)N * G * esz));
+    DSQ_HIP(y.alloc((size_t)G * ldn * sizeof(int32_t)));
+    DSQ_HIP(hipMemcpyAsync(raw.p, counts, (size_t)N * G * esz, hipMemcpyHostToDevice, ctx->stream));
+    int* d_bad = (int*)ctx->d_scratch;
+    DSQ_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    DSQ_HIP(dsq::launch_transpose_counts(ctx->stream, raw.p, count_type, layout, N, G, y.as<int32_t>(), ldn, d_bad));
+    int bad = 0;
+    DSQ_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ctx, DSQ_ERR_RANGE, "counts must be integers in [0, 2^31)");
+    return DSQ_OK;
+}
+
+int upload_f64_matrix(dsq_ctx* ctx, const double* src, int layout, int N, int G, DevBuf& dst, int ldn) {
+    DevBuf raw;
+    DSQ_HIP(raw.alloc((size_t)N * G * sizeof(double)));
+    DSQ_HIP(dst.alloc((size_t)G * ldn * sizeof(double)));
+    DSQ_HIP(hipMemcpyAsync(raw.p, src, (size_t)N * G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(dsq::launch_transpose_f64(ctx->stream, raw.as<double>(), layout, N, G, dst.as<double>(), ldn));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int upload_vec(dsq_ctx* ctx, const void* src, size_t bytes, DevBuf& dst) {
+    DSQ_HIP(dst.alloc(bytes));
+    DSQ_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return DSQ_OK;
+}
+
+// device gene-major [G][ldn] -> host contiguous [G][N]
+int download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N, int G) {
+    DSQ_HIP(hipMemcpy2DAsync(dst, (size_t)N * sizeof(double), d_src, (size_t)ldn * sizeof(double),
+                             (size_t)N * sizeof(double), (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    return DSQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+int dsq_create(int device_id, dsq_ctx** out) {
+    if (!out) return DSQ_ERR_ARG;
+    *out = nullptr;
+    dsq_ctx* ctx = new dsq_ctx();
+    ctx->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch, kScratchBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 64);
+    if (e != hipSuccess) {
+        fprintf(stderr, "dsq_create: %s\n", hipGetErrorString(e));
+        delete ctx;
+        return DSQ_ERR_HIP;
+    }
+    *out = ctx;
+    return DSQ_OK;
+}
+
+void dsq_destroy(dsq_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* dsq_last_error(const dsq_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dsq_device_info(dsq_ctx* ctx, char* name, int name_len, int* cu_count, size_t* mem_bytes, char* arch,
+                    int arch_len) {
+    hipDeviceProp_t p;
+    DSQ_HIP(hipGetDeviceProperties(&p, ctx->device));
+    if (name && name_len > 0) { strncpy(name, p.name, name_len - 1); name[name_len - 1] = 0; }
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = p.totalGlobalMem;
+    return DSQ_OK;
+}
+
+int dsq_sync(dsq_ctx* ctx) {
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_timer_start(dsq_ctx* ctx) {
+    DSQ_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_timer_stop(dsq_ctx* ctx, float* ms) {
+    DSQ_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    DSQ_HIP(hipEventSynchronize(ctx->ev1));
+    DSQ_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return DSQ_OK;
+}
+
+// ------------------------------------------------------------------ memory
+int dsq_malloc(dsq_ctx* ctx, size_t bytes, void** dptr) {
+    DSQ_CHECK_ARG(dptr != nullptr, "dsq_malloc: null out pointer");
+    DSQ_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e == hipErrorOutOfMemory) return fail(ctx, DSQ_ERR_NOMEM, "hipMalloc: out of device memory");
+    DSQ_HIP(e);
+    return DSQ_OK;
+}
+int dsq_free(dsq_ctx* ctx, void* dptr) {
+    if (dptr) DSQ_HIP(hipFree(dptr));
+    return DSQ_OK;
+}
+int dsq_memset(dsq_ctx* ctx, void* dptr, int value, size_t bytes) {
+    DSQ_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return DSQ_OK;
+}
+int dsq_h2d(dsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    DSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+int dsq_d2h(dsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    DSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+int dsq_h2d_2d(dsq_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes,
+               size_t rows) {
+    DSQ_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+int dsq_d2h_2d(dsq_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t row_bytes,
+               size_t rows) {
+    DSQ_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+// ------------------------------------------------------------------ device-resident stages
+int dsq_dev_counts_to_gene_major(dsq_ctx* ctx, const void* d_src, int count_type, int layout, int N, int G,
+                                 int32_t* d_dst, int ldn, int* h_bad) {
+    DSQ_CHECK_ARG(ldn >= N, "ldn < N");
+    int* d_bad = (int*)ctx->d_scratch;
+    DSQ_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    DSQ_HIP(dsq::launch_transpose_counts(ctx->stream, d_src, count_type, layout, N, G, d_dst, ldn, d_bad));
+    if (h_bad) {
+        DSQ_HIP(hipMemcpyAsync(h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return DSQ_OK;
+}
+
+int dsq_dev_f64_to_gene_major(dsq_ctx* ctx, const double* d_src, int layout, int N, int G, double* d_dst,
+                              int ldn) {
+    DSQ_HIP(dsq::launch_transpose_f64(ctx->stream, d_src, layout, N, G, d_dst, ldn));
+    return DSQ_OK;
+}
+
+int dsq_dev_logmeans(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, double* d_logmeans,
+                     uint8_t* d_nonzero) {
+    DSQ_HIP(dsq::launch_logmeans(ctx->stream, d_y, ldn, N, G, d_logmeans, d_nonzero));
+    return DSQ_OK;
+}
+
+int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                         const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
+                         double* d_size_factors) {
+    DSQ_HIP(dsq::launch_size_factors(ctx->stream, d_counts_sm, count_type, N, G, d_logmeans, d_gene_mask,
+                                     d_work, d_size_factors));
+    return DSQ_OK;
+}
+
+int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                double* d_normed_mean, double* d_rough, double* d_moments, double* d_mom) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(N != P, "The number of samples and the number of design variables are equal, i.e., "
+                          "there are no replicates to estimate the dispersion.");
+    DSQ_HIP(dsq::launch_mom(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, min_disp, max_disp,
+                            d_normed_mean, d_rough, d_moments, d_mom, ctx->d_scratch + 8));
+    return DSQ_OK;
+}
+
+int dsq_dev_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                   const double* d_pinvXt, int ldx, int N, int G, int P, double min_mu, double* d_mu) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_HIP(dsq::launch_lin_mu(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, min_mu, d_mu));
+    return DSQ_OK;
+}
+
+int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt,
+                      int ldx, int N, int G, int P, const double* d_alpha_hat, double min_disp,
+                      double max_disp, double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha,
+                      uint8_t* d_converged, int32_t* d_nfev) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp,
+                              max_disp, prior_disp_var, cr_reg, prior_reg, d_alpha, d_converged, d_nfev));
+    return DSQ_OK;
+}
+
+int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                 const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                 double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
+                 double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    if (G <= 0) return DSQ_OK;
+    DevBuf fb;
+    DSQ_HIP(fb.alloc((size_t)G * sizeof(int32_t)));
+    DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, sizeof(int32_t), ctx->stream));
+    DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
+                             min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
+                             d_converged, d_iters, ctx->d_counter, fb.as<int32_t>()));
+    int32_t n_fb = 0;
+    DSQ_HIP(hipMemcpyAsync(&n_fb, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_fb > 0) {
+        DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
+                                        d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
+                                        d_hat, d_converged, d_iters, fb.as<int32_t>(), n_fb));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return DSQ_OK;
+}
+
+int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_mu,
+                  const double* d_hat, const int32_t* d_cell_offsets, const int32_t* d_cell_index,
+                  int n_cells, int whole, int max_cell, const uint8_t* d_flags, int N, int G, int P,
+                  double cutoff, double* d_cooks, double* d_robust_disp, uint8_t* d_any_all,
+                  uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above) {
+    DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
+    DSQ_HIP(dsq::launch_cooks(ctx->stream, d_y, ldn, d_sf, d_mu, d_hat, d_cell_offsets, d_cell_index,
+                              n_cells, whole, max_cell, d_flags, N, G, P, cutoff, d_cooks, d_robust_disp,
+                              d_any_all, d_any_use, d_any_use_nr, d_few_above));
+    return DSQ_OK;
+}
+
+int dsq_dev_replace_outliers(dsq_ctx* ctx, const int32_t* d_y, const double* d_cooks, int ldn,
+                             const double* d_sf, const uint8_t* d_flags, const int32_t* d_gene_idx,
+                             int n_sel, int N, double cutoff, int32_t* d_y_out, uint8_t* d_all_zero) {
+    DSQ_CHECK_ARG(N <= 16384, "more than 16384 samples is not supported by the outlier replacement");
+    DSQ_HIP(dsq::launch_replace(ctx->stream, d_y, d_cooks, ldn, d_sf, d_flags, d_gene_idx, n_sel, N, cutoff,
+                                d_y_out, d_all_zero));
+    return DSQ_OK;
+}
+
+int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, const double* d_Xt, int ldx,
+                 int N, int G, int P, const double* d_disp, const double* d_beta, const double* h_ridge,
+                 const double* h_contrast, double lfc_null, int alt, double* d_pvals, double* d_stats,
+                 double* d_se) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(alt >= 0 && alt <= 4, "unknown alternative hypothesis");
+    double* d_ridge = ctx->d_scratch + 16;
+    double* d_contrast = d_ridge + DSQ_MAX_P * DSQ_MAX_P;
+    DSQ_HIP(hipMemcpyAsync(d_ridge, h_ridge, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(d_contrast, h_contrast, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    DSQ_HIP(dsq::launch_wald(ctx->stream, d_mu, ldn, d_sf, d_Xt, ldx, N, G, P, d_disp, d_beta, d_ridge,
+                             d_contrast, lfc_null, alt, d_pvals, d_stats, d_se));
+    return DSQ_OK;
+}
+
+int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int32_t* d_idx, int n_idx,
+                            int ncols, double* d_dst) {
+    DSQ_HIP(dsq::launch_gather_rows_f64(ctx->stream, d_src, ld, d_idx, n_idx, ncols, d_dst));
+    return DSQ_OK;
+}
+
+int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx, int n_idx,
+                            int ncols, int32_t* d_dst) {
+    DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_src, ld, d_idx, n_idx, ncols, d_dst));
+    return DSQ_OK;
+}
+
+int dsq_dev_trend_loss_grad(dsq_ctx* ctx, const double* d_cov, const double* d_targets, const uint8_t* d_keep,
+                            int n, double a0, double a1, double* loss, double* grad2) {
+    double* d_part = ctx->d_scratch + 256;  // kTrendPartials x 4 doubles = 8 KiB
+    DSQ_HIP(dsq::launch_trend_loss_grad(ctx->stream, d_cov, d_targets, d_keep, n, a0, a1, d_part));
+    std::vector<double> part((size_t)dsq::kTrendPartials * 4);
+    DSQ_HIP(hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    double s[4] = {0, 0, 0, 0};
+    for (int b = 0; b < dsq::kTrendPartials; ++b)
+        for (int k = 0; k < 4; ++k) s[k] += part[(size_t)b * 4 + k];
+    const double cnt = s[3];
+    *loss = s[0] / cnt;
+    grad2[0] = -s[1] / cnt;
+    grad2[1] = -s[2] / cnt;
+    return DSQ_OK;
+}
+
+// ------------------------------------------------------------------ Inference-level API
+int dsq_inf_lin_reg_mu(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                       const double* size_factors, const double* design, int N, int G, int P, double min_mu,
+                       double* mu_out) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf y, sf, mu;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    if ((rc = upload_vec(ctx, size_factors, (size_t)N * sizeof(double), sf))) return rc;
+    DSQ_HIP(mu.alloc((size_t)G * ldn * sizeof(double)));
+    DSQ_HIP(dsq::launch_lin_mu(ctx->stream, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(),
+                               D.pinv.as<double>(), D.ldx, N, G, P, min_mu, mu.as<double>()));
+    if ((rc = download_rows(ctx, mu_out, mu.as<double>(), ldn, N, G))) return rc;
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                 const double* size_factors, const double* design, const double* disp, int N, int G, int P,
+                 double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
+                 double* beta_out, double* mu_out, double* hat_out, uint8_t* converged) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf y, sf, d, beta, mu, hat, conv;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    if ((rc = upload_vec(ctx, size_factors, (size_t)N * sizeof(double), sf))) return rc;
+    if ((rc = upload_vec(ctx, disp, (size_t)G * sizeof(double), d))) return rc;
+    DSQ_HIP(beta.alloc((size_t)G * P * sizeof(double)));
+    DSQ_HIP(mu.alloc((size_t)G * ldn * sizeof(double)));
+    DSQ_HIP(hat.alloc((size_t)G * ldn * sizeof(double)));
+    DSQ_HIP(conv.alloc((size_t)G));
+    rc = dsq_dev_irls(ctx, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(), D.pinv.as<double>(),
+                      D.ldx, N, G, P, D.full_rank, d.as<double>(), min_mu, beta_tol, min_beta, max_beta,
+                      maxiter, beta.as<double>(), mu.as<double>(), hat.as<double>(), conv.as<uint8_t>(),
+                      nullptr);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(beta_out, beta.p, (size_t)G * P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download_rows(ctx, mu_out, mu.as<double>(), ldn, N, G))) return rc;
+    if ((rc = download_rows(ctx, hat_out, hat.as<double>(), ldn, N, G))) return rc;
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                      const double* design, const double* mu, int mu_layout, const double* alpha_hat, int N,
+                      int G, int P, double min_disp, double max_disp, double prior_disp_var, int cr_reg,
+                      int prior_reg, double* alpha_out, uint8_t* converged) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf y, m, ah, a, conv;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    if ((rc = upload_vec(ctx, alpha_hat, (size_t)G * sizeof(double), ah))) return rc;
+    DSQ_HIP(a.alloc((size_t)G * sizeof(double)));
+    DSQ_HIP(conv.alloc((size_t)G));
+    DSQ_HIP(dsq::launch_alpha(ctx->stream, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N,
+                              G, P, ah.as<double>(), min_disp, max_disp, prior_disp_var, cr_reg, prior_reg,
+                              a.as<double>(), conv.as<uint8_t>(), nullptr));
+    DSQ_HIP(hipMemcpyAsync(alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_wald_test(dsq_ctx* ctx, const double* design, const double* disp, const double* lfc,
+                      const double* mu, int mu_layout, const double* ridge, const double* contrast,
+                      double lfc_null, int alt, int N, int G, int P, double* pvals, double* stats,
+                      double* se) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(alt >= 0 && alt <= 4, "unknown alternative hypothesis");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf m, d, b, o;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    if ((rc = upload_vec(ctx, disp, (size_t)G * sizeof(double), d))) return rc;
+    if ((rc = upload_vec(ctx, lfc, (size_t)G * P * sizeof(double), b))) return rc;
+    DSQ_HIP(o.alloc((size_t)3 * G * sizeof(double)));
+    double* dp = o.as<double>();
+    rc = dsq_dev_wald(ctx, m.as<double>(), ldn, nullptr, D.Xt.as<double>(), D.ldx, N, G, P, d.as<double>(),
+                      b.as<double>(), ridge, contrast, lfc_null, alt, dp, dp + G, dp + 2 * (size_t)G);
+    if (rc) return rc;
+    DSQ_HIP(hipMemcpyAsync(pvals, dp, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(stats, dp + G, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(se, dp + 2 * (size_t)G, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_fit_rough_dispersions(dsq_ctx* ctx, const double* normed, int layout, const double* design,
+                                  int N, int G, int P, double* alpha_out) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(N != P, "The number of samples and the number of design variables are equal, i.e., "
+                          "there are no replicates to estimate the dispersion. Please use a design with "
+                          "fewer variables.");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf v, o;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_f64_matrix(ctx, normed, layout, N, G, v, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    DSQ_HIP(o.alloc((size_t)G * sizeof(double)));
+    DSQ_HIP(dsq::launch_rough_from_normed(ctx->stream, v.as<double>(), ldn, D.Xt.as<double>(),
+                                          D.pinv.as<double>(), D.ldx, N, G, P, o.as<double>()));
+    DSQ_HIP(hipMemcpyAsync(alpha_out, o.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_fit_moments_dispersions(dsq_ctx* ctx, const double* normed, int layout,
+                                    const double* size_factors, int N, int G, double* alpha_out) {
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf v, o;
+    int rc;
+    if ((rc = upload_f64_matrix(ctx, normed, layout, N, G, v, ldn))) return rc;
+    double smi = 0.0;
+    for (int n = 0; n < N; ++n) smi += 1.0 / size_factors[n];
+    smi /= (double)N;
+    DSQ_HIP(o.alloc((size_t)G * sizeof(double)));
+    DSQ_HIP(dsq::launch_moments_from_normed(ctx->stream, v.as<double>(), ldn, N, G, smi, o.as<double>()));
+    DSQ_HIP(hipMemcpyAsync(alpha_out, o.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,617 @@
+// dsq_k_stats.hip — layout transforms, size factors, method-of-moments, linear mu,
+// Cook's distances, outlier replacement, Wald test, small reductions (gfx950).
+//
+// HBM-bound stages: every per-gene kernel reads a gene-major row with unit stride
+// (64 lanes x 4 B / 8 B = one 256 B / 512 B request per wave instruction) and writes its
+// API-visible outputs once.  The only cross-gene step that needs the other orientation is
+// the per-sample median of log-ratios (size factors), which streams the sample-major
+// matrix as uploaded and radix-selects each row in LDS-histogram passes.
+#include <cfloat>
+
+#include "dsq_dispatch.h"
+#include "dsq_launch.h"
+#include "dsq_stats.h"
+
+namespace dsq {
+
+// ------------------------------------------------------------------ wave-private LDS sort
+// Bitonic sort of n doubles (padded to L = next pow2 with +inf) held in a wave-private LDS
+// segment; lanes stride over compare-exchange pairs.  Only this wave touches the segment,
+// LDS operations of one wave execute in order, so a wave-level fence is sufficient.
+struct LdsSorter {
+    __device__ __forceinline__ static void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ int operator()(double* buf, int n) const {
+        int L = 1;
+        while (L < n) L <<= 1;
+        const int lane = threadIdx.x & 63;
+        for (int k = n + lane; k < L; k += 64) buf[k] = INFINITY;
+        wave_sync();
+        for (int k = 2; k <= L; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < (L >> 1); i += 64) {
+                    const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                    const int hi = lo | j;
+                    const bool up = ((lo & k) == 0);
+                    const double a = buf[lo], b = buf[hi];
+                    // NaNs sort last (numpy.sort semantics)
+                    const bool gt = (a > b) || (a != a && b == b);
+                    if (gt == up) { buf[lo] = b; buf[hi] = a; }
+                }
+                wave_sync();
+            }
+        }
+        return L;
+    }
+};
+
+// ------------------------------------------------------------------ transposes
+// sample-major [N][G] (SrcT) -> gene-major [G][ldn] (DstT) through a 64x65 LDS tile
+template <class SrcT, class DstT, bool CHECK>
+__global__ __launch_bounds__(256) void k_transpose(const SrcT* __restrict__ src, int N, int G,
+                                                   DstT* __restrict__ dst, int ldn, int* bad) {
+    __shared__ DstT tile[64][65];
+    const int g0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    int isbad = 0;
+    for (int r = ty; r < 64; r += 4) {
+        const int n = n0 + r, g = g0 + tx;
+        if (n < N && g < G) {
+            const SrcT v = src[(size_t)n * G + g];
+            if (CHECK) {
+                if ((double)v < 0.0 || (double)v > 2147483647.0) isbad = 1;
+            }
+            tile[r][tx] = (DstT)v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int g = g0 + r, n = n0 + tx;
+        if (n < N && g < G) dst[(size_t)g * ldn + n] = tile[tx][r];
+    }
+    if (CHECK && isbad) atomicOr(bad, 1);
+}
+
+// gene-major [G][N] (SrcT) -> gene-major [G][ldn] (DstT) (pitch / type change only)
+template <class SrcT, class DstT, bool CHECK>
+__global__ __launch_bounds__(256) void k_repitch(const SrcT* __restrict__ src, int N, int G,
+                                                 DstT* __restrict__ dst, int ldn, int* bad) {
+    const int g = blockIdx.y;
+    int isbad = 0;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        const SrcT v = src[(size_t)g * N + n];
+        if (CHECK) {
+            if ((double)v < 0.0 || (double)v > 2147483647.0) isbad = 1;
+        }
+        dst[(size_t)g * ldn + n] = (DstT)v;
+    }
+    if (CHECK && isbad) atomicOr(bad, 1);
+}
+
+hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
+                                   int G, int32_t* dst, int ldn, int* bad_flag) {
+    if (N <= 0 || G <= 0) return hipSuccess;
+    if (layout == 0) {
+        const dim3 grid((G + 63) / 64, (N + 63) / 64), block(256);
+        if (count_type == 1)
+            hipLaunchKernelGGL((k_transpose<int64_t, int32_t, true>), grid, block, 0, st,
+                               (const int64_t*)src, N, G, dst, ldn, bad_flag);
+        else
+            hipLaunchKernelGGL((k_transpose<int32_t, int32_t, true>), grid, block, 0, st,
+                               (const int32_t*)src, N, G, dst, ldn, bad_flag);
+    } else {
+        const dim3 grid((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, G), block(256);
+        if (count_type == 1)
+            hipLaunchKernelGGL((k_repitch<int64_t, int32_t, true>), grid, block, 0, st,
+                               (const int64_t*)src, N, G, dst, ldn, bad_flag);
+        else
+            hipLaunchKernelGGL((k_repitch<int32_t, int32_t, true>), grid, block, 0, st,
+                               (const int32_t*)src, N, G, dst, ldn, bad_flag);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_f64(hipStream_t st, const double* src, int layout, int N, int G,
+                                double* dst, int ldn) {
+    if (N <= 0 || G <= 0) return hipSuccess;
+    if (layout == 0) {
+        const dim3 grid((G + 63) / 64, (N + 63) / 64), block(256);
+        hipLaunchKernelGGL((k_transpose<double, double, false>), grid, block, 0, st, src, N, G, dst, ldn,
+                           (int*)nullptr);
+    } else {
+        const dim3 grid((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, G), block(256);
+        hipLaunchKernelGGL((k_repitch<double, double, false>), grid, block, 0, st, src, N, G, dst, ldn,
+                           (int*)nullptr);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ logmeans
+__global__ __launch_bounds__(kBlock) void k_logmeans(const int32_t* __restrict__ y, int ldn, int N,
+                                                     int G, double* __restrict__ logmeans,
+                                                     uint8_t* __restrict__ nonzero) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    double lm;
+    int nz;
+    gene_logmean<DeviceWave>(y + (size_t)g * ldn, N, lm, nz);
+    if ((threadIdx.x & 63) == 0) {
+        logmeans[g] = lm;
+        nonzero[g] = (uint8_t)nz;
+    }
+}
+
+hipError_t launch_logmeans(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
+                           uint8_t* nonzero) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_logmeans, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, N, G, logmeans,
+                       nonzero);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ size factors
+// order-preserving map double -> uint64
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// pass 1: keys[n][g] = key(log(count) - logmeans[g]) for usable genes, ~0 (sorts last) otherwise
+template <class SrcT>
+__global__ __launch_bounds__(256) void k_ratio_keys(const SrcT* __restrict__ counts, int N, int G,
+                                                    const double* __restrict__ logmeans,
+                                                    const uint8_t* __restrict__ mask,
+                                                    unsigned long long* __restrict__ keys) {
+    const int n = blockIdx.y;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        const double lm = logmeans[g];
+        const bool use = (lm != -INFINITY) && (lm == lm) && (mask == nullptr || mask[g] != 0);
+        unsigned long long k = ~0ull;
+        if (use) k = f64_key(log((double)counts[(size_t)n * G + g]) - lm);
+        keys[(size_t)n * G + g] = k;
+    }
+}
+
+// pass 2: one workgroup per sample; 8 radix passes of 8 bits find the element of rank k
+// among the M usable keys; done for the two middle ranks -> median -> size factor.
+__global__ __launch_bounds__(1024) void k_row_median(const unsigned long long* __restrict__ keys, int N,
+                                                     int G, double* __restrict__ sf) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned int s_rank;
+    __shared__ unsigned int s_count;
+    const int n = blockIdx.x;
+    const unsigned long long* row = keys + (size_t)n * G;
+    // number of usable genes
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    unsigned int c = 0;
+    for (int g = threadIdx.x; g < G; g += 1024) c += (row[g] != ~0ull) ? 1u : 0u;
+    atomicAdd(&s_count, c);
+    __syncthreads();
+    const unsigned int M = s_count;
+    if (M == 0) {
+        if (threadIdx.x == 0) sf[n] = NAN;  // np.median of an empty row
+        return;
+    }
+    double vals[2];
+    const unsigned int ranks[2] = {(M - 1) / 2, M / 2};
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && ranks[1] == ranks[0]) { vals[1] = vals[0]; break; }
+        if (threadIdx.x == 0) { s_prefix = 0ull; s_rank = ranks[which]; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+            for (int g = threadIdx.x; g < G; g += 1024) {
+                const unsigned long long k = row[g];
+                if (k != ~0ull && (k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xff], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned int r = s_rank, acc = 0;
+                int d = 0;
+                for (; d < 256; ++d) {
+                    if (acc + hist[d] > r) break;
+                    acc += hist[d];
+                }
+                s_rank = r - acc;
+                s_prefix = prefix | ((unsigned long long)d << shift);
+            }
+            __syncthreads();
+        }
+        vals[which] = key_f64(s_prefix);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double med = (ranks[0] == ranks[1]) ? vals[0] : (vals[0] + vals[1]) / 2.0;
+        sf[n] = exp(med);
+    }
+}
+
+hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                               const double* logmeans, const uint8_t* gene_mask, double* work,
+                               double* sf) {
+    if (N <= 0 || G <= 0) return hipSuccess;
+    const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
+    if (count_type == 1)
+        hipLaunchKernelGGL((k_ratio_keys<int64_t>), dim3(gx, N), dim3(256), 0, st,
+                           (const int64_t*)counts_sm, N, G, logmeans, gene_mask,
+                           (unsigned long long*)work);
+    else
+        hipLaunchKernelGGL((k_ratio_keys<int32_t>), dim3(gx, N), dim3(256), 0, st,
+                           (const int32_t*)counts_sm, N, G, logmeans, gene_mask,
+                           (unsigned long long*)work);
+    hipLaunchKernelGGL(k_row_median, dim3(N), dim3(1024), 0, st, (const unsigned long long*)work, N, G,
+                       sf);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ MoM / linear mu
+__global__ void k_mean_inv(const double* __restrict__ sf, int N, double* out) {
+    // single block reduction of mean(1/sf)
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) s += 1.0 / sf[n];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / (double)N;
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_mom(const int32_t* __restrict__ y, int ldn,
+                                                const double* __restrict__ sf,
+                                                const double* __restrict__ Xt,
+                                                const double* __restrict__ pinvXt, int ldx, int N, int G,
+                                                const double* __restrict__ s_mean_inv, double min_disp,
+                                                double max_disp, double* __restrict__ normed_mean,
+                                                double* __restrict__ rough, double* __restrict__ moments,
+                                                double* __restrict__ mom) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const MomOut o = mom_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
+                                             min_disp, max_disp);
+    if ((threadIdx.x & 63) == 0) {
+        normed_mean[g] = o.normed_mean;
+        if (rough) rough[g] = o.rough;
+        if (moments) moments[g] = o.moments;
+        mom[g] = o.mom;
+    }
+}
+
+hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                      const double* pinvXt, int ldx, int N, int G, int P_, double min_disp,
+                      double max_disp, double* normed_mean, double* rough, double* moments,
+                      double* mom, double* d_scalar) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf, N, d_scalar);
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
+                                          (const double*)d_scalar, min_disp, max_disp, normed_mean, rough,
+                                          moments, mom))
+    return hipGetLastError();
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_lin_mu(const int32_t* __restrict__ y, int ldn,
+                                                   const double* __restrict__ sf,
+                                                   const double* __restrict__ Xt,
+                                                   const double* __restrict__ pinvXt, int ldx, int N,
+                                                   int G, double min_mu, double* __restrict__ mu) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    lin_mu_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, min_mu, mu + (size_t)g * ldn);
+}
+
+hipError_t launch_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                         const double* pinvXt, int ldx, int N, int G, int P_, double min_mu,
+                         double* mu) {
+    if (G <= 0) return hipSuccess;
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N,
+                                          G, min_mu, mu))
+    return hipGetLastError();
+}
+
+// rough / moments dispersions from already-normalised counts (Inference-level entry points)
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_rough_normed(const double* __restrict__ normed, int ldn,
+                                                         const double* __restrict__ Xt,
+                                                         const double* __restrict__ pinvXt, int ldx,
+                                                         int N, int G, double* __restrict__ out) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const double* v = normed + (size_t)g * ldn;
+    double b[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = 0.0;
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] += pinvXt[j * ldx + n] * v[n];
+    }
+    DeviceWave::sum_n<P>(b);
+    double rr = 0.0;
+    const double dof = (double)(N - P);
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+        double yh = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
+        yh = dmax(yh, 1.0);
+        rr += ((v[n] - yh) * (v[n] - yh) - yh) / (dof * yh * yh);
+    }
+    rr = DeviceWave::sum(rr);
+    if ((threadIdx.x & 63) == 0) out[g] = dmax(rr, 0.0);
+}
+
+hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
+                                    const double* pinvXt, int ldx, int N, int G, int P_, double* out) {
+    if (G <= 0) return hipSuccess;
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_rough_normed<P>, grid, block, 0, st, normed, ldn, Xt, pinvXt,
+                                          ldx, N, G, out))
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void k_moments_normed(const double* __restrict__ normed, int ldn,
+                                                           int N, int G, double s_mean_inv,
+                                                           double* __restrict__ out) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const double* v = normed + (size_t)g * ldn;
+    double s = 0.0;
+    for (int n = DeviceWave::lane(); n < N; n += 64) s += v[n];
+    const double mean = DeviceWave::sum(s) / (double)N;
+    double ss = 0.0;
+    for (int n = DeviceWave::lane(); n < N; n += 64) ss += (v[n] - mean) * (v[n] - mean);
+    const double var = DeviceWave::sum(ss) / (double)(N - 1);
+    double m = (var - s_mean_inv * mean) / (mean * mean);
+    if (m != m) m = 0.0;
+    else if (m == INFINITY) m = DBL_MAX;
+    else if (m == -INFINITY) m = -DBL_MAX;
+    if ((threadIdx.x & 63) == 0) out[g] = m;
+}
+
+hipError_t launch_moments_from_normed(hipStream_t st, const double* normed, int ldn, int N, int G,
+                                      double s_mean_inv, double* out) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_moments_normed, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, normed, ldn, N, G,
+                       s_mean_inv, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Wald
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_wald(const double* __restrict__ mu, int ldn,
+                                                 const double* __restrict__ sf,
+                                                 const double* __restrict__ Xt, int ldx, int N, int G,
+                                                 const double* __restrict__ disp,
+                                                 const double* __restrict__ beta,
+                                                 const double* __restrict__ ridge,
+                                                 const double* __restrict__ contrast, double lfc_null,
+                                                 int alt, double* __restrict__ pvals,
+                                                 double* __restrict__ stats, double* __restrict__ se) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    double b[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = beta[(size_t)g * P + j];
+    const WaldOut o = wald_gene<DeviceWave, P>(mu ? mu + (size_t)g * ldn : nullptr, sf, Xt, ldx, N,
+                                               disp[g], b, ridge, contrast, lfc_null, alt);
+    if ((threadIdx.x & 63) == 0) {
+        pvals[g] = o.p;
+        stats[g] = o.stat;
+        se[g] = o.se;
+    }
+}
+
+hipError_t launch_wald(hipStream_t st, const double* mu, int ldn, const double* sf, const double* Xt,
+                       int ldx, int N, int G, int P_, const double* disp, const double* beta,
+                       const double* d_ridge, const double* d_contrast, double lfc_null, int alt,
+                       double* pvals, double* stats, double* se) {
+    if (G <= 0) return hipSuccess;
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_wald<P>, grid, block, 0, st, mu, ldn, sf, Xt, ldx, N, G, disp,
+                                          beta, d_ridge, d_contrast, lfc_null, alt, pvals, stats, se))
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Cook's
+// WPB waves per block share the dynamic LDS: each wave owns `cap` doubles.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_cooks(const int32_t* __restrict__ y, int ldn,
+                                                    const double* __restrict__ sf,
+                                                    const double* __restrict__ mu,
+                                                    const double* __restrict__ hat,
+                                                    const int32_t* __restrict__ cell_offsets,
+                                                    const int32_t* __restrict__ cell_index, int n_cells,
+                                                    int whole, int cap, const uint8_t* __restrict__ flags,
+                                                    int N, int G, int P, double cutoff,
+                                                    double* __restrict__ cooks,
+                                                    double* __restrict__ robust_disp,
+                                                    uint8_t* __restrict__ any_all,
+                                                    uint8_t* __restrict__ any_use,
+                                                    uint8_t* __restrict__ any_use_nr,
+                                                    uint8_t* __restrict__ few_above) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= G) return;
+    double* scratch = lds + (size_t)w * cap;
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    const CooksOut o = cooks_gene<DeviceWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
+                                              hat + (size_t)g * ldn, C, flags, N, P, cutoff, scratch,
+                                              LdsSorter(), cooks ? cooks + (size_t)g * ldn : nullptr);
+    if ((threadIdx.x & 63) == 0) {
+        robust_disp[g] = o.robust_disp;
+        any_all[g] = (uint8_t)o.any_gt_all;
+        any_use[g] = (uint8_t)o.any_gt_use;
+        any_use_nr[g] = (uint8_t)o.any_gt_use_nr;
+        few_above[g] = (uint8_t)o.few_above;
+    }
+}
+
+static int next_pow2(int n) {
+    int L = 1;
+    while (L < n) L <<= 1;
+    return L;
+}
+
+hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* mu,
+                        const double* hat, const int32_t* cell_offsets, const int32_t* cell_index,
+                        int n_cells, int whole, int max_cell, const uint8_t* flags, int N, int G,
+                        int P, double cutoff, double* cooks, double* robust_disp, uint8_t* any_all,
+                        uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above) {
+    if (G <= 0) return hipSuccess;
+    const int cap = next_pow2(whole ? N : max_cell);
+    const size_t per_wave = (size_t)cap * sizeof(double);
+    if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // > 20480 samples in one cell
+#define DSQ_COOKS_LAUNCH(WPB)                                                                          \
+    do {                                                                                               \
+        hipFuncSetAttribute((const void*)k_cooks<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                            (int)(per_wave * WPB));                                                    \
+        hipLaunchKernelGGL(k_cooks<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, \
+                           y, ldn, sf, mu, hat, cell_offsets, cell_index, n_cells, whole, cap, flags, \
+                           N, G, P, cutoff, cooks, robust_disp, any_all, any_use, any_use_nr,         \
+                           few_above);                                                                \
+    } while (0)
+    if (per_wave * 4 <= 64 * 1024) DSQ_COOKS_LAUNCH(4);
+    else if (per_wave * 2 <= 160 * 1024) DSQ_COOKS_LAUNCH(2);
+    else DSQ_COOKS_LAUNCH(1);
+#undef DSQ_COOKS_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ outlier replacement
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict__ y,
+                                                      const double* __restrict__ cooks, int ldn,
+                                                      const double* __restrict__ sf,
+                                                      const uint8_t* __restrict__ flags,
+                                                      const int32_t* __restrict__ gene_idx, int n_sel,
+                                                      int N, int cap, double cutoff,
+                                                      int32_t* __restrict__ y_out,
+                                                      uint8_t* __restrict__ all_zero) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int w = threadIdx.x >> 6;
+    const int k = blockIdx.x * WPB + w;
+    if (k >= n_sel) return;
+    const int g = gene_idx[k];
+    const int32_t* yr = y + (size_t)g * ldn;
+    const double* ck = cooks + (size_t)g * ldn;
+    double* scratch = lds + (size_t)w * cap;
+    const double tbm = trimmed_base_mean<DeviceWave>(yr, sf, N, 0.2, scratch, LdsSorter());
+    int nonzero = 0;
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+        int v = yr[n];
+        if ((flags[n] & 2) && ck[n] > cutoff) v = (int)(tbm * sf[n]);  // truncation (astype(int))
+        y_out[(size_t)k * ldn + n] = v;
+        nonzero |= (v != 0);
+    }
+    nonzero = DeviceWave::sumi(nonzero);
+    if ((threadIdx.x & 63) == 0) all_zero[k] = (uint8_t)(nonzero == 0);
+}
+
+hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
+                          const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
+                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero) {
+    if (n_sel <= 0) return hipSuccess;
+    const int cap = next_pow2(N);
+    const size_t per_wave = (size_t)cap * sizeof(double);
+    if (per_wave > 160 * 1024) return hipErrorInvalidValue;
+#define DSQ_REPL_LAUNCH(WPB)                                                                         \
+    do {                                                                                             \
+        hipFuncSetAttribute((const void*)k_replace<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)(per_wave * WPB));                                                  \
+        hipLaunchKernelGGL(k_replace<WPB>, dim3((n_sel + WPB - 1) / WPB), dim3(64 * WPB),            \
+                           per_wave * WPB, st, y, cooks, ldn, sf, flags, gene_idx, n_sel, N, cap,    \
+                           cutoff, y_out, all_zero);                                                 \
+    } while (0)
+    if (per_wave * 4 <= 64 * 1024) DSQ_REPL_LAUNCH(4);
+    else if (per_wave * 2 <= 160 * 1024) DSQ_REPL_LAUNCH(2);
+    else DSQ_REPL_LAUNCH(1);
+#undef DSQ_REPL_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ misc
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T* __restrict__ src, int ld,
+                                                     const int32_t* __restrict__ idx, int n_idx,
+                                                     int ncols, T* __restrict__ dst) {
+    const int k = blockIdx.y;
+    const int g = idx[k];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < ncols; c += gridDim.x * 256)
+        dst[(size_t)k * ld + c] = src[(size_t)g * ld + c];
+}
+
+hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
+                                  int n_idx, int ncols, double* dst) {
+    if (n_idx <= 0) return hipSuccess;
+    const int gx = (ncols + 255) / 256 > 64 ? 64 : (ncols + 255) / 256;
+    hipLaunchKernelGGL(k_gather_rows<double>, dim3(gx, n_idx), dim3(256), 0, st, src, ld, idx, n_idx, ncols,
+                       dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, const int32_t* idx,
+                                  int n_idx, int ncols, int32_t* dst) {
+    if (n_idx <= 0) return hipSuccess;
+    const int gx = (ncols + 255) / 256 > 64 ? 64 : (ncols + 255) / 256;
+    hipLaunchKernelGGL(k_gather_rows<int32_t>, dim3(gx, n_idx), dim3(256), 0, st, src, ld, idx, n_idx,
+                       ncols, dst);
+    return hipGetLastError();
+}
+
+// gamma-GLM trend loss/gradient partial sums, one row of 4 per block (summed by the host in a
+// fixed order => run-to-run deterministic): {sum(t/m + log m), sum g0, sum g1, count}
+constexpr int kTrendBlocks = 256;
+__global__ __launch_bounds__(256) void k_trend(const double* __restrict__ cov,
+                                               const double* __restrict__ targets,
+                                               const uint8_t* __restrict__ keep, int n, double a0,
+                                               double a1, double* __restrict__ partials) {
+    __shared__ double red[4][4];
+    double s = 0.0, g0 = 0.0, g1 = 0.0, cnt = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (keep != nullptr && keep[i] == 0) continue;
+        const double c = cov[i], t = targets[i];
+        const double m = a0 + a1 * c;
+        const double v = t / m + log(m);
+        if (v != v) continue;  // np.nanmean skips NaN terms
+        s += v;
+        const double r = (t / m - 1.0) / m;
+        g0 += r;
+        g1 += r * c;
+        cnt += 1.0;
+    }
+    s = DeviceWave::sum(s); g0 = DeviceWave::sum(g0); g1 = DeviceWave::sum(g1); cnt = DeviceWave::sum(cnt);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = s; red[w][1] = g0; red[w][2] = g1; red[w][3] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        partials[blockIdx.x * 4 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+// partials: [kTrendBlocks][4] device doubles
+hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const double* targets,
+                                  const uint8_t* keep, int n, double a0, double a1, double* partials) {
+    hipLaunchKernelGGL(k_trend, dim3(kTrendBlocks), dim3(256), 0, st, cov, targets, keep, n, a0, a1,
+                       partials);
+    return hipGetLastError();
+}
+
+}  // namespace dsq

@@ -1,0 +1,76 @@
+// dsq_launch.h — host-side launch entry points implemented in the dsq_k_*.hip units.
+// One gene per 64-lane wavefront, 4 genes per 256-thread workgroup (WPB waves / block).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dsq {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+// ---- dsq_k_alpha.hip
+hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
+                        int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
+                        double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
+                        uint8_t* conv, int32_t* nfev);
+
+// ---- dsq_k_irls.hip
+hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                       const double* pinvXt, int ldx, int N, int G, int P, int full_rank,
+                       const double* disp, double min_mu, double beta_tol, double min_beta,
+                       double max_beta, int maxiter, double* beta, double* mu, double* hat,
+                       uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list);
+hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf,
+                              const double* Xt, const double* pinvXt, int ldx, int N, int P,
+                              int full_rank, const double* disp, double min_mu, double beta_tol,
+                              double min_beta, double max_beta, int maxiter, double* beta, double* mu,
+                              double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
+                              int n_fb);
+
+// ---- dsq_k_stats.hip
+hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
+                                   int G, int32_t* dst, int ldn, int* bad_flag);
+hipError_t launch_transpose_f64(hipStream_t st, const double* src, int layout, int N, int G,
+                                double* dst, int ldn);
+hipError_t launch_logmeans(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
+                           uint8_t* nonzero);
+hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                               const double* logmeans, const uint8_t* gene_mask, double* work,
+                               double* sf);
+hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                      const double* pinvXt, int ldx, int N, int G, int P, double min_disp,
+                      double max_disp, double* normed_mean, double* rough, double* moments,
+                      double* mom, double* d_scalar);
+hipError_t launch_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                         const double* pinvXt, int ldx, int N, int G, int P, double min_mu,
+                         double* mu);
+hipError_t launch_wald(hipStream_t st, const double* mu, int ldn, const double* sf, const double* Xt,
+                       int ldx, int N, int G, int P, const double* disp, const double* beta,
+                       const double* d_ridge, const double* d_contrast, double lfc_null, int alt,
+                       double* pvals, double* stats, double* se);
+hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* mu,
+                        const double* hat, const int32_t* cell_offsets, const int32_t* cell_index,
+                        int n_cells, int whole, int max_cell, const uint8_t* flags, int N, int G,
+                        int P, double cutoff, double* cooks, double* robust_disp, uint8_t* any_all,
+                        uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above);
+hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
+                          const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
+                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero);
+hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
+                                  int n_idx, int ncols, double* dst);
+hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, const int32_t* idx,
+                                  int n_idx, int ncols, int32_t* dst);
+constexpr int kTrendPartials = 256;  // rows of 4 doubles
+hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const double* targets,
+                                  const uint8_t* keep, int n, double a0, double a1, double* partials);
+// normed counts (double, gene-major) based rough / moments for the Inference-level API
+hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
+                                    const double* pinvXt, int ldx, int N, int G, int P, double* out);
+hipError_t launch_moments_from_normed(hipStream_t st, const double* normed, int ldn, int N, int G,
+                                      double s_mean_inv, double* out);
+
+}  // namespace dsq

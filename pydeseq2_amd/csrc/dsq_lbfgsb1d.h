@@ -1,0 +1,295 @@
+// dsq_lbfgsb1d.h — L-BFGS-B specialised to ONE boxed variable.
+//
+// The reference fits each gene's dispersion with
+//   scipy.optimize.minimize(method="L-BFGS-B", bounds=[(log min_disp, log max_disp)])
+// (pydeseq2/utils.py:546-554) and returns whatever that optimiser returns with its
+// default stopping rules (ftol = 2.22e-9 = 1e7*eps, gtol = 1e-5, maxls = 20).  To land
+// on the same iterate — not merely near the optimum — this file restates the published
+// L-BFGS-B 3.0 algorithm (Byrd, Lu, Nocedal, Zhu 1995/2011; scipy 1.15.3 ships a C
+// translation of it) for n = 1:
+//   * the generalized Cauchy point + subspace minimisation collapse to
+//       z = clip(x - g/theta)           (theta = y/s of the last accepted pair, 1 at start)
+//   * the line search is MINPACK-2 dcsrch/dcstep verbatim in behaviour
+//     (ftol 1e-3, gtol 0.9, xtol 0.1, stpmin 0, first trial step 1 for a boxed problem);
+//   * the stopping tests are those of mainlb (projected gradient <= pgtol,
+//     (f_old - f) <= factr*eps*max(|f_old|,|f|,1));
+//   * a line search that needs more than `maxls` evaluations, or starts uphill, restores
+//     the iterate and either restarts with fresh memory (col > 0) or terminates
+//     "ABNORMAL" (col == 0)  -> success = false -> caller runs the grid search;
+//   * one quirk is reproduced on purpose: when the Cauchy point sits on a bound while
+//     correction pairs exist, L-BFGS-B skips its `formk` bookkeeping; the next time the
+//     variable is free the stale middle matrix fails its Cholesky factorisation and the
+//     memory is refreshed (theta = 1).  Checked against scipy on 45k random boxed
+//     1-D problems + 1.4k real dispersion fits: identical iterates except in searches
+//     that are pure rounding noise.
+#pragma once
+#include "dsq_math.h"
+
+namespace dsq {
+
+struct Dcsrch {
+    // state
+    bool brackt;
+    int stage;
+    double finit, ginit, gtest, width, width1;
+    double stx, fx, gx, sty, fy, gy, stmin, stmax, stpmax;
+
+    static constexpr double kFtol = 1e-3, kGtol = 0.9, kXtol = 0.1;
+    enum Task { FG = 0, CONV = 1, WARN = 2, ERR = 3 };
+
+    DSQ_HD Task start(double f, double g, double stp, double stpmax_) {
+        stpmax = stpmax_;
+        if (stp < 0.0 || stp > stpmax_ || g >= 0.0) return ERR;
+        brackt = false;
+        stage = 1;
+        finit = f;
+        ginit = g;
+        gtest = kFtol * g;
+        width = stpmax_;
+        width1 = 2.0 * width;
+        stx = 0.0; fx = f; gx = g;
+        sty = 0.0; fy = f; gy = g;
+        stmin = 0.0;
+        stmax = stp + 4.0 * stp;
+        return FG;
+    }
+
+    // safeguarded cubic/quadratic step (MINPACK-2 dcstep)
+    DSQ_HD void dcstep(double& stx_, double& fx_, double& dx_, double& sty_, double& fy_,
+                       double& dy_, double& stp, double fp, double dp, double lo, double hi) {
+        const double sgnd = dp * (dx_ / fabs(dx_));
+        double stpf;
+        if (fp > fx_) {
+            const double theta = 3.0 * (fx_ - fp) / (stp - stx_) + dx_ + dp;
+            const double s = dmax(fabs(theta), dmax(fabs(dx_), fabs(dp)));
+            double gamma = s * sqrt((theta / s) * (theta / s) - (dx_ / s) * (dp / s));
+            if (stp < stx_) gamma = -gamma;
+            const double p = (gamma - dx_) + theta;
+            const double q = ((gamma - dx_) + gamma) + dp;
+            const double r = p / q;
+            const double stpc = stx_ + r * (stp - stx_);
+            const double stpq = stx_ + ((dx_ / ((fx_ - fp) / (stp - stx_) + dx_)) / 2.0) * (stp - stx_);
+            stpf = (fabs(stpc - stx_) < fabs(stpq - stx_)) ? stpc : stpc + (stpq - stpc) / 2.0;
+            brackt = true;
+        } else if (sgnd < 0.0) {
+            const double theta = 3.0 * (fx_ - fp) / (stp - stx_) + dx_ + dp;
+            const double s = dmax(fabs(theta), dmax(fabs(dx_), fabs(dp)));
+            double gamma = s * sqrt((theta / s) * (theta / s) - (dx_ / s) * (dp / s));
+            if (stp > stx_) gamma = -gamma;
+            const double p = (gamma - dp) + theta;
+            const double q = ((gamma - dp) + gamma) + dx_;
+            const double r = p / q;
+            const double stpc = stp + r * (stx_ - stp);
+            const double stpq = stp + (dp / (dp - dx_)) * (stx_ - stp);
+            stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+            brackt = true;
+        } else if (fabs(dp) < fabs(dx_)) {
+            const double theta = 3.0 * (fx_ - fp) / (stp - stx_) + dx_ + dp;
+            const double s = dmax(fabs(theta), dmax(fabs(dx_), fabs(dp)));
+            double gamma = s * sqrt(dmax(0.0, (theta / s) * (theta / s) - (dx_ / s) * (dp / s)));
+            if (stp > stx_) gamma = -gamma;
+            const double p = (gamma - dp) + theta;
+            const double q = (gamma + (dx_ - dp)) + gamma;
+            const double r = p / q;
+            double stpc;
+            if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx_ - stp);
+            else if (stp > stx_) stpc = hi;
+            else stpc = lo;
+            const double stpq = stp + (dp / (dp - dx_)) * (stx_ - stp);
+            if (brackt) {
+                stpf = (fabs(stpc - stp) < fabs(stpq - stp)) ? stpc : stpq;
+                if (stp > stx_) stpf = dmin(stp + 0.66 * (sty_ - stp), stpf);
+                else stpf = dmax(stp + 0.66 * (sty_ - stp), stpf);
+            } else {
+                stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+                stpf = dmin(hi, stpf);
+                stpf = dmax(lo, stpf);
+            }
+        } else {
+            if (brackt) {
+                const double theta = 3.0 * (fp - fy_) / (sty_ - stp) + dy_ + dp;
+                const double s = dmax(fabs(theta), dmax(fabs(dy_), fabs(dp)));
+                double gamma = s * sqrt((theta / s) * (theta / s) - (dy_ / s) * (dp / s));
+                if (stp > sty_) gamma = -gamma;
+                const double p = (gamma - dp) + theta;
+                const double q = ((gamma - dp) + gamma) + dy_;
+                const double r = p / q;
+                stpf = stp + r * (sty_ - stp);
+            } else if (stp > stx_) {
+                stpf = hi;
+            } else {
+                stpf = lo;
+            }
+        }
+        if (fp > fx_) {
+            sty_ = stp; fy_ = fp; dy_ = dp;
+        } else {
+            if (sgnd < 0.0) { sty_ = stx_; fy_ = fx_; dy_ = dx_; }
+            stx_ = stp; fx_ = fp; dx_ = dp;
+        }
+        stp = stpf;
+    }
+
+    // one dcsrch call with f, g evaluated at stp; may update stp
+    DSQ_HD Task step(double f, double g, double& stp) {
+        const double ftest = finit + stp * gtest;
+        if (stage == 1 && f <= ftest && g >= 0.0) stage = 2;
+        Task task = FG;
+        if (brackt && (stp <= stmin || stp >= stmax)) task = WARN;
+        if (brackt && stmax - stmin <= kXtol * stmax) task = WARN;
+        if (stp == stpmax && f <= ftest && g <= gtest) task = WARN;
+        if (stp == 0.0 && (f > ftest || g >= gtest)) task = WARN;
+        if (f <= ftest && fabs(g) <= kGtol * (-ginit)) task = CONV;
+        if (task != FG) return task;
+        if (stage == 1 && f <= fx && f > ftest) {
+            const double fm = f - stp * gtest;
+            double fxm = fx - stx * gtest, fym = fy - sty * gtest;
+            const double gm = g - gtest;
+            double gxm = gx - gtest, gym = gy - gtest;
+            dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, stmin, stmax);
+            fx = fxm + stx * gtest;
+            fy = fym + sty * gtest;
+            gx = gxm + gtest;
+            gy = gym + gtest;
+        } else {
+            dcstep(stx, fx, gx, sty, fy, gy, stp, f, g, stmin, stmax);
+        }
+        if (brackt) {
+            if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+            width1 = width;
+            width = fabs(sty - stx);
+        }
+        if (brackt) {
+            stmin = dmin(stx, sty);
+            stmax = dmax(stx, sty);
+        } else {
+            stmin = stp + 1.1 * (stp - stx);
+            stmax = stp + 4.0 * (stp - stx);
+        }
+        stp = dmax(stp, 0.0);
+        stp = dmin(stp, stpmax);
+        if ((brackt && (stp <= stmin || stp >= stmax)) || (brackt && stmax - stmin <= kXtol * stmax))
+            stp = stx;
+        return FG;
+    }
+};
+
+struct Lbfgsb1dResult {
+    double x, f, g;
+    bool success;
+    int nfev, nit;
+    int status;  // 0 pgtol at start, 1 pgtol, 2 ftol, 3 abnormal, 4 maxiter
+};
+
+DSQ_HD double projgr_1d(double x, double g, double l, double u) {
+    const double gi = (g < 0.0) ? dmax(x - u, g) : dmin(x - l, g);
+    return fabs(gi);
+}
+
+// FG: void(double x, double& f, double& g)
+template <class FG>
+DSQ_HD Lbfgsb1dResult lbfgsb_1d(FG&& fg, double x0, double l, double u, double factr = 1e7,
+                                double pgtol = 1e-5, int maxls = 20, int maxiter = 15000) {
+    Lbfgsb1dResult R;
+    const double tol = factr * kEps;
+    double x = dmin(dmax(x0, l), u);
+    double f, g;
+    fg(x, f, g);
+    int nfev = 1, it = 0, col = 0;
+    double theta = 1.0;
+    bool dirty = false;
+    if (projgr_1d(x, g, l, u) <= pgtol) {
+        R = {x, f, g, true, nfev, 0, 0};
+        return R;
+    }
+    for (;;) {
+        // ---- generalized Cauchy point (cauchy + subsm, n = 1)
+        const double f1 = -(g * g);
+        const double f2 = -theta * f1;
+        const double dtm = -f1 / f2;
+        double tb, bound;
+        if (g < 0.0) { tb = (u - x) / (-g); bound = u; }
+        else { tb = (x - l) / g; bound = l; }
+        double z;
+        bool free_var;
+        if (dtm < tb) { z = x + dtm * (-g); free_var = true; }
+        else { z = bound; free_var = false; }
+        if (col > 0) {
+            if (!free_var) {
+                dirty = true;  // formk skipped: the middle-matrix bookkeeping goes stale
+            } else if (dirty) {
+                theta = 1.0; col = 0; dirty = false;  // Cholesky fails -> refresh memory
+                continue;
+            }
+        }
+        const double d = z - x;
+        // ---- lnsrlb
+        double stpmx;
+        if (it == 0) {
+            stpmx = 1.0;
+        } else {
+            stpmx = 1e10;
+            if (d < 0.0) {
+                const double a2 = l - x;
+                if (a2 >= 0.0) stpmx = 0.0;
+                else if (d * stpmx < a2) stpmx = a2 / d;
+            } else if (d > 0.0) {
+                const double a2 = u - x;
+                if (a2 <= 0.0) stpmx = 0.0;
+                else if (d * stpmx > a2) stpmx = a2 / d;
+            }
+        }
+        double stp = 1.0;
+        const double xold = x, gold = g, fold = f;
+        int ifun = 0;
+        double gd = g * d;
+        const double gdold = gd;
+        bool lsfail = false;
+        Dcsrch ls;
+        if (gd >= 0.0) {
+            lsfail = true;  // "ascent direction in projection"
+        } else {
+            if (ls.start(f, gd, stp, stpmx) == Dcsrch::ERR) lsfail = true;
+            while (!lsfail) {
+                ifun += 1;
+                if (ifun - 1 >= maxls) { lsfail = true; break; }
+                x = (stp == 1.0) ? z : stp * d + xold;
+                fg(x, f, g);
+                nfev += 1;
+                gd = g * d;
+                if (ls.step(f, gd, stp) != Dcsrch::FG) break;
+            }
+        }
+        if (lsfail) {
+            x = xold; g = gold; f = fold;
+            if (col == 0) {
+                R = {x, f, g, false, nfev, it + 1, 3};
+                return R;
+            }
+            theta = 1.0; col = 0; dirty = false;
+            continue;
+        }
+        it += 1;
+        if (projgr_1d(x, g, l, u) <= pgtol) {
+            R = {x, f, g, true, nfev, it, 1};
+            return R;
+        }
+        const double ddum0 = dmax(fabs(fold), dmax(fabs(f), 1.0));
+        if ((fold - f) <= tol * ddum0) {
+            R = {x, f, g, true, nfev, it, 2};
+            return R;
+        }
+        const double r = g - gold;
+        const double rr = r * r;
+        double dr, ddum;
+        if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
+        else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
+        if (!(dr <= kEps * ddum)) { theta = rr / dr; col += 1; }
+        if (it >= maxiter) {
+            R = {x, f, g, false, nfev, it, 4};
+            return R;
+        }
+    }
+}
+
+}  // namespace dsq

@@ -1,0 +1,138 @@
+// dsq_linalg.h — tiny dense symmetric P x P algebra held entirely in registers.
+//
+// The p x p normal-equation matrices X^T W X of the NB-GLM (p = design
+// columns, 1..16) are symmetric positive definite; they are stored packed
+// (lower triangle, tri(i,j) = i(i+1)/2 + j, i >= j).  P is a template parameter
+// so every loop unrolls and nothing is indexed dynamically (no scratch).
+// Replaces numpy.linalg.slogdet / inv and scipy.linalg.solve(assume_a="pos")
+// at pydeseq2/utils.py:370-371, 428-430, 515, 532, 772-776.
+#pragma once
+#include "dsq_math.h"
+
+namespace dsq {
+
+template <int P>
+struct Tri {
+    static constexpr int N = P * (P + 1) / 2;
+};
+
+DSQ_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }          // i >= j
+DSQ_HD constexpr int tris(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }  // any order
+
+// in-place Cholesky A = L L^T (lower, packed).  Non-SPD input yields NaNs (sqrt of <0).
+template <int P>
+DSQ_HD void chol(double (&a)[Tri<P>::N]) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double d = a[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= a[tri(j, k)] * a[tri(j, k)];
+        d = sqrt(d);
+        a[tri(j, j)] = d;
+        const double r = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double s = a[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= a[tri(i, k)] * a[tri(j, k)];
+            a[tri(i, j)] = s * r;
+        }
+    }
+}
+
+template <int P>
+DSQ_HD double chol_logdet(const double (&l)[Tri<P>::N]) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) s += log(l[tri(j, j)]);
+    return 2.0 * s;
+}
+
+// solve (L L^T) x = b in place
+template <int P>
+DSQ_HD void chol_solve(const double (&l)[Tri<P>::N], double (&b)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= l[tri(i, k)] * b[k];
+        b[i] = s / l[tri(i, i)];
+    }
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < P; ++k) s -= l[tri(k, i)] * b[k];
+        b[i] = s / l[tri(i, i)];
+    }
+}
+
+// inv = (L L^T)^-1, packed symmetric
+template <int P>
+DSQ_HD void chol_inverse(const double (&l)[Tri<P>::N], double (&inv)[Tri<P>::N]) {
+    // Linv (lower) first
+    double li[Tri<P>::N];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        li[tri(j, j)] = 1.0 / l[tri(j, j)];
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s -= l[tri(i, k)] * li[tri(k, j)];
+            li[tri(i, j)] = s / l[tri(i, i)];
+        }
+    }
+    // inv = Linv^T Linv
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = i; k < P; ++k) s += li[tri(k, i)] * li[tri(k, j)];
+            inv[tri(i, j)] = s;
+        }
+    }
+}
+
+// x^T A x for packed symmetric A
+template <int P>
+DSQ_HD double sym_quad(const double (&a)[Tri<P>::N], const double (&x)[P]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) r += a[tris(i, j)] * x[j];
+        s += r * x[i];
+    }
+    return s;
+}
+
+// y = A x for packed symmetric A
+template <int P>
+DSQ_HD void sym_matvec(const double (&a)[Tri<P>::N], const double (&x)[P], double (&y)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) r += a[tris(i, j)] * x[j];
+        y[i] = r;
+    }
+}
+
+// sum_ij A_ij B_ij for packed symmetric A, B (off-diagonals count twice)
+template <int P>
+DSQ_HD double sym_frob(const double (&a)[Tri<P>::N], const double (&b)[Tri<P>::N]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) s += 2.0 * a[tri(i, j)] * b[tri(i, j)];
+        s += a[tri(i, i)] * b[tri(i, i)];
+    }
+    return s;
+}
+
+}  // namespace dsq

@@ -1,0 +1,321 @@
+// dsq_stats.h — the cheaper per-gene stages around the two optimisers.
+//
+//   gene_logmean      preprocessing.py:31-56   (deseq2_norm_fit)
+//   mom_gene          utils.py:814-885 + dds.py:1149-1162 (rough / moments dispersions)
+//   lin_mu_gene       utils.py:682-715         (fit_lin_mu)
+//   wald_gene         utils.py:718-811         (wald_test)
+//   cooks_gene        utils.py:567-679, 914-960 + dds.py:986-1040, 1066-1110
+//   trimmed_base_mean utils.py:567-599 as used by dds.py:1332-1352 (outlier replacement)
+// All follow the one-gene-per-wave layout of dsq_wave.h.
+#pragma once
+#include <cfloat>
+
+#include "dsq_linalg.h"
+#include "dsq_wave.h"
+
+namespace dsq {
+
+// ---------------------------------------------------------------- size factors, pass A
+// logmean = mean_n log(y_n)  (-inf as soon as one count is zero); nonzero = any(y > 0)
+template <class Wv>
+DSQ_HD void gene_logmean(const int32_t* y, int N, double& logmean, int& nonzero) {
+    double s = 0.0;
+    int has_zero = 0, any_pos = 0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const int v = y[n];
+        if (v > 0) { s += log((double)v); any_pos = 1; }
+        else has_zero = 1;
+    }
+    s = Wv::sum(s);
+    has_zero = Wv::sumi(has_zero);
+    nonzero = Wv::sumi(any_pos) > 0 ? 1 : 0;
+    logmean = has_zero ? -INFINITY : s / (double)N;
+}
+
+// ---------------------------------------------------------------- method of moments
+struct MomOut {
+    double normed_mean, rough, moments, mom;
+};
+
+// pinvXt rows of (X^T X)^-1 X^T so that beta_ols = pinvX @ normed  (sklearn
+// LinearRegression(fit_intercept=False).fit(X, normed), utils.py:846-848)
+template <class Wv, int P>
+DSQ_HD MomOut mom_gene(const int32_t* y, const double* sf, const double* Xt, const double* pinvXt,
+                       int ldx, int N, double s_mean_inv, double min_disp, double max_disp) {
+    double s = 0.0, b[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double v = (double)y[n] / sf[n];
+        s += v;
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] += pinvXt[j * ldx + n] * v;
+    }
+    s = Wv::sum(s);
+    Wv::template sum_n<P>(b);
+    const double mean = s / (double)N;
+    double ss = 0.0, rr = 0.0;
+    const double dof = (double)(N - P);
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double v = (double)y[n] / sf[n];
+        const double d = v - mean;
+        ss += d * d;
+        double yh = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
+        yh = dmax(yh, 1.0);
+        rr += ((v - yh) * (v - yh) - yh) / (dof * yh * yh);
+    }
+    ss = Wv::sum(ss);
+    rr = Wv::sum(rr);
+    MomOut o;
+    o.normed_mean = mean;
+    o.rough = dmax(rr, 0.0);
+    const double var = ss / (double)(N - 1);
+    double m = (var - s_mean_inv * mean) / (mean * mean);
+    if (m != m) m = 0.0;                       // np.nan_to_num
+    else if (m == INFINITY) m = DBL_MAX;
+    else if (m == -INFINITY) m = -DBL_MAX;
+    o.moments = m;
+    o.mom = dmin(dmax(dmin(o.rough, o.moments), min_disp), max_disp);
+    return o;
+}
+
+// ---------------------------------------------------------------- linear-model mu_hat
+template <class Wv, int P>
+DSQ_HD void lin_mu_gene(const int32_t* y, const double* sf, const double* Xt, const double* pinvXt,
+                        int ldx, int N, double min_mu, double* mu_out) {
+    double b[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double v = (double)y[n] / sf[n];
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] += pinvXt[j * ldx + n] * v;
+    }
+    Wv::template sum_n<P>(b);
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        double yh = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
+        mu_out[n] = dmax(sf[n] * yh, min_mu);
+    }
+}
+
+// ---------------------------------------------------------------- Wald test
+enum WaldAlt { ALT_NONE = 0, ALT_GREATER_ABS = 1, ALT_LESS_ABS = 2, ALT_GREATER = 3, ALT_LESS = 4 };
+
+struct WaldOut {
+    double p, stat, se;
+};
+
+// mu == nullptr: mu_n = sf_n exp(x_n . beta) is recomputed (what ds.py:320-324 builds on the
+// host); otherwise the caller's mu row is used (Inference.wald_test contract).
+template <class Wv, int P>
+DSQ_HD WaldOut wald_gene(const double* mu, const double* sf, const double* Xt, int ldx, int N,
+                         double disp, const double (&beta)[P], const double* ridge /*[P*P]*/,
+                         const double* contrast /*[P]*/, double lfc_null, int alt) {
+    constexpr int T = Tri<P>::N;
+    double M[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) M[k] = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        double x[P];
+        double eta = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { x[j] = Xt[j * ldx + n]; eta += x[j] * beta[j]; }
+        const double m = (mu != nullptr) ? mu[n] : sf[n] * exp(eta);
+        const double w = m / (1.0 + m * disp);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const double xw = x[i] * w;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[tri(i, j)] += xw * x[j];
+        }
+    }
+    Wv::template sum_n<T>(M);
+    double Hm[T], c[P], Hc[P], MHc[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        c[i] = contrast[i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Hm[tri(i, j)] = M[tri(i, j)] + ridge[i * P + j];
+    }
+    chol<P>(Hm);
+#pragma unroll
+    for (int j = 0; j < P; ++j) Hc[j] = c[j];
+    chol_solve<P>(Hm, Hc);                   // H c
+    sym_matvec<P>(M, Hc, MHc);
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) q += Hc[j] * MHc[j];
+    WaldOut o;
+    o.se = sqrt(q);
+    double stat = 0.0, pval;
+    if (alt == ALT_NONE) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) t += c[j] * (beta[j] - lfc_null);
+        stat = t / o.se;
+        pval = 2.0 * norm_sf(fabs(stat));
+    } else if (alt == ALT_GREATER) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) stat += c[j] * np_fmax((beta[j] - lfc_null) / o.se, 0.0);
+        pval = norm_sf(stat);
+    } else if (alt == ALT_LESS) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) stat += c[j] * np_fmin((beta[j] - lfc_null) / o.se, 0.0);
+        pval = norm_sf(fabs(stat));
+    } else if (alt == ALT_GREATER_ABS) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            stat += c[j] * (dsign(beta[j]) * np_fmax((fabs(beta[j]) - lfc_null) / o.se, 0.0));
+        pval = 2.0 * norm_sf(fabs(stat));
+    } else {  // lessAbs: greater(-|null|) vs less(|null|)
+        const double an = fabs(lfc_null);
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            sa += c[j] * np_fmax((beta[j] + an) / o.se, 0.0);
+            sb += c[j] * np_fmin((beta[j] - an) / o.se, 0.0);
+        }
+        const double pa = norm_sf(sa), pb = norm_sf(fabs(sb));
+        stat = (fabs(sb) < fabs(sa)) ? sb : sa;   // min(stat_above, stat_below, key=abs)
+        pval = (pb > pa) ? pb : pa;              // max(pval_above, pval_below)
+    }
+    o.stat = stat;
+    o.p = pval;
+    return o;
+}
+
+// ---------------------------------------------------------------- Cook's distances
+struct CellPlan {
+    // samples grouped by design cell; only cells with >= 3 replicates are listed.
+    // If n_cells == 0 the whole sample set is one pseudo-cell (utils.py:949-952, trim 1/8,
+    // scale 1.51) and cell_index = 0..N-1.
+    const int32_t* cell_offsets;  // [n_cells + 1]
+    const int32_t* cell_index;    // [cell_offsets[n_cells]] sample ids
+    int n_cells;
+    int whole;                    // 1: no cell has >= 3 replicates
+};
+
+DSQ_HD int trim_class(int n) { return n >= 24 ? 2 : (n >= 4 ? 1 : 0); }  // >=23.5 / >=3.5
+
+// sum of sorted buf[lo:hi) (buf ascending, length n)
+template <class Wv>
+DSQ_HD double range_sum(const double* buf, int lo, int hi) {
+    double s = 0.0;
+    for (int k = lo + Wv::lane(); k < hi; k += Wv::W) s += buf[k];
+    return Wv::sum(s);
+}
+
+struct CooksOut {
+    double robust_disp;
+    int any_gt_all;      // any sample with cooks > cutoff                     (dds.py:1325-1326)
+    int any_gt_use;      // any(cooks[use_for_max] > cutoff)                   (dds.py:1093)
+    int any_gt_use_nr;   // same with replaceable samples zeroed               (dds.py:1089, 1458)
+    int few_above;       // (#samples with y > y[argmax cooks]) < 3           (dds.py:1097-1101)
+};
+
+// scratch: Wv::sort-able buffer of >= next_pow2(max cell) doubles (LDS on the device).
+// flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
+template <class Wv, class Sorter>
+DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu, const double* H,
+                           const CellPlan& C, const uint8_t* flags, int N, int P, double cutoff,
+                           double* scratch, Sorter&& sorter, double* cooks_out) {
+    const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
+    const double scales[3] = {2.04, 1.86, 1.51};
+    double vmax = -INFINITY;
+    const int ncell = C.whole ? 1 : C.n_cells;
+    for (int c = 0; c < ncell; ++c) {
+        const int beg = C.whole ? 0 : C.cell_offsets[c];
+        const int end = C.whole ? N : C.cell_offsets[c + 1];
+        const int n = end - beg;
+        const int cls = C.whole ? 2 : trim_class(n);
+        const int nt = (int)floor((double)n * ratios[cls]);
+        // trimmed mean of normalised counts
+        for (int k = Wv::lane(); k < n; k += Wv::W) {
+            const int sidx = C.whole ? k : C.cell_index[beg + k];
+            scratch[k] = (double)y[sidx] / sf[sidx];
+        }
+        const int L = sorter(scratch, n);
+        (void)L;
+        const double tm = range_sum<Wv>(scratch, nt, n - nt) / (double)(n - 2 * nt);
+        // trimmed mean of squared errors
+        for (int k = Wv::lane(); k < n; k += Wv::W) {
+            const int sidx = C.whole ? k : C.cell_index[beg + k];
+            const double d = (double)y[sidx] / sf[sidx] - tm;
+            scratch[k] = d * d;
+        }
+        sorter(scratch, n);
+        const double tv = scales[cls] * (range_sum<Wv>(scratch, nt, n - nt) / (double)(n - 2 * nt));
+        vmax = (tv > vmax || tv != tv) ? tv : vmax;
+    }
+    // mean of normalised counts over ALL samples (utils.py:954)
+    double s = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) s += (double)y[n] / sf[n];
+    const double m = Wv::sum(s) / (double)N;
+    double ar = (vmax - m) / (m * m);
+    ar = (ar > 0.04) ? ar : 0.04;  // np.maximum(alpha, 0.04) (NaN -> stays NaN in numpy; see below)
+    if (vmax != vmax) ar = vmax;
+    CooksOut o;
+    o.robust_disp = ar;
+    // cooks + outlier bookkeeping
+    int g_all = 0, g_use = 0, g_use_nr = 0;
+    double best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    bool best_nan = false;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double yv = (double)y[n], mv = mu[n], h = H[n];
+        const double V = (mv * mv) * ar + mv;
+        const double r = yv - mv;
+        const double ck = (r * r) / V / (double)P * (h / ((1.0 - h) * (1.0 - h)));
+        if (cooks_out != nullptr) cooks_out[n] = ck;
+        const bool gt = ck > cutoff;
+        const int fl = flags[n];
+        g_all |= gt ? 1 : 0;
+        if (gt && (fl & 1)) { g_use = 1; if (!(fl & 2)) g_use_nr = 1; }
+        // np.argmax: first NaN wins, else first maximum
+        const bool isn = (ck != ck);
+        if (!best_nan) {
+            if (isn) { best_nan = true; best_idx = n; }
+            else if (ck > best) { best = ck; best_idx = n; }
+        }
+    }
+    o.any_gt_all = Wv::sumi(g_all) > 0;
+    o.any_gt_use = Wv::sumi(g_use) > 0;
+    o.any_gt_use_nr = Wv::sumi(g_use_nr) > 0;
+    // wave argmax: (nan first, then value desc, then index asc)
+    {
+        const int any_nan = Wv::sumi(best_nan ? 1 : 0);
+        int cand;
+        if (any_nan > 0) {
+            cand = best_nan ? best_idx : 0x7fffffff;
+        } else {
+            const double wmax = Wv::max(best);
+            cand = (best == wmax) ? best_idx : 0x7fffffff;
+        }
+        // min index over lanes
+        const double ci = -Wv::max(-(double)cand);
+        best_idx = (int)ci;
+    }
+    int above = 0;
+    if (best_idx >= 0 && best_idx < N) {
+        const int yref = y[best_idx];
+        for (int n = Wv::lane(); n < N; n += Wv::W) above += (y[n] > yref) ? 1 : 0;
+    }
+    o.few_above = Wv::sumi(above) < 3;
+    return o;
+}
+
+// trimmed mean (trim 0.2) of the normalised counts over all samples (dds.py:1332-1340)
+template <class Wv, class Sorter>
+DSQ_HD double trimmed_base_mean(const int32_t* y, const double* sf, int N, double trim,
+                                double* scratch, Sorter&& sorter) {
+    for (int k = Wv::lane(); k < N; k += Wv::W) scratch[k] = (double)y[k] / sf[k];
+    sorter(scratch, N);
+    const int nt = (int)floor((double)N * trim);
+    return range_sum<Wv>(scratch, nt, N - nt) / (double)(N - 2 * nt);
+}
+
+}  // namespace dsq

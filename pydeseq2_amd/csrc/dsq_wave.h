@@ -1,0 +1,87 @@
+// dsq_wave.h — "one gene per wavefront" execution policy.
+//
+// Every per-gene routine is a template over a Wave policy:
+//   * DeviceWave : a 64-lane CDNA4 wavefront; lane l owns samples l, l+64, ...
+//                  (gene-major rows => each strided access is one coalesced
+//                  256 B / 512 B request); cross-lane sums are butterfly
+//                  all-reduces, so every lane ends up with the bit-identical
+//                  total and all control flow stays wave-uniform.
+//   * HostWave   : a single "lane" that walks all samples; used only by
+//                  tests/hostsim to unit-test the same code on a CPU.
+#pragma once
+#include "dsq_math.h"
+
+namespace dsq {
+
+// Neumaier-compensated accumulator.  The alpha-dependent NLL terms are O(count) each and
+// cancel against an alpha-independent constant, so plain accumulation would leave
+// ulp(sum of counts) noise in a loss whose line search resolves ~1e-12 differences.
+struct KSum {
+    double s = 0.0, c = 0.0;
+    DSQ_HD void add(double x) {
+        const double t = s + x;
+        c += (fabs(s) >= fabs(x)) ? ((s - t) + x) : ((x - t) + s);
+        s = t;
+    }
+    DSQ_HD void merge(double os, double oc) {  // symmetric in (this, other)
+        const double t = s + os;
+        const double e = (fabs(s) >= fabs(os)) ? ((s - t) + os) : ((os - t) + s);
+        c = (c + oc) + e;
+        s = t;
+    }
+    DSQ_HD double value() const { return s + c; }
+};
+
+#if defined(__HIPCC__)
+struct DeviceWave {
+    static constexpr int W = 64;
+    static __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
+    static __device__ __forceinline__ double sum(double v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    static __device__ __forceinline__ double max(double v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(v, m, 64);
+            v = v > o ? v : o;
+        }
+        return v;
+    }
+    static __device__ __forceinline__ int sumi(int v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    static __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    static __device__ __forceinline__ double sum_comp(KSum k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double os = __shfl_xor(k.s, m, 64);
+            const double oc = __shfl_xor(k.c, m, 64);
+            k.merge(os, oc);
+        }
+        return k.value();
+    }
+    template <int K>
+    static __device__ __forceinline__ void sum_n(double (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = sum(v[k]);
+    }
+};
+#endif
+
+struct HostWave {
+    static constexpr int W = 1;
+    static inline int lane() { return 0; }
+    static inline double sum(double v) { return v; }
+    static inline double max(double v) { return v; }
+    static inline int sumi(int v) { return v; }
+    static inline bool any(bool p) { return p; }
+    static inline double sum_comp(KSum k) { return k.value(); }
+    template <int K>
+    static inline void sum_n(double (&)[K]) {}
+};
+
+}  // namespace dsq

@@ -1,0 +1,197 @@
+"""HipInference — MI355X drop-in for PyDESeq2's ``Inference`` plug-in interface.
+
+Mirrors ``pydeseq2.inference.Inference`` (pydeseq2/inference.py:9-362) method for method
+(same names, argument meaning, return shapes/orders and error behaviour as
+``DefaultInference``, pydeseq2/default_inference.py:14-264), so it can be passed as
+``DeseqDataSet(..., inference=HipInference())`` / ``DeseqStats(..., inference=...)``
+(dds.py:226, 323-336; ds.py:143, 194-207).  Every method is a thin marshalling layer over
+one ``dsq_inf_*`` entry point of libdeseq_hip.so; there is no CPU implementation behind it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Literal
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context
+
+_vp, c_int, c_double = C.c_void_p, C.c_int, C.c_double
+
+
+def _counts_arg(counts):
+    """(array kept alive, count_type, layout) for an N x G count matrix."""
+    a = np.asarray(counts)
+    if a.dtype.kind == "f":
+        if (a % 1 != 0).any():
+            raise ValueError("The count matrix should only contain integers.")
+        a = a.astype(np.int64)
+    elif a.dtype.kind == "b":
+        a = a.astype(np.int32)
+    elif a.dtype.kind not in "iu":
+        raise ValueError("The count matrix should only contain numbers.")
+    if a.dtype not in (np.int32, np.int64):
+        a = a.astype(np.int64)
+    ctype = I32 if a.dtype == np.int32 else I64
+    if a.flags.c_contiguous:
+        return a, ctype, SAMPLE_MAJOR
+    if a.flags.f_contiguous:
+        return a, ctype, GENE_MAJOR
+    return np.ascontiguousarray(a), ctype, SAMPLE_MAJOR
+
+
+def _matrix_arg(m):
+    a = np.asarray(m, dtype=np.float64)
+    if a.flags.c_contiguous:
+        return a, SAMPLE_MAJOR
+    if a.flags.f_contiguous:
+        return a, GENE_MAJOR
+    return np.ascontiguousarray(a), SAMPLE_MAJOR
+
+
+def _vec(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float64))
+
+
+class HipInference:
+    """GPU implementation of the 8 inference routines of the DESeq2 pipeline.
+
+    Parameters
+    ----------
+    device : int
+        HIP device ordinal (one process per GPU).
+    n_cpus : int, optional
+        Accepted for interface compatibility (``DeseqDataSet`` sets it when present,
+        dds.py:324-333); ignored.
+    """
+
+    def __init__(self, device: int = 0, n_cpus: int | None = None, ctx: Context | None = None):
+        self.ctx = ctx if ctx is not None else Context(device)
+        self._n_cpus = n_cpus
+
+    @property
+    def n_cpus(self):  # noqa: D102
+        return self._n_cpus
+
+    @n_cpus.setter
+    def n_cpus(self, n_cpus):
+        self._n_cpus = n_cpus
+
+    # ------------------------------------------------------------------ lin_reg_mu
+    def lin_reg_mu(self, counts, size_factors, design_matrix, min_mu):
+        """See ``Inference.lin_reg_mu`` (inference.py:13-44). Returns mu_hat (N x G)."""
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        sf = _vec(size_factors)
+        out = np.empty((G, N))
+        self.ctx.call("dsq_inf_lin_reg_mu", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data),
+                      _vp(X.ctypes.data), N, G, X.shape[1], c_double(min_mu), _vp(out.ctypes.data))
+        return out.T
+
+    # ------------------------------------------------------------------ irls
+    def irls(self, counts, size_factors, design_matrix, disp, min_mu, beta_tol, min_beta=-30,
+             max_beta=30, optimizer: Literal["BFGS", "L-BFGS-B"] = "L-BFGS-B", maxiter=250):
+        """See ``Inference.irls`` (inference.py:46-119).
+
+        Returns (beta G x p, mu N x G, hat diagonals N x G, converged G).
+        """
+        assert optimizer in ["BFGS", "L-BFGS-B"]
+        if optimizer != "L-BFGS-B":
+            raise NotImplementedError("HipInference implements the bounded (L-BFGS-B) rescue only")
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        P = X.shape[1]
+        sf, d = _vec(size_factors), _vec(disp)
+        beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
+        conv = np.empty(G, dtype=np.uint8)
+        self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
+                      _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
+                      c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
+                      _vp(H.ctypes.data), _vp(conv.ctypes.data))
+        return beta, mu.T, H.T, conv.astype(bool)
+
+    # ------------------------------------------------------------------ alpha_mle
+    def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
+                  cr_reg=True, prior_reg=False, optimizer: Literal["BFGS", "L-BFGS-B"] = "L-BFGS-B"):
+        """See ``Inference.alpha_mle`` (inference.py:121-178). Returns (alpha G, converged G)."""
+        assert optimizer in ["BFGS", "L-BFGS-B"]
+        if optimizer != "L-BFGS-B":
+            raise NotImplementedError("HipInference implements the L-BFGS-B dispersion fit only")
+        if prior_reg and prior_disp_var is None:
+            raise ValueError("Sigma_prior is required for prior regularization")
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        m, mlay = _matrix_arg(mu)
+        ah = _vec(alpha_hat)
+        out, conv = np.empty(G), np.empty(G, dtype=np.uint8)
+        self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
+                      mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
+                      c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
+                      int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data))
+        return out, conv.astype(bool)
+
+    # ------------------------------------------------------------------ wald_test
+    def wald_test(self, design_matrix, disp, lfc, mu, ridge_factor, contrast, lfc_null, alt_hypothesis=None):
+        """See ``Inference.wald_test`` (inference.py:180-235). Returns (pvals, stats, se)."""
+        if alt_hypothesis not in ALT:
+            raise KeyError(alt_hypothesis)
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        N, P = X.shape
+        m, mlay = _matrix_arg(mu)
+        G = m.shape[1]
+        d, b = _vec(disp), np.ascontiguousarray(np.asarray(lfc, dtype=np.float64))
+        r = np.ascontiguousarray(np.asarray(ridge_factor, dtype=np.float64))
+        c = _vec(contrast)
+        p, s, se = np.empty(G), np.empty(G), np.empty(G)
+        self.ctx.call("dsq_inf_wald_test", _vp(X.ctypes.data), _vp(d.ctypes.data), _vp(b.ctypes.data),
+                      _vp(m.ctypes.data), mlay, _vp(r.ctypes.data), _vp(c.ctypes.data), c_double(float(lfc_null)),
+                      ALT[alt_hypothesis], N, G, P, _vp(p.ctypes.data), _vp(s.ctypes.data), _vp(se.ctypes.data))
+        return p, s, se
+
+    # ------------------------------------------------------------------ MoM dispersions
+    def fit_rough_dispersions(self, normed_counts, design_matrix):
+        """See ``Inference.fit_rough_dispersions`` (inference.py:237-259)."""
+        v, lay = _matrix_arg(normed_counts)
+        N, G = v.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        out = np.empty(G)
+        self.ctx.call("dsq_inf_fit_rough_dispersions", _vp(v.ctypes.data), lay, _vp(X.ctypes.data), N, G,
+                      X.shape[1], _vp(out.ctypes.data))
+        return out
+
+    def fit_moments_dispersions(self, normed_counts, size_factors):
+        """See ``Inference.fit_moments_dispersions`` (inference.py:261-282)."""
+        v = np.asarray(normed_counts, dtype=np.float64)
+        v = v[:, ~(v == 0).all(axis=0)]  # utils.py:878
+        v, lay = _matrix_arg(v)
+        N, G = v.shape
+        sf = _vec(size_factors)
+        out = np.empty(G)
+        self.ctx.call("dsq_inf_fit_moments_dispersions", _vp(v.ctypes.data), lay, _vp(sf.ctypes.data), N, G,
+                      _vp(out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ trend
+    def dispersion_trend_gamma_glm(self, covariates, targets):
+        """See ``Inference.dispersion_trend_gamma_glm`` (inference.py:284-308).
+
+        A two-coefficient cross-gene fit (not a per-gene kernel): SURVEY §8 a8 keeps it on
+        the host.  Same objective, start point, bounds and optimiser as
+        default_inference.py:200-230.
+        """
+        from .trend import gamma_glm_fit
+
+        cov = np.asarray(getattr(covariates, "values", covariates), dtype=np.float64)
+        tgt = np.asarray(getattr(targets, "values", targets), dtype=np.float64)
+        return gamma_glm_fit(cov, tgt)
+
+    # ------------------------------------------------------------------ apeGLM (next row)
+    def lfc_shrink_nbinom_glm(self, design_matrix, counts, size, offset, prior_no_shrink_scale, prior_scale,
+                              optimizer, shrink_index):
+        """``Inference.lfc_shrink_nbinom_glm`` (inference.py:310-362) is outside the
+        deseq2() -> Wald hot path and is not built yet."""
+        raise NotImplementedError("apeGLM LFC shrinkage is not part of the deseq2()->Wald hot path yet")

@@ -1,0 +1,412 @@
+"""Device-resident ``deseq2()`` + Wald: the whole hot path without host round trips.
+
+Follows ``DeseqDataSet.deseq2()`` (pydeseq2/dds.py:516-562) stage by stage and then
+``DeseqStats.run_wald_test()`` (pydeseq2/ds.py:303-360).  Counts are uploaded once,
+transposed on the device into the gene-major int32 layout every per-gene kernel reads,
+and the N x G intermediates (mu_hat, mu, hat diagonals, Cook's distances) never leave
+HBM unless the caller asks for them.  Only O(G) vectors cross PCIe between stages, for
+the two cross-gene steps (dispersion trend / prior, dds.py:799-884) and the bookkeeping
+of the outlier refit (dds.py:1042-1110, 1301-1458).
+
+Result fields carry the reference's names: size_factors, normed_means
+(var["_normed_means"]), non_zero, genewise_dispersions, fitted_dispersions,
+MAP_dispersions, dispersions, LFC (natural log, G x p), cooks_outlier, replaced,
+refitted, pvalue / stat / lfcSE, ...
+"""
+from __future__ import annotations
+
+import time
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.stats import f as f_dist
+
+from . import trend as _trend
+from ._design import DesignPack, pad16
+from ._lib import ALT, I32, I64, SAMPLE_MAJOR, Context, DeviceArray
+
+import ctypes as C
+
+_vp, c_double = C.c_void_p, C.c_double
+
+
+@dataclass
+class DeseqResult:
+    size_factors: np.ndarray = None
+    normed_means: np.ndarray = None
+    non_zero: np.ndarray = None
+    mom_dispersions: np.ndarray = None
+    genewise_dispersions: np.ndarray = None
+    genewise_converged: np.ndarray = None
+    trend_coeffs: np.ndarray = None
+    disp_function_type: str = "parametric"
+    mean_disp: float = None
+    fitted_dispersions: np.ndarray = None
+    squared_logres: float = None
+    prior_disp_var: float = None
+    MAP_dispersions: np.ndarray = None
+    MAP_converged: np.ndarray = None
+    outlier_genes: np.ndarray = None
+    dispersions: np.ndarray = None
+    LFC: np.ndarray = None
+    LFC_converged: np.ndarray = None
+    replaced: np.ndarray = None
+    refitted: np.ndarray = None
+    new_all_zeroes: np.ndarray = None
+    cooks_outlier: np.ndarray = None
+    pvalue: np.ndarray = None
+    stat: np.ndarray = None
+    lfcSE: np.ndarray = None
+    timings: dict = field(default_factory=dict)
+    kernel_ms: dict = field(default_factory=dict)
+
+
+def _scatter(G, idx, v, fill=np.nan):
+    out = np.full(G, fill)
+    out[idx] = v
+    return out
+
+
+class DeseqPipeline:
+    """Holds the device-resident state of one dataset on one GPU.
+
+    Parameters mirror ``DeseqDataSet.__init__`` (dds.py:206-229) where they affect the
+    numerics: min_mu, min_disp, max_disp (raised to n_obs, dds.py:312), refit_cooks,
+    min_replicates, beta_tol, fit_type.
+    """
+
+    def __init__(self, counts, design_matrix, *, ctx: Context | None = None, device: int = 0, min_mu=0.5,
+                 min_disp=1e-8, max_disp=10.0, refit_cooks=True, min_replicates=7, beta_tol=1e-8,
+                 fit_type="parametric", keep_cooks=True):
+        self.ctx = ctx if ctx is not None else Context(device)
+        counts = np.asarray(counts)
+        if counts.ndim != 2:
+            raise ValueError("counts must be samples x genes")
+        if counts.dtype.kind == "f":
+            if np.isnan(counts).any():
+                raise ValueError("NaNs are not allowed in the count matrix.")
+            if (counts % 1 != 0).any():
+                raise ValueError("The count matrix should only contain integers.")
+            counts = counts.astype(np.int64)
+        elif counts.dtype.kind not in "iu":
+            raise ValueError("The count matrix should only contain numbers.")
+        if counts.dtype not in (np.int32, np.int64):
+            counts = counts.astype(np.int64)
+        self.N, self.G = counts.shape
+        self.design = DesignPack(design_matrix, min_replicates)
+        if self.design.N != self.N:
+            raise ValueError("design matrix and counts disagree on the number of samples")
+        self.P = self.design.P
+        self.min_mu, self.min_disp = float(min_mu), float(min_disp)
+        self.max_disp = float(max(max_disp, self.N))  # dds.py:312
+        self.refit_cooks, self.min_replicates = bool(refit_cooks), int(min_replicates)
+        self.beta_tol, self.fit_type = float(beta_tol), fit_type
+        self.keep_cooks = keep_cooks
+        self.ldn = pad16(self.N)
+        self._count_type = I32 if counts.dtype == np.int32 else I64
+        ctx_ = self.ctx
+        # ---- resident inputs
+        self.d_raw = DeviceArray.from_host(ctx_, np.ascontiguousarray(counts))  # sample-major, as given
+        self.d_y = DeviceArray(ctx_, (self.G, self.N), np.int32, ld=self.ldn)
+        bad = C.c_int(0)
+        ctx_.call("dsq_dev_counts_to_gene_major", _vp(self.d_raw.ptr), self._count_type, SAMPLE_MAJOR, self.N,
+                  self.G, _vp(self.d_y.ptr), self.ldn, C.byref(bad))
+        if bad.value:
+            raise ValueError("The count matrix should only contain non-negative integers below 2^31.")
+        D = self.design
+        self.d_Xt = DeviceArray.from_host(ctx_, D.Xt)
+        self.d_pinv = DeviceArray.from_host(ctx_, D.pinvXt)
+        self.d_flags = DeviceArray.from_host(ctx_, D.flags)
+        self.d_cell_off = DeviceArray.from_host(ctx_, D.cell_offsets)
+        self.d_cell_idx = DeviceArray.from_host(ctx_, D.cell_index)
+        self._work = None
+        self.layers = {}
+        ctx_.sync()
+
+    # ------------------------------------------------------------------ helpers
+    def _dvec(self, n, dtype=np.float64):
+        return DeviceArray(self.ctx, (max(int(n), 1),), dtype)
+
+    def _dmat(self, rows, dtype=np.float64):
+        return DeviceArray(self.ctx, (max(int(rows), 1), self.N), dtype, ld=self.ldn)
+
+    def _up(self, arr, dtype=np.float64):
+        return DeviceArray.from_host(self.ctx, np.ascontiguousarray(arr, dtype=dtype))
+
+    def _down(self, darr, n, dtype=np.float64):
+        out = np.empty(int(n), dtype=dtype)
+        if n:
+            self.ctx.d2h(out, darr.ptr)
+        return out
+
+    # ------------------------------------------------------------------ stages
+    def _stage_genewise(self, d_y, Gs, d_sf):
+        """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797). Returns device mu_hat and
+        host vectors (normed_means, mom, genewise (clipped), converged)."""
+        ctx, D = self.ctx, self.design
+        d_nm, d_mom = self._dvec(Gs), self._dvec(Gs)
+        ctx.call("dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr),
+                 D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp), _vp(d_nm.ptr),
+                 None, None, _vp(d_mom.ptr))
+        d_mu = self._dmat(Gs)
+        if D.linear_mu:  # dds.py:747-756
+            ctx.call("dsq_dev_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_mu), _vp(d_mu.ptr))
+        else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
+            d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
+            ctx.call("dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_mom.ptr),
+                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                     _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
+        d_gw, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
+        ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr), D.ldx, self.N,
+                 Gs, self.P, _vp(d_mom.ptr), c_double(self.min_disp), c_double(self.max_disp), c_double(1.0), 1,
+                 0, _vp(d_gw.ptr), _vp(d_conv.ptr), None)
+        nm = self._down(d_nm, Gs)
+        mom = self._down(d_mom, Gs)
+        gw = np.clip(self._down(d_gw, Gs), self.min_disp, self.max_disp)  # dds.py:792-794
+        conv = self._down(d_conv, Gs, np.uint8).astype(bool)
+        return d_mu, nm, mom, gw, conv
+
+    def _stage_map(self, d_y, d_mu, Gs, fitted, prior_var):
+        """MAP dispersions (dds.py:886-935) -> host (map clipped, converged)."""
+        d_fit = self._up(fitted)
+        d_map, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
+        self.ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
+                      self.design.ldx, self.N, Gs, self.P, _vp(d_fit.ptr), c_double(self.min_disp),
+                      c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(d_map.ptr), _vp(d_conv.ptr), None)
+        return (np.clip(self._down(d_map, Gs), self.min_disp, self.max_disp),
+                self._down(d_conv, Gs, np.uint8).astype(bool))
+
+    def _stage_lfc(self, d_y, Gs, d_sf, disp, want_layers=True):
+        """IRLS LFC fit (dds.py:937-984) -> (beta host, device mu, device hat, converged)."""
+        D = self.design
+        d_disp = self._up(disp)
+        d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
+        d_mu = self._dmat(Gs) if want_layers else None
+        d_hat = self._dmat(Gs) if want_layers else None
+        self.ctx.call("dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+                      _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_disp.ptr),
+                      c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                      _vp(d_b.ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
+                      _vp(d_c.ptr), None)
+        beta = self._down(d_b, Gs * self.P).reshape(Gs, self.P)
+        return beta, d_mu, d_hat, self._down(d_c, Gs, np.uint8).astype(bool)
+
+    # ------------------------------------------------------------------ the pipeline
+    def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False) -> DeseqResult:
+        """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald."""
+        ctx, D, N, G, P = self.ctx, self.design, self.N, self.G, self.P
+        if alt_hypothesis not in ALT:
+            raise KeyError(alt_hypothesis)
+        if lfc_null < 0 and alt_hypothesis in {"greaterAbs", "lessAbs"}:
+            raise ValueError(f"The alternative hypothesis being {alt_hypothesis}, please provide a "
+                             f"positive lfc_null value (got {lfc_null}).")
+        if contrast is None:
+            contrast = np.zeros(P)
+            contrast[-1] = 1.0
+        contrast = np.ascontiguousarray(contrast, dtype=np.float64)
+        r = DeseqResult()
+        T = r.timings
+
+        def tick():
+            if profile:
+                ctx.sync()
+            return time.perf_counter()
+
+        t0 = tick()
+        # ---- size factors (dds.py:692-708)
+        d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
+        ctx.call("dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
+        if self._work is None:
+            self._work = DeviceArray(ctx, (N * G,), np.float64)
+        d_sf = self._dvec(N)
+        ctx.call("dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, N, G, _vp(d_lm.ptr), None,
+                 _vp(self._work.ptr), _vp(d_sf.ptr))
+        sf = self._down(d_sf, N)
+        if np.isnan(sf).any():
+            raise NotImplementedError(
+                "Every gene contains at least one zero: the reference switches to iterative size "
+                "factors (dds.py:682-690), which is outside the hot path built here.")
+        non_zero = self._down(d_nz, G, np.uint8).astype(bool)
+        r.size_factors, r.non_zero = sf, non_zero
+        self.d_sf = d_sf
+        nzi = np.nonzero(non_zero)[0]
+        Gn = len(nzi)
+        t1 = tick(); T["size_factors"] = t1 - t0
+
+        # ---- compact to the non-zero genes (dds.py:729-731)
+        if Gn < G:
+            d_idx = self._up(nzi.astype(np.int32), np.int32)
+            d_ynz = self._dmat(Gn, np.int32)
+            ctx.call("dsq_dev_gather_rows_i32", _vp(self.d_y.ptr), self.ldn, _vp(d_idx.ptr), Gn, N,
+                     _vp(d_ynz.ptr))
+        else:
+            d_ynz = self.d_y
+
+        # ---- genewise dispersions (dds.py:713-797)
+        d_mu_hat, nm, mom, gw, gconv = self._stage_genewise(d_ynz, Gn, d_sf)
+        # all-zero genes have normed mean 0 (dds.py:708)
+        r.normed_means = _scatter(G, nzi, nm, fill=0.0)
+        r.mom_dispersions = _scatter(G, nzi, mom)
+        r.genewise_dispersions = _scatter(G, nzi, gw)
+        r.genewise_converged = _scatter(G, nzi, gconv.astype(float))
+        t2 = tick(); T["genewise"] = t2 - t1
+
+        # ---- trend (dds.py:799-838) + prior (dds.py:840-884): cross-gene, O(G), host
+        coeffs = None
+        if self.fit_type == "parametric":
+            coeffs = _trend.fit_parametric_trend(gw, nm)
+            if coeffs is None:
+                warnings.warn("The dispersion trend curve fitting did not converge. "
+                              "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
+        elif self.fit_type != "mean":
+            raise NotImplementedError(f"Expected 'parametric' or 'mean' trend curve fit types, received "
+                                      f"{self.fit_type}")
+        if coeffs is not None:
+            r.trend_coeffs, r.disp_function_type = coeffs, "parametric"
+            fitted_nz = coeffs[0] + coeffs[1] / nm
+            fitted = _scatter(G, nzi, fitted_nz)
+        else:
+            r.disp_function_type = "mean"
+            r.mean_disp = _trend.mean_trend(r.genewise_dispersions, self.min_disp)
+            fitted = np.full(G, r.mean_disp)
+            fitted_nz = fitted[nzi]
+        r.fitted_dispersions = fitted
+        if (N - P) <= 3:
+            warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
+                          "dispersions is especially asymmetric and likely to be poorly estimated by the MAD.",
+                          UserWarning, stacklevel=2)
+        r.squared_logres, r.prior_disp_var = _trend.dispersion_prior(gw, fitted_nz, N, P, self.min_disp)
+        t3 = tick(); T["trend_prior"] = t3 - t2
+
+        # ---- MAP dispersions (dds.py:886-935)
+        mp, mconv = self._stage_map(d_ynz, d_mu_hat, Gn, fitted_nz, r.prior_disp_var)
+        r.MAP_dispersions = _scatter(G, nzi, mp)
+        r.MAP_converged = _scatter(G, nzi, mconv.astype(float))
+        disp_nz = mp.copy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out_nz = np.log(gw) > np.log(fitted_nz) + 2 * np.sqrt(r.squared_logres)
+        disp_nz[out_nz] = gw[out_nz]
+        r.outlier_genes = _scatter(G, nzi, out_nz.astype(float), fill=0.0).astype(bool)
+        r.dispersions = _scatter(G, nzi, disp_nz)
+        d_mu_hat.free()
+        t4 = tick(); T["MAP"] = t4 - t3
+
+        # ---- LFC (dds.py:937-984)
+        beta, d_mu, d_hat, lconv = self._stage_lfc(d_ynz, Gn, d_sf, disp_nz)
+        r.LFC = np.full((G, P), np.nan)
+        r.LFC[nzi] = beta
+        r.LFC_converged = _scatter(G, nzi, lconv.astype(float))
+        t5 = tick(); T["LFC"] = t5 - t4
+
+        # ---- Cook's (dds.py:986-1040)
+        cutoff = float(f_dist.ppf(0.99, P, N - P))
+        d_cooks = self._dmat(Gn)
+        d_rd = self._dvec(Gn)
+        d_f = [self._dvec(Gn, np.uint8) for _ in range(4)]
+        ctx.call("dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),
+                 _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
+                 _vp(self.d_flags.ptr), N, Gn, P, c_double(cutoff), _vp(d_cooks.ptr), _vp(d_rd.ptr),
+                 *[_vp(x.ptr) for x in d_f])
+        any_all, any_use, any_use_nr, few_above = [self._down(x, Gn, np.uint8).astype(bool) for x in d_f]
+        self.layers = {"nz_idx": nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat, "cooks": d_cooks}
+        t6 = tick(); T["cooks"] = t6 - t5
+
+        # ---- refit (dds.py:1042-1064, 1301-1458)
+        replaced_nz = np.zeros(Gn, dtype=bool)
+        refitted_nz = np.zeros(Gn, dtype=bool)
+        new_zero_nz = np.zeros(Gn, dtype=bool)
+        if self.refit_cooks and D.replaceable.sum() > 0:
+            replaced_nz = any_all.copy()  # idx.any(axis=0), dds.py:1325-1326
+            if replaced_nz.sum() > 0:
+                rp = np.nonzero(replaced_nz)[0]
+                Gr = len(rp)
+                d_rp = self._up(rp.astype(np.int32), np.int32)
+                d_ysub = self._dmat(Gr, np.int32)
+                d_az = self._dvec(Gr, np.uint8)
+                ctx.call("dsq_dev_replace_outliers", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
+                         _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(cutoff), _vp(d_ysub.ptr),
+                         _vp(d_az.ptr))
+                naz = self._down(d_az, Gr, np.uint8).astype(bool)
+                new_zero_nz[rp[naz]] = True
+                refitted_nz[rp[~naz]] = True
+                if naz.any():  # dds.py:1380-1383
+                    r.normed_means[nzi[rp[naz]]] = 0.0
+                    r.LFC[nzi[rp[naz]], :] = 0.0
+                if (~naz).any():
+                    keep = np.nonzero(~naz)[0]
+                    rf = rp[keep]
+                    Gf = len(rf)
+                    if Gf < Gr:
+                        d_keep = self._up(keep.astype(np.int32), np.int32)
+                        d_yf = self._dmat(Gf, np.int32)
+                        ctx.call("dsq_dev_gather_rows_i32", _vp(d_ysub.ptr), self.ldn, _vp(d_keep.ptr), Gf, N,
+                                 _vp(d_yf.ptr))
+                    else:
+                        d_yf = d_ysub
+                    s_mu, s_nm, _, s_gw, _ = self._stage_genewise(d_yf, Gf, d_sf)
+                    if r.disp_function_type == "parametric":
+                        s_fit = r.trend_coeffs[0] + r.trend_coeffs[1] / s_nm
+                    else:
+                        s_fit = np.full(Gf, r.mean_disp)
+                    s_map, _ = self._stage_map(d_yf, s_mu, Gf, s_fit, r.prior_disp_var)
+                    s_disp = s_map.copy()
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        s_out = np.log(s_gw) > np.log(s_fit) + 2 * np.sqrt(r.squared_logres)
+                    s_disp[s_out] = s_gw[s_out]
+                    s_beta, _, _, _ = self._stage_lfc(d_yf, Gf, d_sf, s_disp, want_layers=False)
+                    gi = nzi[rf]
+                    r.normed_means[gi] = s_nm
+                    r.LFC[gi, :] = s_beta
+                    r.genewise_dispersions[gi] = s_gw
+                    r.fitted_dispersions[gi] = s_fit
+                    r.dispersions[gi] = s_disp
+        r.replaced = _scatter(G, nzi, replaced_nz.astype(float), fill=0.0).astype(bool)
+        r.refitted = _scatter(G, nzi, refitted_nz.astype(float), fill=0.0).astype(bool)
+        r.new_all_zeroes = _scatter(G, nzi, new_zero_nz.astype(float), fill=0.0).astype(bool)
+        # ---- cooks_outlier (dds.py:1066-1110)
+        use_rc = self.refit_cooks and refitted_nz.sum() > 0
+        co_nz = np.where(refitted_nz, any_use_nr, any_use) if use_rc else any_use.copy()
+        co_nz = co_nz & few_above
+        r.cooks_outlier = _scatter(G, nzi, co_nz.astype(float), fill=0.0).astype(bool)
+        t7 = tick(); T["refit"] = t7 - t6
+
+        # ---- Wald (ds.py:303-360); mu = sf * exp(X beta) is recomputed on the device
+        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
+        d_beta = self._up(r.LFC)
+        d_disp = self._up(r.dispersions)
+        d_p, d_s, d_se = self._dvec(G), self._dvec(G), self._dvec(G)
+        ctx.call("dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P,
+                 _vp(d_disp.ptr), _vp(d_beta.ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data),
+                 c_double(np.log(2) * lfc_null), ALT[alt_hypothesis], _vp(d_p.ptr), _vp(d_s.ptr), _vp(d_se.ptr))
+        pv, st, se = self._down(d_p, G), self._down(d_s, G), self._down(d_se, G)
+        if self.refit_cooks and r.replaced.sum() > 0:  # ds.py:357-360
+            z = r.new_all_zeroes
+            se[z], st[z], pv[z] = 0.0, 0.0, 1.0
+        r.pvalue, r.stat, r.lfcSE = pv, st, se
+        t8 = tick(); T["wald"] = t8 - t7
+        T["total"] = t8 - t0
+        if not self.keep_cooks:
+            for k in ("mu_LFC", "hat_diagonals", "cooks"):
+                self.layers[k].free()
+            self.layers = {}
+        return r
+
+    # ------------------------------------------------------------------ lazy N x G layers
+    def layer(self, name):
+        """Fetch an N x G layer ("mu_LFC", "hat_diagonals", "cooks") to the host (NaN for zero genes)."""
+        d = self.layers[name]
+        nzi = self.layers["nz_idx"]
+        rows = self.ctx.d2h_rows(d.ptr, len(nzi), self.N, self.ldn)
+        out = np.full((self.N, self.G), np.nan)
+        out[:, nzi] = rows.T
+        return out
+
+
+def deseq2(counts, design_matrix, contrast=None, *, device=0, ctx=None, lfc_null=0.0, alt_hypothesis=None,
+           **kw) -> DeseqResult:
+    """One-shot convenience wrapper: upload, run, return the result vectors."""
+    pipe = DeseqPipeline(counts, design_matrix, ctx=ctx, device=device, **kw)
+    return pipe.deseq2(contrast=contrast, lfc_null=lfc_null, alt_hypothesis=alt_hypothesis)

@@ -52,7 +52,9 @@ def assert_close(a, b, rtol, atol=0.0, what=""):
     a, b = np.asarray(a, float), np.asarray(b, float)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     assert (np.isnan(a) == np.isnan(b)).all(), f"{what}: NaN pattern differs"
-    ok = ~np.isnan(b)
+    inf = np.isinf(b)
+    assert (a[inf] == b[inf]).all() and (np.isinf(a) == inf).all(), f"{what}: inf pattern differs"
+    ok = ~np.isnan(b) & ~inf
     err = np.abs(a[ok] - b[ok]) - (atol + rtol * np.abs(b[ok]))
     assert (err <= 0).all(), (
         f"{what}: max excess {err.max():.3e}; worst rel "

@@ -1,0 +1,224 @@
+"""ctypes front-end of the TEST-ONLY host build of the per-gene templates (see hostsim.cpp)."""
+import ctypes as C
+
+import numpy as np
+
+from .build import build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def gene_major(counts):
+    """N x G counts -> contiguous int32 [G][N]."""
+    return np.ascontiguousarray(np.asarray(counts).T.astype(np.int32))
+
+
+def design_pack(X):
+    X = np.asarray(X, dtype=np.float64)
+    Xt = np.ascontiguousarray(X.T)
+    pinv = np.ascontiguousarray(np.linalg.pinv(X))
+    full_rank = int(np.linalg.matrix_rank(X) == X.shape[1])
+    return Xt, pinv, full_rank
+
+
+def lgamma_digamma(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lg, dg = np.empty_like(x), np.empty_like(x)
+    lib().hs_lgamma_digamma(_p(x, C.c_double), C.c_int(x.size), _p(lg, C.c_double), _p(dg, C.c_double))
+    return lg, dg
+
+
+def norm_sf(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    o = np.empty_like(x)
+    lib().hs_norm_sf(_p(x, C.c_double), C.c_int(x.size), _p(o, C.c_double))
+    return o
+
+
+FG_CB = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def lbfgsb1d(fg, x0, l, u):
+    def cb(x, pf, pg):
+        f, g = fg(x)
+        pf[0], pg[0] = f, g
+
+    x, f = C.c_double(), C.c_double()
+    ok, nfev, nit, st = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    lib().hs_lbfgsb1d(FG_CB(cb), C.c_double(x0), C.c_double(l), C.c_double(u), C.byref(x), C.byref(f),
+                      C.byref(ok), C.byref(nfev), C.byref(nit), C.byref(st))
+    return x.value, f.value, bool(ok.value), nfev.value, nit.value, st.value
+
+
+def alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False):
+    y = gene_major(counts)
+    G, N = y.shape
+    m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
+    Xt, _, _ = design_pack(X)
+    ah = np.ascontiguousarray(alpha_hat, dtype=np.float64)
+    out, conv, nfev = np.empty(G), np.empty(G, np.uint8), np.empty(G, np.int32)
+    rc = lib().hs_alpha_mle(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
+                            C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), _p(ah, C.c_double),
+                            C.c_double(min_disp), C.c_double(max_disp),
+                            C.c_double(prior_var if prior_var is not None else 1.0), C.c_int(cr_reg),
+                            C.c_int(prior_reg), _p(out, C.c_double), _p(conv, C.c_uint8), _p(nfev, C.c_int32))
+    assert rc == 0
+    return out, conv.astype(bool), nfev
+
+
+def grid_alpha(counts, X, mu, min_disp, max_disp):
+    y = gene_major(counts)
+    G, N = y.shape
+    m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
+    Xt, _, _ = design_pack(X)
+    out = np.empty(G)
+    rc = lib().hs_grid_alpha(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
+                             C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), C.c_double(min_disp),
+                             C.c_double(max_disp), _p(out, C.c_double))
+    assert rc == 0
+    return out
+
+
+def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30.0, max_beta=30.0, maxiter=250):
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, fr = design_pack(X)
+    P = Xt.shape[0]
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    d = np.ascontiguousarray(disp, dtype=np.float64)
+    beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
+    conv, it, fb = np.empty(G, np.uint8), np.empty(G, np.int32), np.empty(G, np.uint8)
+    rc = lib().hs_irls(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double),
+                       _p(pinv, C.c_double), C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(P), _p(d, C.c_double),
+                       C.c_double(min_mu), C.c_double(beta_tol), C.c_double(min_beta), C.c_double(max_beta),
+                       C.c_int(maxiter), C.c_int(fr), _p(beta, C.c_double), _p(mu, C.c_double),
+                       _p(H, C.c_double), _p(conv, C.c_uint8), _p(it, C.c_int32), _p(fb, C.c_uint8))
+    assert rc == 0
+    return beta, mu.T, H.T, conv.astype(bool), it, fb.astype(bool)
+
+
+def logmeans(counts):
+    y = gene_major(counts)
+    G, N = y.shape
+    lm, nz = np.empty(G), np.empty(G, np.uint8)
+    lib().hs_logmeans(_p(y, C.c_int32), C.c_int(N), C.c_int(N), C.c_int(G), _p(lm, C.c_double), _p(nz, C.c_uint8))
+    return lm, nz.astype(bool)
+
+
+def mom(counts, sf, X, min_disp, max_disp):
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, _ = design_pack(X)
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    o = [np.empty(G) for _ in range(4)]
+    rc = lib().hs_mom(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
+                      C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), C.c_double(min_disp),
+                      C.c_double(max_disp), *[_p(a, C.c_double) for a in o])
+    assert rc == 0
+    return dict(normed_mean=o[0], rough=o[1], moments=o[2], mom=o[3])
+
+
+def lin_mu(counts, sf, X, min_mu):
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, _ = design_pack(X)
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    mu = np.empty((G, N))
+    rc = lib().hs_lin_mu(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
+                         C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), C.c_double(min_mu),
+                         _p(mu, C.c_double))
+    assert rc == 0
+    return mu.T
+
+
+ALT = {None: 0, "greaterAbs": 1, "lessAbs": 2, "greater": 3, "less": 4}
+
+
+def wald(X, disp, beta, sf, ridge, contrast, lfc_null, alt, mu=None):
+    Xt, _, _ = design_pack(X)
+    P, N = Xt.shape
+    G = len(disp)
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T) if mu is not None else None
+    d = np.ascontiguousarray(disp, dtype=np.float64)
+    b = np.ascontiguousarray(beta, dtype=np.float64)
+    r = np.ascontiguousarray(ridge, dtype=np.float64)
+    c = np.ascontiguousarray(contrast, dtype=np.float64)
+    p, s, se = np.empty(G), np.empty(G), np.empty(G)
+    rc = lib().hs_wald(_p(m, C.c_double), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), C.c_int(N),
+                       C.c_int(N), C.c_int(G), C.c_int(P), _p(d, C.c_double), _p(b, C.c_double), _p(r, C.c_double),
+                       _p(c, C.c_double), C.c_double(lfc_null), C.c_int(ALT[alt]), _p(p, C.c_double),
+                       _p(s, C.c_double), _p(se, C.c_double))
+    assert rc == 0
+    return p, s, se
+
+
+def cell_plan(X, min_replicates=7):
+    """Group samples by identical design rows (cells with >= 3 replicates are listed)."""
+    X = np.asarray(X, dtype=np.float64)
+    _, inv, cnt = np.unique(X, axis=0, return_inverse=True, return_counts=True)
+    inv = np.asarray(inv).reshape(-1)
+    size = cnt[inv]
+    flags = ((size >= 3).astype(np.uint8)) | ((size >= min_replicates).astype(np.uint8) << 1)
+    cells = [np.nonzero(inv == c)[0] for c in range(len(cnt)) if cnt[c] >= 3]
+    whole = int(len(cells) == 0)
+    if whole:
+        offsets = np.array([0, len(inv)], np.int32)
+        index = np.arange(len(inv), dtype=np.int32)
+        ncell = 0
+    else:
+        offsets = np.concatenate([[0], np.cumsum([len(c) for c in cells])]).astype(np.int32)
+        index = np.concatenate(cells).astype(np.int32)
+        ncell = len(cells)
+    return offsets, index, ncell, whole, np.ascontiguousarray(flags)
+
+
+def cooks(counts, sf, X, mu, H, cutoff, min_replicates=7):
+    y = gene_major(counts)
+    G, N = y.shape
+    P = np.asarray(X).shape[1]
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
+    h = np.ascontiguousarray(np.asarray(H, dtype=np.float64).T)
+    off, idx, ncell, whole, flags = cell_plan(X, min_replicates)
+    ck, rd = np.empty((G, N)), np.empty(G)
+    fl = [np.empty(G, np.uint8) for _ in range(4)]
+    rc = lib().hs_cooks(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(m, C.c_double), _p(h, C.c_double),
+                        _p(off, C.c_int32), _p(idx, C.c_int32), C.c_int(ncell), C.c_int(whole), _p(flags, C.c_uint8),
+                        C.c_int(N), C.c_int(G), C.c_int(P), C.c_double(cutoff), _p(ck, C.c_double),
+                        _p(rd, C.c_double), *[_p(a, C.c_uint8) for a in fl])
+    assert rc == 0
+    return ck.T, rd, [a.astype(bool) for a in fl]
+
+
+def trimmed_base_mean(counts, sf, trim=0.2):
+    y = gene_major(counts)
+    G, N = y.shape
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    out = np.empty(G)
+    lib().hs_trimmed_base_mean(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), C.c_int(N), C.c_int(G),
+                               C.c_double(trim), _p(out, C.c_double))
+    return out
+
+
+def alpha_eval(y, mu, X, la, la_hat=0.0, prior_var=1.0, cr_reg=True, prior_reg=False):
+    yv = np.ascontiguousarray(y, dtype=np.int32)
+    m = np.ascontiguousarray(mu, dtype=np.float64)
+    Xt, _, _ = design_pack(X)
+    f, g = C.c_double(), C.c_double()
+    rc = lib().hs_alpha_eval(_p(yv, C.c_int32), _p(m, C.c_double), _p(Xt, C.c_double), C.c_int(len(yv)),
+                             C.c_int(len(yv)), C.c_int(Xt.shape[0]), C.c_double(la), C.c_double(la_hat),
+                             C.c_double(prior_var), C.c_int(cr_reg), C.c_int(prior_reg), C.byref(f), C.byref(g))
+    assert rc == 0
+    return f.value, g.value

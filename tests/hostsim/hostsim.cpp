@@ -1,0 +1,195 @@
+// hostsim.cpp — TEST-ONLY host instantiation of the per-gene device templates.
+//
+// The per-gene math of the HIP engine (pydeseq2_amd/csrc/dsq_*.h) is written against a
+// Wave policy.  Here it is instantiated with HostWave (one lane walks all samples) and
+// compiled with g++, so the exact same source that runs on gfx950 can be unit-tested
+// against the oracle in a container that has no GPU.  This library is built by
+// tests/hostsim/build.py into tests/hostsim/_hostsim.so, is loaded only by tests, and is
+// never imported by the pydeseq2_amd package (whose ops fail loudly without the HIP .so).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "dsq_alpha.h"
+#include "dsq_dispatch.h"
+#include "dsq_irls.h"
+#include "dsq_stats.h"
+
+using namespace dsq;
+
+namespace {
+struct HostSorter {
+    int operator()(double* buf, int n) const {
+        std::sort(buf, buf + n);
+        return n;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+void hs_lgamma_digamma(const double* x, int n, double* lg, double* dg) {
+    for (int i = 0; i < n; ++i) lgamma_digamma<true>(x[i], lg[i], dg[i]);
+}
+
+void hs_norm_sf(const double* x, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = norm_sf(x[i]);
+}
+
+typedef void (*fg_cb)(double x, double* f, double* g);
+void hs_lbfgsb1d(fg_cb cb, double x0, double l, double u, double* x, double* f, int* success,
+                 int* nfev, int* nit, int* status) {
+    auto fg = [&](double xx, double& ff, double& gg) { cb(xx, &ff, &gg); };
+    Lbfgsb1dResult r = lbfgsb_1d(fg, x0, l, u);
+    *x = r.x; *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
+}
+
+// gene-major inputs: y[G][ldn] int32, mu[G][ldn]; Xt[P][ldx]
+int hs_alpha_mle(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N,
+                 int G, int P_, const double* alpha_hat, double min_disp, double max_disp,
+                 double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
+                 int32_t* nfev) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        AlphaOut o = fit_alpha_gene<HostWave, P>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx,
+                                                 N, alpha_hat[g], min_disp, max_disp, prior_var,
+                                                 cr_reg != 0, prior_reg != 0);
+        alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
+        if (nfev) nfev[g] = o.nfev;
+    })
+    return 0;
+}
+
+int hs_grid_alpha(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N,
+                  int G, int P_, double min_disp, double max_disp, double* log_alpha) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        AlphaArgs A;
+        A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
+        A.la_hat = 0; A.prior_var = 1; A.cr_reg = true; A.prior_reg = false;
+        double c = 0;
+        for (int n = 0; n < N; ++n) c += lgamma_pos(A.y[n] + 1.0) - A.y[n] * log(A.mu[n]);
+        A.cst = c;
+        log_alpha[g] = grid_fit_alpha<HostWave, P>(A, log(min_disp), log(max_disp));
+    })
+    return 0;
+}
+
+int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
+            int ldx, int N, int G, int P_, const double* disp, double min_mu, double beta_tol,
+            double min_beta, double max_beta, int maxiter, int full_rank, double* beta /*[G][P]*/,
+            double* mu /*[G][ldn]*/, double* H /*[G][ldn]*/, uint8_t* conv, int32_t* iters,
+            uint8_t* fallback) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        IrlsArgs A;
+        A.y = y + (size_t)g * ldn; A.sf = sf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+        A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
+        A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
+        double b[P];
+        double* mo = mu ? mu + (size_t)g * ldn : nullptr;
+        double* ho = H ? H + (size_t)g * ldn : nullptr;
+        IrlsOut o = irls_gene<HostWave, P>(A, b, mo, ho);
+        if (o.fallback) o = irls_rescue_gene<HostWave, P>(A, b, mo, ho);
+        for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
+        conv[g] = (uint8_t)o.converged;
+        if (iters) iters[g] = o.iters;
+        if (fallback) fallback[g] = (uint8_t)o.fallback;
+    })
+    return 0;
+}
+
+int hs_logmeans(const int32_t* y, int ldn, int N, int G, double* logmeans, uint8_t* nonzero) {
+    for (int g = 0; g < G; ++g) {
+        int nz;
+        gene_logmean<HostWave>(y + (size_t)g * ldn, N, logmeans[g], nz);
+        nonzero[g] = (uint8_t)nz;
+    }
+    return 0;
+}
+
+int hs_mom(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
+           int ldx, int N, int G, int P_, double min_disp, double max_disp, double* normed_mean,
+           double* rough, double* moments, double* mom) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    double smi = 0;
+    for (int n = 0; n < N; ++n) smi += 1.0 / sf[n];
+    smi /= N;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        MomOut o = mom_gene<HostWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, smi, min_disp,
+                                         max_disp);
+        normed_mean[g] = o.normed_mean; rough[g] = o.rough; moments[g] = o.moments; mom[g] = o.mom;
+    })
+    return 0;
+}
+
+int hs_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
+              int ldx, int N, int G, int P_, double min_mu, double* mu) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g)
+        lin_mu_gene<HostWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, min_mu,
+                                 mu + (size_t)g * ldn);)
+    return 0;
+}
+
+int hs_wald(const double* mu, int ldn, const double* sf, const double* Xt, int ldx, int N, int G,
+            int P_, const double* disp, const double* beta, const double* ridge,
+            const double* contrast, double lfc_null, int alt, double* pval, double* stat,
+            double* se) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        double b[P];
+        for (int j = 0; j < P; ++j) b[j] = beta[(size_t)g * P + j];
+        WaldOut o = wald_gene<HostWave, P>(mu ? mu + (size_t)g * ldn : nullptr, sf, Xt, ldx, N,
+                                           disp[g], b, ridge, contrast, lfc_null, alt);
+        pval[g] = o.p; stat[g] = o.stat; se[g] = o.se;
+    })
+    return 0;
+}
+
+int hs_cooks(const int32_t* y, int ldn, const double* sf, const double* mu, const double* H,
+             const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
+             const uint8_t* flags, int N, int G, int P_, double cutoff, double* cooks,
+             double* robust_disp, uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr,
+             uint8_t* few_above) {
+    std::vector<double> scratch(N + 8);
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    for (int g = 0; g < G; ++g) {
+        CooksOut o = cooks_gene<HostWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
+                                          H + (size_t)g * ldn, C, flags, N, P_, cutoff,
+                                          scratch.data(), HostSorter(),
+                                          cooks ? cooks + (size_t)g * ldn : nullptr);
+        robust_disp[g] = o.robust_disp; any_all[g] = o.any_gt_all; any_use[g] = o.any_gt_use;
+        any_use_nr[g] = o.any_gt_use_nr; few_above[g] = o.few_above;
+    }
+    return 0;
+}
+
+int hs_trimmed_base_mean(const int32_t* y, int ldn, const double* sf, int N, int G, double trim,
+                         double* out) {
+    std::vector<double> scratch(N + 8);
+    for (int g = 0; g < G; ++g)
+        out[g] = trimmed_base_mean<HostWave>(y + (size_t)g * ldn, sf, N, trim, scratch.data(),
+                                             HostSorter());
+    return 0;
+}
+
+// loss/gradient of one gene at log_alpha (debug / unit tests)
+int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx, int N, int P_,
+                  double la, double la_hat, double prior_var, int cr_reg, int prior_reg, double* f,
+                  double* g) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, {
+        AlphaArgs A;
+        A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N; A.la_hat = la_hat;
+        A.prior_var = prior_var; A.cr_reg = cr_reg; A.prior_reg = prior_reg;
+        double c = 0;
+        for (int n = 0; n < N; ++n) c += lgamma_pos(y[n] + 1.0) - y[n] * log(mu[n]);
+        A.cst = c;
+        alpha_eval<HostWave, P, true>(A, la, cr_reg != 0, prior_reg != 0, *f, *g);
+    })
+    return 0;
+}
+
+}  // extern "C"

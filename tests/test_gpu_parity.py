@@ -1,0 +1,208 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(ctypes -> libdeseq_hip.so), against the reference's kernels (golden KATs), the oracle on seeded
+synthetic inputs, and the reference's R fixtures.  Tolerance for floating point results is the
+north-star's 1e-5 relative (LFC, dispersions, Wald p-values); genes on which either optimiser's
+line search fails at rounding-noise level (reference falls back to a quantised grid search) are
+counted and bounded separately."""
+import numpy as np
+import pytest
+from scipy.stats import f as f_dist
+
+from oracle import nbglm_oracle as orc
+from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def inf():
+    from pydeseq2_amd import HipInference
+
+    return HipInference(device=0)
+
+
+def test_library_is_native(inf):
+    info = inf.ctx.device_info()
+    assert "gfx950" in info["arch"], info
+    assert info["cu_count"] >= 200
+
+
+@pytest.mark.parametrize("case", ["p2", "p4", "p8"])
+def test_inference_vs_reference_kats(inf, case):
+    k = load_kat(case)
+    N, P = k["X"].shape
+    maxd = float(max(10, N))
+    assert_close(inf.fit_rough_dispersions(k["normed"], k["X"]), k["rough"], 1e-9, 1e-13, "rough")
+    assert_close(inf.fit_moments_dispersions(k["normed"], k["sf"]), k["moments"], 1e-10, 1e-14, "moments")
+    assert_close(inf.lin_reg_mu(k["counts"], k["sf"], k["X"], 0.5), k["lin_mu"], 1e-10, 0, "lin_mu")
+    b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], k["mom"], 0.5, 1e-8)
+    assert (conv == k["irls_conv"]).all()
+    assert_close(b, k["irls_beta"], 1e-8, 1e-10, "irls beta")
+    assert_close(mu, k["irls_mu"], 1e-8, 1e-10, "irls mu")
+    assert_close(H, k["irls_H"], 1e-8, 1e-12, "irls H")
+    a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, maxd)
+    assert (c == k["gw_conv"]).all()
+    assert_close(a, k["gw_alpha"], 1e-6, 0, "genewise alpha")
+    a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["fitted"], 1e-8, maxd,
+                         prior_disp_var=float(k["prior_var"]), cr_reg=True, prior_reg=True)
+    assert (c == k["map_conv"]).all()
+    assert_close(a, k["map_alpha"], 1e-6, 0, "MAP alpha")
+    disp = np.clip(k["map_alpha"], 1e-8, maxd)
+    b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], disp, 0.5, 1e-8)
+    assert_close(b, k["lfc_beta"], 1e-8, 1e-10, "lfc beta")
+    mu_w = np.exp(k["X"] @ k["lfc_beta"].T) * k["sf"][:, None]
+    ridge = np.diag(np.repeat(1e-6, P))
+    for alt, null in ((None, 0.0), ("greater", 0.5), ("less", -0.5), ("greaterAbs", 0.5), ("lessAbs", 0.5)):
+        tag = alt or "none"
+        p, s, se = inf.wald_test(k["X"], disp, k["lfc_beta"], mu_w, ridge, k["contrast"], np.log(2) * null, alt)
+        assert_close(se, k[f"wald_se_{tag}"], 1e-10, 0, f"se {tag}")
+        assert_close(s, k[f"wald_stat_{tag}"], 1e-9, 1e-13, f"stat {tag}")
+        assert_close(p, k[f"wald_p_{tag}"], 1e-8, 1e-300, f"p {tag}")
+    coeffs, pred, ok = inf.dispersion_trend_gamma_glm(1 / k["normed"].mean(0), np.clip(k["gw_alpha"], 1e-8, maxd))
+    assert ok == bool(k["trend_conv"])
+    assert_close(coeffs, k["trend_coeffs"], 1e-10, 0, "trend")
+
+
+def test_rough_dispersions_n_equals_p_raises(inf):
+    X = np.eye(3)
+    with pytest.raises(ValueError):
+        inf.fit_rough_dispersions(np.ones((3, 5)), X)
+
+
+def _compare(res, ref, frac_noise=0.004):
+    """1e-5 parity on the north-star outputs; genes where the two L-BFGS-B runs disagree on
+    convergence (line search lost in rounding noise, grid-search fallback) are excluded and
+    must be a tiny fraction."""
+    G = len(ref.dispersions)
+    assert_close(res.size_factors, ref.size_factors, 1e-12, 0, "size factors")
+    assert (res.non_zero == ref.non_zero).all()
+    with np.errstate(invalid="ignore"):
+        noisy = (res.genewise_converged != ref.genewise_converged) | (res.MAP_converged != ref.MAP_converged)
+        noisy |= (ref.genewise_converged == 0) | (ref.MAP_converged == 0)
+    noisy &= ref.non_zero
+    noisy |= res.refitted != ref.refitted
+    assert noisy.sum() <= max(2, frac_noise * G), f"{noisy.sum()} noise-limited genes of {G}"
+    ok = ~noisy
+    assert (res.refitted[ok] == ref.refitted[ok]).all()
+    assert (res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()
+    assert_close(res.dispersions[ok], ref.dispersions[ok], RTOL, 0, "dispersions")
+    assert_close(res.LFC[ok], ref.LFC[ok], RTOL, 1e-8, "LFC")
+    assert_close(res.pvalue[ok], ref.pvalue[ok], 2e-5, 1e-300, "pvalue")
+    assert_close(res.lfcSE[ok], ref.lfcSE[ok], RTOL, 0, "lfcSE")
+    # the trend is fitted on all genes, so it carries the noise genes' influence
+    assert_close(res.trend_coeffs, ref.trend_coeffs, 1e-4, 0, "trend coeffs")
+    return int(noisy.sum())
+
+
+@pytest.mark.parametrize("G,N,design,seed", [(1000, 100, "2level", 1), (1500, 60, "3factor", 2),
+                                              (800, 80, "mixed", 3)])
+def test_pipeline_vs_oracle(G, N, design, seed):
+    import pydeseq2_amd
+
+    counts, X = orc.synth_counts(G, N, design, seed)
+    counts[:, 5] = 0  # an all-zero gene -> NaN outputs (tests/test_edge_cases.py:10-52)
+    if design == "2level":  # inject outliers so the Cook's refit path is live
+        counts[3, 10] = 200000
+        counts[7, 11] = 150000
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    ref = orc.deseq2(counts, X, n_jobs=8)
+    assert np.isnan(res.dispersions[5]) and np.isnan(res.pvalue[5]) and np.isnan(res.LFC[5]).all()
+    _compare(res, ref)
+    if design == "2level":
+        assert ref.replaced.sum() >= 2 and (res.replaced == ref.replaced).all()
+
+
+def test_cooks_layer_vs_oracle():
+    import pydeseq2_amd
+
+    counts, X = orc.synth_counts(300, 60, "3factor", 7)
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0)
+    res = pipe.deseq2()
+    ref = orc.deseq2(counts, X, n_jobs=4)
+    assert_close(pipe.layer("cooks"), ref.cooks, 1e-6, 1e-12, "cooks")
+    assert_close(pipe.layer("hat_diagonals")[:, ref.non_zero], ref.hat_diagonals, 1e-7, 1e-12, "hat")
+    assert_close(pipe.layer("mu_LFC")[:, ref.non_zero], ref.mu_LFC, 1e-7, 1e-10, "mu")
+
+
+def _r_case(which, factors, continuous=(), with_outliers=False):
+    counts, meta = load_dataset(which)
+    if with_outliers:
+        counts.loc["sample1", "gene1"] = 2000
+        counts.loc["sample11", "gene7"] = 1000
+        meta.loc["sample1", "condition"] = "C"
+    X, names = treatment_design(meta, factors, continuous)
+    return counts.to_numpy(), X, names
+
+
+@pytest.mark.parametrize("which,factors,cont,sub,fn,tol,outl", [
+    ("synthetic", ["condition"], (), "single_factor", "r_test_res.csv", 0.02, False),
+    ("synthetic", ["group", "condition"], (), "multi_factor", "r_test_res.csv", 0.04, False),
+    ("synthetic", ["group", "condition"], (), "multi_factor", "r_test_res_outliers.csv", 0.04, True),
+    ("continuous", ["group", "condition"], ("measurement",), "continuous", "r_test_res.csv", 0.04, False),
+    ("continuous", ["group", "condition"], ("measurement",), "continuous", "r_test_res_outliers.csv", 0.04, True),
+    ("wide", ["group", "condition"], (), "wide", "r_test_res.csv", 0.02, False),
+])
+def test_r_fixtures(which, factors, cont, sub, fn, tol, outl):
+    """The reference's own known-answer tests (tests/test_pydeseq2.py:94-176, 432-560, 625-660)."""
+    import pydeseq2_amd
+
+    counts, X, names = _r_case(which, factors, cont, outl)
+    ci = names.index("condition[T.B]") if not cont else len(names) - 1
+    c = np.zeros(len(names))
+    c[ci] = 1
+    res = pydeseq2_amd.deseq2(counts, X, contrast=c, device=0)
+    r_res = r_csv(sub, fn)
+    assert max_rel_err(res.LFC[:, ci] / np.log(2), r_res["log2FoldChange"].to_numpy()) < tol
+    p = np.where(res.cooks_outlier, np.nan, res.pvalue)
+    assert max_rel_err(p, r_res["pvalue"].to_numpy()) < tol
+    if sub == "single_factor":
+        np.testing.assert_array_almost_equal(
+            res.size_factors, r_csv(sub, "r_test_size_factors.csv")["x"].to_numpy(), decimal=6)
+
+
+@pytest.mark.parametrize("alt,null", [("greater", 0.5), ("less", -0.5), ("greaterAbs", 0.5), ("lessAbs", 0.5)])
+def test_r_alt_hypotheses(alt, null):
+    import pydeseq2_amd
+
+    counts, X, _ = _r_case("synthetic", ["condition"])
+    res = pydeseq2_amd.deseq2(counts, X, contrast=[0, 1], lfc_null=null, alt_hypothesis=alt, device=0)
+    r_res = r_csv("single_factor", f"r_test_res_{alt}.csv")
+    st = np.abs(res.stat) if alt == "lessAbs" else res.stat
+    r_st = r_res["stat"].to_numpy()
+    nzs = r_st != 0
+    assert np.max(np.abs(r_st[nzs] - st[nzs]) / np.abs(r_st[nzs])) < 0.02
+    p = np.where(res.cooks_outlier, np.nan, res.pvalue)
+    assert max_rel_err(p[nzs], r_res["pvalue"].to_numpy()[nzs]) < 0.02
+
+
+def test_full_size_properties():
+    """Config C2-like size (20k x 200): properties that do not need the (slow) oracle."""
+    import pydeseq2_amd
+
+    counts, X = orc.synth_counts(20000, 200, "2level", 0)
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    nz = res.non_zero
+    assert np.isfinite(res.dispersions[nz]).all() and (res.dispersions[nz] >= 1e-8).all()
+    assert (res.dispersions[nz] <= 200).all()
+    ok = nz & ~np.isnan(res.pvalue)
+    assert ((res.pvalue[ok] >= 0) & (res.pvalue[ok] <= 1)).all()
+    # Wald consistency: stat = LFC/SE and p = 2*sf(|stat|)
+    from scipy.stats import norm
+    z = res.LFC[ok, 1] / res.lfcSE[ok]
+    assert np.allclose(z, res.stat[ok], rtol=1e-9, atol=1e-12)
+    assert np.allclose(res.pvalue[ok], 2 * norm.sf(np.abs(res.stat[ok])), rtol=1e-9, atol=1e-300)
+    # permutation invariance over genes: shuffling genes only permutes per-gene outputs of the
+    # stages that do not depend on other genes (size factors are permutation invariant too)
+    perm = np.random.default_rng(0).permutation(20000)
+    res2 = pydeseq2_amd.deseq2(counts[:, perm], X, device=0)
+    assert np.allclose(res2.size_factors, res.size_factors, rtol=1e-13)
+    assert np.allclose(res2.genewise_dispersions, res.genewise_dispersions[perm], rtol=1e-9, equal_nan=True)
+    # subset check against the oracle's per-gene kernels on 300 random genes
+    sel = np.sort(np.random.default_rng(1).choice(np.nonzero(nz)[0], 300, replace=False))
+    mu = orc.lin_reg_mu(counts[:, sel], res.size_factors, X, 0.5)
+    a, c = orc.alpha_mle(counts[:, sel], X, mu, res.mom_dispersions[sel], 1e-8, 200.0, n_jobs=8)
+    same = c == res.genewise_converged[sel].astype(bool)
+    assert same.mean() > 0.99
+    assert_close(res.genewise_dispersions[sel][same & c], np.clip(a, 1e-8, 200)[same & c], RTOL, 0, "gw subset")

@@ -13,6 +13,8 @@
 // one the hat diagonal needs (:427-433).  lgamma terms of the deviance do not depend on
 // mu and are computed once per gene.
 #pragma once
+#include "dsq_alpha.h"
+#include "dsq_lbfgsb.h"
 #include "dsq_linalg.h"
 #include "dsq_wave.h"
 
@@ -62,44 +64,6 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
     S = Wv::sum(s);
     Wv::template sum_n<T>(M);
     Wv::template sum_n<P>(r);
-}
-
-// objective/gradient/Fisher matrix of the fallback problem (utils.py:376-387):
-//   f = nb_nll(y, max(sf exp(X b), min_mu), disp) + 0.5*1e-6*|b|^2
-template <class Wv, int P>
-DSQ_HD void irls_fb_eval(const IrlsArgs& A, const double (&beta)[P], double a, double cst,
-                         double& f, double (&grad)[P], double (&M)[Tri<P>::N]) {
-    constexpr int T = Tri<P>::N;
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < T; ++k) M[k] = 0.0;
-#pragma unroll
-    for (int j = 0; j < P; ++j) grad[j] = 0.0;
-    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        const double yv = (double)A.y[n];
-        double x[P];
-        double eta = 0.0;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
-        const double mu = dmax(A.sf[n] * exp(eta), A.min_mu);
-        s += (yv + a) * log(a + mu) - yv * log(mu);
-        const double gk = -yv + (a + yv) * mu / (a + mu);
-        const double w = mu / (1.0 + mu * A.disp);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            grad[i] += gk * x[i];
-            const double xw = x[i] * w;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) M[tri(i, j)] += xw * x[j];
-        }
-    }
-    s = Wv::sum(s);
-    Wv::template sum_n<T>(M);
-    Wv::template sum_n<P>(grad);
-    double pen = 0.0;
-#pragma unroll
-    for (int j = 0; j < P; ++j) { pen += beta[j] * beta[j]; grad[j] += 1e-6 * beta[j]; }
-    f = A.N * a * log(A.disp) - cst + s + 0.5e-6 * pen;
 }
 
 struct IrlsOut {
@@ -203,71 +167,104 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     return out;
 }
 
-// Rescue for genes whose IRLS diverged: bounded, damped Fisher scoring on the reference's
-// fallback objective, restarted from beta_init (utils.py:374-403).  The reference hands
-// this problem to scipy's p-dimensional L-BFGS-B; both converge to the same bounded
-// optimum but stop at slightly different points (see DESIGN.md "known deviations").
+// Workspace of the rescue (wave-private LDS on the device).
+template <int P>
+struct IrlsRescueWork {
+    LbfgsbWork<P> lb;
+    double x[P], l[P], u[P];
+    int nbd[P];
+};
+
+// grid_fit_beta (grid_search.py:145-221): two-level 60 x 60 grid on [min_beta, max_beta]^2, P == 2.
+template <class Wv>
+DSQ_HD void grid_fit_beta2(const IrlsArgs& A, double a, double cst, double (&beta)[2],
+                           int grid_length = 60) {
+    auto loss = [&](double bx, double by) {
+        double s = 0.0;
+        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            const double yv = (double)A.y[n];
+            const double eta = A.Xt[n] * bx + A.Xt[A.ldx + n] * by;
+            const double mu = dmax(A.sf[n] * exp(eta), A.min_mu);
+            s += (yv + a) * log(mu + a) - yv * log(mu);
+        }
+        s = Wv::sum(s);
+        return (A.N * a * log(A.disp) - cst + s) + 0.5 * (1e-6 * bx * bx + 1e-6 * by * by);
+    };
+    double xlo = A.min_beta, xhi = A.max_beta, ylo = A.min_beta, yhi = A.max_beta;
+    for (int level = 0; level < 2; ++level) {
+        double best = 0.0;
+        int bi = 0, bj = 0;
+        bool best_nan = false, first = true;
+        for (int i = 0; i < grid_length; ++i) {
+            for (int j = 0; j < grid_length; ++j) {
+                const double v = loss(linspace_at(xlo, xhi, grid_length, i), linspace_at(ylo, yhi, grid_length, j));
+                const bool isn = (v != v);
+                if (first || (!best_nan && (isn || v < best))) { best = v; bi = i; bj = j; best_nan = isn; first = false; }
+            }
+        }
+        const double cx = linspace_at(xlo, xhi, grid_length, bi), cy = linspace_at(ylo, yhi, grid_length, bj);
+        if (level == 0) {
+            const double delta = linspace_at(xlo, xhi, grid_length, 1) - linspace_at(xlo, xhi, grid_length, 0);
+            xlo = cx - delta; xhi = cx + delta; ylo = cy - delta; yhi = cy + delta;
+        } else {
+            beta[0] = cx; beta[1] = cy;
+        }
+    }
+}
+
+// Rescue for genes whose IRLS diverged (utils.py:374-413): L-BFGS-B on
+//   f(b) = nb_nll(y, max(sf exp(X b), min_mu), disp) + 0.5 * 1e-6 |b|^2,  -30 <= b <= 30,
+// restarted from beta_init, gradient as utils.py:381-387 (it ignores the clamp, as the
+// reference does); if that does not converge and P <= 2 the 2-D grid search.  `converged`
+// is scipy's res.success.
 template <class Wv, int P>
-DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out,
-                                double* H_out) {
+DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double (&beta)[P],
+                                double* mu_out, double* H_out) {
     constexpr int T = Tri<P>::N;
     IrlsOut out;
     out.converged = 0; out.iters = 0; out.fallback = 1;
     const double a = 1.0 / A.disp;
     double cst, b0[P];
     irls_init<Wv, P>(A, a, b0, cst);
+    const double nlogterm = A.N * a * log(A.disp);
 #pragma unroll
-    for (int j = 0; j < P; ++j) beta[j] = dmin(dmax(b0[j], A.min_beta), A.max_beta);
-    double f, g[P], M[T];
-    irls_fb_eval<Wv, P>(A, beta, a, cst, f, g, M);
-    bool ok = false;
-    int it = 0;
-    for (; it < 200 && !ok; ++it) {
-        double pg = 0.0;
+    for (int j = 0; j < P; ++j) { Wk.x[j] = b0[j]; Wk.l[j] = A.min_beta; Wk.u[j] = A.max_beta; Wk.nbd[j] = 2; }
+    auto fg = [&](const double* xb, double& f, double* g) {
+        double b[P];
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            double gj = g[j];
-            if (gj < 0.0) gj = dmax(beta[j] - A.max_beta, gj);
-            else gj = dmin(beta[j] - A.min_beta, gj);
-            pg = dmax(pg, fabs(gj));
+        for (int j = 0; j < P; ++j) b[j] = xb[j];
+        double s = 0.0, gr[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) gr[j] = 0.0;
+        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            const double yv = (double)A.y[n];
+            double x[P];
+            double eta = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * b[j]; }
+            const double mu = dmax(A.sf[n] * exp(eta), A.min_mu);
+            s += (yv + a) * log(a + mu) - yv * log(mu);
+            const double gk = -yv + (a + yv) * mu / (a + mu);
+#pragma unroll
+            for (int j = 0; j < P; ++j) gr[j] += gk * x[j];
         }
-        if (pg <= 1e-5) { ok = true; break; }
-        double Hf[T];
+        s = Wv::sum(s);
+        Wv::template sum_n<P>(gr);
+        double pen = 0.0;
 #pragma unroll
-        for (int k = 0; k < T; ++k) Hf[k] = M[k];
+        for (int j = 0; j < P; ++j) { pen += 1e-6 * (b[j] * b[j]); g[j] = gr[j] + 1e-6 * b[j]; }
+        f = (nlogterm - cst + s) + 0.5 * pen;
+    };
+    const LbfgsbResult res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb);
 #pragma unroll
-        for (int j = 0; j < P; ++j) Hf[tri(j, j)] += 1e-6;
-        chol<P>(Hf);
-        double d[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) d[j] = -g[j];
-        chol_solve<P>(Hf, d);
-        double t = 1.0;
-        bool accepted = false;
-        for (int h = 0; h < 30; ++h) {
-            double bn[P], fn, gn[P], Mn[T];
-#pragma unroll
-            for (int j = 0; j < P; ++j)
-                bn[j] = dmin(dmax(beta[j] + t * d[j], A.min_beta), A.max_beta);
-            irls_fb_eval<Wv, P>(A, bn, a, cst, fn, gn, Mn);
-            if (fn <= f) {
-                const double df = f - fn;
-#pragma unroll
-                for (int j = 0; j < P; ++j) { beta[j] = bn[j]; g[j] = gn[j]; }
-#pragma unroll
-                for (int k = 0; k < T; ++k) M[k] = Mn[k];
-                const double fm = dmax(fabs(f), dmax(fabs(fn), 1.0));
-                f = fn;
-                accepted = true;
-                if (df <= 1e7 * kEps * fm) ok = true;
-                break;
-            }
-            t *= 0.5;
-        }
-        if (!accepted) break;
+    for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
+    out.converged = res.success ? 1 : 0;
+    out.iters = res.nit;
+    if (!res.success && P <= 2) {
+        if constexpr (P == 2) grid_fit_beta2<Wv>(A, a, cst, beta);
     }
-    out.converged = ok ? 1 : 0;
-    out.iters = it;
+    double M[T], r[P], S2;
+    irls_sweep<Wv, P>(A, beta, a, S2, M, r);  // M = X^T W X at the final (clamped) mu
     irls_finish<Wv, P>(A, beta, M, mu_out, H_out);
     return out;
 }

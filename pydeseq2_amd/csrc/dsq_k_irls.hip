@@ -50,15 +50,18 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
                                                         uint8_t* __restrict__ conv,
                                                         int32_t* __restrict__ iters,
                                                         const int32_t* __restrict__ fb_list, int n_fb) {
-    const int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (k >= n_fb) return;
+    int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool live = k < n_fb;
+    if (!live) return;
     const int g = fb_list[k];
     IrlsArgs A;
     A.y = y + (size_t)g * ldn; A.sf = sf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
+    __shared__ IrlsRescueWork<P> work[kWavesPerBlock];
     double b[P];
-    const IrlsOut o = irls_rescue_gene<DeviceWave, P>(A, b, mu ? mu + (size_t)g * ldn : nullptr,
+    const IrlsOut o = irls_rescue_gene<DeviceWave, P>(A, work[threadIdx.x >> 6], b,
+                                                      mu ? mu + (size_t)g * ldn : nullptr,
                                                       hat ? hat + (size_t)g * ldn : nullptr);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll

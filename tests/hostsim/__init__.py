@@ -222,3 +222,35 @@ def alpha_eval(y, mu, X, la, la_hat=0.0, prior_var=1.0, cr_reg=True, prior_reg=F
                              C.c_double(prior_var), C.c_int(cr_reg), C.c_int(prior_reg), C.byref(f), C.byref(g))
     assert rc == 0
     return f.value, g.value
+
+
+FGN_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def lbfgsb_nd(fg, x0, bounds):
+    """bounds: list of (lo, hi) with None/inf for unbounded (scipy convention)."""
+    n = len(x0)
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    l, u, nbd = np.zeros(n), np.zeros(n), np.zeros(n, np.int32)
+    for i, (lo, hi) in enumerate(bounds):
+        has_l = lo is not None and np.isfinite(lo)
+        has_u = hi is not None and np.isfinite(hi)
+        if has_l:
+            l[i] = lo
+        if has_u:
+            u[i] = hi
+        nbd[i] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[(has_l, has_u)]
+
+    def cb(px, pf, pg):
+        xx = np.array([px[i] for i in range(n)])
+        f, g = fg(xx)
+        pf[0] = f
+        for i in range(n):
+            pg[i] = g[i]
+
+    f = C.c_double()
+    ok, nfev, nit, st = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().hs_lbfgsb_nd(FGN_CB(cb), C.c_int(n), _p(x, C.c_double), _p(l, C.c_double), _p(u, C.c_double),
+                            _p(nbd, C.c_int32), C.byref(f), C.byref(ok), C.byref(nfev), C.byref(nit), C.byref(st))
+    assert rc == 0
+    return x, f.value, bool(ok.value), nfev.value, nit.value, st.value

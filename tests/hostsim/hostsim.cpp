@@ -14,6 +14,7 @@
 #include "dsq_alpha.h"
 #include "dsq_dispatch.h"
 #include "dsq_irls.h"
+#include "dsq_lbfgsb.h"
 #include "dsq_stats.h"
 
 using namespace dsq;
@@ -91,7 +92,11 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
         double* mo = mu ? mu + (size_t)g * ldn : nullptr;
         double* ho = H ? H + (size_t)g * ldn : nullptr;
         IrlsOut o = irls_gene<HostWave, P>(A, b, mo, ho);
-        if (o.fallback) o = irls_rescue_gene<HostWave, P>(A, b, mo, ho);
+        if (o.fallback) {
+            static IrlsRescueWork<P> Wk;
+            std::memset(&Wk, 0, sizeof(Wk));
+            o = irls_rescue_gene<HostWave, P>(A, Wk, b, mo, ho);
+        }
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
         conv[g] = (uint8_t)o.converged;
         if (iters) iters[g] = o.iters;
@@ -189,6 +194,18 @@ int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx,
         A.cst = c;
         alpha_eval<HostWave, P, true>(A, la, cr_reg != 0, prior_reg != 0, *f, *g);
     })
+    return 0;
+}
+
+typedef void (*fgn_cb)(const double* x, double* f, double* g);
+int hs_lbfgsb_nd(fgn_cb cb, int n, double* x, const double* l, const double* u, const int* nbd,
+                 double* f, int* success, int* nfev, int* nit, int* status) {
+    if (n < 1 || n > 16) return -1;
+    static LbfgsbWork<16> W;
+    std::memset(&W, 0, sizeof(W));
+    auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
+    LbfgsbResult r = lbfgsb_nd<16>(fg, n, x, l, u, nbd, W);
+    *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
     return 0;
 }
 

@@ -130,3 +130,51 @@ def test_cooks(case):
     few_ref = (k["counts"] > k["counts"][pos, np.arange(ck.shape[1])]).sum(0) < 3
     assert (few == few_ref).all()
     assert_close(hs.trimmed_base_mean(k["counts"], k["sf"], 0.2), k["trim_mean_02"], 1e-13, 0, "tbm")
+
+
+def test_lbfgsb_nd_matches_scipy():
+    """The n-dimensional L-BFGS-B restatement against scipy on random bounded problems
+    (smooth and kinked objectives).  Iterates agree to rounding; evaluation counts may differ by
+    a few in line searches that are resolved at rounding level (BLAS summation order)."""
+    rng = np.random.default_rng(3)
+    bad = 0
+    for t in range(120):
+        n = int(rng.integers(1, 9))
+        A = rng.normal(size=(n + 3, n))
+        Q = A.T @ A * 10 ** rng.uniform(-1, 2) + np.eye(n) * 10 ** rng.uniform(-3, 0)
+        c, b, w = rng.normal(0, 3, n), rng.normal(0, 2, n), rng.uniform(0.2, 2, n)
+        kinked = t % 2 == 1
+
+        def fg(x):
+            d = x - c
+            e = np.exp(np.clip(w * d, -50, 50))
+            if kinked:
+                ge = np.where(e > 0.5, w * e, 0.0)
+                e = np.maximum(e, 0.5)
+                return 0.05 * d @ Q @ d + e.sum() - (b * d).sum(), 0.1 * Q @ d + ge - b
+            return 0.5 * d @ Q @ d + e.sum(), Q @ d + w * e
+
+        bounds = [(-30, 30)] * n if t % 3 else [(ci - abs(rng.normal(0, 2)), None) for ci in c]
+        x0 = c + rng.normal(0, 3, n)
+        res = minimize(lambda x: fg(x)[0], x0, jac=lambda x: fg(x)[1], method="L-BFGS-B", bounds=bounds)
+        x, f, ok, nfev, nit, st = hs.lbfgsb_nd(fg, x0, bounds)
+        if ok != res.success or nit != res.nit or np.max(np.abs(x - res.x)) > 1e-8 * max(1, np.max(np.abs(res.x))):
+            bad += 1
+    assert bad <= 1
+
+
+def test_irls_rescue_matches_reference_fallback():
+    """Low-count genes on a 30-cell design: IRLS diverges and the reference falls back to scipy's
+    p-dimensional L-BFGS-B (utils.py:374-403), keeping whatever iterate it stops at."""
+    counts, X = orc.synth_counts(1500, 60, "3factor", 2)
+    sf, normed, _, _ = orc.size_factors_ratio(counts)
+    nz = ~(counts == 0).all(0)
+    c, nrm = counts[:, nz], normed[:, nz]
+    mom = orc.mom_dispersions(nrm, X, sf, 1e-8, 60)
+    b_h, mu_h, H_h, conv_h, it_h, fb_h = hs.irls(c, sf, X, mom)
+    assert fb_h.sum() >= 2
+    sel = np.nonzero(fb_h)[0]
+    b_o, mu_o, H_o, conv_o = orc.irls(c[:, sel], sf, X, mom[sel])
+    assert (conv_o == conv_h[sel]).all()
+    assert_close(b_h[sel], b_o, 1e-7, 1e-9, "fallback beta")
+    assert_close(H_h[:, sel], H_o, 1e-6, 1e-12, "fallback H")

@@ -122,6 +122,8 @@ class DeseqPipeline:
         self.d_cell_idx = DeviceArray.from_host(ctx_, D.cell_index)
         self._work = None
         self.layers = {}
+        self.time_kernels = False
+        self.kernel_log = {}
         ctx_.sync()
 
     # ------------------------------------------------------------------ helpers
@@ -140,27 +142,37 @@ class DeseqPipeline:
             self.ctx.d2h(out, darr.ptr)
         return out
 
+    def _k(self, name, genes, cname, *args):
+        """Launch a per-gene stage; with ``time_kernels`` bracket it with HIP events on the
+        context's stream and record (milliseconds, genes) under ``name``."""
+        if self.time_kernels:
+            self.ctx.timer_start()
+            self.ctx.call(cname, *args)
+            self.kernel_log.setdefault(name, []).append((self.ctx.timer_stop(), int(genes)))
+        else:
+            self.ctx.call(cname, *args)
+
     # ------------------------------------------------------------------ stages
     def _stage_genewise(self, d_y, Gs, d_sf):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797). Returns device mu_hat and
         host vectors (normed_means, mom, genewise (clipped), converged)."""
         ctx, D = self.ctx, self.design
         d_nm, d_mom = self._dvec(Gs), self._dvec(Gs)
-        ctx.call("dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr),
+        self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr),
                  D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp), _vp(d_nm.ptr),
                  None, None, _vp(d_mom.ptr))
         d_mu = self._dmat(Gs)
         if D.linear_mu:  # dds.py:747-756
-            ctx.call("dsq_dev_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+            self._k("lin_mu", Gs, "dsq_dev_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                      _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_mu), _vp(d_mu.ptr))
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
-            ctx.call("dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+            self._k("irls_mu", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                      _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_mom.ptr),
                      c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                      _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
         d_gw, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
-        ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr), D.ldx, self.N,
+        self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr), D.ldx, self.N,
                  Gs, self.P, _vp(d_mom.ptr), c_double(self.min_disp), c_double(self.max_disp), c_double(1.0), 1,
                  0, _vp(d_gw.ptr), _vp(d_conv.ptr), None)
         nm = self._down(d_nm, Gs)
@@ -173,7 +185,7 @@ class DeseqPipeline:
         """MAP dispersions (dds.py:886-935) -> host (map clipped, converged)."""
         d_fit = self._up(fitted)
         d_map, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
-        self.ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
+        self._k("alpha_map", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
                       self.design.ldx, self.N, Gs, self.P, _vp(d_fit.ptr), c_double(self.min_disp),
                       c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(d_map.ptr), _vp(d_conv.ptr), None)
         return (np.clip(self._down(d_map, Gs), self.min_disp, self.max_disp),
@@ -186,7 +198,7 @@ class DeseqPipeline:
         d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
         d_mu = self._dmat(Gs) if want_layers else None
         d_hat = self._dmat(Gs) if want_layers else None
-        self.ctx.call("dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+        self._k("irls_lfc", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                       _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_disp.ptr),
                       c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                       _vp(d_b.ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
@@ -218,11 +230,11 @@ class DeseqPipeline:
         t0 = tick()
         # ---- size factors (dds.py:692-708)
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
-        ctx.call("dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
+        self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
         if self._work is None:
             self._work = DeviceArray(ctx, (N * G,), np.float64)
         d_sf = self._dvec(N)
-        ctx.call("dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, N, G, _vp(d_lm.ptr), None,
+        self._k("size_factors", G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, N, G, _vp(d_lm.ptr), None,
                  _vp(self._work.ptr), _vp(d_sf.ptr))
         sf = self._down(d_sf, N)
         if np.isnan(sf).any():
@@ -306,7 +318,7 @@ class DeseqPipeline:
         d_cooks = self._dmat(Gn)
         d_rd = self._dvec(Gn)
         d_f = [self._dvec(Gn, np.uint8) for _ in range(4)]
-        ctx.call("dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),
+        self._k("cooks", Gn, "dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),
                  _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
                  _vp(self.d_flags.ptr), N, Gn, P, c_double(cutoff), _vp(d_cooks.ptr), _vp(d_rd.ptr),
                  *[_vp(x.ptr) for x in d_f])
@@ -378,7 +390,7 @@ class DeseqPipeline:
         d_beta = self._up(r.LFC)
         d_disp = self._up(r.dispersions)
         d_p, d_s, d_se = self._dvec(G), self._dvec(G), self._dvec(G)
-        ctx.call("dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P,
+        self._k("wald", G, "dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P,
                  _vp(d_disp.ptr), _vp(d_beta.ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data),
                  c_double(np.log(2) * lfc_null), ALT[alt_hypothesis], _vp(d_p.ptr), _vp(d_s.ptr), _vp(d_se.ptr))
         pv, st, se = self._down(d_p, G), self._down(d_s, G), self._down(d_se, G)

@@ -131,6 +131,15 @@ int dsq_dev_trend_loss_grad(dsq_ctx* ctx, const double* d_cov, const double* d_t
                             const uint8_t* d_keep, int n, double a0, double a1, double* loss,
                             double* grad2);
 
+/* DeseqDataSet._fit_parametric_dispersion_trend (dds.py:1199-1275): the whole iterated
+ * gamma-GLM trend fit (L-BFGS-B, default_inference.py:200-230) in one single-wavefront launch.
+ * d_disp: raw genewise dispersions of the n non-zero genes (clipped to [min,max] on the fly),
+ * d_means: their normalised means, d_keep: n bytes of device scratch.  *h_ok == 0: the fit did
+ * not converge -> caller switches to the mean trend (dds.py:1243-1252). */
+int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n,
+                      double min_disp, double max_disp, uint8_t* d_keep, double* h_coeffs2,
+                      int* h_ok, int* h_n_outer);
+
 /* ================================================================== device-resident stage API
  * All pointers are device pointers unless named h_*.  Gene-major rows have pitch ldn.
  * Xt and pinvXt are [P][ldx] (design transposed; rows of (X^T X)^-1 X^T). */

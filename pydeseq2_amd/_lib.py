@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeseq_hip.so")
+LIB_PATH = os.environ.get("DSQ_LIB", os.path.join(_HERE, "libdeseq_hip.so"))  # DSQ_LIB: developer A/B builds
 
 DSQ_MAX_P = 12
 SAMPLE_MAJOR, GENE_MAJOR = 0, 1
@@ -73,6 +73,8 @@ def load():
     proto("dsq_inf_fit_moments_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
     proto("dsq_dev_trend_loss_grad", _vp, _vp, _vp, _vp, c_int, c_double, c_double, C.POINTER(c_double),
           C.POINTER(c_double))
+    proto("dsq_dev_trend_fit", _vp, _vp, _vp, c_int, c_double, c_double, _vp, C.POINTER(c_double),
+          C.POINTER(c_int), C.POINTER(c_int))
     # device-resident stages
     proto("dsq_dev_counts_to_gene_major", _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_int, C.POINTER(c_int))
     proto("dsq_dev_f64_to_gene_major", _vp, _vp, c_int, c_int, c_int, _vp, c_int)
@@ -100,7 +102,7 @@ EXPORTS = [
     "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_timer_start",
     "dsq_timer_stop", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
     "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
-    "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad",
+    "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit",
     "dsq_dev_counts_to_gene_major", "dsq_dev_f64_to_gene_major", "dsq_dev_logmeans",
     "dsq_dev_size_factors", "dsq_dev_mom", "dsq_dev_lin_mu", "dsq_dev_alpha_mle", "dsq_dev_irls",
     "dsq_dev_cooks", "dsq_dev_replace_outliers", "dsq_dev_wald", "dsq_dev_gather_rows_f64",

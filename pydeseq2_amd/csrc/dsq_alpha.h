@@ -29,31 +29,84 @@ struct AlphaArgs {
     bool cr_reg, prior_reg;
 };
 
+// lgamma(a) - lgamma(y + a) and digamma(a) - digamma(y + a) for a count y >= 0.
+//   y <= 9 : exact recurrences  -log prod_{i<y}(a+i),  -sum_{i<y} 1/(a+i)   (y = 0 costs nothing)
+//   y >= 10: Stirling series at z = y + a >= 10 minus the per-gene lgamma(a), digamma(a)
+// (the reference evaluates gammaln / polygamma at both arguments and subtracts, utils.py:218,
+// 263-264; the differences are what enters the likelihood).
+constexpr int kSmallCount = 9;
+
+template <class Wv, bool GRAD>
+DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double& dl, double& dd) {
+    const bool small = yi <= kSmallCount;
+    // small counts: prod = prod_{i<y}(a+i), num/prod = sum_{i<y} 1/(a+i)
+    double prod = 1.0, num = 0.0;
+    if (Wv::any(small && yi > 0)) {
+#pragma unroll
+        for (int i = 0; i < kSmallCount; ++i) {
+            if (i < yi && small) {
+                const double t = a + (double)i;
+                if (GRAD) num = num * t + prod;
+                prod *= t;
+            }
+        }
+    }
+    // ONE log and ONE reciprocal serve both branches (each lane needs only its own)
+    const double z = (double)yi + a;
+    const double arg = small ? prod : z;
+    const double lg = flog(arg);
+    const double rc = frcp(arg);
+    if (small) {
+        dl = -lg;
+        dd = GRAD ? -(num * rc) : 0.0;
+    } else {
+        dl = lga - ((z - 0.5) * lg - z + kHalfLog2Pi + stirling_tail(rc));
+        dd = GRAD ? dga - (lg + digamma_tail(rc)) : 0.0;
+    }
+}
+
 // loss (and gradient) of the Cox-Reid / prior regularised NB negative log-likelihood at
 // log_alpha.  GRAD = false is used by the grid search.
+//
+// Per sample, with L1 = log1p(mu*alpha) and a = 1/alpha, the reference's
+//     n*a*log(alpha) + sum[ -logbinom + (y+a) log(a+mu) - y log mu ]          (utils.py:227-234)
+// is evaluated as  sum[ (lgamma(a) - lgamma(y+a)) + y (L1 - log alpha) + a L1 ] + cst, i.e. the
+// n*a*log(alpha) term is folded into the sum analytically (it cancels a*log(a+mu) to O(mu)), which
+// removes the reference's largest rounding-noise source instead of reproducing it; one log1p
+// serves the loss, the gradient's log(1 + mu alpha) (utils.py:265) and, through its argument's
+// reciprocal, both W = mu/(1+mu alpha) and (y-mu)/(mu+a).
 template <class Wv, int P, bool GRAD>
 DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
                        double& g) {
     constexpr int T = Tri<P>::N;
-    const double alpha = exp(la);
-    const double a = 1.0 / alpha;
+    la = Wv::uniform(la);
+    const double alpha = Wv::uniform(exp(la));
+    const double a = Wv::uniform(1.0 / alpha);
+    // log of the ROUNDED alpha: keeps every term a function of the same alpha (using `la` itself
+    // would leave an inconsistency of ulp(1) * sum(y) in the loss, i.e. line-search noise)
+    const double lal = Wv::uniform(log(alpha));
     double lga, dga;
     lgamma_digamma<GRAD>(a, lga, dga);
+    lga = Wv::uniform(lga);
+    dga = Wv::uniform(dga);
     KSum accf;
     double accg = 0.0;
     double M[T], dM[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        const double yv = (double)A.y[n];
+        const int yi = A.y[n];
+        const double yv = (double)yi;
         const double m = A.mu[n];
-        double lgy, dgy;
-        lgamma_digamma<GRAD>(yv + a, lgy, dgy);
-        const double lam = log(a + m);
-        accf.add((lga - lgy) + (yv + a) * lam);
-        if (GRAD) accg += dga - dgy + log(1.0 + m * alpha) + (yv - m) / (m + a);
+        double dl, dd;
+        lgamma_digamma_diff<Wv, GRAD>(yi, a, lga, dga, dl, dd);
+        const double ma = m * alpha;
+        const double r1 = frcp(1.0 + ma);
+        const double L1 = flog1p(ma);
+        accf.add(dl + yv * (L1 - lal) + a * L1);
+        if (GRAD) accg += dd + L1 + (yv - m) * alpha * r1;
         if (cr_reg) {
-            const double w = m / (1.0 + m * alpha);
+            const double w = m * r1;
             const double dw = -(w * w);
             double x[P];
 #pragma unroll
@@ -71,7 +124,7 @@ DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_re
     }
     const double sumf = Wv::sum_comp(accf);
     if (GRAD) accg = Wv::sum(accg);
-    f = A.N * a * log(alpha) + (sumf + A.cst);
+    f = sumf + A.cst;
     g = 0.0;
     if (GRAD) g = alpha * (-(a * a * accg));
     if (cr_reg) {
@@ -131,33 +184,55 @@ struct AlphaOut {
     int nfev, nit, status;
 };
 
-// one gene: L-BFGS-B in log(alpha) from log(alpha_hat), grid search if it did not converge.
-template <class Wv, int P>
-DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
-                               double alpha_hat, double min_disp, double max_disp,
-                               double prior_var, bool cr_reg, bool prior_reg) {
-    AlphaArgs A;
-    A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
-    A.la_hat = log(alpha_hat);
-    A.prior_var = prior_var;
-    A.cr_reg = cr_reg; A.prior_reg = prior_reg;
+// alpha-independent part of the NLL:  sum lgamma(y+1) - y log(mu)
+template <class Wv>
+DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
     KSum c;
     for (int n = Wv::lane(); n < N; n += Wv::W) {
         const double yv = (double)y[n];
         c.add(lgamma_pos(yv + 1.0) - yv * log(mu[n]));
     }
-    A.cst = Wv::sum_comp(c);
+    return Wv::sum_comp(c);
+}
+
+// one gene: L-BFGS-B in log(alpha) from log(alpha_hat).  RUN_GRID: on non-convergence run the
+// reference's grid search right here (host simulation / single-kernel use); otherwise only report
+// converged = 0 and the caller schedules grid_alpha_gene for the gene (device: second tiny kernel,
+// which keeps the 200-evaluation grid code out of the main kernel's register budget).
+template <class Wv, int P, bool RUN_GRID>
+DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
+                               double alpha_hat, double min_disp, double max_disp,
+                               double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m) {
+    AlphaArgs A;
+    A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.la_hat = log(alpha_hat);
+    A.prior_var = prior_var;
+    A.cr_reg = cr_reg; A.prior_reg = prior_reg;
+    A.cst = alpha_const<Wv>(y, mu, N);
     const double lo = log(min_disp), hi = log(max_disp);
-    auto fg = [&](double la, double& f, double& g) {
-        alpha_eval<Wv, P, true>(A, la, cr_reg, prior_reg, f, g);
-    };
-    const Lbfgsb1dResult r = lbfgsb_1d(fg, A.la_hat, lo, hi);
+    m.start(A.la_hat, lo, hi);
+    while (!m.done) {
+        double f, g;
+        alpha_eval<Wv, P, true>(A, m.x, cr_reg, prior_reg, f, g);
+        m.feed(f, g);
+    }
     AlphaOut o;
-    o.converged = r.success ? 1 : 0;
-    o.nfev = r.nfev; o.nit = r.nit; o.status = r.status;
-    if (r.success) o.alpha = exp(r.x);
-    else o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
+    o.converged = m.success ? 1 : 0;
+    o.nfev = m.nfev; o.nit = m.it; o.status = m.status;
+    o.alpha = exp(m.x);
+    if (RUN_GRID && !m.success) o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
     return o;
+}
+
+// grid-search fallback of one gene (utils.py:556-564)
+template <class Wv, int P>
+DSQ_HD double grid_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
+                              double min_disp, double max_disp) {
+    AlphaArgs A;
+    A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.la_hat = 0.0; A.prior_var = 1.0; A.cr_reg = true; A.prior_reg = false;
+    A.cst = alpha_const<Wv>(y, mu, N);
+    return exp(grid_fit_alpha<Wv, P>(A, log(min_disp), log(max_disp)));
 }
 
 }  // namespace dsq

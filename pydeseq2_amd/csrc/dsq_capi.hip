@@ -17,7 +17,9 @@ struct dsq_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_scratch = nullptr;  // 8 KiB of device scratch (scalars, trend partials)
-    int32_t* d_counter = nullptr; // IRLS fallback counter
+    int32_t* d_counter = nullptr; // IRLS fallback / dispersion grid-search counters
+    int32_t* d_list = nullptr;    // gene index list of the rare second-pass kernels (grown on demand)
+    size_t list_cap = 0;
     std::string err;
 };
 
@@ -43,6 +45,21 @@ int fail(dsq_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 inline int pad16(int n) { return (n + 15) & ~15; }
+
+hipError_t ensure_list(dsq_ctx* c, size_t n) {
+    if (n <= c->list_cap) return hipSuccess;
+    if (c->d_list) (void)hipFree(c->d_list);
+    c->d_list = nullptr;
+    c->list_cap = 0;
+    hipError_t e = hipMalloc((void**)&c->d_list, n * sizeof(int32_t));
+    if (e == hipSuccess) c->list_cap = n;
+    return e;
+}
+
+// dispersion fit + (rare) grid-search second pass
+int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
+              int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
+              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev);
 
 // RAII device buffer for the Inference-level calls
 struct DevBuf {
@@ -167,6 +184,24 @@ int download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N
     return DSQ_OK;
 }
 
+int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
+              int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
+              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev) {
+    if (G <= 0) return DSQ_OK;
+    DSQ_HIP(ensure_list(ctx, (size_t)G));
+    int32_t* d_cnt = ctx->d_counter + 4;
+    DSQ_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+    DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
+                              prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list));
+    int32_t n_grid = 0;
+    DSQ_HIP(hipMemcpyAsync(&n_grid, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_grid > 0)
+        DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
+                                       ctx->d_list, n_grid));
+    return DSQ_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +232,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    if (ctx->d_list) (void)hipFree(ctx->d_list);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -330,9 +366,8 @@ int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int 
                       double max_disp, double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha,
                       uint8_t* d_converged, int32_t* d_nfev) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
-    DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp,
-                              max_disp, prior_disp_var, cr_reg, prior_reg, d_alpha, d_converged, d_nfev));
-    return DSQ_OK;
+    return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
+                     cr_reg, prior_reg, d_alpha, d_converged, d_nfev);
 }
 
 int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
@@ -341,19 +376,18 @@ int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, 
                  double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     if (G <= 0) return DSQ_OK;
-    DevBuf fb;
-    DSQ_HIP(fb.alloc((size_t)G * sizeof(int32_t)));
+    DSQ_HIP(ensure_list(ctx, (size_t)G));
     DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, sizeof(int32_t), ctx->stream));
     DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
-                             d_converged, d_iters, ctx->d_counter, fb.as<int32_t>()));
+                             d_converged, d_iters, ctx->d_counter, ctx->d_list));
     int32_t n_fb = 0;
     DSQ_HIP(hipMemcpyAsync(&n_fb, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     if (n_fb > 0) {
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
-                                        d_hat, d_converged, d_iters, fb.as<int32_t>(), n_fb));
+                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb));
         DSQ_HIP(hipStreamSynchronize(ctx->stream));
     }
     return DSQ_OK;
@@ -405,6 +439,19 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
 int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx, int n_idx,
                             int ncols, int32_t* d_dst) {
     DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_src, ld, d_idx, n_idx, ncols, d_dst));
+    return DSQ_OK;
+}
+
+int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n, double min_disp,
+                      double max_disp, uint8_t* d_keep, double* h_coeffs2, int* h_ok, int* h_n_outer) {
+    double* d_out = ctx->d_scratch + 1536;
+    DSQ_HIP(dsq::launch_trend_fit(ctx->stream, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out));
+    double out5[5];
+    DSQ_HIP(hipMemcpyAsync(out5, d_out, sizeof(out5), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    h_coeffs2[0] = out5[0]; h_coeffs2[1] = out5[1];
+    if (h_ok) *h_ok = (int)out5[2];
+    if (h_n_outer) *h_n_outer = (int)out5[3];
     return DSQ_OK;
 }
 
@@ -493,9 +540,10 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
     if ((rc = upload_vec(ctx, alpha_hat, (size_t)G * sizeof(double), ah))) return rc;
     DSQ_HIP(a.alloc((size_t)G * sizeof(double)));
     DSQ_HIP(conv.alloc((size_t)G));
-    DSQ_HIP(dsq::launch_alpha(ctx->stream, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N,
-                              G, P, ah.as<double>(), min_disp, max_disp, prior_disp_var, cr_reg, prior_reg,
-                              a.as<double>(), conv.as<uint8_t>(), nullptr));
+    if ((rc = run_alpha(ctx, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N, G, P,
+                        ah.as<double>(), min_disp, max_disp, prior_disp_var, cr_reg, prior_reg, a.as<double>(),
+                        conv.as<uint8_t>(), nullptr)))
+        return rc;
     DSQ_HIP(hipMemcpyAsync(alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));

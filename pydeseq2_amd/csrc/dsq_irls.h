@@ -49,9 +49,11 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
 #pragma unroll
         for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
         const double mu = dmax(sfn * exp(eta), A.min_mu);
-        s += (yv + a) * log(a + mu) - yv * log(mu);
-        const double w = mu / (1.0 + mu * A.disp);
-        const double z = log(mu / sfn) + (yv - mu) / mu;
+        const double lmu = flog(mu);
+        const double rmu = frcp(mu);
+        s += (yv + a) * flog(a + mu) - yv * lmu;
+        const double w = mu * frcp(1.0 + mu * A.disp);
+        const double z = flog(mu * frcp(sfn)) + (yv - mu) * rmu;
         const double wz = w * z;
 #pragma unroll
         for (int i = 0; i < P; ++i) {

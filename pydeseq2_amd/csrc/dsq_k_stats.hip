@@ -11,6 +11,7 @@
 #include "dsq_dispatch.h"
 #include "dsq_launch.h"
 #include "dsq_stats.h"
+#include "dsq_trend.h"
 
 namespace dsq {
 
@@ -611,6 +612,109 @@ hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const doubl
                                   const uint8_t* keep, int n, double a0, double a1, double* partials) {
     hipLaunchKernelGGL(k_trend, dim3(kTrendBlocks), dim3(256), 0, st, cov, targets, keep, n, a0, a1,
                        partials);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ trend fit (one workgroup)
+// Wave 0 runs the L-BFGS-B state machine (dsq_lbfgsb.h) on an LDS workspace; every loss/gradient
+// evaluation, the initial mask and the outlier filter are data passes over the G genes that all
+// kTrendWaves waves share: the leader posts a command in LDS, the workgroup meets at barrier A,
+// everybody reduces its stripe, barrier B, the leader combines the per-wave partials in a fixed
+// order (deterministic).  Helper waves spin on the same two barriers until the leader posts 0.
+constexpr int kTrendWaves = 16;
+
+struct TrendShared {
+    TrendWork W;
+    double a0, a1;
+    int cmd;  // 1 eval, 2 filter, 3 init mask, 0 done
+    double part[kTrendWaves][3];
+    int ipart[kTrendWaves][3];
+};
+
+struct BlockTrendOps {
+    TrendData D;
+    TrendShared* S;
+    __device__ void work(int cmd, double a0, double a1) {
+        const int w = threadIdx.x >> 6, tid = threadIdx.x, NT = 64 * kTrendWaves;
+        if (cmd == 1) {
+            TrendPartial P;
+            trend_eval_partial(D, tid, NT, a0, a1, P);
+            const double s = DeviceWave::sum_comp(P.s), g0 = DeviceWave::sum_comp(P.g0),
+                         g1 = DeviceWave::sum_comp(P.g1);
+            const int cf = DeviceWave::sumi(P.cf), c0 = DeviceWave::sumi(P.c0), c1 = DeviceWave::sumi(P.c1);
+            if ((tid & 63) == 0) {
+                S->part[w][0] = s; S->part[w][1] = g0; S->part[w][2] = g1;
+                S->ipart[w][0] = cf; S->ipart[w][1] = c0; S->ipart[w][2] = c1;
+            }
+        } else {
+            const int k = DeviceWave::sumi(cmd == 3 ? trend_init_keep(D, tid, NT) : trend_filter(D, tid, NT, a0, a1));
+            if ((tid & 63) == 0) S->ipart[w][0] = k;
+        }
+    }
+    __device__ void post(int cmd, double a0, double a1) {  // leader only
+        if ((threadIdx.x & 63) == 0) { S->cmd = cmd; S->a0 = a0; S->a1 = a1; }
+        __syncthreads();  // A
+        work(cmd, a0, a1);
+        __syncthreads();  // B
+    }
+    __device__ int init_keep() {
+        post(3, 0.0, 0.0);
+        int k = 0;
+        for (int w = 0; w < kTrendWaves; ++w) k += S->ipart[w][0];
+        return k;
+    }
+    __device__ void eval(double a0, double a1, double& f, double* g) {
+        post(1, a0, a1);
+        KSum s, g0, g1;
+        int cf = 0, c0 = 0, c1 = 0;
+        for (int w = 0; w < kTrendWaves; ++w) {
+            s.add(S->part[w][0]); g0.add(S->part[w][1]); g1.add(S->part[w][2]);
+            cf += S->ipart[w][0]; c0 += S->ipart[w][1]; c1 += S->ipart[w][2];
+        }
+        f = s.value() / (double)cf;
+        g[0] = -(g0.value() / (double)c0);
+        g[1] = -(g1.value() / (double)c1);
+    }
+    __device__ int filter(double a0, double a1) {
+        post(2, a0, a1);
+        int k = 0;
+        for (int w = 0; w < kTrendWaves; ++w) k += S->ipart[w][0];
+        return k;
+    }
+};
+
+__global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __restrict__ disp,
+                                                                const double* __restrict__ means, int n,
+                                                                double min_disp, double max_disp,
+                                                                uint8_t* __restrict__ keep,
+                                                                double* __restrict__ out5) {
+    __shared__ TrendShared S;
+    BlockTrendOps ops;
+    ops.D = TrendData{disp, means, keep, n, min_disp, max_disp};
+    ops.S = &S;
+    if ((threadIdx.x >> 6) == 0) {
+        const TrendOut o = trend_fit_core(ops, S.W);
+        if (threadIdx.x == 0) {
+            out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
+            out5[4] = (double)o.n_kept;
+            S.cmd = 0;
+        }
+        __syncthreads();  // A (release the helpers)
+    } else {
+        for (;;) {
+            __syncthreads();  // A
+            const int cmd = S.cmd;
+            if (cmd == 0) break;
+            ops.work(cmd, S.a0, S.a1);
+            __syncthreads();  // B
+        }
+    }
+}
+
+hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
+                            double max_disp, uint8_t* keep, double* out5) {
+    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, disp, means, n, min_disp, max_disp,
+                       keep, out5);
     return hipGetLastError();
 }
 

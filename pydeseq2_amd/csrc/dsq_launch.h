@@ -16,7 +16,10 @@ inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerB
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
-                        uint8_t* conv, int32_t* nfev);
+                        uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list);
+hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
+                             int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
+                             const int32_t* grid_list, int n_grid);
 
 // ---- dsq_k_irls.hip
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
@@ -67,6 +70,8 @@ hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, co
 constexpr int kTrendPartials = 256;  // rows of 4 doubles
 hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const double* targets,
                                   const uint8_t* keep, int n, double a0, double a1, double* partials);
+hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
+                            double max_disp, uint8_t* keep, double* out5);
 // normed counts (double, gene-major) based rough / moments for the Inference-level API
 hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
                                     const double* pinvXt, int ldx, int N, int G, int P, double* out);

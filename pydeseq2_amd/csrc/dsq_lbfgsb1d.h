@@ -186,110 +186,150 @@ DSQ_HD double projgr_1d(double x, double g, double l, double u) {
     return fabs(gi);
 }
 
-// FG: void(double x, double& f, double& g)
-template <class FG>
-DSQ_HD Lbfgsb1dResult lbfgsb_1d(FG&& fg, double x0, double l, double u, double factr = 1e7,
-                                double pgtol = 1e-5, int maxls = 20, int maxiter = 15000) {
-    Lbfgsb1dResult R;
-    const double tol = factr * kEps;
-    double x = dmin(dmax(x0, l), u);
-    double f, g;
-    fg(x, f, g);
-    int nfev = 1, it = 0, col = 0;
-    double theta = 1.0;
-    bool dirty = false;
-    if (projgr_1d(x, g, l, u) <= pgtol) {
-        R = {x, f, g, true, nfev, 0, 0};
-        return R;
+// The optimiser as a resumable state machine: the caller owns the (expensive, wave-parallel)
+// function evaluation and there is exactly ONE evaluation site in the kernel:
+//     Lbfgsb1d m; m.start(x0, l, u);
+//     while (!m.done) { eval(m.x, f, g); m.feed(f, g); }
+struct Lbfgsb1d {
+    // configuration
+    double l, u, tol, pgtol;
+    int maxls, maxiter;
+    // iterate
+    double x, f, g, theta;
+    int col, it, nfev;
+    bool dirty, done, success;
+    int status;  // 0 pgtol at start, 1 pgtol, 2 ftol, 3 abnormal, 4 maxiter
+    // line-search bookkeeping
+    double z, d, xold, gold, fold, gd, gdold, stp, stpmx;
+    int ifun, phase;
+    Dcsrch ls;
+
+    DSQ_HD void start(double x0, double l_, double u_, double factr = 1e7, double pgtol_ = 1e-5,
+                      int maxls_ = 20, int maxiter_ = 15000) {
+        l = l_; u = u_; tol = factr * kEps; pgtol = pgtol_; maxls = maxls_; maxiter = maxiter_;
+        x = dmin(dmax(x0, l), u);
+        theta = 1.0; col = 0; it = 0; nfev = 0; dirty = false; done = false; success = false;
+        status = 3; phase = 0;
+        f = 0.0; g = 0.0;
     }
-    for (;;) {
-        // ---- generalized Cauchy point (cauchy + subsm, n = 1)
-        const double f1 = -(g * g);
-        const double f2 = -theta * f1;
-        const double dtm = -f1 / f2;
-        double tb, bound;
-        if (g < 0.0) { tb = (u - x) / (-g); bound = u; }
-        else { tb = (x - l) / g; bound = l; }
-        double z;
-        bool free_var;
-        if (dtm < tb) { z = x + dtm * (-g); free_var = true; }
-        else { z = bound; free_var = false; }
-        if (col > 0) {
-            if (!free_var) {
-                dirty = true;  // formk skipped: the middle-matrix bookkeeping goes stale
-            } else if (dirty) {
-                theta = 1.0; col = 0; dirty = false;  // Cholesky fails -> refresh memory
+
+    DSQ_HD void finish(bool ok, int st) { done = true; success = ok; status = st; }
+
+    // restore the last accepted iterate after a failed line search; returns false if finished
+    DSQ_HD bool ls_failed() {
+        x = xold; g = gold; f = fold;
+        if (col == 0) {
+            it += 1;  // mainlb counts the aborted iteration
+            finish(false, 3);
+            return false;
+        }
+        theta = 1.0; col = 0; dirty = false;
+        return true;
+    }
+
+    // compute the search direction from (x, f, g) and set x to the first trial point
+    DSQ_HD void begin_iteration() {
+        for (;;) {
+            const double f1 = -(g * g);
+            const double f2 = -theta * f1;
+            const double dtm = -f1 / f2;
+            double tb, bound;
+            if (g < 0.0) { tb = (u - x) / (-g); bound = u; }
+            else { tb = (x - l) / g; bound = l; }
+            bool free_var;
+            if (dtm < tb) { z = x + dtm * (-g); free_var = true; }
+            else { z = bound; free_var = false; }
+            if (col > 0) {
+                if (!free_var) {
+                    dirty = true;
+                } else if (dirty) {
+                    theta = 1.0; col = 0; dirty = false;
+                    continue;
+                }
+            }
+            d = z - x;
+            if (it == 0) {
+                stpmx = 1.0;
+            } else {
+                stpmx = 1e10;
+                if (d < 0.0) {
+                    const double a2 = l - x;
+                    if (a2 >= 0.0) stpmx = 0.0;
+                    else if (d * stpmx < a2) stpmx = a2 / d;
+                } else if (d > 0.0) {
+                    const double a2 = u - x;
+                    if (a2 <= 0.0) stpmx = 0.0;
+                    else if (d * stpmx > a2) stpmx = a2 / d;
+                }
+            }
+            stp = 1.0;
+            xold = x; gold = g; fold = f;
+            ifun = 0;
+            gd = g * d;
+            gdold = gd;
+            bool fail = (gd >= 0.0);
+            if (!fail) fail = (ls.start(f, gd, stp, stpmx) == Dcsrch::ERR);
+            if (!fail) {
+                ifun = 1;
+                if (ifun - 1 >= maxls) fail = true;
+            }
+            if (fail) {
+                if (!ls_failed()) return;
                 continue;
             }
+            x = (stp == 1.0) ? z : stp * d + xold;
+            phase = 1;
+            return;
         }
-        const double d = z - x;
-        // ---- lnsrlb
-        double stpmx;
-        if (it == 0) {
-            stpmx = 1.0;
-        } else {
-            stpmx = 1e10;
-            if (d < 0.0) {
-                const double a2 = l - x;
-                if (a2 >= 0.0) stpmx = 0.0;
-                else if (d * stpmx < a2) stpmx = a2 / d;
-            } else if (d > 0.0) {
-                const double a2 = u - x;
-                if (a2 <= 0.0) stpmx = 0.0;
-                else if (d * stpmx > a2) stpmx = a2 / d;
+    }
+
+    DSQ_HD void feed(double fv, double gv) {
+        f = fv; g = gv;
+        nfev += 1;
+        if (phase == 0) {
+            if (projgr_1d(x, g, l, u) <= pgtol) { finish(true, 0); return; }
+            begin_iteration();
+            return;
+        }
+        gd = g * d;
+        if (ls.step(f, gd, stp) == Dcsrch::FG) {
+            ifun += 1;
+            if (ifun - 1 >= maxls) {
+                if (ls_failed()) begin_iteration();
+                return;
             }
+            x = (stp == 1.0) ? z : stp * d + xold;
+            return;
         }
-        double stp = 1.0;
-        const double xold = x, gold = g, fold = f;
-        int ifun = 0;
-        double gd = g * d;
-        const double gdold = gd;
-        bool lsfail = false;
-        Dcsrch ls;
-        if (gd >= 0.0) {
-            lsfail = true;  // "ascent direction in projection"
-        } else {
-            if (ls.start(f, gd, stp, stpmx) == Dcsrch::ERR) lsfail = true;
-            while (!lsfail) {
-                ifun += 1;
-                if (ifun - 1 >= maxls) { lsfail = true; break; }
-                x = (stp == 1.0) ? z : stp * d + xold;
-                fg(x, f, g);
-                nfev += 1;
-                gd = g * d;
-                if (ls.step(f, gd, stp) != Dcsrch::FG) break;
-            }
-        }
-        if (lsfail) {
-            x = xold; g = gold; f = fold;
-            if (col == 0) {
-                R = {x, f, g, false, nfev, it + 1, 3};
-                return R;
-            }
-            theta = 1.0; col = 0; dirty = false;
-            continue;
-        }
+        // line search accepted x
         it += 1;
-        if (projgr_1d(x, g, l, u) <= pgtol) {
-            R = {x, f, g, true, nfev, it, 1};
-            return R;
-        }
+        if (projgr_1d(x, g, l, u) <= pgtol) { finish(true, 1); return; }
         const double ddum0 = dmax(fabs(fold), dmax(fabs(f), 1.0));
-        if ((fold - f) <= tol * ddum0) {
-            R = {x, f, g, true, nfev, it, 2};
-            return R;
-        }
+        if ((fold - f) <= tol * ddum0) { finish(true, 2); return; }
         const double r = g - gold;
         const double rr = r * r;
         double dr, ddum;
         if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
         else { dr = (gd - gdold) * stp; ddum = -gdold * stp; }
         if (!(dr <= kEps * ddum)) { theta = rr / dr; col += 1; }
-        if (it >= maxiter) {
-            R = {x, f, g, false, nfev, it, 4};
-            return R;
-        }
+        if (it >= maxiter) { finish(false, 4); return; }
+        begin_iteration();
     }
+};
+
+// FG: void(double x, double& f, double& g)
+template <class FG>
+DSQ_HD Lbfgsb1dResult lbfgsb_1d(FG&& fg, double x0, double l, double u, double factr = 1e7,
+                                double pgtol = 1e-5, int maxls = 20, int maxiter = 15000) {
+    Lbfgsb1d m;
+    m.start(x0, l, u, factr, pgtol, maxls, maxiter);
+    while (!m.done) {
+        double f, g;
+        fg(m.x, f, g);
+        m.feed(f, g);
+    }
+    Lbfgsb1dResult R = {m.x, m.f, m.g, m.success, m.nfev, m.it, m.status};
+    return R;
 }
 
 }  // namespace dsq

@@ -55,6 +55,13 @@ struct DeviceWave {
         return v;
     }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    // a value known to be identical in every lane -> scalar registers (frees VGPRs)
+    static __device__ __forceinline__ double uniform(double v) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+        const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
     static __device__ __forceinline__ double sum_comp(KSum k) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -79,6 +86,7 @@ struct HostWave {
     static inline double max(double v) { return v; }
     static inline int sumi(int v) { return v; }
     static inline bool any(bool p) { return p; }
+    static inline double uniform(double v) { return v; }
     static inline double sum_comp(KSum k) { return k.value(); }
     template <int K>
     static inline void sum_n(double (&)[K]) {}

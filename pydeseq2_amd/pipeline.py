@@ -179,6 +179,7 @@ class DeseqPipeline:
         mom = self._down(d_mom, Gs)
         gw = np.clip(self._down(d_gw, Gs), self.min_disp, self.max_disp)  # dds.py:792-794
         conv = self._down(d_conv, Gs, np.uint8).astype(bool)
+        self._last_gw_dev = (d_gw, d_nm)  # raw genewise dispersions / means stay on the device for the trend fit
         return d_mu, nm, mom, gw, conv
 
     def _stage_map(self, d_y, d_mu, Gs, fitted, prior_var):
@@ -269,7 +270,13 @@ class DeseqPipeline:
         # ---- trend (dds.py:799-838) + prior (dds.py:840-884): cross-gene, O(G), host
         coeffs = None
         if self.fit_type == "parametric":
-            coeffs = _trend.fit_parametric_trend(gw, nm)
+            d_gw, d_nm = self._last_gw_dev
+            c2, ok, n_outer = (C.c_double * 2)(), C.c_int(0), C.c_int(0)
+            d_keep = self._dvec(Gn, np.uint8)
+            self._k("trend_fit", Gn, "dsq_dev_trend_fit", _vp(d_gw.ptr), _vp(d_nm.ptr), Gn,
+                    c_double(self.min_disp), c_double(self.max_disp), _vp(d_keep.ptr), c2, C.byref(ok),
+                    C.byref(n_outer))
+            coeffs = np.array([c2[0], c2[1]]) if ok.value else None
             if coeffs is None:
                 warnings.warn("The dispersion trend curve fitting did not converge. "
                               "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)

@@ -254,3 +254,20 @@ def lbfgsb_nd(fg, x0, bounds):
                             _p(nbd, C.c_int32), C.byref(f), C.byref(ok), C.byref(nfev), C.byref(nit), C.byref(st))
     assert rc == 0
     return x, f.value, bool(ok.value), nfev.value, nit.value, st.value
+
+
+def trend_fit(disp, means, min_disp, max_disp):
+    d = np.ascontiguousarray(disp, dtype=np.float64)
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    c = np.empty(2)
+    ok, no = C.c_int(), C.c_int()
+    lib().hs_trend_fit(_p(d, C.c_double), _p(m, C.c_double), C.c_int(len(d)), C.c_double(min_disp),
+                       C.c_double(max_disp), _p(c, C.c_double), C.byref(ok), C.byref(no))
+    return c, bool(ok.value), no.value
+
+
+def flog(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    a, b, c = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    lib().hs_flog(_p(x, C.c_double), C.c_int(x.size), _p(a, C.c_double), _p(b, C.c_double), _p(c, C.c_double))
+    return a, b, c

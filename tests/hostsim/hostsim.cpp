@@ -16,6 +16,7 @@
 #include "dsq_irls.h"
 #include "dsq_lbfgsb.h"
 #include "dsq_stats.h"
+#include "dsq_trend.h"
 
 using namespace dsq;
 
@@ -32,6 +33,10 @@ extern "C" {
 
 void hs_lgamma_digamma(const double* x, int n, double* lg, double* dg) {
     for (int i = 0; i < n; ++i) lgamma_digamma<true>(x[i], lg[i], dg[i]);
+}
+
+void hs_flog(const double* x, int n, double* lg, double* l1p, double* rc) {
+    for (int i = 0; i < n; ++i) { lg[i] = flog(x[i]); l1p[i] = flog1p(x[i]); rc[i] = frcp(x[i]); }
 }
 
 void hs_norm_sf(const double* x, int n, double* out) {
@@ -52,10 +57,11 @@ int hs_alpha_mle(const int32_t* y, const double* mu, int ldn, const double* Xt, 
                  double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
                  int32_t* nfev) {
     if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    Lbfgsb1d mach;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
-        AlphaOut o = fit_alpha_gene<HostWave, P>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx,
+        AlphaOut o = fit_alpha_gene<HostWave, P, true>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx,
                                                  N, alpha_hat[g], min_disp, max_disp, prior_var,
-                                                 cr_reg != 0, prior_reg != 0);
+                                                 cr_reg != 0, prior_reg != 0, mach);
         alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
         if (nfev) nfev[g] = o.nfev;
     })
@@ -69,9 +75,7 @@ int hs_grid_alpha(const int32_t* y, const double* mu, int ldn, const double* Xt,
         AlphaArgs A;
         A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
         A.la_hat = 0; A.prior_var = 1; A.cr_reg = true; A.prior_reg = false;
-        double c = 0;
-        for (int n = 0; n < N; ++n) c += lgamma_pos(A.y[n] + 1.0) - A.y[n] * log(A.mu[n]);
-        A.cst = c;
+        A.cst = alpha_const<HostWave>(A.y, A.mu, N);
         log_alpha[g] = grid_fit_alpha<HostWave, P>(A, log(min_disp), log(max_disp));
     })
     return 0;
@@ -189,9 +193,7 @@ int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx,
         AlphaArgs A;
         A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N; A.la_hat = la_hat;
         A.prior_var = prior_var; A.cr_reg = cr_reg; A.prior_reg = prior_reg;
-        double c = 0;
-        for (int n = 0; n < N; ++n) c += lgamma_pos(y[n] + 1.0) - y[n] * log(mu[n]);
-        A.cst = c;
+        A.cst = alpha_const<HostWave>(y, mu, N);
         alpha_eval<HostWave, P, true>(A, la, cr_reg != 0, prior_reg != 0, *f, *g);
     })
     return 0;
@@ -206,6 +208,16 @@ int hs_lbfgsb_nd(fgn_cb cb, int n, double* x, const double* l, const double* u, 
     auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
     LbfgsbResult r = lbfgsb_nd<16>(fg, n, x, l, u, nbd, W);
     *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
+    return 0;
+}
+
+int hs_trend_fit(const double* disp, const double* means, int n, double min_disp, double max_disp,
+                 double* coeffs, int* ok, int* n_outer) {
+    std::vector<uint8_t> keep(n + 1);
+    static TrendWork W;
+    std::memset(&W, 0, sizeof(W));
+    TrendOut o = trend_fit<HostWave>(disp, means, n, min_disp, max_disp, keep.data(), W);
+    coeffs[0] = o.a0; coeffs[1] = o.a1; *ok = o.ok; *n_outer = o.n_outer;
     return 0;
 }
 

@@ -178,3 +178,30 @@ def test_irls_rescue_matches_reference_fallback():
     assert (conv_o == conv_h[sel]).all()
     assert_close(b_h[sel], b_o, 1e-7, 1e-9, "fallback beta")
     assert_close(H_h[:, sel], H_o, 1e-6, 1e-12, "fallback H")
+
+
+def test_trend_fit_matches_reference_loop():
+    """Device trend-fit template (n-dim L-BFGS-B, n = 2) vs the oracle's restatement of
+    dds.py:1199-1275 / default_inference.py:200-230 (scipy L-BFGS-B on numpy sums)."""
+    for G, N, design, seed in [(3000, 60, "2level", 1), (2500, 60, "3factor", 2)]:
+        counts, X = orc.synth_counts(G, N, design, seed)
+        sf, normed, _, _ = orc.size_factors_ratio(counts)
+        nz = ~(counts == 0).all(0)
+        c, nrm = counts[:, nz], normed[:, nz]
+        mom = orc.mom_dispersions(nrm, X, sf, 1e-8, N)
+        mu = orc.lin_reg_mu(c, sf, X, 0.5) if design == "2level" else orc.irls(c, sf, X, mom)[1]
+        gw, _, _ = hs.alpha_mle(c, X, mu, mom, 1e-8, N)
+        nm = nrm.mean(0)
+        co, n_outer = orc.fit_parametric_trend(np.clip(gw, 1e-8, N), nm)
+        ch, ok, no = hs.trend_fit(gw, nm, 1e-8, N)
+        assert ok and no == n_outer
+        assert_close(ch, co, 1e-10, 0, "trend coefficients")
+
+
+def test_lean_log_matches_libm():
+    x = np.concatenate([10 ** np.random.default_rng(1).uniform(-12, 80, 50000), np.linspace(0.5, 2, 20001)])
+    lg, _, rc = hs.flog(x)
+    assert np.max(np.abs(lg - np.log(x)) / np.spacing(np.abs(np.log(x)) + 1e-300)) <= 1.0
+    u = np.concatenate([10 ** np.random.default_rng(2).uniform(-20, 6, 50000), [0.0, 4.9e-9, 5e-9]])
+    _, l1, _ = hs.flog(u)
+    assert np.max(np.abs(l1 - np.log1p(u)) / (np.spacing(np.log1p(u)) + 1e-320)) <= 1.0

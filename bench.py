@@ -81,11 +81,11 @@ def main():
 
     dist = None
     if world > 1:
-        import torch
+        # control plane of this harness only (barrier, max-over-ranks, unique-id broadcast);
+        # the data-path collectives are RCCL calls made by the product through its C ABI
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import pydeseq2_amd
     from pydeseq2_amd._lib import Context
@@ -96,20 +96,22 @@ def main():
     counts, X = synth_fast(G, N, design, seed=1000 * rank + {"c2": 1, "c3": 2, "c4": 3}[args.config])
     t_gen = time.perf_counter() - t_gen
 
-    if world > 1:
-        from pydeseq2_amd.distributed import DistDeseqPipeline
+    if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
+        from pydeseq2_amd.distributed import DistDeseqPipeline, RcclComm
 
-        pipe = DistDeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
+        box = [RcclComm.unique_id(ctx) if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        comm = RcclComm(ctx, box[0], rank, world)
+        pipe = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True)
     else:
         pipe = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
 
     def barrier():
-        ctx.sync()
+        ctx.sync()  # hipStreamSynchronize on the engine's stream (it owns all device work)
         if dist is not None:
-            import torch
-
             dist.barrier()
-            torch.cuda.synchronize()
+            ctx.sync()
 
     for _ in range(args.warmup):
         res = pipe.deseq2()
@@ -124,7 +126,7 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([dt], device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     barrier()

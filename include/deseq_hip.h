@@ -209,6 +209,28 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
 int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx,
                             int n_idx, int ncols, int32_t* d_dst);
 
+/* ================================================================== multi-GPU exchanges (RCCL over xGMI)
+ * One process per GPU; genes shard across ranks.  Only two steps of the path need other ranks'
+ * genes: the per-sample median of log-ratios (size factors) and the dispersion
+ * trend / prior.  librccl is dlopen()ed on first use. */
+int dsq_comm_unique_id(dsq_ctx* ctx, char* out128, int len);           /* rank 0, then broadcast */
+int dsq_comm_init(dsq_ctx* ctx, const char* uid128, int rank, int world);
+int dsq_comm_destroy(dsq_ctx* ctx);
+int dsq_comm_allreduce_sum(dsq_ctx* ctx, void* d_buf, size_t count, int dtype /*0 u32, 1 f64*/);
+int dsq_comm_allgather(dsq_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* size factors pass by pass: keys -> per-sample counts -> (all-reduce) -> init -> 8 x
+ * [hist -> (all-reduce) -> pick] -> finish.  d_keys: N*G u64, d_prefix: 2*N u64, d_rank: 2*N u32,
+ * d_hist: 2*N*256 u32. */
+int dsq_dev_sf_keys(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                    const double* d_logmeans, const uint8_t* d_gene_mask, void* d_keys);
+int dsq_dev_sf_count(dsq_ctx* ctx, const void* d_keys, int N, int G, uint32_t* d_counts);
+int dsq_dev_sf_init(dsq_ctx* ctx, const uint32_t* d_total, int N, void* d_prefix, uint32_t* d_rank);
+int dsq_dev_sf_hist(dsq_ctx* ctx, const void* d_keys, int N, int G, const void* d_prefix, int shift,
+                    uint32_t* d_hist);
+int dsq_dev_sf_pick(dsq_ctx* ctx, const uint32_t* d_hist, int N, int shift, void* d_prefix,
+                    uint32_t* d_rank);
+int dsq_dev_sf_finish(dsq_ctx* ctx, const void* d_prefix, const uint32_t* d_total, int N, double* d_sf);
+
 #ifdef __cplusplus
 }
 #endif

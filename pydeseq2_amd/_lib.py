@@ -94,6 +94,17 @@ def load():
           c_double, c_int, _vp, _vp, _vp)
     proto("dsq_dev_gather_rows_f64", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
     proto("dsq_dev_gather_rows_i32", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    proto("dsq_comm_unique_id", _vp, C.c_char_p, c_int)
+    proto("dsq_comm_init", _vp, C.c_char_p, c_int, c_int)
+    proto("dsq_comm_destroy", _vp)
+    proto("dsq_comm_allreduce_sum", _vp, _vp, c_size_t, c_int)
+    proto("dsq_comm_allgather", _vp, _vp, _vp, c_size_t)
+    proto("dsq_dev_sf_keys", _vp, _vp, c_int, c_int, c_int, _vp, _vp, _vp)
+    proto("dsq_dev_sf_count", _vp, _vp, c_int, c_int, _vp)
+    proto("dsq_dev_sf_init", _vp, _vp, c_int, _vp, _vp)
+    proto("dsq_dev_sf_hist", _vp, _vp, c_int, c_int, _vp, c_int, _vp)
+    proto("dsq_dev_sf_pick", _vp, _vp, c_int, c_int, _vp, _vp)
+    proto("dsq_dev_sf_finish", _vp, _vp, _vp, c_int, _vp)
     _lib = lib
     return lib
 
@@ -106,7 +117,9 @@ EXPORTS = [
     "dsq_dev_counts_to_gene_major", "dsq_dev_f64_to_gene_major", "dsq_dev_logmeans",
     "dsq_dev_size_factors", "dsq_dev_mom", "dsq_dev_lin_mu", "dsq_dev_alpha_mle", "dsq_dev_irls",
     "dsq_dev_cooks", "dsq_dev_replace_outliers", "dsq_dev_wald", "dsq_dev_gather_rows_f64",
-    "dsq_dev_gather_rows_i32",
+    "dsq_dev_gather_rows_i32", "dsq_comm_unique_id", "dsq_comm_init", "dsq_comm_destroy",
+    "dsq_comm_allreduce_sum", "dsq_comm_allgather", "dsq_dev_sf_keys", "dsq_dev_sf_count", "dsq_dev_sf_init",
+    "dsq_dev_sf_hist", "dsq_dev_sf_pick", "dsq_dev_sf_finish",
 ]
 
 

@@ -89,28 +89,43 @@ DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_re
     lgamma_digamma<GRAD>(a, lga, dga);
     lga = Wv::uniform(lga);
     dga = Wv::uniform(dga);
+    // Wave-level memo: lane k evaluates the two gamma-function differences for the COUNT k once
+    // per evaluation; samples whose count is < 64 then fetch them with a cross-lane read instead
+    // of recomputing log/Stirling/recurrences per sample (counts repeat heavily within a gene).
+    // Only counts >= 64 take the per-sample Stirling path.  (Host build: table of one entry.)
+    double tab_dl, tab_dd;
+    lgamma_digamma_diff<Wv, GRAD>(Wv::lane(), a, lga, dga, tab_dl, tab_dd);
     KSum accf;
     double accg = 0.0;
     double M[T], dM[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
-    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        const int yi = A.y[n];
+    for (int base = 0; base < A.N; base += Wv::W) {  // wave-uniform trip count: all lanes stay active
+        const int n = base + Wv::lane();
+        const bool valid = n < A.N;
+        const int yi = valid ? A.y[n] : 0;
         const double yv = (double)yi;
-        const double m = A.mu[n];
-        double dl, dd;
-        lgamma_digamma_diff<Wv, GRAD>(yi, a, lga, dga, dl, dd);
+        const double m = valid ? A.mu[n] : 1.0;
+        const bool in_tab = yi < Wv::W;
+        double dl = Wv::from_lane(tab_dl, in_tab ? yi : 0);
+        double dd = GRAD ? Wv::from_lane(tab_dd, in_tab ? yi : 0) : 0.0;
+        if (Wv::any(!in_tab)) {
+            double dl2, dd2;
+            lgamma_digamma_diff<Wv, GRAD>(in_tab ? 64 : yi, a, lga, dga, dl2, dd2);
+            if (!in_tab) { dl = dl2; dd = dd2; }
+        }
         const double ma = m * alpha;
         const double r1 = frcp(1.0 + ma);
         const double L1 = flog1p(ma);
-        accf.add(dl + yv * (L1 - lal) + a * L1);
-        if (GRAD) accg += dd + L1 + (yv - m) * alpha * r1;
+        const double vz = valid ? 1.0 : 0.0;
+        accf.add(vz * (dl + yv * (L1 - lal) + a * L1));
+        if (GRAD) accg += vz * (dd + L1 + (yv - m) * alpha * r1);
         if (cr_reg) {
-            const double w = m * r1;
+            const double w = vz * (m * r1);
             const double dw = -(w * w);
             double x[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) x[j] = A.Xt[j * A.ldx + n];
+            for (int j = 0; j < P; ++j) x[j] = valid ? A.Xt[j * A.ldx + n] : 0.0;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const double xw = x[i] * w, xdw = x[i] * dw;

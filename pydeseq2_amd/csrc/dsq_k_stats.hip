@@ -718,4 +718,122 @@ hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* me
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ distributed size factors
+// Multi-GPU layout: every rank owns a gene shard, but a sample's size factor is the median over
+// ALL genes.  The radix select of k_row_median is therefore split into per-pass kernels whose
+// per-sample 256-bin digit histograms are summed across ranks (RCCL all-reduce) between passes.
+// state (per sample): prefix[2] (u64), rank[2] (u32) for the two middle order statistics.
+struct SfState {
+    unsigned long long* prefix;  // [2][N]
+    unsigned int* rank;          // [2][N]
+};
+
+__global__ __launch_bounds__(256) void k_sf_count(const unsigned long long* __restrict__ keys, int N, int G,
+                                                  unsigned int* __restrict__ counts) {
+    __shared__ unsigned int s;
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    unsigned int c = 0;
+    for (int g = threadIdx.x; g < G; g += 256) c += (keys[(size_t)n * G + g] != ~0ull) ? 1u : 0u;
+    atomicAdd(&s, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[n] = s;
+}
+
+__global__ void k_sf_init(const unsigned int* __restrict__ total, int N, unsigned long long* prefix,
+                          unsigned int* rank) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const unsigned int M = total[n];
+    prefix[n] = 0ull; prefix[N + n] = 0ull;
+    rank[n] = M ? (M - 1) / 2 : 0;
+    rank[N + n] = M / 2;
+}
+
+// hist[which][n][256]: digit (key >> shift) & 255 of the keys matching prefix[which][n] above it
+__global__ __launch_bounds__(1024) void k_sf_hist(const unsigned long long* __restrict__ keys, int N, int G,
+                                                  const unsigned long long* __restrict__ prefix, int shift,
+                                                  unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[2][256];
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < 512; i += 1024) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long p0 = prefix[n], p1 = prefix[N + n];
+    const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+    const unsigned long long* row = keys + (size_t)n * G;
+    for (int g = threadIdx.x; g < G; g += 1024) {
+        const unsigned long long k = row[g];
+        if (k == ~0ull) continue;
+        const unsigned int d = (unsigned int)(k >> shift) & 0xff;
+        if ((k & himask) == p0) atomicAdd(&h[0][d], 1u);
+        if ((k & himask) == p1) atomicAdd(&h[1][d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 1024)
+        hist[((size_t)(i >> 8) * N + n) * 256 + (i & 255)] = (&h[0][0])[i];
+}
+
+__global__ void k_sf_pick(const unsigned int* __restrict__ hist, int N, int shift, unsigned long long* prefix,
+                          unsigned int* rank) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // which * N + n
+    if (idx >= 2 * N) return;
+    const unsigned int* h = hist + (size_t)idx * 256;
+    unsigned int r = rank[idx], acc = 0;
+    int d = 0;
+    for (; d < 255; ++d) {
+        if (acc + h[d] > r) break;
+        acc += h[d];
+    }
+    rank[idx] = r - acc;
+    prefix[idx] |= ((unsigned long long)d << shift);
+}
+
+__global__ void k_sf_finish(const unsigned long long* __restrict__ prefix, const unsigned int* __restrict__ total,
+                            int N, double* __restrict__ sf) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const unsigned int M = total[n];
+    if (M == 0) { sf[n] = NAN; return; }
+    const double v0 = key_f64(prefix[n]), v1 = key_f64(prefix[N + n]);
+    const double med = ((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0;
+    sf[n] = exp(med);
+}
+
+hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                          const double* logmeans, const uint8_t* gene_mask, unsigned long long* keys) {
+    const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
+    if (count_type == 1)
+        hipLaunchKernelGGL((k_ratio_keys<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N,
+                           G, logmeans, gene_mask, keys);
+    else
+        hipLaunchKernelGGL((k_ratio_keys<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N,
+                           G, logmeans, gene_mask, keys);
+    return hipGetLastError();
+}
+hipError_t launch_sf_count(hipStream_t st, const unsigned long long* keys, int N, int G, unsigned int* counts) {
+    hipLaunchKernelGGL(k_sf_count, dim3(N), dim3(256), 0, st, keys, N, G, counts);
+    return hipGetLastError();
+}
+hipError_t launch_sf_init(hipStream_t st, const unsigned int* total, int N, unsigned long long* prefix,
+                          unsigned int* rank) {
+    hipLaunchKernelGGL(k_sf_init, dim3((N + 255) / 256), dim3(256), 0, st, total, N, prefix, rank);
+    return hipGetLastError();
+}
+hipError_t launch_sf_hist(hipStream_t st, const unsigned long long* keys, int N, int G,
+                          const unsigned long long* prefix, int shift, unsigned int* hist) {
+    hipLaunchKernelGGL(k_sf_hist, dim3(N), dim3(1024), 0, st, keys, N, G, prefix, shift, hist);
+    return hipGetLastError();
+}
+hipError_t launch_sf_pick(hipStream_t st, const unsigned int* hist, int N, int shift, unsigned long long* prefix,
+                          unsigned int* rank) {
+    hipLaunchKernelGGL(k_sf_pick, dim3((2 * N + 255) / 256), dim3(256), 0, st, hist, N, shift, prefix, rank);
+    return hipGetLastError();
+}
+hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, const unsigned int* total, int N,
+                            double* sf) {
+    hipLaunchKernelGGL(k_sf_finish, dim3((N + 255) / 256), dim3(256), 0, st, prefix, total, N, sf);
+    return hipGetLastError();
+}
+
 }  // namespace dsq

@@ -72,6 +72,18 @@ hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const doubl
                                   const uint8_t* keep, int n, double a0, double a1, double* partials);
 hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
                             double max_disp, uint8_t* keep, double* out5);
+// distributed size factors (per-pass radix select, histograms all-reduced between passes)
+hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                          const double* logmeans, const uint8_t* gene_mask, unsigned long long* keys);
+hipError_t launch_sf_count(hipStream_t st, const unsigned long long* keys, int N, int G, unsigned int* counts);
+hipError_t launch_sf_init(hipStream_t st, const unsigned int* total, int N, unsigned long long* prefix,
+                          unsigned int* rank);
+hipError_t launch_sf_hist(hipStream_t st, const unsigned long long* keys, int N, int G,
+                          const unsigned long long* prefix, int shift, unsigned int* hist);
+hipError_t launch_sf_pick(hipStream_t st, const unsigned int* hist, int N, int shift, unsigned long long* prefix,
+                          unsigned int* rank);
+hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, const unsigned int* total, int N,
+                            double* sf);
 // normed counts (double, gene-major) based rough / moments for the Inference-level API
 hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
                                     const double* pinvXt, int ldx, int N, int G, int P, double* out);

@@ -55,6 +55,8 @@ struct DeviceWave {
         return v;
     }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    // value held by lane `src` (all lanes must be active); src in [0, 64)
+    static __device__ __forceinline__ double from_lane(double v, int src) { return __shfl(v, src, 64); }
     // a value known to be identical in every lane -> scalar registers (frees VGPRs)
     static __device__ __forceinline__ double uniform(double v) {
         const long long b = __double_as_longlong(v);
@@ -86,6 +88,7 @@ struct HostWave {
     static inline double max(double v) { return v; }
     static inline int sumi(int v) { return v; }
     static inline bool any(bool p) { return p; }
+    static inline double from_lane(double v, int) { return v; }
     static inline double uniform(double v) { return v; }
     static inline double sum_comp(KSum k) { return k.value(); }
     template <int K>

@@ -207,6 +207,37 @@ class DeseqPipeline:
         beta = self._down(d_b, Gs * self.P).reshape(Gs, self.P)
         return beta, d_mu, d_hat, self._down(d_c, Gs, np.uint8).astype(bool)
 
+    # ------------------------------------------------------------------ cross-gene steps (hooks)
+    # The only places where a gene needs other genes; DistDeseqPipeline (distributed.py) overrides
+    # them with their multi-GPU versions.
+    def _size_factors(self, d_lm):
+        """Median-of-ratios size factors on the device (preprocessing.py:59-102) -> device array [N]."""
+        if self._work is None:
+            self._work = DeviceArray(self.ctx, (self.N * self.G,), np.float64)
+        d_sf = self._dvec(self.N)
+        self._k("size_factors", self.G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, self.N,
+                self.G, _vp(d_lm.ptr), None, _vp(self._work.ptr), _vp(d_sf.ptr))
+        return d_sf
+
+    def _fit_trend(self, Gn):
+        """Parametric trend on the device (dds.py:1199-1275) -> coeffs[2] or None."""
+        d_gw, d_nm = self._last_gw_dev
+        return self._run_trend_kernel(d_gw, d_nm, Gn)
+
+    def _run_trend_kernel(self, d_gw, d_nm, n):
+        c2, ok, n_outer = (C.c_double * 2)(), C.c_int(0), C.c_int(0)
+        d_keep = self._dvec(n, np.uint8)
+        self._k("trend_fit", n, "dsq_dev_trend_fit", _vp(d_gw.ptr), _vp(d_nm.ptr), int(n),
+                c_double(self.min_disp), c_double(self.max_disp), _vp(d_keep.ptr), c2, C.byref(ok),
+                C.byref(n_outer))
+        return np.array([c2[0], c2[1]]) if ok.value else None
+
+    def _mean_trend(self, genewise_all):
+        return _trend.mean_trend(genewise_all, self.min_disp)
+
+    def _prior(self, gw, fitted_nz, r):
+        return _trend.dispersion_prior(gw, fitted_nz, self.N, self.P, self.min_disp)
+
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False) -> DeseqResult:
         """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald."""
@@ -232,11 +263,7 @@ class DeseqPipeline:
         # ---- size factors (dds.py:692-708)
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
         self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
-        if self._work is None:
-            self._work = DeviceArray(ctx, (N * G,), np.float64)
-        d_sf = self._dvec(N)
-        self._k("size_factors", G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, N, G, _vp(d_lm.ptr), None,
-                 _vp(self._work.ptr), _vp(d_sf.ptr))
+        d_sf = self._size_factors(d_lm)
         sf = self._down(d_sf, N)
         if np.isnan(sf).any():
             raise NotImplementedError(
@@ -270,13 +297,7 @@ class DeseqPipeline:
         # ---- trend (dds.py:799-838) + prior (dds.py:840-884): cross-gene, O(G), host
         coeffs = None
         if self.fit_type == "parametric":
-            d_gw, d_nm = self._last_gw_dev
-            c2, ok, n_outer = (C.c_double * 2)(), C.c_int(0), C.c_int(0)
-            d_keep = self._dvec(Gn, np.uint8)
-            self._k("trend_fit", Gn, "dsq_dev_trend_fit", _vp(d_gw.ptr), _vp(d_nm.ptr), Gn,
-                    c_double(self.min_disp), c_double(self.max_disp), _vp(d_keep.ptr), c2, C.byref(ok),
-                    C.byref(n_outer))
-            coeffs = np.array([c2[0], c2[1]]) if ok.value else None
+            coeffs = self._fit_trend(Gn)
             if coeffs is None:
                 warnings.warn("The dispersion trend curve fitting did not converge. "
                               "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
@@ -289,7 +310,7 @@ class DeseqPipeline:
             fitted = _scatter(G, nzi, fitted_nz)
         else:
             r.disp_function_type = "mean"
-            r.mean_disp = _trend.mean_trend(r.genewise_dispersions, self.min_disp)
+            r.mean_disp = self._mean_trend(r.genewise_dispersions)
             fitted = np.full(G, r.mean_disp)
             fitted_nz = fitted[nzi]
         r.fitted_dispersions = fitted
@@ -297,7 +318,7 @@ class DeseqPipeline:
             warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
                           "dispersions is especially asymmetric and likely to be poorly estimated by the MAD.",
                           UserWarning, stacklevel=2)
-        r.squared_logres, r.prior_disp_var = _trend.dispersion_prior(gw, fitted_nz, N, P, self.min_disp)
+        r.squared_logres, r.prior_disp_var = self._prior(gw, fitted_nz, r)
         t3 = tick(); T["trend_prior"] = t3 - t2
 
         # ---- MAP dispersions (dds.py:886-935)

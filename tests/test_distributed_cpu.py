@@ -1,0 +1,83 @@
+"""World-size-2 CPU tests (gloo) of the gene-sharded multi-GPU protocol: the distributed radix
+select for the size-factor medians and the trend-input gathering give the single-process answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import nbglm_oracle as orc
+from pydeseq2_amd import distributed as D
+from tests.dist_numpy_ops import NumpySfOps, f64_keys, key_f64
+
+
+def test_key_mapping_roundtrip_and_order():
+    v = np.array([-np.inf, -3.5, -1e-300, -0.0, 0.0, 1e-300, 2.0, np.inf])
+    k = f64_keys(v)
+    assert (np.diff(k.astype(np.float64)) >= 0).all()
+    assert (key_f64(k) == v).all()
+
+
+def test_median_protocol_single_rank_matches_numpy():
+    counts, X = orc.synth_counts(301, 24, "2level", 3)
+    lm, keep = orc.logmeans_and_filter(counts)
+    sf_ref = orc.size_factors_ratio(counts)[0]
+    ops = NumpySfOps(counts, lm)
+    sf = D.median_select_protocol(ops, lambda x: x)
+    np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts, X = orc.synth_counts(400, 20, "2level", 11)
+    shard = np.array_split(np.arange(400), world)[rank]
+    mine = counts[:, shard]
+    lm, _ = orc.logmeans_and_filter(mine)
+
+    def allreduce(x):
+        t = torch.from_numpy(x.astype(np.int64))
+        dist.all_reduce(t)
+        return t.numpy().astype(x.dtype)
+
+    sf = D.median_select_protocol(NumpySfOps(mine, lm), allreduce)
+    # trend inputs: gather padded vectors
+    G = len(shard) + 3
+    gw, nm = D.trend_inputs_padded(np.full(len(shard), 0.1 * (rank + 1)), np.arange(len(shard)) + 1.0, G)
+    out = [torch.zeros(2 * G, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, torch.from_numpy(np.concatenate([gw, nm])))
+    allv = torch.stack(out).numpy().reshape(world, 2, G)
+    q.put((rank, sf, allv))
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_protocol_matches_single_process():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    counts, X = orc.synth_counts(400, 20, "2level", 11)
+    sf_ref = orc.size_factors_ratio(counts)[0]
+    for rank, sf, allv in res:
+        np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
+        assert np.isnan(allv[:, :, -3:]).all() and not np.isnan(allv[:, :, :-3]).any()
+        assert np.allclose(allv[1, 0, :-3], 0.2)

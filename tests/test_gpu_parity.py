@@ -206,3 +206,24 @@ def test_full_size_properties():
     same = c == res.genewise_converged[sel].astype(bool)
     assert same.mean() > 0.99
     assert_close(res.genewise_dispersions[sel][same & c], np.clip(a, 1e-8, 200)[same & c], RTOL, 0, "gw subset")
+
+
+def test_distributed_pipeline_world1_equals_single():
+    """RCCL path with a one-rank communicator: dlopen(librccl), comm init, all-reduce / all-gather
+    on device buffers, per-pass size-factor kernels, gathered trend fit == single-GPU pipeline."""
+    import pydeseq2_amd
+    from pydeseq2_amd._lib import Context
+    from pydeseq2_amd.distributed import DistDeseqPipeline, RcclComm
+
+    counts, X = orc.synth_counts(1200, 40, "2level", 4)
+    counts[:, 7] = 0
+    ctx = Context(0)
+    comm = RcclComm(ctx, RcclComm.unique_id(ctx), 0, 1)
+    res_d = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx).deseq2()
+    res_s = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx).deseq2()
+    assert_close(res_d.size_factors, res_s.size_factors, 1e-15, 0, "sf")
+    assert_close(res_d.trend_coeffs, res_s.trend_coeffs, 1e-12, 0, "trend")
+    assert abs(res_d.prior_disp_var - res_s.prior_disp_var) < 1e-12
+    assert_close(res_d.dispersions, res_s.dispersions, 1e-10, 0, "disp")
+    assert_close(res_d.pvalue, res_s.pvalue, 1e-9, 1e-300, "p")
+    comm.close()

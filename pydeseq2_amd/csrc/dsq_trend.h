@@ -60,13 +60,15 @@ DSQ_HD void trend_eval_partial(const TrendData& D, int first, int stride, double
                                TrendPartial& P) {
     for (int i = first; i < D.n; i += stride) {
         if (!D.keep[i]) continue;
-        const double cov = 1.0 / D.means[i];
+        const double cov = frcp(D.means[i]);
         const double t = dmin(dmax(D.disp[i], D.min_disp), D.max_disp);
         const double mu = a0 + a1 * cov;
-        const double v = t / mu + log(mu);
+        const double rmu = frcp(mu);
+        const double tm = t * rmu;
+        const double v = tm + flog(mu);
         if (v == v) { P.s.add(v); P.cf += 1; }
-        const double r = t / mu - 1.0;
-        const double v0 = r / mu, v1 = (r * cov) / mu;
+        const double r = tm - 1.0;
+        const double v0 = r * rmu, v1 = (r * cov) * rmu;
         if (v0 == v0) { P.g0.add(v0); P.c0 += 1; }
         if (v1 == v1) { P.g1.add(v1); P.c1 += 1; }
     }

@@ -146,13 +146,13 @@ class _DeviceSfOps:
     def __init__(self, pipe: DeseqPipeline, d_lm):
         self.p, ctx = pipe, pipe.ctx
         N, G = pipe.N, pipe.G
-        self.d_keys = DeviceArray(ctx, (N * G,), np.uint64)
+        self.d_keys = pipe._pooled((N * G,), np.uint64)
         ctx.call("dsq_dev_sf_keys", _vp(pipe.d_raw.ptr), pipe._count_type, N, G, _vp(d_lm.ptr), None,
                  _vp(self.d_keys.ptr))
-        self.d_cnt = DeviceArray(ctx, (N,), np.uint32)
-        self.d_prefix = DeviceArray(ctx, (2 * N,), np.uint64)
-        self.d_rank = DeviceArray(ctx, (2 * N,), np.uint32)
-        self.d_hist = DeviceArray(ctx, (2 * N * 256,), np.uint32)
+        self.d_cnt = pipe._pooled((N,), np.uint32)
+        self.d_prefix = pipe._pooled((2 * N,), np.uint64)
+        self.d_rank = pipe._pooled((2 * N,), np.uint32)
+        self.d_hist = pipe._pooled((2 * N * 256,), np.uint32)
 
     def count(self):
         self.p.ctx.call("dsq_dev_sf_count", _vp(self.d_keys.ptr), self.p.N, self.p.G, _vp(self.d_cnt.ptr))
@@ -171,7 +171,7 @@ class _DeviceSfOps:
                         _vp(self.d_rank.ptr))
 
     def finish(self, total):
-        d_sf = DeviceArray(self.p.ctx, (self.p.N,), np.float64)
+        d_sf = self.p._pooled((self.p.N,), np.float64)
         self.p.ctx.call("dsq_dev_sf_finish", _vp(self.d_prefix.ptr), _vp(total.ptr), self.p.N, _vp(d_sf.ptr))
         return d_sf
 
@@ -199,7 +199,7 @@ class DistDeseqPipeline(DeseqPipeline):
         G, W = self.G, self.comm.world
         gw, nm = trend_inputs_padded(self._down(d_gw, Gn), self._down(d_nm, Gn), G)
         d_send = self._up(np.concatenate([gw, nm]))
-        d_all = DeviceArray(self.ctx, (2 * G * W,), np.float64)
+        d_all = self._pooled((2 * G * W,), np.float64)
         self.comm.allgather(d_send, d_all)
         allv = self._down(d_all, 2 * G * W).reshape(W, 2, G)
         gw_all = np.ascontiguousarray(allv[:, 0, :].reshape(-1))

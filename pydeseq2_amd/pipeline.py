@@ -124,17 +124,54 @@ class DeseqPipeline:
         self.layers = {}
         self.time_kernels = False
         self.kernel_log = {}
+        self._pool_free, self._pool_used = [], []
         ctx_.sync()
 
     # ------------------------------------------------------------------ helpers
+    # Device buffers are pooled: a deseq2() step re-uses the allocations of the previous one
+    # (hipMalloc/hipFree of the 0.5 GB N x G layers every step costs milliseconds and hipFree
+    # synchronises the device).  Buffers handed out during a step stay valid until the next step.
+    def _take(self, nbytes):
+        nbytes = max(int(nbytes), 8)
+        best = None
+        for i, (cap, ptr) in enumerate(self._pool_free):
+            if cap >= nbytes and (best is None or cap < self._pool_free[best][0]) and cap <= 2 * nbytes + 4096:
+                best = i
+        if best is not None:
+            cap, ptr = self._pool_free.pop(best)
+        else:
+            cap, ptr = nbytes, self.ctx.malloc(nbytes)
+        self._pool_used.append((cap, ptr))
+        return ptr
+
+    def _pool_reset(self):
+        self._pool_free.extend(self._pool_used)
+        self._pool_used = []
+
+    def _pooled(self, shape, dtype, ld=None):
+        arr = DeviceArray.__new__(DeviceArray)
+        arr.ctx = self.ctx
+        arr.shape = tuple(shape)
+        arr.dtype = np.dtype(dtype)
+        arr.ld = ld if ld is not None else (arr.shape[-1] if len(arr.shape) > 1 else None)
+        n = arr.shape[0] * (arr.ld if len(arr.shape) > 1 else 1)
+        arr.nbytes = int(n) * arr.dtype.itemsize
+        arr.ptr = self._take(arr.nbytes)
+        arr.free = lambda: None  # owned by the pool
+        return arr
+
     def _dvec(self, n, dtype=np.float64):
-        return DeviceArray(self.ctx, (max(int(n), 1),), dtype)
+        return self._pooled((max(int(n), 1),), dtype)
 
     def _dmat(self, rows, dtype=np.float64):
-        return DeviceArray(self.ctx, (max(int(rows), 1), self.N), dtype, ld=self.ldn)
+        return self._pooled((max(int(rows), 1), self.N), dtype, ld=self.ldn)
 
     def _up(self, arr, dtype=np.float64):
-        return DeviceArray.from_host(self.ctx, np.ascontiguousarray(arr, dtype=dtype))
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        d = self._pooled(arr.shape if arr.ndim else (1,), arr.dtype)
+        if arr.size:
+            self.ctx.h2d(d.ptr, arr)
+        return d
 
     def _down(self, darr, n, dtype=np.float64):
         out = np.empty(int(n), dtype=dtype)
@@ -259,6 +296,7 @@ class DeseqPipeline:
                 ctx.sync()
             return time.perf_counter()
 
+        self._pool_reset()
         t0 = tick()
         # ---- size factors (dds.py:692-708)
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
@@ -331,7 +369,6 @@ class DeseqPipeline:
         disp_nz[out_nz] = gw[out_nz]
         r.outlier_genes = _scatter(G, nzi, out_nz.astype(float), fill=0.0).astype(bool)
         r.dispersions = _scatter(G, nzi, disp_nz)
-        d_mu_hat.free()
         t4 = tick(); T["MAP"] = t4 - t3
 
         # ---- LFC (dds.py:937-984)
@@ -429,10 +466,20 @@ class DeseqPipeline:
         t8 = tick(); T["wald"] = t8 - t7
         T["total"] = t8 - t0
         if not self.keep_cooks:
-            for k in ("mu_LFC", "hat_diagonals", "cooks"):
-                self.layers[k].free()
             self.layers = {}
         return r
+
+    def close(self):
+        """Release the pooled device buffers."""
+        for _cap, ptr in self._pool_free + self._pool_used:
+            self.ctx.free(ptr)
+        self._pool_free, self._pool_used = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ lazy N x G layers
     def layer(self, name):

@@ -63,6 +63,9 @@ int dsq_sync(dsq_ctx* ctx);
 /* HIP-event stopwatch on the context's stream (used by bench.py for kernel timing) */
 int dsq_timer_start(dsq_ctx* ctx);
 int dsq_timer_stop(dsq_ctx* ctx, float* elapsed_ms);
+/* duration of the k_alpha launch inside the last *_alpha_mle call (HIP events on the launch
+ * stream) and the number of genes that needed the grid-search fallback */
+int dsq_last_alpha_kernel(dsq_ctx* ctx, float* kernel_ms, int* n_grid_fallback);
 
 /* ------------------------------------------------------------------ device memory */
 int dsq_malloc(dsq_ctx* ctx, size_t bytes, void** dptr);

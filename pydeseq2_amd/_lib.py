@@ -54,6 +54,7 @@ def load():
     proto("dsq_sync", _vp)
     proto("dsq_timer_start", _vp)
     proto("dsq_timer_stop", _vp, C.POINTER(C.c_float))
+    proto("dsq_last_alpha_kernel", _vp, C.POINTER(C.c_float), C.POINTER(c_int))
     proto("dsq_malloc", _vp, c_size_t, C.POINTER(_vp))
     proto("dsq_free", _vp, _vp)
     proto("dsq_memset", _vp, _vp, c_int, c_size_t)
@@ -111,7 +112,7 @@ def load():
 
 EXPORTS = [
     "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_timer_start",
-    "dsq_timer_stop", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
+    "dsq_timer_stop", "dsq_last_alpha_kernel", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
     "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
     "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit",
     "dsq_dev_counts_to_gene_major", "dsq_dev_f64_to_gene_major", "dsq_dev_logmeans",

@@ -17,7 +17,9 @@
 struct dsq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    float last_kernel_ms = 0.0f;  // k_alpha launch of the last dsq_*_alpha_mle call (HIP events)
+    int last_n_grid = 0;          // genes that took the grid-search fallback in that call
     double* d_scratch = nullptr;  // 8 KiB of device scratch (scalars, trend partials)
     int32_t* d_counter = nullptr; // IRLS fallback / dispersion grid-search counters
     int32_t* d_list = nullptr;    // gene index list of the rare second-pass kernels (grown on demand)
@@ -195,14 +197,22 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     int32_t* d_cnt = ctx->d_counter + 4;
     DSQ_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+    DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
                               prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list));
+    DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t n_grid = 0;
     DSQ_HIP(hipMemcpyAsync(&n_grid, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (n_grid > 0)
+    DSQ_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->evk0, ctx->evk1));
+    ctx->last_n_grid = n_grid;
+    if (n_grid > 0) {
+        DevBuf work;
+        DSQ_HIP(work.alloc((size_t)n_grid * 102 * sizeof(double)));
         DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
-                                       ctx->d_list, n_grid));
+                                       ctx->d_list, n_grid, work.as<double>()));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return DSQ_OK;
 }
 
@@ -220,6 +230,8 @@ int dsq_create(int device_id, dsq_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evk0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evk1);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch, kScratchBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 64);
     if (e != hipSuccess) {
@@ -258,6 +270,12 @@ int dsq_device_info(dsq_ctx* ctx, char* name, int name_len, int* cu_count, size_
 
 int dsq_sync(dsq_ctx* ctx) {
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_last_alpha_kernel(dsq_ctx* ctx, float* kernel_ms, int* n_grid_fallback) {
+    if (kernel_ms) *kernel_ms = ctx->last_kernel_ms;
+    if (n_grid_fallback) *n_grid_fallback = ctx->last_n_grid;
     return DSQ_OK;
 }
 

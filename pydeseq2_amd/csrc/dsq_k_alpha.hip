@@ -38,20 +38,60 @@ __global__ __launch_bounds__(kBlock, DSQ_ALPHA_WAVES) void k_alpha(const int32_t
     }
 }
 
-// grid-search fallback for the (rare) genes whose L-BFGS-B run reported success = False
+// Grid-search fallback (grid_search.py:54-142) for the (rare) genes whose L-BFGS-B run reported
+// success = False.  A gene's 100 grid evaluations are independent, so they are spread over 100
+// wavefronts (one grid point each) instead of one wave walking them serially (which cost ~2 ms of
+// pure latency per launch): eval(coarse) -> pick -> eval(fine) -> pick, four tiny launches.
+constexpr int kGridLen = 100;
+
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_alpha_grid(const int32_t* __restrict__ y,
-                                                       const double* __restrict__ mu, int ldn,
-                                                       const double* __restrict__ Xt, int ldx, int N,
-                                                       double min_disp, double max_disp,
-                                                       double* __restrict__ alpha,
-                                                       const int32_t* __restrict__ grid_list, int n_grid) {
-    const int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (k >= n_grid) return;
+__global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __restrict__ y,
+                                                            const double* __restrict__ mu, int ldn,
+                                                            const double* __restrict__ Xt, int ldx, int N,
+                                                            const int32_t* __restrict__ grid_list, int n_grid,
+                                                            const double* __restrict__ lohi,
+                                                            double* __restrict__ ll) {
+    const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= n_grid * kGridLen) return;
+    const int k = w / kGridLen, i = w % kGridLen;
     const int g = grid_list[k];
-    const double a = grid_alpha_gene<DeviceWave, P>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx, N,
-                                                    min_disp, max_disp);
-    if ((threadIdx.x & 63) == 0) alpha[g] = a;
+    AlphaArgs A;
+    A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.la_hat = 0.0; A.prior_var = 1.0; A.cr_reg = true; A.prior_reg = false;
+    A.cst = alpha_const<DeviceWave>(A.y, A.mu, N);
+    double f, gu;
+    alpha_eval<DeviceWave, P, false>(A, linspace_at(lohi[2 * k], lohi[2 * k + 1], kGridLen, i), true, false, f, gu);
+    if ((threadIdx.x & 63) == 0) ll[(size_t)k * kGridLen + i] = f;
+}
+
+// argmin over a gene's grid (numpy.argmin: first minimum, first NaN wins); stage 0 -> refine
+// interval [c - delta, c + delta] into lohi, stage 1 -> alpha = exp(best log alpha)
+__global__ void k_alpha_grid_pick(const double* __restrict__ ll, const int32_t* __restrict__ grid_list, int n_grid,
+                                  double* __restrict__ lohi, int stage, double* __restrict__ alpha) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_grid) return;
+    const double lo = lohi[2 * k], hi = lohi[2 * k + 1];
+    double best = 0.0;
+    int kb = 0;
+    bool best_nan = false;
+    for (int i = 0; i < kGridLen; ++i) {
+        const double f = ll[(size_t)k * kGridLen + i];
+        const bool isn = (f != f);
+        if (i == 0 || (!best_nan && (isn || f < best))) { best = f; kb = i; best_nan = isn; }
+    }
+    const double c = linspace_at(lo, hi, kGridLen, kb);
+    if (stage == 0) {
+        const double delta = linspace_at(lo, hi, kGridLen, 1) - linspace_at(lo, hi, kGridLen, 0);
+        lohi[2 * k] = c - delta;
+        lohi[2 * k + 1] = c + delta;
+    } else {
+        alpha[grid_list[k]] = exp(c);
+    }
+}
+
+__global__ void k_fill_lohi(double* lohi, int n, double lo, double hi) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { lohi[2 * k] = lo; lohi[2 * k + 1] = hi; }
 }
 
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
@@ -66,13 +106,21 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     return hipGetLastError();
 }
 
+// work: n_grid * (2 + kGridLen) doubles of device scratch
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P_, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid) {
+                             const int32_t* grid_list, int n_grid, double* work) {
     if (n_grid <= 0) return hipSuccess;
-    const dim3 grid(genes_to_blocks(n_grid)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha_grid<P>, grid, block, 0, st, y, mu, ldn, Xt, ldx, N,
-                                          min_disp, max_disp, alpha, grid_list, n_grid))
+    double* lohi = work;
+    double* ll = work + 2 * (size_t)n_grid;
+    const dim3 ge(genes_to_blocks(n_grid * kGridLen)), block(kBlock), gp((n_grid + 63) / 64), bp(64);
+    hipLaunchKernelGGL(k_fill_lohi, gp, bp, 0, st, lohi, n_grid, log(min_disp), log(max_disp));
+    for (int stage = 0; stage < 2; ++stage) {
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha_grid_eval<P>, ge, block, 0, st, y, mu, ldn, Xt, ldx, N,
+                                              grid_list, n_grid, (const double*)lohi, ll))
+        hipLaunchKernelGGL(k_alpha_grid_pick, gp, bp, 0, st, (const double*)ll, grid_list, n_grid, lohi, stage,
+                           alpha);
+    }
     return hipGetLastError();
 }
 

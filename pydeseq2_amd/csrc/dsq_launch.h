@@ -19,7 +19,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid);
+                             const int32_t* grid_list, int n_grid, double* work);
 
 // ---- dsq_k_irls.hip
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,

@@ -185,7 +185,13 @@ class DeseqPipeline:
         if self.time_kernels:
             self.ctx.timer_start()
             self.ctx.call(cname, *args)
-            self.kernel_log.setdefault(name, []).append((self.ctx.timer_stop(), int(genes)))
+            ms = self.ctx.timer_stop()
+            self.kernel_log.setdefault(name, []).append((ms, int(genes)))
+            if cname == "dsq_dev_alpha_mle":  # kernel-only duration of k_alpha (events inside the C call)
+                kms, ng = C.c_float(), C.c_int()
+                self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
+                self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
+                self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
         else:
             self.ctx.call(cname, *args)
 

@@ -7,16 +7,16 @@
 // leaves [1e-4, 15) until the coefficients stop moving.  It is a cross-gene step (needs every
 // gene) but touches only two doubles per gene, so ONE wavefront runs the whole thing in one
 // launch: lanes stride over the genes for the loss/gradient sums (compensated, fixed order =>
-// run-to-run deterministic), the L-BFGS-B state machine (dsq_lbfgsb.h, n = 2) runs
+// run-to-run deterministic), the L-BFGS-B state machine (dsq_lbfgsb_dense.h, n = 2) runs
 // wave-uniformly on an LDS workspace.  No host round trip per function evaluation.
 #pragma once
-#include "dsq_lbfgsb.h"
+#include "dsq_lbfgsb_dense.h"
 #include "dsq_wave.h"
 
 namespace dsq {
 
 struct TrendWork {
-    LbfgsbWork<2> lb;
+    LbfgsbDenseWork<2> lb;
     double x[2], l[2], u[2];
     int nbd[2];
 };
@@ -102,7 +102,7 @@ DSQ_HD TrendOut trend_fit_core(Ops& ops, TrendWork& W) {
         W.x[0] = 1.0; W.x[1] = 1.0;
         W.l[0] = 1e-12; W.l[1] = 1e-12; W.u[0] = 0.0; W.u[1] = 0.0;
         W.nbd[0] = 1; W.nbd[1] = 1;
-        const LbfgsbResult res = lbfgsb_nd<2>(fg, 2, W.x, W.l, W.u, W.nbd, W.lb);
+        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, W.x, W.l, W.u, W.nbd, W.lb);
         a0 = W.x[0]; a1 = W.x[1];
         out.n_outer += 1;
         out.n_kept = kept;

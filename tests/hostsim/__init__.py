@@ -227,7 +227,11 @@ def alpha_eval(y, mu, X, la, la_hat=0.0, prior_var=1.0, cr_reg=True, prior_reg=F
 FGN_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
-def lbfgsb_nd(fg, x0, bounds):
+def lbfgsb_dense(fg, x0, bounds):
+    return lbfgsb_nd(fg, x0, bounds, entry="hs_lbfgsb_dense")
+
+
+def lbfgsb_nd(fg, x0, bounds, entry="hs_lbfgsb_nd"):
     """bounds: list of (lo, hi) with None/inf for unbounded (scipy convention)."""
     n = len(x0)
     x = np.ascontiguousarray(x0, dtype=np.float64).copy()
@@ -250,7 +254,7 @@ def lbfgsb_nd(fg, x0, bounds):
 
     f = C.c_double()
     ok, nfev, nit, st = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    rc = lib().hs_lbfgsb_nd(FGN_CB(cb), C.c_int(n), _p(x, C.c_double), _p(l, C.c_double), _p(u, C.c_double),
+    rc = getattr(lib(), entry)(FGN_CB(cb), C.c_int(n), _p(x, C.c_double), _p(l, C.c_double), _p(u, C.c_double),
                             _p(nbd, C.c_int32), C.byref(f), C.byref(ok), C.byref(nfev), C.byref(nit), C.byref(st))
     assert rc == 0
     return x, f.value, bool(ok.value), nfev.value, nit.value, st.value

@@ -15,6 +15,7 @@
 #include "dsq_dispatch.h"
 #include "dsq_irls.h"
 #include "dsq_lbfgsb.h"
+#include "dsq_lbfgsb_dense.h"
 #include "dsq_stats.h"
 #include "dsq_trend.h"
 
@@ -218,6 +219,16 @@ int hs_trend_fit(const double* disp, const double* means, int n, double min_disp
     std::memset(&W, 0, sizeof(W));
     TrendOut o = trend_fit<HostWave>(disp, means, n, min_disp, max_disp, keep.data(), W);
     coeffs[0] = o.a0; coeffs[1] = o.a1; *ok = o.ok; *n_outer = o.n_outer;
+    return 0;
+}
+
+int hs_lbfgsb_dense(fgn_cb cb, int n, double* x, const double* l, const double* u, const int* nbd,
+                    double* f, int* success, int* nfev, int* nit, int* status) {
+    if (n < 1 || n > 4) return -1;
+    static LbfgsbDenseWork<4> W;
+    auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
+    LbfgsbResult r = lbfgsb_dense<4>(fg, n, x, l, u, nbd, W);
+    *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
     return 0;
 }
 

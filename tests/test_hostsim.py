@@ -205,3 +205,25 @@ def test_lean_log_matches_libm():
     u = np.concatenate([10 ** np.random.default_rng(2).uniform(-20, 6, 50000), [0.0, 4.9e-9, 5e-9]])
     _, l1, _ = hs.flog(u)
     assert np.max(np.abs(l1 - np.log1p(u)) / (np.spacing(np.log1p(u)) + 1e-320)) <= 1.0
+
+
+def test_lbfgsb_dense_matches_scipy():
+    """Dense-matrix L-BFGS-B (n <= 4) used by the trend fit: same iterates as scipy."""
+    rng = np.random.default_rng(8)
+    for t in range(150):
+        n = int(rng.integers(1, 5))
+        A = rng.normal(size=(n + 3, n))
+        Q = A.T @ A * 10 ** rng.uniform(-1, 2) + np.eye(n) * 10 ** rng.uniform(-3, 0)
+        c, w = rng.normal(0, 3, n), rng.uniform(0.2, 2, n)
+
+        def fg(x):
+            d = x - c
+            e = np.exp(np.clip(w * d, -50, 50))
+            return 0.5 * d @ Q @ d + e.sum(), Q @ d + w * e
+
+        bounds = [(-30, 30)] * n if t % 2 else [(ci - abs(rng.normal(0, 2)), None) for ci in c]
+        x0 = c + rng.normal(0, 3, n)
+        res = minimize(lambda x: fg(x)[0], x0, jac=lambda x: fg(x)[1], method="L-BFGS-B", bounds=bounds)
+        x, f, ok, nfev, nit, st = hs.lbfgsb_dense(fg, x0, bounds)
+        assert ok == res.success and nit == res.nit
+        assert np.max(np.abs(x - res.x)) <= 1e-7 * max(1, np.max(np.abs(res.x)))

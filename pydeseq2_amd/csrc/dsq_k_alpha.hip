@@ -6,14 +6,19 @@
 #include "dsq_dispatch.h"
 #include "dsq_launch.h"
 
-#ifndef DSQ_ALPHA_WAVES
-#define DSQ_ALPHA_WAVES 1
+// minimum waves per SIMD requested from the register allocator: the kernel alternates long
+// dependent fp64 chains with L2-latency loads, so 4 waves/SIMD (<= 128 VGPRs) beats the
+// compiler's default 2 (measured 4.32 -> 3.69 ms per launch at 60k x 1k, p = 2); wide designs keep
+// their p(p+1) accumulators in registers and are left at lower occupancy instead of spilling.
+#ifndef DSQ_ALPHA_WAVES_WIDE
+#define DSQ_ALPHA_WAVES_WIDE 2
 #endif
+constexpr int alpha_min_waves(int p) { return p <= 3 ? 4 : (p <= 5 ? 2 : DSQ_ALPHA_WAVES_WIDE); }
 
 namespace dsq {
 
 template <int P>
-__global__ __launch_bounds__(kBlock, DSQ_ALPHA_WAVES) void k_alpha(const int32_t* __restrict__ y,
+__global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int32_t* __restrict__ y,
                                                   const double* __restrict__ mu, int ldn,
                                                   const double* __restrict__ Xt, int ldx, int N, int G,
                                                   const double* __restrict__ alpha_hat,

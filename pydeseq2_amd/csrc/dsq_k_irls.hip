@@ -7,8 +7,12 @@
 
 namespace dsq {
 
+// wide designs: ask for 2 waves/SIMD (a few spilled accumulators cost less than running one
+// wave per SIMD with nothing to overlap its fp64 dependency chains)
+constexpr int irls_min_waves(int p) { return p <= 5 ? 1 : 2; }
+
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_irls(const int32_t* __restrict__ y, int ldn,
+__global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
                                                  const double* __restrict__ sf,
                                                  const double* __restrict__ Xt,
                                                  const double* __restrict__ pinvXt, int ldx, int N,

@@ -143,6 +143,14 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
                       double min_disp, double max_disp, uint8_t* d_keep, double* h_coeffs2,
                       int* h_ok, int* h_n_outer);
 
+/* DeseqDataSet.fit_dispersion_prior (dds.py:866-879) + utils.mean_absolute_deviation
+ * (utils.py:1210-1227): squared_logres = (MAD(log genewise - log fitted) / norm.ppf(0.75))^2 over
+ * the genes with genewise >= 100*min_disp; exact medians by radix select in one workgroup.
+ * d_gw_raw: raw genewise dispersions (clipped on the fly), d_fitted: trend values, n genes,
+ * d_work: n doubles of device scratch. */
+int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitted, int n,
+                      double min_disp, double max_disp, double* d_work, double* h_squared_logres);
+
 /* ================================================================== device-resident stage API
  * All pointers are device pointers unless named h_*.  Gene-major rows have pitch ldn.
  * Xt and pinvXt are [P][ldx] (design transposed; rows of (X^T X)^-1 X^T). */

@@ -76,6 +76,7 @@ def load():
           C.POINTER(c_double))
     proto("dsq_dev_trend_fit", _vp, _vp, _vp, c_int, c_double, c_double, _vp, C.POINTER(c_double),
           C.POINTER(c_int), C.POINTER(c_int))
+    proto("dsq_dev_prior_mad", _vp, _vp, _vp, c_int, c_double, c_double, _vp, C.POINTER(c_double))
     # device-resident stages
     proto("dsq_dev_counts_to_gene_major", _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_int, C.POINTER(c_int))
     proto("dsq_dev_f64_to_gene_major", _vp, _vp, c_int, c_int, c_int, _vp, c_int)
@@ -114,7 +115,7 @@ EXPORTS = [
     "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_timer_start",
     "dsq_timer_stop", "dsq_last_alpha_kernel", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
     "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
-    "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit",
+    "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit", "dsq_dev_prior_mad",
     "dsq_dev_counts_to_gene_major", "dsq_dev_f64_to_gene_major", "dsq_dev_logmeans",
     "dsq_dev_size_factors", "dsq_dev_mom", "dsq_dev_lin_mu", "dsq_dev_alpha_mle", "dsq_dev_irls",
     "dsq_dev_cooks", "dsq_dev_replace_outliers", "dsq_dev_wald", "dsq_dev_gather_rows_f64",

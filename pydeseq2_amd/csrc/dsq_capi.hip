@@ -24,6 +24,8 @@ struct dsq_ctx {
     int32_t* d_counter = nullptr; // IRLS fallback / dispersion grid-search counters
     int32_t* d_list = nullptr;    // gene index list of the rare second-pass kernels (grown on demand)
     size_t list_cap = 0;
+    double* d_lsf = nullptr;      // log(size factors) of the current IRLS call (grown on demand)
+    size_t lsf_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -249,6 +251,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_list) (void)hipFree(ctx->d_list);
+    if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -399,15 +402,22 @@ int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, 
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     if (G <= 0) return DSQ_OK;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
+    if ((size_t)N > ctx->lsf_cap) {
+        if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
+        ctx->d_lsf = nullptr; ctx->lsf_cap = 0;
+        DSQ_HIP(hipMalloc((void**)&ctx->d_lsf, (size_t)N * sizeof(double)));
+        ctx->lsf_cap = (size_t)N;
+    }
+    DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
     DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, sizeof(int32_t), ctx->stream));
-    DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
+    DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
                              d_converged, d_iters, ctx->d_counter, ctx->d_list));
     int32_t n_fb = 0;
     DSQ_HIP(hipMemcpyAsync(&n_fb, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     if (n_fb > 0) {
-        DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
+        DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
                                         d_hat, d_converged, d_iters, ctx->d_list, n_fb));
         DSQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -474,6 +484,17 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
     h_coeffs2[0] = out5[0]; h_coeffs2[1] = out5[1];
     if (h_ok) *h_ok = (int)out5[2];
     if (h_n_outer) *h_n_outer = (int)out5[3];
+    return DSQ_OK;
+}
+
+int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitted, int n, double min_disp,
+                      double max_disp, double* d_work, double* h_squared_logres) {
+    double* d_out = ctx->d_scratch + 1600;
+    DSQ_HIP(dsq::launch_prior_mad(ctx->stream, d_gw_raw, d_fitted, n, min_disp, max_disp, d_work, d_out));
+    double out2[2];
+    DSQ_HIP(hipMemcpyAsync(out2, d_out, sizeof(out2), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    *h_squared_logres = out2[0];
     return DSQ_OK;
 }
 

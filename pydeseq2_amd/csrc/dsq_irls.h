@@ -23,6 +23,7 @@ namespace dsq {
 struct IrlsArgs {
     const int32_t* y;     // [N]
     const double* sf;     // [N]
+    const double* lsf;    // [N] log(sf) (optional, nullptr -> computed on the fly)
     const double* Xt;     // [P][ldx]
     const double* pinvXt; // [P][ldx] rows of (X^T X)^-1 X^T  (QR initialisation, :349-353)
     int ldx, N;
@@ -37,6 +38,7 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
                        double (&M)[Tri<P>::N], double (&r)[P]) {
     constexpr int T = Tri<P>::N;
     double s = 0.0;
+    const double lmin = log(A.min_mu);
 #pragma unroll
     for (int k = 0; k < T; ++k) M[k] = 0.0;
 #pragma unroll
@@ -48,12 +50,17 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
         double eta = 0.0;
 #pragma unroll
         for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
-        const double mu = dmax(sfn * exp(eta), A.min_mu);
-        const double lmu = flog(mu);
+        // mu = max(sf exp(eta), min_mu).  While mu is not clamped, log(mu) = eta + log(sf) and
+        // log(mu/sf) = eta hold exactly in real arithmetic, so only log(a + mu) needs a log.
+        const double mu_raw = sfn * exp(eta);
+        const bool clamped = !(mu_raw > A.min_mu);
+        const double mu = clamped ? A.min_mu : mu_raw;
+        const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
+        const double lmu = clamped ? lmin : eta + lsfn;
         const double rmu = frcp(mu);
         s += (yv + a) * flog(a + mu) - yv * lmu;
         const double w = mu * frcp(1.0 + mu * A.disp);
-        const double z = flog(mu * frcp(sfn)) + (yv - mu) * rmu;
+        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
         const double wz = w * z;
 #pragma unroll
         for (int i = 0; i < P; ++i) {

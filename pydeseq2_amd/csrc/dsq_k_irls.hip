@@ -13,7 +13,7 @@ constexpr int irls_min_waves(int p) { return p <= 5 ? 1 : 2; }
 
 template <int P>
 __global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
-                                                 const double* __restrict__ sf,
+                                                 const double* __restrict__ sf, const double* __restrict__ lsf,
                                                  const double* __restrict__ Xt,
                                                  const double* __restrict__ pinvXt, int ldx, int N,
                                                  int G, int full_rank, const double* __restrict__ disp,
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (g >= G) return;
     IrlsArgs A;
-    A.y = y + (size_t)g * ldn; A.sf = sf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+    A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
     double b[P];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_
 
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restrict__ y, int ldn,
-                                                        const double* __restrict__ sf,
+                                                        const double* __restrict__ sf, const double* __restrict__ lsf,
                                                         const double* __restrict__ Xt,
                                                         const double* __restrict__ pinvXt, int ldx,
                                                         int N, int full_rank,
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     if (!live) return;
     const int g = fb_list[k];
     IrlsArgs A;
-    A.y = y + (size_t)g * ldn; A.sf = sf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+    A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
     __shared__ IrlsRescueWork<P> work[kWavesPerBlock];
@@ -75,28 +75,29 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     }
 }
 
-hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
+                       const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P_, int full_rank,
                        const double* disp, double min_mu, double beta_tol, double min_beta,
                        double max_beta, int maxiter, double* beta, double* mu, double* hat,
                        uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list) {
     if (G <= 0) return hipSuccess;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N,
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N,
                                           G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
                                           maxiter, beta, mu, hat, conv, iters, fb_count, fb_list))
     return hipGetLastError();
 }
 
 hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf,
-                              const double* Xt, const double* pinvXt, int ldx, int N, int P_,
+                              const double* lsf, const double* Xt, const double* pinvXt, int ldx, int N, int P_,
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
                               int n_fb) {
     if (n_fb <= 0) return hipSuccess;
     const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt,
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
                                           ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
                                           maxiter, beta, mu, hat, conv, iters, fb_list, n_fb))
     return hipGetLastError();

@@ -180,63 +180,152 @@ __global__ __launch_bounds__(256) void k_ratio_keys(const SrcT* __restrict__ cou
     }
 }
 
-// pass 2: one workgroup per sample; 8 radix passes of 8 bits find the element of rank k
-// among the M usable keys; done for the two middle ranks -> median -> size factor.
-__global__ __launch_bounds__(1024) void k_row_median(const unsigned long long* __restrict__ keys, int N,
-                                                     int G, double* __restrict__ sf) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ unsigned int s_rank;
-    __shared__ unsigned int s_count;
-    const int n = blockIdx.x;
-    const unsigned long long* row = keys + (size_t)n * G;
-    // number of usable genes
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    unsigned int c = 0;
-    for (int g = threadIdx.x; g < G; g += 1024) c += (row[g] != ~0ull) ? 1u : 0u;
-    atomicAdd(&s_count, c);
-    __syncthreads();
-    const unsigned int M = s_count;
-    if (M == 0) {
-        if (threadIdx.x == 0) sf[n] = NAN;  // np.median of an empty row
-        return;
+// ---- workgroup-wide exact median by radix select --------------------------------------------
+// 64-bit order-preserving keys are resolved 11 bits at a time (6 passes: 11,11,11,11,11,9 bits);
+// both middle order statistics (ranks (M-1)/2 and M/2) are tracked in the same sweeps, and the
+// first sweep's histogram also yields the number M of valid keys.  key(i) may recompute its value
+// (no key array needed).  All 1024 threads of the block must call it.
+struct MedianShared {
+    unsigned int hist[2][2048];
+    unsigned long long prefix[2];
+    unsigned int rank[2];
+    unsigned int M;
+};
+
+// one wave: digit d with cumsum(h[0..d-1]) <= r < cumsum(h[0..d]); r becomes the rank inside bin d
+__device__ __forceinline__ int pick_digit(const unsigned int* h, int nbins, unsigned int& r) {
+    const int lane = threadIdx.x & 63;
+    const int per = nbins / 64;  // 32 (2048 bins) or 8 (512 bins)
+    unsigned int mine = 0;
+    for (int k = 0; k < per; ++k) mine += h[lane * per + k];
+    unsigned int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
-    double vals[2];
-    const unsigned int ranks[2] = {(M - 1) / 2, M / 2};
-    for (int which = 0; which < 2; ++which) {
-        if (which == 1 && ranks[1] == ranks[0]) { vals[1] = vals[0]; break; }
-        if (threadIdx.x == 0) { s_prefix = 0ull; s_rank = ranks[which]; }
+    const unsigned int excl = incl - mine;
+    const bool here = (excl <= r) && (r < incl);
+    const unsigned long long ball = __ballot(here);
+    const int src = ball ? (__ffsll((long long)ball) - 1) : 63;
+    int d = nbins - 1;
+    unsigned int rr = 0;
+    if (lane == src) {
+        unsigned int acc = excl;
+        int k = 0;
+        for (; k < per - 1; ++k) {
+            const unsigned int c = h[lane * per + k];
+            if (acc + c > r) break;
+            acc += c;
+        }
+        d = lane * per + k;
+        rr = r - acc;
+    }
+    d = __shfl(d, src, 64);
+    r = __shfl(rr, src, 64);
+    return d;
+}
+
+template <class KeyFn>
+__device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, unsigned int& M_out) {
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int pass = 0; pass < 6; ++pass) {
+        const int shift = shifts[pass];
+        const int nbins = pass == 5 ? 512 : 2048;
+        for (int i = tid; i < 2 * 2048; i += NT) (&S.hist[0][0])[i] = 0;
         __syncthreads();
-        for (int shift = 56; shift >= 0; shift -= 8) {
-            for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
-            __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
-            for (int g = threadIdx.x; g < G; g += 1024) {
-                const unsigned long long k = row[g];
-                if (k != ~0ull && (k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xff], 1u);
+        const unsigned long long p0 = S.prefix[0], p1 = S.prefix[1];
+        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
+        for (int i = tid; i < n; i += NT) {
+            const unsigned long long k = key(i);
+            if (k == ~0ull) continue;
+            const unsigned int d = (unsigned int)(k >> shift) & (unsigned int)(nbins - 1);
+            if (pass == 0) {
+                atomicAdd(&S.hist[0][d], 1u);
+            } else {
+                if ((k & himask) == p0) atomicAdd(&S.hist[0][d], 1u);
+                if ((k & himask) == p1) atomicAdd(&S.hist[1][d], 1u);
             }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int r = s_rank, acc = 0;
-                int d = 0;
-                for (; d < 256; ++d) {
-                    if (acc + hist[d] > r) break;
-                    acc += hist[d];
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (tid < 64) {  // total count and the two target ranks
+                unsigned int c = 0;
+                for (int k = tid; k < 2048; k += 64) c += S.hist[0][k];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                if (tid == 0) {
+                    S.M = c;
+                    S.rank[0] = c ? (c - 1) / 2 : 0;
+                    S.rank[1] = c / 2;
+                    S.prefix[0] = 0ull;
+                    S.prefix[1] = 0ull;
                 }
-                s_rank = r - acc;
-                s_prefix = prefix | ((unsigned long long)d << shift);
             }
             __syncthreads();
         }
-        vals[which] = key_f64(s_prefix);
+        const int w = tid >> 6;
+        if (w < 2) {
+            unsigned int r = S.rank[w];
+            const int d = pick_digit(S.hist[pass == 0 ? 0 : w], nbins, r);
+            if ((tid & 63) == 0) {
+                S.rank[w] = r;
+                S.prefix[w] |= ((unsigned long long)d << shift);
+            }
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double med = (ranks[0] == ranks[1]) ? vals[0] : (vals[0] + vals[1]) / 2.0;
-        sf[n] = exp(med);
+    const unsigned int M = S.M;
+    M_out = M;
+    if (M == 0) { median = NAN; return; }
+    const double v0 = key_f64(S.prefix[0]), v1 = key_f64(S.prefix[1]);
+    median = ((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0;
+}
+
+// per-sample median of the log-ratio keys -> size factor (preprocessing.py:96-100)
+__global__ __launch_bounds__(1024) void k_row_median(const unsigned long long* __restrict__ keys, int N,
+                                                     int G, double* __restrict__ sf) {
+    __shared__ MedianShared S;
+    const int n = blockIdx.x;
+    const unsigned long long* row = keys + (size_t)n * G;
+    double med;
+    unsigned int M;
+    block_median([&](int g) { return row[g]; }, G, S, med, M);
+    if (threadIdx.x == 0) sf[n] = (M == 0) ? NAN : exp(med);
+}
+
+// dispersion prior (dds.py:866-884, utils.py:1210-1227): MAD^2 of log(genewise) - log(fitted) over
+// the genes with genewise >= 100 * min_disp, one workgroup.  out[0] = squared_logres.
+__global__ __launch_bounds__(1024) void k_prior_mad(const double* __restrict__ gw_raw,
+                                                    const double* __restrict__ fitted, int n, double min_disp,
+                                                    double max_disp, double* __restrict__ res,
+                                                    double* __restrict__ out) {
+    __shared__ MedianShared S;
+    // residuals once (NaN marks genes below the 100*min_disp threshold), then two radix selects
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double g = dmin(dmax(gw_raw[i], min_disp), max_disp);
+        res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
     }
+    __syncthreads();
+    double center, mad;
+    unsigned int M;
+    block_median([&](int i) { const double r = res[i]; return (r == r) ? f64_key(r) : ~0ull; }, n, S, center, M);
+    __syncthreads();
+    block_median([&](int i) { const double r = res[i]; return (r == r) ? f64_key(fabs(r - center)) : ~0ull; },
+                 n, S, mad, M);
+    if (threadIdx.x == 0) {
+        const double m = mad / 0.67448975019608171;  // norm.ppf(0.75)
+        out[0] = m * m;
+        out[1] = (double)M;
+    }
+}
+
+hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
+                            double max_disp, double* res_scratch, double* out2) {
+    hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, gw_raw, fitted, n, min_disp, max_disp,
+                       res_scratch, out2);
+    return hipGetLastError();
 }
 
 hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
@@ -833,6 +922,16 @@ hipError_t launch_sf_pick(hipStream_t st, const unsigned int* hist, int N, int s
 hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, const unsigned int* total, int N,
                             double* sf) {
     hipLaunchKernelGGL(k_sf_finish, dim3((N + 255) / 256), dim3(256), 0, st, prefix, total, N, sf);
+    return hipGetLastError();
+}
+
+__global__ void k_log_vec(const double* __restrict__ in, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = log(in[i]);
+}
+hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_log_vec, dim3((n + 255) / 256), dim3(256), 0, st, in, n, out);
     return hipGetLastError();
 }
 

@@ -22,13 +22,14 @@ hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu,
                              const int32_t* grid_list, int n_grid, double* work);
 
 // ---- dsq_k_irls.hip
-hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
+                       const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P, int full_rank,
                        const double* disp, double min_mu, double beta_tol, double min_beta,
                        double max_beta, int maxiter, double* beta, double* mu, double* hat,
                        uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list);
 hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf,
-                              const double* Xt, const double* pinvXt, int ldx, int N, int P,
+                              const double* lsf, const double* Xt, const double* pinvXt, int ldx, int N, int P,
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
@@ -84,6 +85,9 @@ hipError_t launch_sf_pick(hipStream_t st, const unsigned int* hist, int N, int s
                           unsigned int* rank);
 hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, const unsigned int* total, int N,
                             double* sf);
+hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
+                            double max_disp, double* res_scratch, double* out2);
+hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out);
 // normed counts (double, gene-major) based rough / moments for the Inference-level API
 hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
                                     const double* pinvXt, int ldx, int N, int G, int P, double* out);

@@ -279,7 +279,17 @@ class DeseqPipeline:
         return _trend.mean_trend(genewise_all, self.min_disp)
 
     def _prior(self, gw, fitted_nz, r):
-        return _trend.dispersion_prior(gw, fitted_nz, self.N, self.P, self.min_disp)
+        """(squared_logres, prior_disp_var) (dds.py:866-884); the two medians run on the device."""
+        from scipy.special import polygamma
+
+        d_gw, _ = self._last_gw_dev
+        d_fit = self._up(fitted_nz)
+        sq = C.c_double()
+        d_work = self._dvec(len(fitted_nz))
+        self._k("prior_mad", len(fitted_nz), "dsq_dev_prior_mad", _vp(d_gw.ptr), _vp(d_fit.ptr), len(fitted_nz),
+                c_double(self.min_disp), c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
+        sq = float(sq.value)
+        return sq, float(np.maximum(sq - polygamma(1, (self.N - self.P) / 2), 0.25))
 
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False) -> DeseqResult:

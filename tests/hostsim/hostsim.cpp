@@ -90,7 +90,7 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
     if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         IrlsArgs A;
-        A.y = y + (size_t)g * ldn; A.sf = sf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+        A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
         A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
         A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
         double b[P];

@@ -54,10 +54,15 @@ def cpu_baseline(counts, X, n_sample, n_jobs):
     """Oracle deseq2()+Wald on the first n_sample genes, all host cores (kind = 'port')."""
     from oracle import nbglm_oracle as orc
 
-    sub = np.ascontiguousarray(counts[:, :n_sample])
-    t = time.perf_counter()
-    orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
-    dt = time.perf_counter() - t
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        orc.deseq2(np.ascontiguousarray(counts[:, : 2 * n_jobs]), X, n_jobs=n_jobs, keep_layers=False)  # warm the pool
+        sub = np.ascontiguousarray(counts[:, :n_sample])
+        t = time.perf_counter()
+        orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
+        dt = time.perf_counter() - t
     return sub.shape[1] / dt, dt
 
 
@@ -175,12 +180,13 @@ def main():
     if not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         n_jobs = min(cores, 64)
-        n_sample = args.cpu_sample or {"c2": 6000, "c3": 3000, "c4": 3000}[args.config]
+        n_sample = args.cpu_sample or {"c2": 20000, "c3": 8000, "c4": 8000}[args.config]
         n_sample = min(n_sample, G)
         v, secs = cpu_baseline(counts, X, n_sample, n_jobs)
         cpu = {"value": round(v, 1), "unit": "genes/s", "cores": n_jobs, "kind": "port",
-               "sample": f"oracle (numpy/scipy restatement of the reference, joblib) on the first "
-                         f"{n_sample} genes x {N} samples of the same matrix, {secs:.1f} s"}
+               "sample": f"oracle (numpy/scipy restatement of the reference incl. scipy L-BFGS-B per gene, "
+                         f"joblib/loky workers warmed up) on the first {n_sample} genes x {N} samples of the "
+                         f"same matrix, {secs:.1f} s"}
 
     out = {
         "metric": "genes/sec end-to-end deseq2() (size factors->dispersion->IRLS->Wald)",

@@ -17,7 +17,11 @@ constexpr int alpha_min_waves(int p) { return p <= 3 ? 4 : (p <= 5 ? 2 : DSQ_ALP
 
 namespace dsq {
 
-template <int P>
+// STAGE: each wave first copies its gene's counts and mu_hat (12 B per sample) into a wave-private
+// LDS segment and runs all ~5 evaluations from there.  Without it every evaluation re-reads the
+// row through L2 (16 resident genes x 12 KB per CU overflow L1 and the CU's share of L2), which the
+// PMC counters showed as ~10x the algorithmic HBM traffic and ~40 % of wave time in s_waitcnt.
+template <int P, bool STAGE>
 __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int32_t* __restrict__ y,
                                                   const double* __restrict__ mu, int ldn,
                                                   const double* __restrict__ Xt, int ldx, int N, int G,
@@ -29,12 +33,26 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
                                                   int32_t* __restrict__ grid_list) {
     // the (wave-uniform) optimiser state lives in LDS, not in every lane's registers
     __shared__ Lbfgsb1d machine[kWavesPerBlock];
-    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) double stage[];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * kWavesPerBlock + w;
     if (g >= G) return;
-    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt,
-                                                            ldx, N, alpha_hat[g], min_disp, max_disp,
-                                                            prior_var, cr_reg != 0, prior_reg != 0,
-                                                            machine[threadIdx.x >> 6]);
+    const int32_t* yg = y + (size_t)g * ldn;
+    const double* mg = mu + (size_t)g * ldn;
+    if (STAGE) {
+        const int npad = (N + 1) & ~1;
+        double* ms = stage + (size_t)w * (npad + npad / 2);
+        int32_t* ys = (int32_t*)(ms + npad);
+        for (int n = threadIdx.x & 63; n < N; n += 64) {  // lane n%64 later reads exactly what it wrote
+            ms[n] = mg[n];
+            ys[n] = yg[n];
+        }
+        yg = ys;
+        mg = ms;
+    }
+    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false>(yg, mg, Xt, ldx, N, alpha_hat[g], min_disp,
+                                                            max_disp, prior_var, cr_reg != 0, prior_reg != 0,
+                                                            machine[w]);
     if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
@@ -105,9 +123,21 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list) {
     if (G <= 0) return hipSuccess;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha<P>, grid, block, 0, st, y, mu, ldn, Xt, ldx, N, G,
-                                          alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
-                                          alpha, conv, nfev, grid_count, grid_list))
+    const int npad = (N + 1) & ~1;
+    const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
+    if (smem <= 80 * 1024) {  // >= 2 workgroups per CU keep their rows in LDS
+        DSQ_DISPATCH_P(P_, {
+            (void)hipFuncSetAttribute((const void*)k_alpha<P, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)smem);
+            hipLaunchKernelGGL((k_alpha<P, true>), grid, block, smem, st, y, mu, ldn, Xt, ldx, N, G, alpha_hat,
+                               min_disp, max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count,
+                               grid_list);
+        })
+    } else {
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_alpha<P, false>), grid, block, 0, st, y, mu, ldn, Xt, ldx, N, G,
+                                              alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
+                                              alpha, conv, nfev, grid_count, grid_list))
+    }
     return hipGetLastError();
 }
 

@@ -60,6 +60,8 @@ const char* dsq_last_error(const dsq_ctx* ctx);
 int dsq_device_info(dsq_ctx* ctx, char* name, int name_len, int* cu_count, size_t* mem_bytes,
                     char* arch, int arch_len);
 int dsq_sync(dsq_ctx* ctx);
+/* developer aid: text of a pending (unconsumed) HIP error of the calling thread, "" if none */
+const char* dsq_debug_pending_error(void);
 /* HIP-event stopwatch on the context's stream (used by bench.py for kernel timing) */
 int dsq_timer_start(dsq_ctx* ctx);
 int dsq_timer_stop(dsq_ctx* ctx, float* elapsed_ms);

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSQ_LIB", os.path.join(_HERE, "libdeseq_hip.so"))  # DSQ_LIB: developer A/B builds
 
 DSQ_MAX_P = 12
+_DEBUG = bool(os.environ.get("DSQ_DEBUG"))
 SAMPLE_MAJOR, GENE_MAJOR = 0, 1
 I32, I64 = 0, 1
 ALT = {None: 0, "greaterAbs": 1, "lessAbs": 2, "greater": 3, "less": 4}
@@ -52,6 +53,7 @@ def load():
     proto("dsq_last_error", _vp, res=C.c_char_p)
     proto("dsq_device_info", _vp, C.c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_size_t), C.c_char_p, c_int)
     proto("dsq_sync", _vp)
+    proto("dsq_debug_pending_error", res=C.c_char_p)
     proto("dsq_timer_start", _vp)
     proto("dsq_timer_stop", _vp, C.POINTER(C.c_float))
     proto("dsq_last_alpha_kernel", _vp, C.POINTER(C.c_float), C.POINTER(c_int))
@@ -112,7 +114,7 @@ def load():
 
 
 EXPORTS = [
-    "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_timer_start",
+    "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_debug_pending_error", "dsq_timer_start",
     "dsq_timer_stop", "dsq_last_alpha_kernel", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
     "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
     "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit", "dsq_dev_prior_mad",
@@ -162,6 +164,10 @@ class Context:
 
     def call(self, name, *args):
         rc = getattr(self.lib, name)(self.h, *args)
+        if _DEBUG:
+            pend = self.lib.dsq_debug_pending_error().decode()
+            if pend:
+                print(f"[dsq debug] pending HIP error after {name}: {pend}", flush=True)
         if rc != 0:
             msg = self.lib.dsq_last_error(self.h).decode(errors="replace")
             if rc == -2:

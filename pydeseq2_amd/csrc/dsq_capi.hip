@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@ struct dsq_ctx {
     int32_t* d_counter = nullptr; // IRLS fallback / dispersion grid-search counters
     int32_t* d_list = nullptr;    // gene index list of the rare second-pass kernels (grown on demand)
     size_t list_cap = 0;
+    void* d_trend_grid = nullptr; // global-memory mailbox of the multi-workgroup trend fit
     double* d_lsf = nullptr;      // log(size factors) of the current IRLS call (grown on demand)
     size_t lsf_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
@@ -252,8 +254,11 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_list) (void)hipFree(ctx->d_list);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
+    if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
+    if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -280,6 +285,12 @@ int dsq_last_alpha_kernel(dsq_ctx* ctx, float* kernel_ms, int* n_grid_fallback) 
     if (kernel_ms) *kernel_ms = ctx->last_kernel_ms;
     if (n_grid_fallback) *n_grid_fallback = ctx->last_n_grid;
     return DSQ_OK;
+}
+
+// developer aid: name of the thread's pending (unconsumed) HIP error, "" if none; clears it
+const char* dsq_debug_pending_error() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? "" : hipGetErrorString(e);
 }
 
 int dsq_timer_start(dsq_ctx* ctx) {
@@ -477,7 +488,10 @@ int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const in
 int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n, double min_disp,
                       double max_disp, uint8_t* d_keep, double* h_coeffs2, int* h_ok, int* h_n_outer) {
     double* d_out = ctx->d_scratch + 1536;
-    DSQ_HIP(dsq::launch_trend_fit(ctx->stream, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out));
+    if (ctx->d_trend_grid == nullptr) DSQ_HIP(hipMalloc(&ctx->d_trend_grid, dsq::trend_grid_mem_bytes()));
+    static const int force_grid = getenv("DSQ_TREND_GRID") ? atoi(getenv("DSQ_TREND_GRID")) : 0;
+    DSQ_HIP(dsq::launch_trend_fit(ctx->stream, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out,
+                                  ctx->d_trend_grid, force_grid));
     double out5[5];
     DSQ_HIP(hipMemcpyAsync(out5, d_out, sizeof(out5), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));

@@ -127,8 +127,11 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
     if (smem <= 80 * 1024) {  // >= 2 workgroups per CU keep their rows in LDS
         DSQ_DISPATCH_P(P_, {
-            (void)hipFuncSetAttribute((const void*)k_alpha<P, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem);
+            if (smem > 48 * 1024) {
+                (void)hipFuncSetAttribute((const void*)k_alpha<P, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                (void)hipGetLastError();
+            }
             hipLaunchKernelGGL((k_alpha<P, true>), grid, block, smem, st, y, mu, ldn, Xt, ldx, N, G, alpha_hat,
                                min_disp, max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count,
                                grid_list);

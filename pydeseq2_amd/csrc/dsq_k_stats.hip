@@ -7,6 +7,7 @@
 // the per-sample median of log-ratios (size factors), which streams the sample-major
 // matrix as uploaded and radix-selects each row in LDS-histogram passes.
 #include <cfloat>
+#include <hip/hip_cooperative_groups.h>
 
 #include "dsq_dispatch.h"
 #include "dsq_launch.h"
@@ -570,8 +571,11 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
     if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // > 20480 samples in one cell
 #define DSQ_COOKS_LAUNCH(WPB)                                                                          \
     do {                                                                                               \
-        hipFuncSetAttribute((const void*)k_cooks<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                            (int)(per_wave * WPB));                                                    \
+        if (per_wave * WPB > 48 * 1024) {                                                              \
+            (void)hipFuncSetAttribute((const void*)k_cooks<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(per_wave * WPB));                                          \
+            (void)hipGetLastError();                                                                   \
+        }                                                                                              \
         hipLaunchKernelGGL(k_cooks<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, \
                            y, ldn, sf, mu, hat, cell_offsets, cell_index, n_cells, whole, cap, flags, \
                            N, G, P, cutoff, cooks, robust_disp, any_all, any_use, any_use_nr,         \
@@ -623,8 +627,11 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
     if (per_wave > 160 * 1024) return hipErrorInvalidValue;
 #define DSQ_REPL_LAUNCH(WPB)                                                                         \
     do {                                                                                             \
-        hipFuncSetAttribute((const void*)k_replace<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)(per_wave * WPB));                                                  \
+        if (per_wave * WPB > 48 * 1024) {                                                            \
+            (void)hipFuncSetAttribute((const void*)k_replace<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(per_wave * WPB));                                        \
+            (void)hipGetLastError();                                                                 \
+        }                                                                                            \
         hipLaunchKernelGGL(k_replace<WPB>, dim3((n_sel + WPB - 1) / WPB), dim3(64 * WPB),            \
                            per_wave * WPB, st, y, cooks, ldn, sf, flags, gene_idx, n_sel, N, cap,    \
                            cutoff, y_out, all_zero);                                                 \
@@ -800,8 +807,175 @@ __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __
     }
 }
 
+// ---- multi-workgroup variant (cooperative launch) for large gene sets (the all-gathered vectors of
+// the multi-GPU layout): same leader / helper protocol, but the data passes are spread over
+// kTrendGridBlocks workgroups that meet at grid-wide barriers; per-wave partials go through global
+// memory and are combined by the leader in a fixed order.
+constexpr int kTrendGridBlocks = 32;
+
+struct TrendGridMem {  // device global memory (zeroed before every launch)
+    double a0, a1;
+    int cmd;
+    unsigned int arrive;  // monotonic arrival counter of the grid barrier
+    unsigned int timeout; // set if a spin ever exceeds its bound (never observed; avoids a hung GPU)
+    int pad;
+    double part[64][3];  // one slot per workgroup (kTrendGridBlocks <= 64)
+    int ipart[64][3];
+};
+
+// Grid-wide barrier on one monotonic counter (MI355X_MICROARCH.md "barrier-counter", ~3 us at 32
+// workgroups vs ~45 us measured for cooperative_groups::grid.sync()): agent-scope release before
+// the arrival, relaxed polling with s_sleep, agent-scope acquire after; all exchanged words are
+// agent-scope atomics on both sides.  The launch is cooperative so all workgroups are resident.
+__device__ __forceinline__ void trend_grid_barrier(TrendGridMem* Gm, unsigned int& target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&Gm->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&Gm->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 200000000u) {
+                __hip_atomic_store(&Gm->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    target += gridDim.x;
+}
+
+struct TrendBlockScratch {
+    double part[kTrendWaves][3];
+    int ipart[kTrendWaves][3];
+};
+
+struct GridTrendOps {
+    TrendData D;
+    TrendGridMem* Gm;
+    TrendBlockScratch* B;  // LDS of this workgroup
+    unsigned int target;
+    __device__ void wr(double* p, double v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ void wri(int* p, int v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ double rd(const double* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ int rdi(const int* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // every thread of every workgroup calls work() once per command: wave partials -> LDS ->
+    // one slot per workgroup in global memory (agent-scope atomics on both sides: the per-XCD L2s
+    // are not coherent for plain accesses)
+    __device__ void work(int cmd, double a0, double a1) {
+        const int w = threadIdx.x >> 6;
+        const int tid = blockIdx.x * (64 * kTrendWaves) + threadIdx.x, NT = gridDim.x * 64 * kTrendWaves;
+        if (cmd == 1) {
+            TrendPartial P;
+            trend_eval_partial(D, tid, NT, a0, a1, P);
+            const double s = DeviceWave::sum_comp(P.s), g0 = DeviceWave::sum_comp(P.g0),
+                         g1 = DeviceWave::sum_comp(P.g1);
+            const int cf = DeviceWave::sumi(P.cf), c0 = DeviceWave::sumi(P.c0), c1 = DeviceWave::sumi(P.c1);
+            if ((threadIdx.x & 63) == 0) {
+                B->part[w][0] = s; B->part[w][1] = g0; B->part[w][2] = g1;
+                B->ipart[w][0] = cf; B->ipart[w][1] = c0; B->ipart[w][2] = c1;
+            }
+        } else {
+            const int k = DeviceWave::sumi(cmd == 3 ? trend_init_keep(D, tid, NT) : trend_filter(D, tid, NT, a0, a1));
+            if ((threadIdx.x & 63) == 0) { B->ipart[w][0] = k; B->ipart[w][1] = 0; B->ipart[w][2] = 0;
+                                           B->part[w][0] = 0.0; B->part[w][1] = 0.0; B->part[w][2] = 0.0; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            KSum s;
+            int c = 0;
+            for (int q = 0; q < kTrendWaves; ++q) { s.add(B->part[q][threadIdx.x]); c += B->ipart[q][threadIdx.x]; }
+            wr(&Gm->part[blockIdx.x][threadIdx.x], s.value());
+            wri(&Gm->ipart[blockIdx.x][threadIdx.x], c);
+        }
+        __syncthreads();
+    }
+    __device__ void post(int cmd, double a0, double a1) {  // leader wave only
+        if ((threadIdx.x & 63) == 0) { wr(&Gm->a0, a0); wr(&Gm->a1, a1); wri(&Gm->cmd, cmd); }
+        trend_grid_barrier(Gm, target);  // A
+        work(cmd, a0, a1);
+        trend_grid_barrier(Gm, target);  // B
+    }
+    // leader wave: lane b fetches workgroup b's slot, butterfly-combine (fixed order)
+    __device__ void combine(double& s, double& g0, double& g1, int& cf, int& c0, int& c1) {
+        const int b = threadIdx.x & 63;
+        const bool on = b < (int)gridDim.x;
+        KSum ks, k0, k1;
+        ks.s = on ? rd(&Gm->part[b][0]) : 0.0;
+        k0.s = on ? rd(&Gm->part[b][1]) : 0.0;
+        k1.s = on ? rd(&Gm->part[b][2]) : 0.0;
+        s = DeviceWave::sum_comp(ks); g0 = DeviceWave::sum_comp(k0); g1 = DeviceWave::sum_comp(k1);
+        cf = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][0]) : 0);
+        c0 = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][1]) : 0);
+        c1 = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][2]) : 0);
+    }
+    __device__ int init_keep() {
+        post(3, 0.0, 0.0);
+        double s, g0, g1; int cf, c0, c1;
+        combine(s, g0, g1, cf, c0, c1);
+        return cf;
+    }
+    __device__ void eval(double a0, double a1, double& f, double* g) {
+        post(1, a0, a1);
+        double s, g0, g1; int cf, c0, c1;
+        combine(s, g0, g1, cf, c0, c1);
+        f = s / (double)cf;
+        g[0] = -(g0 / (double)c0);
+        g[1] = -(g1 / (double)c1);
+    }
+    __device__ int filter(double a0, double a1) {
+        post(2, a0, a1);
+        double s, g0, g1; int cf, c0, c1;
+        combine(s, g0, g1, cf, c0, c1);
+        return cf;
+    }
+};
+
+__global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit_grid(const double* disp, const double* means, int n,
+                                                                     double min_disp, double max_disp,
+                                                                     uint8_t* keep, TrendGridMem* Gm,
+                                                                     double* out5) {
+    __shared__ TrendWork W;
+    __shared__ TrendBlockScratch Bs;
+    GridTrendOps ops;
+    ops.D = TrendData{disp, means, keep, n, min_disp, max_disp};
+    ops.Gm = Gm;
+    ops.B = &Bs;
+    ops.target = gridDim.x;
+    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 0) {
+        const TrendOut o = trend_fit_core(ops, W);
+        if (threadIdx.x == 0) {
+            out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
+            out5[4] = (double)o.n_kept;
+            __hip_atomic_store(&Gm->cmd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        trend_grid_barrier(Gm, ops.target);  // A (release the helpers)
+    } else {
+        for (;;) {
+            trend_grid_barrier(Gm, ops.target);  // A
+            const int cmd = ops.rdi(&Gm->cmd);
+            if (cmd == 0 || ops.rdi((const int*)&Gm->timeout) != 0) break;
+            ops.work(cmd, ops.rd(&Gm->a0), ops.rd(&Gm->a1));
+            trend_grid_barrier(Gm, ops.target);  // B
+        }
+    }
+}
+
+size_t trend_grid_mem_bytes() { return sizeof(TrendGridMem); }
+
 hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
-                            double max_disp, uint8_t* keep, double* out5) {
+                            double max_disp, uint8_t* keep, double* out5, void* grid_mem, int force_grid) {
+    if (grid_mem != nullptr && force_grid >= 0 && (force_grid > 0 || n >= 2048)) {
+        TrendGridMem* gm = (TrendGridMem*)grid_mem;
+        hipError_t e0 = hipMemsetAsync(gm, 0, 64, st);  // cmd / arrival counter / timeout flag
+        if (e0 != hipSuccess) return e0;
+        void* args[] = {(void*)&disp, (void*)&means, (void*)&n, (void*)&min_disp, (void*)&max_disp, (void*)&keep,
+                        (void*)&gm, (void*)&out5};
+        return hipLaunchCooperativeKernel((const void*)k_trend_fit_grid, dim3(kTrendGridBlocks),
+                                          dim3(64 * kTrendWaves), args, 0, st);
+    }
     hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, disp, means, n, min_disp, max_disp,
                        keep, out5);
     return hipGetLastError();

@@ -71,8 +71,9 @@ hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, co
 constexpr int kTrendPartials = 256;  // rows of 4 doubles
 hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const double* targets,
                                   const uint8_t* keep, int n, double a0, double a1, double* partials);
+size_t trend_grid_mem_bytes();
 hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
-                            double max_disp, uint8_t* keep, double* out5);
+                            double max_disp, uint8_t* keep, double* out5, void* grid_mem, int force_grid);
 // distributed size factors (per-pass radix select, histograms all-reduced between passes)
 hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
                           const double* logmeans, const uint8_t* gene_mask, unsigned long long* keys);

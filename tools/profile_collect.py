@@ -1,0 +1,50 @@
+"""Assemble profiles/<tag>_<config>.txt and profiles/traffic_<config>.json from gpurun_out/<tag>/
+(written on the GPU box by tools/profile_round.sh).
+
+    python tools/profile_collect.py <tag> [config] [extra bench logs ...]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
+    extra = sys.argv[3:]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    bench = [l for l in open(os.path.join(src, "bench_prof.log")) if l.startswith("{")][-1].strip()
+    out = [f"# {tag} — rocprofv3 --kernel-trace --stats -- python bench.py --config {cfg} --steps 5 --warmup 2  (MI355X)",
+           "# bench line of the same (profiled) run:", bench, "", open(os.path.join(src, "stats.txt")).read(),
+           "# separate PMC passes (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE; 1 step, no warmup).",
+           "# Units KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE is doubled on gfx950, WRITE_SIZE taken as is."]
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        out.append(open(os.path.join(src, f"pmc_{c}.txt")).read())
+    for f in extra:
+        lines = [l for l in open(f) if l.startswith("{")]
+        if lines:
+            out.append(f"# un-profiled bench line of the same build ({os.path.basename(f)}):")
+            out.append(lines[-1].strip())
+    path = os.path.join(ROOT, "profiles", f"{tag}_{cfg}.txt")
+    open(path, "w").write("\n".join(out) + "\n")
+
+    fetch = json.load(open(os.path.join(src, "pmc_FETCH_SIZE.json")))
+    write = json.load(open(os.path.join(src, "pmc_WRITE_SIZE.json")))
+    # the full-size k_alpha launches are the ones with the largest grid
+    keys = [k for k in fetch if k.startswith("dsq::k_alpha<")]
+    big = max(keys, key=lambda k: int(k.split("@")[1]))
+    f_kib, w_kib = fetch[big], write.get(big, 0.0)
+    traffic = {
+        "k_alpha_hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024),
+        "source": f"profiles/{tag}_{cfg}.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB of the full-size {big.split('@')[0]} "
+                  "launches (gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md)",
+        "fetch_kib": f_kib, "write_kib": w_kib,
+    }
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{cfg}.json"), "w"), indent=1)
+    print(path, traffic)
+
+
+if __name__ == "__main__":
+    main()

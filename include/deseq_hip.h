@@ -47,6 +47,10 @@ enum dsq_status {
 };
 
 enum dsq_layout { DSQ_SAMPLE_MAJOR = 0, DSQ_GENE_MAJOR = 1 };
+/* alpha-independent constant of a gene's NLL, sum lgamma(y+1) - y log(mu) (utils.py:227-234): the
+ * genewise (MLE) and MAP fits of one deseq2() run see the same counts and mu_hat, so the second
+ * launch can re-use what the first one stored (8 B per gene) instead of recomputing it. */
+enum dsq_const_mode { DSQ_CONST_COMPUTE = 0, DSQ_CONST_STORE = 1, DSQ_CONST_LOAD = 2 };
 enum dsq_count_type { DSQ_I32 = 0, DSQ_I64 = 1 };
 /* alternative hypotheses of utils.wald_test (pydeseq2/utils.py:778-806) */
 enum dsq_alt { DSQ_ALT_NONE = 0, DSQ_ALT_GREATER_ABS = 1, DSQ_ALT_LESS_ABS = 2,
@@ -183,11 +187,13 @@ int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, c
 int dsq_dev_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf,
                    const double* d_Xt, const double* d_pinvXt, int ldx, int N, int G, int P,
                    double min_mu, double* d_mu);
-/* d_nfev may be null.  alpha is NOT clipped (the caller clips, dds.py:792-794). */
+/* d_nfev may be null.  alpha is NOT clipped (the caller clips, dds.py:792-794).
+ * d_nll_const [G] (may be null -> DSQ_CONST_COMPUTE) with const_mode: see dsq_const_mode. */
 int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn,
                       const double* d_Xt, int ldx, int N, int G, int P, const double* d_alpha_hat,
                       double min_disp, double max_disp, double prior_disp_var, int cr_reg,
-                      int prior_reg, double* d_alpha, uint8_t* d_converged, int32_t* d_nfev);
+                      int prior_reg, double* d_alpha, uint8_t* d_converged, int32_t* d_nfev,
+                      double* d_nll_const, int const_mode);
 /* d_mu / d_hat may be null.  d_iters may be null. */
 int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                  const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank,

@@ -88,7 +88,7 @@ def load():
           _vp, _vp, _vp, _vp)
     proto("dsq_dev_lin_mu", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, _vp)
     proto("dsq_dev_alpha_mle", _vp, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_int, _vp, c_double,
-          c_double, c_double, c_int, c_int, _vp, _vp, _vp)
+          c_double, c_double, c_int, c_int, _vp, _vp, _vp, _vp, c_int)
     proto("dsq_dev_irls", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, _vp, c_double,
           c_double, c_double, c_double, c_int, _vp, _vp, _vp, _vp, _vp)
     proto("dsq_dev_cooks", _vp, _vp, c_int, _vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, c_int, c_int,

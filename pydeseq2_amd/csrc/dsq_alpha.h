@@ -12,6 +12,7 @@
 // these sizes).
 #pragma once
 #include "dsq_lbfgsb1d.h"
+#include "dsq_lgamma_int.h"
 #include "dsq_linalg.h"
 #include "dsq_wave.h"
 
@@ -199,13 +200,27 @@ struct AlphaOut {
     int nfev, nit, status;
 };
 
-// alpha-independent part of the NLL:  sum lgamma(y+1) - y log(mu)
+// alpha-independent part of the NLL:  sum lgamma(y+1) - y log(mu)      (utils.py:227-234)
+// lgamma(y+1) = log(y!) comes from a 256-entry table (correctly rounded) and from the Stirling
+// series at z = y + 1 >= 257 beyond it; log(mu) through the lean log (mu >= min_mu > 0).
 template <class Wv>
 DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
     KSum c;
-    for (int n = Wv::lane(); n < N; n += Wv::W) {
-        const double yv = (double)y[n];
-        c.add(lgamma_pos(yv + 1.0) - yv * log(mu[n]));
+    for (int base = 0; base < N; base += Wv::W) {
+        const int n = base + Wv::lane();
+        const bool valid = n < N;
+        const int yi = valid ? y[n] : 0;
+        const double yv = (double)yi;
+        const double m = valid ? mu[n] : 1.0;
+        const bool in_tab = yi < kLgammaIntN;
+        double lg = kLgammaInt[in_tab ? yi : 0];
+        if (Wv::any(!in_tab)) {
+            const double z = in_tab ? 300.0 : yv + 1.0;
+            const double lz = flog(z);
+            const double big = (z - 0.5) * lz - z + kHalfLog2Pi + stirling_tail(frcp(z));
+            if (!in_tab) lg = big;
+        }
+        c.add(lg - yv * flog(m));
     }
     return Wv::sum_comp(c);
 }
@@ -217,13 +232,16 @@ DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
 template <class Wv, int P, bool RUN_GRID>
 DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
                                double alpha_hat, double min_disp, double max_disp,
-                               double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m) {
+                               double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
+                               const double* cst_in = nullptr, double* cst_out = nullptr) {
     AlphaArgs A;
     A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = log(alpha_hat);
     A.prior_var = prior_var;
     A.cr_reg = cr_reg; A.prior_reg = prior_reg;
-    A.cst = alpha_const<Wv>(y, mu, N);
+    // the constant depends on (y, mu) only: the MAP fit re-uses the one the MLE fit stored
+    A.cst = cst_in != nullptr ? *cst_in : alpha_const<Wv>(y, mu, N);
+    if (cst_out != nullptr && Wv::lane() == 0) *cst_out = A.cst;
     const double lo = log(min_disp), hi = log(max_disp);
     m.start(A.la_hat, lo, hi);
     while (!m.done) {

@@ -69,7 +69,8 @@ hipError_t ensure_list(dsq_ctx* c, size_t n) {
 // dispersion fit + (rare) grid-search second pass
 int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
-              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev);
+              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
+              double* d_nll_const = nullptr, int const_mode = DSQ_CONST_COMPUTE);
 
 // RAII device buffer for the Inference-level calls
 struct DevBuf {
@@ -196,14 +197,16 @@ int download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N
 
 int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
-              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev) {
+              int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
+              double* d_nll_const, int const_mode) {
     if (G <= 0) return DSQ_OK;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     int32_t* d_cnt = ctx->d_counter + 4;
     DSQ_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
-                              prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list));
+                              prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
+                              d_nll_const, const_mode));
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t n_grid = 0;
     DSQ_HIP(hipMemcpyAsync(&n_grid, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -400,10 +403,11 @@ int dsq_dev_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf
 int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt,
                       int ldx, int N, int G, int P, const double* d_alpha_hat, double min_disp,
                       double max_disp, double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha,
-                      uint8_t* d_converged, int32_t* d_nfev) {
+                      uint8_t* d_converged, int32_t* d_nfev, double* d_nll_const, int const_mode) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
     return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
-                     cr_reg, prior_reg, d_alpha, d_converged, d_nfev);
+                     cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode);
 }
 
 int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,

@@ -13,7 +13,10 @@
 #ifndef DSQ_ALPHA_WAVES_WIDE
 #define DSQ_ALPHA_WAVES_WIDE 2
 #endif
-constexpr int alpha_min_waves(int p) { return p <= 3 ? 4 : (p <= 5 ? 2 : DSQ_ALPHA_WAVES_WIDE); }
+#ifndef DSQ_ALPHA_WAVES_NARROW
+#define DSQ_ALPHA_WAVES_NARROW 3
+#endif
+constexpr int alpha_min_waves(int p) { return p <= 3 ? DSQ_ALPHA_WAVES_NARROW : (p <= 5 ? 2 : DSQ_ALPHA_WAVES_WIDE); }
 
 namespace dsq {
 
@@ -30,7 +33,8 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
                                                   int cr_reg, int prior_reg, double* __restrict__ alpha,
                                                   uint8_t* __restrict__ conv, int32_t* __restrict__ nfev,
                                                   int32_t* __restrict__ grid_count,
-                                                  int32_t* __restrict__ grid_list) {
+                                                  int32_t* __restrict__ grid_list,
+                                                  double* __restrict__ nll_const, int const_mode) {
     // the (wave-uniform) optimiser state lives in LDS, not in every lane's registers
     __shared__ Lbfgsb1d machine[kWavesPerBlock];
     extern __shared__ __attribute__((aligned(16))) double stage[];
@@ -52,7 +56,9 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
     }
     const AlphaOut o = fit_alpha_gene<DeviceWave, P, false>(yg, mg, Xt, ldx, N, alpha_hat[g], min_disp,
                                                             max_disp, prior_var, cr_reg != 0, prior_reg != 0,
-                                                            machine[w]);
+                                                            machine[w],
+                                                            const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
+                                                            const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr);
     if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
@@ -120,8 +126,10 @@ __global__ void k_fill_lohi(double* lohi, int n, double lo, double hi) {
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P_, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
-                        uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list) {
+                        uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
+                        double* nll_const, int const_mode) {
     if (G <= 0) return hipSuccess;
+    if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     const int npad = (N + 1) & ~1;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
@@ -134,12 +142,12 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
             }
             hipLaunchKernelGGL((k_alpha<P, true>), grid, block, smem, st, y, mu, ldn, Xt, ldx, N, G, alpha_hat,
                                min_disp, max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count,
-                               grid_list);
+                               grid_list, nll_const, const_mode);
         })
     } else {
         DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_alpha<P, false>), grid, block, 0, st, y, mu, ldn, Xt, ldx, N, G,
                                               alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
-                                              alpha, conv, nfev, grid_count, grid_list))
+                                              alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode))
     }
     return hipGetLastError();
 }

@@ -5,6 +5,8 @@
 
 #include <cstdint>
 
+#include "../../include/deseq_hip.h"
+
 namespace dsq {
 
 constexpr int kWavesPerBlock = 4;
@@ -16,7 +18,8 @@ inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerB
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
-                        uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list);
+                        uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
+                        double* nll_const, int const_mode);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
                              const int32_t* grid_list, int n_grid, double* work);

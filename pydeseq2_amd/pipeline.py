@@ -215,9 +215,10 @@ class DeseqPipeline:
                      c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                      _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
         d_gw, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
+        d_mu.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
         self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr), D.ldx, self.N,
                  Gs, self.P, _vp(d_mom.ptr), c_double(self.min_disp), c_double(self.max_disp), c_double(1.0), 1,
-                 0, _vp(d_gw.ptr), _vp(d_conv.ptr), None)
+                 0, _vp(d_gw.ptr), _vp(d_conv.ptr), None, _vp(d_mu.nll_const.ptr), 1)
         nm = self._down(d_nm, Gs)
         mom = self._down(d_mom, Gs)
         gw = np.clip(self._down(d_gw, Gs), self.min_disp, self.max_disp)  # dds.py:792-794
@@ -231,7 +232,8 @@ class DeseqPipeline:
         d_map, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
         self._k("alpha_map", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
                       self.design.ldx, self.N, Gs, self.P, _vp(d_fit.ptr), c_double(self.min_disp),
-                      c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(d_map.ptr), _vp(d_conv.ptr), None)
+                      c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(d_map.ptr), _vp(d_conv.ptr), None,
+                      *((_vp(d_mu.nll_const.ptr), 2) if getattr(d_mu, "nll_const", None) is not None else (None, 0)))
         return (np.clip(self._down(d_map, Gs), self.min_disp, self.max_disp),
                 self._down(d_conv, Gs, np.uint8).astype(bool))
 

@@ -37,8 +37,18 @@ struct AlphaArgs {
 // 263-264; the differences are what enters the likelihood).
 constexpr int kSmallCount = 9;
 
-template <class Wv, bool GRAD>
+constexpr int kMemoBlocks = 4;  // memo of up to 256 counts: lane k holds counts k, k+64, k+128, k+192
+
+template <class Wv, bool GRAD, bool BIG = false>
 DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double& dl, double& dd) {
+    if (BIG) {  // caller guarantees yi >= 256: Stirling only, truncated tails
+        const double z = (double)yi + a;
+        const double lg = flog(z);
+        const double rc = frcp(z);
+        dl = lga - ((z - 0.5) * lg - z + kHalfLog2Pi + stirling_tail_big(rc));
+        dd = GRAD ? dga - (lg + digamma_tail_big(rc)) : 0.0;
+        return;
+    }
     const bool small = yi <= kSmallCount;
     // small counts: prod = prod_{i<y}(a+i), num/prod = sum_{i<y} 1/(a+i)
     double prod = 1.0, num = 0.0;
@@ -76,68 +86,171 @@ DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double
 // removes the reference's largest rounding-noise source instead of reproducing it; one log1p
 // serves the loss, the gradient's log(1 + mu alpha) (utils.py:265) and, through its argument's
 // reciprocal, both W = mu/(1+mu alpha) and (y-mu)/(mu+a).
-template <class Wv, int P, bool GRAD>
-DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
+#if defined(__HIPCC__)
+#define DSQ_EVAL_FN __host__ __device__ __attribute__((noinline))
+#else
+#define DSQ_EVAL_FN inline
+#endif
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
                        double& g) {
     constexpr int T = Tri<P>::N;
+    constexpr bool kSplitDM = P >= 9;
+    DSQ_PHASE(2);
     la = Wv::uniform(la);
     const double alpha = Wv::uniform(exp(la));
-    const double a = Wv::uniform(1.0 / alpha);
+    const double a = Wv::uniform(frcp(alpha));
     // log of the ROUNDED alpha: keeps every term a function of the same alpha (using `la` itself
     // would leave an inconsistency of ulp(1) * sum(y) in the loss, i.e. line-search noise)
-    const double lal = Wv::uniform(log(alpha));
+    const double lal = Wv::uniform(flog(alpha));
     double lga, dga;
     lgamma_digamma<GRAD>(a, lga, dga);
     lga = Wv::uniform(lga);
     dga = Wv::uniform(dga);
-    // Wave-level memo: lane k evaluates the two gamma-function differences for the COUNT k once
-    // per evaluation; samples whose count is < 64 then fetch them with a cross-lane read instead
-    // of recomputing log/Stirling/recurrences per sample (counts repeat heavily within a gene).
-    // Only counts >= 64 take the per-sample Stirling path.  (Host build: table of one entry.)
-    double tab_dl, tab_dd;
-    lgamma_digamma_diff<Wv, GRAD>(Wv::lane(), a, lga, dga, tab_dl, tab_dd);
+    // Wave-level memo: lane k evaluates the two gamma-function differences for the COUNTS k, k+64,
+    // ... once per evaluation; samples whose count is < 64 * memo_blocks then fetch them with a
+    // cross-lane read instead of recomputing log/Stirling/recurrences per sample (counts repeat
+    // heavily within a gene).  memo_blocks follows the gene's largest count (wave-uniform), so a
+    // low-count gene builds one block only; counts >= 256 take the per-sample Stirling path.
+    // (Host build: table of one entry.)
+    // NB (1, 2 or 4 blocks of 64 counts) is a template parameter so that the sample loop carries no
+    // branches: fit_alpha_gene picks the instantiation from the gene's largest count.
+    static_assert(NB >= 1 && NB <= kMemoBlocks, "memo blocks");
+    double tab_dl[NB], tab_dd[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+        lgamma_digamma_diff<Wv, GRAD>(Wv::lane() + t * Wv::W, a, lga, dga, tab_dl[t], tab_dd[t]);
+    constexpr int tab_n = NB * Wv::W;
     KSum accf;
     double accg = 0.0;
     double M[T], dM[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
-    for (int base = 0; base < A.N; base += Wv::W) {  // wave-uniform trip count: all lanes stay active
-        const int n = base + Wv::lane();
-        const bool valid = n < A.N;
-        const int yi = valid ? A.y[n] : 0;
+    DSQ_PHASE(3);
+    // PAD: y / mu are padded to a multiple of the wave width with (0, 0.0), which makes every
+    // per-sample contribution exactly zero (L1 = 0, w = 0, memo[0] = 0) without masking; without PAD
+    // out-of-range lanes are given the same (0, 0.0).
+    //
+    // The loop is software-pipelined: iteration i issues the LDS / global reads of iteration i+1
+    // (counts: i+2) and the cross-lane memo fetch of iteration i+1 before it starts its own ~100
+    // dependent fp64 instructions, so that none of those latencies is exposed (3 waves per SIMD are
+    // not enough to hide a serial  ds_read -> ds_bpermute -> use  chain per iteration).
+    const int n_end = PAD ? ((A.N + Wv::W - 1) / Wv::W) * Wv::W : A.N;
+    const int n_last = n_end - Wv::W + Wv::lane();  // PAD: this lane's slot of the last iteration
+    auto load_y = [&](int n) -> int { return PAD ? A.y[n < n_last ? n : n_last] : (n < A.N ? A.y[n] : 0); };
+    auto load_m = [&](int n) -> double { return PAD ? A.mu[n < n_last ? n : n_last] : (n < A.N ? A.mu[n] : 0.0); };
+    auto memo_issue = [&](int yi, double (&rl)[NB], double (&rd)[NB]) {
+        const int src = yi & (Wv::W - 1);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            rl[t] = Wv::from_lane(tab_dl[t], src);
+            rd[t] = GRAD ? Wv::from_lane(tab_dd[t], src) : 0.0;
+        }
+    };
+    auto memo_pick = [&](int yi, const double (&rl)[NB], const double (&rd)[NB], double& dl, double& dd) {
+        const int blk = yi / Wv::W;
+        dl = rl[0]; dd = rd[0];
+#pragma unroll
+        for (int t = 1; t < NB; ++t) {
+            dl = (blk == t) ? rl[t] : dl;
+            dd = (blk == t) ? rd[t] : dd;
+        }
+    };
+    int nl = Wv::lane();
+    int y1 = load_y(nl), y2 = load_y(nl + Wv::W);
+    double m1 = load_m(nl);
+    double x1[P];
+    if (cr_reg) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) x1[j] = A.Xt[j * A.ldx + (nl < A.N ? nl : A.N - 1)];
+    }
+    // the 4-block memo keeps 16 fetched values in flight per prefetch, which costs more registers
+    // than the 168 a wave may use at 3 waves per SIMD: it fetches at the point of use instead
+    constexpr bool kPrefetchMemo = NB <= 2;
+    double dl1 = 0.0, dd1 = 0.0;
+    if (kPrefetchMemo) {
+        double rl[NB], rd[NB];
+        memo_issue(y1, rl, rd);
+        memo_pick(y1, rl, rd, dl1, dd1);
+    }
+    for (int base = 0; base < n_end; base += Wv::W) {  // wave-uniform trip count: all lanes stay active
+        const int yi = y1;
+        const double m = m1, dl0 = dl1, dd0 = dd1;
+        double x[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) x[j] = x1[j];
+        // ---- issue the next iteration's reads
+        nl += Wv::W;
+        y1 = y2;
+        y2 = load_y(nl + Wv::W);
+        m1 = load_m(nl);
+        if (cr_reg) {
+            const int nx = nl < A.N ? nl : A.N - 1;  // padded / out-of-range samples have w = 0
+#pragma unroll
+            for (int j = 0; j < P; ++j) x1[j] = A.Xt[j * A.ldx + nx];
+        }
+        double rl[NB], rd[NB];
+        memo_issue(kPrefetchMemo ? y1 : yi, rl, rd);
+        // ---- this iteration
         const double yv = (double)yi;
-        const double m = valid ? A.mu[n] : 1.0;
-        const bool in_tab = yi < Wv::W;
-        double dl = Wv::from_lane(tab_dl, in_tab ? yi : 0);
-        double dd = GRAD ? Wv::from_lane(tab_dd, in_tab ? yi : 0) : 0.0;
-        if (Wv::any(!in_tab)) {
+        double dl = dl0, dd = dd0;
+        if (!kPrefetchMemo) memo_pick(yi, rl, rd, dl, dd);
+        // counts beyond the memo exist only when the gene's largest count is >= 256 (NB == 4);
+        // HostWave's memo holds NB counts, so the host instantiation takes the general formula
+        const bool in_tab = yi < tab_n;
+        if ((NB == kMemoBlocks || Wv::W == 1) && Wv::any(!in_tab)) {
             double dl2, dd2;
-            lgamma_digamma_diff<Wv, GRAD>(in_tab ? 64 : yi, a, lga, dga, dl2, dd2);
-            if (!in_tab) { dl = dl2; dd = dd2; }
+            if (Wv::W == 1)
+                lgamma_digamma_diff<Wv, GRAD>(yi, a, lga, dga, dl2, dd2);
+            else
+                lgamma_digamma_diff<Wv, GRAD, true>(in_tab ? 256 : yi, a, lga, dga, dl2, dd2);
+            dl = in_tab ? dl : dl2;
+            dd = in_tab ? dd : dd2;
         }
         const double ma = m * alpha;
         const double r1 = frcp(1.0 + ma);
         const double L1 = flog1p(ma);
-        const double vz = valid ? 1.0 : 0.0;
-        accf.add(vz * (dl + yv * (L1 - lal) + a * L1));
-        if (GRAD) accg += vz * (dd + L1 + (yv - m) * alpha * r1);
+        accf.add(dl + yv * (L1 - lal) + a * L1);
+        if (GRAD) accg += dd + L1 + (yv - m) * alpha * r1;
         if (cr_reg) {
-            const double w = vz * (m * r1);
+            const double w = m * r1;
             const double dw = -(w * w);
-            double x[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) x[j] = valid ? A.Xt[j * A.ldx + n] : 0.0;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const double xw = x[i] * w, xdw = x[i] * dw;
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
                     M[tri(i, j)] += xw * x[j];
-                    if (GRAD) dM[tri(i, j)] += xdw * x[j];
+                    if (GRAD && !kSplitDM) dM[tri(i, j)] += xdw * x[j];
                 }
             }
         }
+        // ---- the memo values fetched above are consumed by the next iteration
+        if (kPrefetchMemo) memo_pick(y1, rl, rd, dl1, dd1);
     }
+    if (GRAD && kSplitDM && cr_reg) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) dM[k] = 0.0;
+        // wide designs: X^T dW X in a second sweep, so that only p(p+1)/2 accumulators are live per
+        // sweep (both sets together exceed the register file and spill heavily from p = 9 on)
+        for (int base = 0; base < n_end; base += Wv::W) {
+            const int n = base + Wv::lane();
+            const double m = load_m(n);
+            const double w = m * frcp(1.0 + m * alpha);
+            const double dw = -(w * w);
+            const int nx = n < A.N ? n : A.N - 1;
+            double x[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) x[j] = A.Xt[j * A.ldx + nx];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const double xdw = x[i] * dw;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) dM[tri(i, j)] += xdw * x[j];
+            }
+        }
+    }
+    DSQ_PHASE(4);
     const double sumf = Wv::sum_comp(accf);
     if (GRAD) accg = Wv::sum(accg);
     f = sumf + A.cst;
@@ -146,6 +259,7 @@ DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_re
     if (cr_reg) {
         Wv::template sum_n<T>(M);
         if (GRAD) Wv::template sum_n<T>(dM);
+        DSQ_PHASE(5);
         chol<P>(M);
         f += 0.5 * chol_logdet<P>(M);
         if (GRAD) {
@@ -229,26 +343,32 @@ DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
 // reference's grid search right here (host simulation / single-kernel use); otherwise only report
 // converged = 0 and the caller schedules grid_alpha_gene for the gene (device: second tiny kernel,
 // which keeps the 200-evaluation grid code out of the main kernel's register budget).
-template <class Wv, int P, bool RUN_GRID>
+template <class Wv, int P, bool RUN_GRID, bool PAD = false>
 DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
                                double alpha_hat, double min_disp, double max_disp,
                                double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
-                               const double* cst_in = nullptr, double* cst_out = nullptr) {
+                               const double* cst_in = nullptr, double* cst_out = nullptr,
+                               int memo_blocks = 1) {
     AlphaArgs A;
     A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = log(alpha_hat);
     A.prior_var = prior_var;
     A.cr_reg = cr_reg; A.prior_reg = prior_reg;
     // the constant depends on (y, mu) only: the MAP fit re-uses the one the MLE fit stored
+    DSQ_PHASE(1);
     A.cst = cst_in != nullptr ? *cst_in : alpha_const<Wv>(y, mu, N);
     if (cst_out != nullptr && Wv::lane() == 0) *cst_out = A.cst;
     const double lo = log(min_disp), hi = log(max_disp);
     m.start(A.la_hat, lo, hi);
     while (!m.done) {
         double f, g;
-        alpha_eval<Wv, P, true>(A, m.x, cr_reg, prior_reg, f, g);
+        if (memo_blocks <= 1) alpha_eval<Wv, P, true, PAD, 1>(A, m.x, cr_reg, prior_reg, f, g);
+        else if (memo_blocks == 2) alpha_eval<Wv, P, true, PAD, 2>(A, m.x, cr_reg, prior_reg, f, g);
+        else alpha_eval<Wv, P, true, PAD, 4>(A, m.x, cr_reg, prior_reg, f, g);
+        DSQ_PHASE(6);
         m.feed(f, g);
     }
+    DSQ_PHASE(7);
     AlphaOut o;
     o.converged = m.success ? 1 : 0;
     o.nfev = m.nfev; o.nit = m.it; o.status = m.status;

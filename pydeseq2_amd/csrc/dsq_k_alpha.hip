@@ -20,6 +20,10 @@ constexpr int alpha_min_waves(int p) { return p <= 3 ? DSQ_ALPHA_WAVES_NARROW : 
 
 namespace dsq {
 
+#if defined(DSQ_PHASE_TIMING)
+__device__ unsigned long long g_phase_total[16];
+#endif
+
 // STAGE: each wave first copies its gene's counts and mu_hat (12 B per sample) into a wave-private
 // LDS segment and runs all ~5 evaluations from there.  Without it every evaluation re-reads the
 // row through L2 (16 resident genes x 12 KB per CU overflow L1 and the CU's share of L2), which the
@@ -41,30 +45,51 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
     if (g >= G) return;
+#if defined(DSQ_PHASE_TIMING)
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < kPhases; ++k) g_ph_acc[w][k] = 0;
+        g_ph_last[w] = clock64();
+        g_ph_cur[w] = 0;
+    }
+#endif
     const int32_t* yg = y + (size_t)g * ldn;
     const double* mg = mu + (size_t)g * ldn;
+    int maxc = 0;
     if (STAGE) {
-        const int npad = (N + 1) & ~1;
+        // rows are padded to a multiple of 64 samples with (y, mu) = (0, 0): such samples contribute
+        // exactly zero to every sum of alpha_eval, which then runs without per-sample masks
+        const int npad = (N + 63) & ~63;
         double* ms = stage + (size_t)w * (npad + npad / 2);
         int32_t* ys = (int32_t*)(ms + npad);
-        for (int n = threadIdx.x & 63; n < N; n += 64) {  // lane n%64 later reads exactly what it wrote
-            ms[n] = mg[n];
-            ys[n] = yg[n];
+        for (int n = threadIdx.x & 63; n < npad; n += 64) {  // lane n%64 later reads exactly what it wrote
+            const bool valid = n < N;
+            const int yv = valid ? yg[n] : 0;
+            ms[n] = valid ? mg[n] : 0.0;
+            ys[n] = yv;
+            maxc = yv > maxc ? yv : maxc;
         }
         yg = ys;
         mg = ms;
+    } else {
+        for (int n = threadIdx.x & 63; n < N; n += 64) maxc = yg[n] > maxc ? yg[n] : maxc;
     }
-    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false>(yg, mg, Xt, ldx, N, alpha_hat[g], min_disp,
-                                                            max_disp, prior_var, cr_reg != 0, prior_reg != 0,
-                                                            machine[w],
-                                                            const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
-                                                            const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr);
+    maxc = DeviceWave::maxi(maxc);
+    const int memo_blocks = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (maxc >> 6) + 1));
+    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false, STAGE>(
+        yg, mg, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var, cr_reg != 0, prior_reg != 0, machine[w],
+        const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
+        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks);
     if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
         if (nfev != nullptr) nfev[g] = o.nfev;
         if (!o.converged) grid_list[atomicAdd(grid_count, 1)] = g;
     }
+#if defined(DSQ_PHASE_TIMING)
+    DSQ_PHASE(0);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < kPhases; ++k) atomicAdd(&g_phase_total[k], (unsigned long long)g_ph_acc[w][k]);
+#endif
 }
 
 // Grid-search fallback (grid_search.py:54-142) for the (rare) genes whose L-BFGS-B run reported
@@ -131,7 +156,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     if (G <= 0) return hipSuccess;
     if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
-    const int npad = (N + 1) & ~1;
+    const int npad = (N + 63) & ~63;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
     if (smem <= 80 * 1024) {  // >= 2 workgroups per CU keep their rows in LDS
         DSQ_DISPATCH_P(P_, {
@@ -171,3 +196,15 @@ hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu,
 }
 
 }  // namespace dsq
+
+#if defined(DSQ_PHASE_TIMING)
+// developer build only (tools/phase_probe.py): read / reset the per-phase cycle totals of k_alpha
+extern "C" int dsq_debug_phase_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dsq::g_phase_total), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dsq::g_phase_total), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

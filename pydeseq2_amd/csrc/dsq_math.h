@@ -19,6 +19,31 @@
 #define DSQ_D inline
 #endif
 
+// Developer aid (tools/phase_probe): per-wave cycle accounting of the phases of a per-gene routine.
+// Compiled out (empty macro) in the product.
+#if defined(DSQ_PHASE_TIMING) && defined(__HIPCC__)
+namespace dsq {
+constexpr int kPhases = 12;
+__shared__ long long g_ph_acc[4][kPhases];
+__shared__ long long g_ph_last[4];
+__shared__ int g_ph_cur[4];
+__device__ __forceinline__ void phase_mark(int k) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the compiler from moving arithmetic across the mark
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        const long long t = clock64();
+        g_ph_acc[w][g_ph_cur[w]] += t - g_ph_last[w];
+        g_ph_last[w] = t;
+        g_ph_cur[w] = k;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+}  // namespace dsq
+#define DSQ_PHASE(k) ::dsq::phase_mark(k)
+#else
+#define DSQ_PHASE(k) ((void)0)
+#endif
+
 namespace dsq {
 
 DSQ_HD double flog(double x);
@@ -54,6 +79,16 @@ DSQ_HD double digamma_tail(double rz) {
     return s * r2 - 0.5 * rz;
 }
 
+// the same two series truncated for z >= 256 (dropped terms < 1e-15 absolute)
+DSQ_HD double stirling_tail_big(double rz) {
+    const double r2 = rz * rz;
+    return (8.3333333333333333333e-2 - 2.7777777777777777778e-3 * r2) * rz;
+}
+DSQ_HD double digamma_tail_big(double rz) {
+    const double r2 = rz * rz;
+    return (8.3333333333333333333e-3 * r2 - 8.3333333333333333333e-2) * r2 - 0.5 * rz;
+}
+
 // lgamma(x) and digamma(x) for x > 0, sharing the upward shift to z >= 10.
 // want_dg == false skips the digamma arithmetic.
 template <bool WANT_DG>
@@ -72,7 +107,7 @@ DSQ_HD void lgamma_digamma(double x, double& lg, double& dg) {
     if (shifted) lg -= flog(prod);
     if (WANT_DG) {
         dg = lz + digamma_tail(rz);
-        if (shifted) dg -= num / prod;
+        if (shifted) dg -= num * frcp(prod);
     }
 }
 
@@ -155,7 +190,8 @@ DSQ_HD double flog(double x) {
 
 // log(1 + u), u >= 0 finite (accurate for tiny u: the rounding of 1+u is corrected)
 DSQ_HD double flog1p(double u) {
-    if (u < 5.0e-9) return u - 0.5 * u * u;  // |err| < u^3/3 < 4e-26
+    // no special case for tiny u: then w - 1 is u rounded to the 2^-52 grid, the polynomial returns
+    // log(w) = f - f^2/2 + ... and c restores exactly what the rounding of 1 + u dropped
     const double w = 1.0 + u;
     int k;
     double m = frexp(w, &k);

@@ -18,9 +18,10 @@ namespace dsq {
 // ulp(sum of counts) noise in a loss whose line search resolves ~1e-12 differences.
 struct KSum {
     double s = 0.0, c = 0.0;
-    DSQ_HD void add(double x) {
+    DSQ_HD void add(double x) {  // Knuth TwoSum: e = exact rounding error of s + x, no compare/select
         const double t = s + x;
-        c += (fabs(s) >= fabs(x)) ? ((s - t) + x) : ((x - t) + s);
+        const double bp = t - s;
+        c += (s - (t - bp)) + (x - bp);
         s = t;
     }
     DSQ_HD void merge(double os, double oc) {  // symmetric in (this, other)
@@ -52,6 +53,14 @@ struct DeviceWave {
     static __device__ __forceinline__ int sumi(int v) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
+    static __device__ __forceinline__ int maxi(int v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(v, m, 64);
+            v = v > o ? v : o;
+        }
         return v;
     }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }
@@ -87,6 +96,7 @@ struct HostWave {
     static inline double sum(double v) { return v; }
     static inline double max(double v) { return v; }
     static inline int sumi(int v) { return v; }
+    static inline int maxi(int v) { return v; }
     static inline bool any(bool p) { return p; }
     static inline double from_lane(double v, int) { return v; }
     static inline double uniform(double v) { return v; }

@@ -29,6 +29,39 @@ def test_library_is_native(inf):
     assert info["cu_count"] >= 200
 
 
+@pytest.mark.parametrize("P", list(range(1, 13)))
+def test_dispersion_kernel_every_design_width(inf, P):
+    """k_alpha<P> (every template instantiation, all memo sizes: genes whose largest count is < 64,
+    < 128, < 256 and beyond) against the host instantiation of the same templates, for the MLE and
+    the MAP objective.  Guards the register-heavy wide-design variants against miscompiles."""
+    from tests import hostsim as hs
+
+    rng = np.random.default_rng(100 + P)
+    N, G = 150, 96
+    X = np.ones((N, P))
+    for j in range(1, P):
+        X[:, j] = rng.integers(0, 2, N) if j % 3 else rng.normal(0, 1, N)
+    scale = np.repeat([3.0, 30.0, 90.0, 400.0], G // 4)  # one block of genes per memo size
+    beta = rng.normal(0, 0.3, (P, G))
+    beta[0] = np.log(scale) + rng.normal(0, 0.2, G)
+    mu_true = np.exp(np.clip(X @ beta, -20, 9))
+    disp = rng.uniform(0.02, 1.0, G)
+    counts = rng.negative_binomial(1.0 / disp, 1.0 / (1.0 + mu_true * disp)).astype(np.int64)
+    mu = np.maximum(mu_true * np.exp(rng.normal(0, 0.05, (N, G))), 0.5)
+    a0 = disp * np.exp(rng.normal(0, 0.3, G))
+    for kw in (dict(), dict(prior_disp_var=0.7, cr_reg=True, prior_reg=True)):
+        a, c = inf.alpha_mle(counts, X, mu, a0, 1e-8, float(N), **kw)
+        ra, rc, _ = hs.alpha_mle(counts, X, mu, a0, 1e-8, float(N),
+                                 prior_var=kw.get("prior_disp_var"), cr_reg=True, prior_reg=bool(kw))
+        both = c & rc
+        assert both.mean() > 0.9, (c.mean(), rc.mean())
+        assert (c == rc).mean() > 0.97
+        # device and host sum in different orders; a gene whose line search ends inside that rounding
+        # noise may stop one step apart (DESIGN.md "parity caveat"): allow a few such genes
+        rel = np.abs(a[both] - ra[both]) / np.abs(ra[both])
+        assert (rel > 1e-6).mean() <= 0.03 and rel.max() < 5e-3, (P, bool(kw), np.sort(rel)[-5:])
+
+
 @pytest.mark.parametrize("case", ["p2", "p4", "p8"])
 def test_inference_vs_reference_kats(inf, case):
     k = load_kat(case)

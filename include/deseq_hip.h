@@ -223,6 +223,22 @@ int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, 
                  const double* h_ridge, const double* h_contrast, double lfc_null, int alt,
                  double* d_pvals, double* d_stats, double* d_se);
 /* row gathers for the refit sub-problem: dst[k][:] = src[idx[k]][:] */
+/* O(G) glue that keeps the dispersion vectors device-resident between the stages:
+ * fitted trend a0 + a1/normed_mean (dds.py:826-833; a1 == 0: mean trend), final dispersions with the
+ * dispersion-outlier rule (dds.py:912-935; inputs are the UNclipped fits), and the write-back of the
+ * refitted genes (dds.py:1410-1458). */
+int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1,
+                       double* d_fitted);
+int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const double* d_map_raw,
+                               const double* d_fitted, int n, double min_disp, double max_disp,
+                               double squared_logres, double* d_disp, uint8_t* d_outlier);
+int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
+                             double* d_dst);
+/* page-locked host memory + asynchronous copies on the context's stream (complete at dsq_sync) */
+int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out);
+int dsq_host_free(dsq_ctx* ctx, void* p);
+int dsq_d2h_async(dsq_ctx* ctx, void* pinned_dst, const void* d_src, size_t bytes);
+int dsq_h2d_async(dsq_ctx* ctx, void* d_dst, const void* pinned_src, size_t bytes);
 int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int32_t* d_idx,
                             int n_idx, int ncols, double* d_dst);
 int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx,

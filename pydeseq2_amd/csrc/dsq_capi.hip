@@ -483,6 +483,44 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
     return DSQ_OK;
 }
 
+int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1, double* d_fitted) {
+    DSQ_HIP(dsq::launch_trend_eval(ctx->stream, d_normed_means, n, a0, a1, d_fitted));
+    return DSQ_OK;
+}
+
+int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const double* d_map_raw,
+                               const double* d_fitted, int n, double min_disp, double max_disp,
+                               double squared_logres, double* d_disp, uint8_t* d_outlier) {
+    DSQ_HIP(dsq::launch_select_disp(ctx->stream, d_genewise_raw, d_map_raw, d_fitted, n, min_disp, max_disp,
+                                    2.0 * sqrt(squared_logres), d_disp, d_outlier));
+    return DSQ_OK;
+}
+
+int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
+                             double* d_dst) {
+    DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, d_src, d_idx, n_idx, width, d_dst));
+    return DSQ_OK;
+}
+
+int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out) {
+    DSQ_CHECK_ARG(out != nullptr, "null output pointer");
+    DSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
+    return DSQ_OK;
+}
+int dsq_host_free(dsq_ctx* ctx, void* p) {
+    if (p) DSQ_HIP(hipHostFree(p));
+    return DSQ_OK;
+}
+// asynchronous device -> pinned-host copy on the context's stream (pair with dsq_sync)
+int dsq_d2h_async(dsq_ctx* ctx, void* pinned_dst, const void* d_src, size_t bytes) {
+    if (bytes) DSQ_HIP(hipMemcpyAsync(pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return DSQ_OK;
+}
+int dsq_h2d_async(dsq_ctx* ctx, void* d_dst, const void* pinned_src, size_t bytes) {
+    if (bytes) DSQ_HIP(hipMemcpyAsync(d_dst, pinned_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return DSQ_OK;
+}
+
 int dsq_dev_gather_rows_i32(dsq_ctx* ctx, const int32_t* d_src, int ld, const int32_t* d_idx, int n_idx,
                             int ncols, int32_t* d_dst) {
     DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_src, ld, d_idx, n_idx, ncols, d_dst));

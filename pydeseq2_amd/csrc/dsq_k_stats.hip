@@ -672,6 +672,58 @@ hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, co
     return hipGetLastError();
 }
 
+// ---- O(G) glue between the per-gene stages (keeps the dispersion vectors on the device)
+// fitted trend  a0 + a1 / normed_mean  (dds.py:826-833; a1 = 0 gives the mean trend, dds.py:1277-1299)
+__global__ void k_trend_eval(const double* __restrict__ nm, int n, double a0, double a1,
+                             double* __restrict__ fitted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fitted[i] = (a1 == 0.0) ? a0 : a0 + a1 / nm[i];
+}
+
+// final dispersions (dds.py:912-935): MAP value, except for dispersion outliers
+// log(genewise) > log(fitted) + 2 sqrt(squared_logres), which keep the (clipped) genewise value
+__global__ void k_select_disp(const double* __restrict__ gw_raw, const double* __restrict__ map_raw,
+                              const double* __restrict__ fitted, int n, double min_disp, double max_disp,
+                              double two_sd, double* __restrict__ disp, uint8_t* __restrict__ outlier) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double gw = fmin(fmax(gw_raw[i], min_disp), max_disp);
+    const double mp = fmin(fmax(map_raw[i], min_disp), max_disp);
+    const bool out = log(gw) > log(fitted[i]) + two_sd;
+    disp[i] = out ? gw : mp;
+    outlier[i] = out ? 1 : 0;
+}
+
+// dst[idx[k]][0..width) = src[k][0..width)   (results of the outlier refit back into the full vectors)
+__global__ void k_scatter_rows(const double* __restrict__ src, const int32_t* __restrict__ idx, int n_idx,
+                               int width, double* __restrict__ dst) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * width) return;
+    const int k = t / width, c = t % width;
+    dst[(size_t)idx[k] * width + c] = src[t];
+}
+
+hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trend_eval, dim3((n + 255) / 256), dim3(256), 0, st, nm, n, a0, a1, fitted);
+    return hipGetLastError();
+}
+hipError_t launch_select_disp(hipStream_t st, const double* gw_raw, const double* map_raw, const double* fitted,
+                              int n, double min_disp, double max_disp, double two_sd, double* disp,
+                              uint8_t* outlier) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select_disp, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, map_raw, fitted, n,
+                       min_disp, max_disp, two_sd, disp, outlier);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,
+                               double* dst) {
+    if (n_idx <= 0 || width <= 0) return hipSuccess;
+    const int total = n_idx * width;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((total + 255) / 256), dim3(256), 0, st, src, idx, n_idx, width, dst);
+    return hipGetLastError();
+}
+
 // gamma-GLM trend loss/gradient partial sums, one row of 4 per block (summed by the host in a
 // fixed order => run-to-run deterministic): {sum(t/m + log m), sum g0, sum g1, count}
 constexpr int kTrendBlocks = 256;

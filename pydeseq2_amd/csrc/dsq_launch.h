@@ -69,6 +69,12 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero);
 hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
                                   int n_idx, int ncols, double* dst);
+hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted);
+hipError_t launch_select_disp(hipStream_t st, const double* gw_raw, const double* map_raw, const double* fitted,
+                              int n, double min_disp, double max_disp, double two_sd, double* disp,
+                              uint8_t* outlier);
+hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,
+                               double* dst);
 hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, const int32_t* idx,
                                   int n_idx, int ncols, int32_t* dst);
 constexpr int kTrendPartials = 256;  // rows of 4 doubles

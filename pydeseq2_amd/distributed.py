@@ -211,14 +211,14 @@ class DistDeseqPipeline(DeseqPipeline):
         gw_all, nm_all = self._gather_trend_inputs(Gn)
         return self._run_trend_kernel(self._up(gw_all), self._up(nm_all), len(gw_all))
 
-    def _mean_trend(self, genewise_all):
+    def _mean_trend(self, Gn):
         if self._gathered is None:
-            self._gather_trend_inputs(int(np.sum(~np.isnan(genewise_all))))
+            self._gather_trend_inputs(Gn)
         gw_all = np.clip(self._gathered[0], self.min_disp, self.max_disp)
         return _trend.mean_trend(gw_all, self.min_disp)
 
-    def _prior(self, gw, fitted_nz, r):
-        gw_all, nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(len(gw))
+    def _prior(self, Gn, d_fit, r):
+        gw_all, nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(Gn)
         ok = ~np.isnan(nm_all)
         gwc = np.clip(gw_all[ok], self.min_disp, self.max_disp)
         if r.disp_function_type == "parametric":

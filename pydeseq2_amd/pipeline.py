@@ -68,6 +68,61 @@ def _scatter(G, idx, v, fill=np.nan):
     return out
 
 
+class _View:
+    """A vector inside a larger device buffer (only the address; the buffer is pool-owned)."""
+
+    __slots__ = ("ptr",)
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+class _PinnedPool:
+    """Free list of page-locked host buffers of one pipeline (results may outlive the pipeline)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.free, self.closed = ctx, [], False
+
+    def take(self, nbytes):
+        for k, (cap, ptr) in enumerate(self.free):
+            if cap >= nbytes:
+                self.free.pop(k)
+                return _PinnedSlab(self, cap, ptr)
+        p = _vp()
+        self.ctx.call("dsq_host_alloc", C.c_size_t(int(nbytes)), C.byref(p))
+        return _PinnedSlab(self, int(nbytes), p.value)
+
+    def release(self, cap, ptr):
+        if self.closed:
+            self.ctx.call("dsq_host_free", _vp(ptr))
+        else:
+            self.free.append((cap, ptr))
+
+    def close(self):
+        self.closed = True
+        while self.free:
+            _cap, ptr = self.free.pop()
+            self.ctx.call("dsq_host_free", _vp(ptr))
+
+
+class _PinnedSlab:
+    """Page-locked host buffer; numpy views keep it alive, the last one returns it to the pool."""
+
+    def __init__(self, pool, cap, ptr):
+        self._pool, self.cap, self.ptr = pool, cap, ptr
+
+    def view(self, offset, count, dtype):
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(self.ptr + offset)
+        buf._slab = self  # numpy array -> ctypes buffer -> slab
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    def __del__(self):
+        try:
+            self._pool.release(self.cap, self.ptr)
+        except Exception:
+            pass
+
+
 class DeseqPipeline:
     """Holds the device-resident state of one dataset on one GPU.
 
@@ -125,6 +180,7 @@ class DeseqPipeline:
         self.time_kernels = False
         self.kernel_log = {}
         self._pool_free, self._pool_used = [], []
+        self._pinned = _PinnedPool(ctx_)
         ctx_.sync()
 
     # ------------------------------------------------------------------ helpers
@@ -181,76 +237,123 @@ class DeseqPipeline:
 
     def _k(self, name, genes, cname, *args):
         """Launch a per-gene stage; with ``time_kernels`` bracket it with HIP events on the
-        context's stream and record (milliseconds, genes) under ``name``."""
+        context's stream and record (milliseconds, genes) under ``name`` (this synchronises the host
+        after every stage: profiling mode only).  The dispersion kernel's own duration comes from
+        events recorded inside the C call and is logged in every mode."""
         if self.time_kernels:
             self.ctx.timer_start()
             self.ctx.call(cname, *args)
             ms = self.ctx.timer_stop()
             self.kernel_log.setdefault(name, []).append((ms, int(genes)))
-            if cname == "dsq_dev_alpha_mle":  # kernel-only duration of k_alpha (events inside the C call)
-                kms, ng = C.c_float(), C.c_int()
-                self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
-                self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
-                self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
         else:
             self.ctx.call(cname, *args)
+        if cname == "dsq_dev_alpha_mle":
+            kms, ng = C.c_float(), C.c_int()
+            self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
+            self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
+            self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
 
-    # ------------------------------------------------------------------ stages
-    def _stage_genewise(self, d_y, Gs, d_sf):
-        """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797). Returns device mu_hat and
-        host vectors (normed_means, mom, genewise (clipped), converged)."""
-        ctx, D = self.ctx, self.design
-        d_nm, d_mom = self._dvec(Gs), self._dvec(Gs)
+    # ------------------------------------------------------------------ result slabs
+    # All per-gene result vectors of a step live in ONE device buffer laid out like one page-locked
+    # host buffer, so that they come back with two DMA copies at the end of the step instead of ~20
+    # pageable round trips in between.  _F64 / _U8 name the vectors (each Gs long; "beta" is Gs x P).
+    _F64 = ("nm", "mom", "gw", "fit", "map", "disp", "p", "stat", "se", "rd")
+    _U8 = ("gconv", "mconv", "outl", "lconv", "any_all", "any_use", "any_use_nr", "few_above")
+
+    def _slab_layout(self, Gs):
+        off, o = {}, 0
+        for k in self._F64:
+            off[k] = o
+            o += 8 * Gs
+        off["beta"] = o
+        o += 8 * Gs * self.P
+        n_f64 = o
+        for k in self._U8:
+            off[k] = o
+            o += Gs
+        return off, n_f64, ((o + 63) // 64) * 64
+
+    def _dev_slab(self, Gs):
+        """Device result buffer of a (sub-)problem of Gs genes: namespace of _View objects."""
+        off, n_f64, total = self._slab_layout(Gs)
+        base = self._take(total)
+        v = {k: _View(base + o) for k, o in off.items()}
+        v["_base"], v["_off"], v["_n_f64"], v["_total"], v["_Gs"] = base, off, n_f64, total, Gs
+        return v
+
+    def _host_slab(self, nbytes):
+        """Page-locked host buffer from the pipeline's free list (returned to it when the last numpy
+        view of the previous result dies)."""
+        return self._pinned.take(nbytes)
+
+    def _fetch(self, slab, names=None):
+        """Device slab -> numpy views over a pinned host slab (dict name -> array)."""
+        Gs, off = slab["_Gs"], slab["_off"]
+        host = self._host_slab(slab["_total"])
+        if names is None:
+            self.ctx.call("dsq_d2h_async", _vp(host.ptr), _vp(slab["_base"]), C.c_size_t(slab["_total"]))
+            names = list(self._F64) + ["beta"] + list(self._U8)
+        else:
+            for k in names:
+                nb = Gs * (8 * self.P if k == "beta" else (8 if k in self._F64 else 1))
+                self.ctx.call("dsq_d2h_async", _vp(host.ptr + off[k]), _vp(slab["_base"] + off[k]), C.c_size_t(nb))
+        self.ctx.sync()
+        out = {}
+        for k in names:
+            if k == "beta":
+                out[k] = host.view(off[k], Gs * self.P, np.float64).reshape(Gs, self.P)
+            elif k in self._F64:
+                out[k] = host.view(off[k], Gs, np.float64)
+            else:
+                out[k] = host.view(off[k], Gs, np.uint8)
+        return out
+
+    # ------------------------------------------------------------------ stages (device in, device out)
+    def _stage_genewise(self, d_y, Gs, d_sf, S):
+        """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
+        unclipped), gconv]; returns the device mu_hat matrix."""
+        D = self.design
         self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr),
-                 D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp), _vp(d_nm.ptr),
-                 None, None, _vp(d_mom.ptr))
+                D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp), _vp(S["nm"].ptr),
+                None, None, _vp(S["mom"].ptr))
         d_mu = self._dmat(Gs)
         if D.linear_mu:  # dds.py:747-756
             self._k("lin_mu", Gs, "dsq_dev_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
-                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_mu), _vp(d_mu.ptr))
+                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_mu), _vp(d_mu.ptr))
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
             self._k("irls_mu", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
-                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_mom.ptr),
-                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
-                     _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
-        d_gw, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
+                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
+                    c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                    _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
         d_mu.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
-        self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr), D.ldx, self.N,
-                 Gs, self.P, _vp(d_mom.ptr), c_double(self.min_disp), c_double(self.max_disp), c_double(1.0), 1,
-                 0, _vp(d_gw.ptr), _vp(d_conv.ptr), None, _vp(d_mu.nll_const.ptr), 1)
-        nm = self._down(d_nm, Gs)
-        mom = self._down(d_mom, Gs)
-        gw = np.clip(self._down(d_gw, Gs), self.min_disp, self.max_disp)  # dds.py:792-794
-        conv = self._down(d_conv, Gs, np.uint8).astype(bool)
-        self._last_gw_dev = (d_gw, d_nm)  # raw genewise dispersions / means stay on the device for the trend fit
-        return d_mu, nm, mom, gw, conv
+        self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
+                D.ldx, self.N, Gs, self.P, _vp(S["mom"].ptr), c_double(self.min_disp), c_double(self.max_disp),
+                c_double(1.0), 1, 0, _vp(S["gw"].ptr), _vp(S["gconv"].ptr), None, _vp(d_mu.nll_const.ptr), 1)
+        return d_mu
 
-    def _stage_map(self, d_y, d_mu, Gs, fitted, prior_var):
-        """MAP dispersions (dds.py:886-935) -> host (map clipped, converged)."""
-        d_fit = self._up(fitted)
-        d_map, d_conv = self._dvec(Gs), self._dvec(Gs, np.uint8)
+    def _stage_map(self, d_y, d_mu, Gs, prior_var, squared_logres, S):
+        """MAP dispersions (dds.py:886-935) from S[fit] -> S[map (raw), mconv], then the final
+        dispersions S[disp] and the dispersion-outlier flags S[outl]."""
         self._k("alpha_map", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
-                      self.design.ldx, self.N, Gs, self.P, _vp(d_fit.ptr), c_double(self.min_disp),
-                      c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(d_map.ptr), _vp(d_conv.ptr), None,
-                      *((_vp(d_mu.nll_const.ptr), 2) if getattr(d_mu, "nll_const", None) is not None else (None, 0)))
-        return (np.clip(self._down(d_map, Gs), self.min_disp, self.max_disp),
-                self._down(d_conv, Gs, np.uint8).astype(bool))
+                self.design.ldx, self.N, Gs, self.P, _vp(S["fit"].ptr), c_double(self.min_disp),
+                c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(S["map"].ptr), _vp(S["mconv"].ptr), None,
+                *((_vp(d_mu.nll_const.ptr), 2) if getattr(d_mu, "nll_const", None) is not None else (None, 0)))
+        self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
+                      c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
+                      _vp(S["disp"].ptr), _vp(S["outl"].ptr))
 
-    def _stage_lfc(self, d_y, Gs, d_sf, disp, want_layers=True):
-        """IRLS LFC fit (dds.py:937-984) -> (beta host, device mu, device hat, converged)."""
+    def _stage_lfc(self, d_y, Gs, d_sf, S, want_layers=True):
+        """IRLS LFC fit (dds.py:937-984) with S[disp] -> S[beta, lconv]; returns device (mu, hat)."""
         D = self.design
-        d_disp = self._up(disp)
-        d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
         d_mu = self._dmat(Gs) if want_layers else None
         d_hat = self._dmat(Gs) if want_layers else None
         self._k("irls_lfc", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
-                      _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(d_disp.ptr),
-                      c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
-                      _vp(d_b.ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
-                      _vp(d_c.ptr), None)
-        beta = self._down(d_b, Gs * self.P).reshape(Gs, self.P)
-        return beta, d_mu, d_hat, self._down(d_c, Gs, np.uint8).astype(bool)
+                _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
+                c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                _vp(S["beta"].ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
+                _vp(S["lconv"].ptr), None)
+        return d_mu, d_hat
 
     # ------------------------------------------------------------------ cross-gene steps (hooks)
     # The only places where a gene needs other genes; DistDeseqPipeline (distributed.py) overrides
@@ -277,25 +380,32 @@ class DeseqPipeline:
                 C.byref(n_outer))
         return np.array([c2[0], c2[1]]) if ok.value else None
 
-    def _mean_trend(self, genewise_all):
-        return _trend.mean_trend(genewise_all, self.min_disp)
+    def _mean_trend(self, Gn):
+        """Mean-based trend (dds.py:1277-1299) over this pipeline's (clipped) genewise dispersions."""
+        d_gw, _ = self._last_gw_dev
+        gw = np.clip(self._down(d_gw, Gn), self.min_disp, self.max_disp)
+        return _trend.mean_trend(gw, self.min_disp)
 
-    def _prior(self, gw, fitted_nz, r):
+    def _prior(self, Gn, d_fit, r):
         """(squared_logres, prior_disp_var) (dds.py:866-884); the two medians run on the device."""
         from scipy.special import polygamma
 
         d_gw, _ = self._last_gw_dev
-        d_fit = self._up(fitted_nz)
         sq = C.c_double()
-        d_work = self._dvec(len(fitted_nz))
-        self._k("prior_mad", len(fitted_nz), "dsq_dev_prior_mad", _vp(d_gw.ptr), _vp(d_fit.ptr), len(fitted_nz),
+        d_work = self._dvec(Gn)
+        self._k("prior_mad", Gn, "dsq_dev_prior_mad", _vp(d_gw.ptr), _vp(d_fit.ptr), Gn,
                 c_double(self.min_disp), c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
         sq = float(sq.value)
         return sq, float(np.maximum(sq - polygamma(1, (self.N - self.P) / 2), 0.25))
 
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False) -> DeseqResult:
-        """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald."""
+        """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald.
+
+        The per-gene vectors stay in HBM from the first kernel to the Wald test; the host sees
+        scalars (trend coefficients, prior variance), the Cook's flags that decide the refit, and at
+        the end one block copy of all result vectors.
+        """
         ctx, D, N, G, P = self.ctx, self.design, self.N, self.G, self.P
         if alt_hypothesis not in ALT:
             raise KeyError(alt_hypothesis)
@@ -328,29 +438,27 @@ class DeseqPipeline:
         non_zero = self._down(d_nz, G, np.uint8).astype(bool)
         r.size_factors, r.non_zero = sf, non_zero
         self.d_sf = d_sf
-        nzi = np.nonzero(non_zero)[0]
-        Gn = len(nzi)
+        Gn = int(non_zero.sum())
+        all_nz = Gn == G
+        nzi = None if all_nz else np.nonzero(non_zero)[0]
         t1 = tick(); T["size_factors"] = t1 - t0
 
         # ---- compact to the non-zero genes (dds.py:729-731)
-        if Gn < G:
+        if all_nz:
+            d_ynz = self.d_y
+        else:
             d_idx = self._up(nzi.astype(np.int32), np.int32)
             d_ynz = self._dmat(Gn, np.int32)
             ctx.call("dsq_dev_gather_rows_i32", _vp(self.d_y.ptr), self.ldn, _vp(d_idx.ptr), Gn, N,
                      _vp(d_ynz.ptr))
-        else:
-            d_ynz = self.d_y
+        S = self._dev_slab(Gn)
 
         # ---- genewise dispersions (dds.py:713-797)
-        d_mu_hat, nm, mom, gw, gconv = self._stage_genewise(d_ynz, Gn, d_sf)
-        # all-zero genes have normed mean 0 (dds.py:708)
-        r.normed_means = _scatter(G, nzi, nm, fill=0.0)
-        r.mom_dispersions = _scatter(G, nzi, mom)
-        r.genewise_dispersions = _scatter(G, nzi, gw)
-        r.genewise_converged = _scatter(G, nzi, gconv.astype(float))
+        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S)
+        self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
         t2 = tick(); T["genewise"] = t2 - t1
 
-        # ---- trend (dds.py:799-838) + prior (dds.py:840-884): cross-gene, O(G), host
+        # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
         coeffs = None
         if self.fit_type == "parametric":
             coeffs = self._fit_trend(Gn)
@@ -362,62 +470,51 @@ class DeseqPipeline:
                                       f"{self.fit_type}")
         if coeffs is not None:
             r.trend_coeffs, r.disp_function_type = coeffs, "parametric"
-            fitted_nz = coeffs[0] + coeffs[1] / nm
-            fitted = _scatter(G, nzi, fitted_nz)
+            a0, a1 = float(coeffs[0]), float(coeffs[1])
         else:
             r.disp_function_type = "mean"
-            r.mean_disp = self._mean_trend(r.genewise_dispersions)
-            fitted = np.full(G, r.mean_disp)
-            fitted_nz = fitted[nzi]
-        r.fitted_dispersions = fitted
+            r.mean_disp = self._mean_trend(Gn)
+            a0, a1 = float(r.mean_disp), 0.0
+        ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(a0), c_double(a1), _vp(S["fit"].ptr))
         if (N - P) <= 3:
             warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
                           "dispersions is especially asymmetric and likely to be poorly estimated by the MAD.",
                           UserWarning, stacklevel=2)
-        r.squared_logres, r.prior_disp_var = self._prior(gw, fitted_nz, r)
+        r.squared_logres, r.prior_disp_var = self._prior(Gn, S["fit"], r)
         t3 = tick(); T["trend_prior"] = t3 - t2
 
-        # ---- MAP dispersions (dds.py:886-935)
-        mp, mconv = self._stage_map(d_ynz, d_mu_hat, Gn, fitted_nz, r.prior_disp_var)
-        r.MAP_dispersions = _scatter(G, nzi, mp)
-        r.MAP_converged = _scatter(G, nzi, mconv.astype(float))
-        disp_nz = mp.copy()
-        with np.errstate(invalid="ignore", divide="ignore"):
-            out_nz = np.log(gw) > np.log(fitted_nz) + 2 * np.sqrt(r.squared_logres)
-        disp_nz[out_nz] = gw[out_nz]
-        r.outlier_genes = _scatter(G, nzi, out_nz.astype(float), fill=0.0).astype(bool)
-        r.dispersions = _scatter(G, nzi, disp_nz)
+        # ---- MAP dispersions + dispersion outliers (dds.py:886-935)
+        self._stage_map(d_ynz, d_mu_hat, Gn, r.prior_disp_var, r.squared_logres, S)
         t4 = tick(); T["MAP"] = t4 - t3
 
         # ---- LFC (dds.py:937-984)
-        beta, d_mu, d_hat, lconv = self._stage_lfc(d_ynz, Gn, d_sf, disp_nz)
-        r.LFC = np.full((G, P), np.nan)
-        r.LFC[nzi] = beta
-        r.LFC_converged = _scatter(G, nzi, lconv.astype(float))
+        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S)
         t5 = tick(); T["LFC"] = t5 - t4
 
         # ---- Cook's (dds.py:986-1040)
         cutoff = float(f_dist.ppf(0.99, P, N - P))
         d_cooks = self._dmat(Gn)
-        d_rd = self._dvec(Gn)
-        d_f = [self._dvec(Gn, np.uint8) for _ in range(4)]
+        flag_names = ["any_all", "any_use", "any_use_nr", "few_above"]
         self._k("cooks", Gn, "dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),
-                 _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
-                 _vp(self.d_flags.ptr), N, Gn, P, c_double(cutoff), _vp(d_cooks.ptr), _vp(d_rd.ptr),
-                 *[_vp(x.ptr) for x in d_f])
-        any_all, any_use, any_use_nr, few_above = [self._down(x, Gn, np.uint8).astype(bool) for x in d_f]
-        self.layers = {"nz_idx": nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat, "cooks": d_cooks}
+                _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
+                _vp(self.d_flags.ptr), N, Gn, P, c_double(cutoff), _vp(d_cooks.ptr), _vp(S["rd"].ptr),
+                *[_vp(S[x].ptr) for x in flag_names])
+        want_refit = self.refit_cooks and D.replaceable.sum() > 0
+        flags = self._fetch(S, ["any_all"]) if want_refit else None
+        self.layers = {"nz_idx": np.arange(G) if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
+                       "cooks": d_cooks}
         t6 = tick(); T["cooks"] = t6 - t5
 
-        # ---- refit (dds.py:1042-1064, 1301-1458)
+        # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem, patched into the device vectors
         replaced_nz = np.zeros(Gn, dtype=bool)
         refitted_nz = np.zeros(Gn, dtype=bool)
         new_zero_nz = np.zeros(Gn, dtype=bool)
-        if self.refit_cooks and D.replaceable.sum() > 0:
-            replaced_nz = any_all.copy()  # idx.any(axis=0), dds.py:1325-1326
-            if replaced_nz.sum() > 0:
-                rp = np.nonzero(replaced_nz)[0]
-                Gr = len(rp)
+        patch = None
+        if want_refit:
+            replaced_nz = flags["any_all"].astype(bool)  # idx.any(axis=0), dds.py:1325-1326
+            rp = np.nonzero(replaced_nz)[0]
+            Gr = len(rp)
+            if Gr > 0:
                 d_rp = self._up(rp.astype(np.int32), np.int32)
                 d_ysub = self._dmat(Gr, np.int32)
                 d_az = self._dvec(Gr, np.uint8)
@@ -427,9 +524,10 @@ class DeseqPipeline:
                 naz = self._down(d_az, Gr, np.uint8).astype(bool)
                 new_zero_nz[rp[naz]] = True
                 refitted_nz[rp[~naz]] = True
-                if naz.any():  # dds.py:1380-1383
-                    r.normed_means[nzi[rp[naz]]] = 0.0
-                    r.LFC[nzi[rp[naz]], :] = 0.0
+                if naz.any():  # dds.py:1380-1383: LFC = 0 for the genes that became all-zero
+                    zi = rp[naz].astype(np.int32)
+                    ctx.call("dsq_dev_scatter_rows_f64", _vp(self._up(np.zeros((len(zi), P))).ptr),
+                             _vp(self._up(zi, np.int32).ptr), len(zi), P, _vp(S["beta"].ptr))
                 if (~naz).any():
                     keep = np.nonzero(~naz)[0]
                     rf = rp[keep]
@@ -441,48 +539,70 @@ class DeseqPipeline:
                                  _vp(d_yf.ptr))
                     else:
                         d_yf = d_ysub
-                    s_mu, s_nm, _, s_gw, _ = self._stage_genewise(d_yf, Gf, d_sf)
-                    if r.disp_function_type == "parametric":
-                        s_fit = r.trend_coeffs[0] + r.trend_coeffs[1] / s_nm
-                    else:
-                        s_fit = np.full(Gf, r.mean_disp)
-                    s_map, _ = self._stage_map(d_yf, s_mu, Gf, s_fit, r.prior_disp_var)
-                    s_disp = s_map.copy()
-                    with np.errstate(invalid="ignore", divide="ignore"):
-                        s_out = np.log(s_gw) > np.log(s_fit) + 2 * np.sqrt(r.squared_logres)
-                    s_disp[s_out] = s_gw[s_out]
-                    s_beta, _, _, _ = self._stage_lfc(d_yf, Gf, d_sf, s_disp, want_layers=False)
-                    gi = nzi[rf]
-                    r.normed_means[gi] = s_nm
-                    r.LFC[gi, :] = s_beta
-                    r.genewise_dispersions[gi] = s_gw
-                    r.fitted_dispersions[gi] = s_fit
-                    r.dispersions[gi] = s_disp
-        r.replaced = _scatter(G, nzi, replaced_nz.astype(float), fill=0.0).astype(bool)
-        r.refitted = _scatter(G, nzi, refitted_nz.astype(float), fill=0.0).astype(bool)
-        r.new_all_zeroes = _scatter(G, nzi, new_zero_nz.astype(float), fill=0.0).astype(bool)
-        # ---- cooks_outlier (dds.py:1066-1110)
-        use_rc = self.refit_cooks and refitted_nz.sum() > 0
-        co_nz = np.where(refitted_nz, any_use_nr, any_use) if use_rc else any_use.copy()
-        co_nz = co_nz & few_above
-        r.cooks_outlier = _scatter(G, nzi, co_nz.astype(float), fill=0.0).astype(bool)
+                    S2 = self._dev_slab(Gf)
+                    s_mu = self._stage_genewise(d_yf, Gf, d_sf, S2)
+                    ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gf, c_double(a0), c_double(a1),
+                             _vp(S2["fit"].ptr))
+                    self._stage_map(d_yf, s_mu, Gf, r.prior_disp_var, r.squared_logres, S2)
+                    self._stage_lfc(d_yf, Gf, d_sf, S2, want_layers=False)
+                    d_rf = self._up(rf.astype(np.int32), np.int32)
+                    for k, wdt in (("disp", 1), ("beta", P)):
+                        ctx.call("dsq_dev_scatter_rows_f64", _vp(S2[k].ptr), _vp(d_rf.ptr), Gf, wdt, _vp(S[k].ptr))
+                    patch = (rf, self._fetch(S2, ["nm", "gw", "fit"]))
         t7 = tick(); T["refit"] = t7 - t6
 
-        # ---- Wald (ds.py:303-360); mu = sf * exp(X beta) is recomputed on the device
+        # ---- Wald (ds.py:303-360) on the device vectors; mu = sf * exp(X beta) is recomputed there
         ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
-        d_beta = self._up(r.LFC)
-        d_disp = self._up(r.dispersions)
-        d_p, d_s, d_se = self._dvec(G), self._dvec(G), self._dvec(G)
-        self._k("wald", G, "dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P,
-                 _vp(d_disp.ptr), _vp(d_beta.ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data),
-                 c_double(np.log(2) * lfc_null), ALT[alt_hypothesis], _vp(d_p.ptr), _vp(d_s.ptr), _vp(d_se.ptr))
-        pv, st, se = self._down(d_p, G), self._down(d_s, G), self._down(d_se, G)
-        if self.refit_cooks and r.replaced.sum() > 0:  # ds.py:357-360
-            z = r.new_all_zeroes
-            se[z], st[z], pv[z] = 0.0, 0.0, 1.0
-        r.pvalue, r.stat, r.lfcSE = pv, st, se
+        self._k("wald", Gn, "dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, Gn, P,
+                _vp(S["disp"].ptr), _vp(S["beta"].ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data),
+                c_double(np.log(2) * lfc_null), ALT[alt_hypothesis], _vp(S["p"].ptr), _vp(S["stat"].ptr),
+                _vp(S["se"].ptr))
+        H = self._fetch(S)
         t8 = tick(); T["wald"] = t8 - t7
-        T["total"] = t8 - t0
+
+        # ---- host view of the results (reference field names), scattered to all G genes
+        def full(v, fill=np.nan, dtype=None):
+            if all_nz:
+                return v if dtype is None else v.astype(dtype)
+            out = np.full((G,) + v.shape[1:], fill, dtype=dtype or v.dtype)
+            out[nzi] = v
+            return out
+
+        gw = np.clip(H["gw"], self.min_disp, self.max_disp)  # dds.py:792-794
+        nm, fit, disp, beta = H["nm"], H["fit"], H["disp"], H["beta"]
+        if patch is not None or new_zero_nz.any():
+            nm, fit = nm.copy(), fit.copy()
+            if patch is not None:  # dds.py:1410-1458: the refitted genes take their new values
+                rf, h2 = patch
+                nm[rf] = h2["nm"]
+                gw[rf] = np.clip(h2["gw"], self.min_disp, self.max_disp)
+                fit[rf] = h2["fit"]
+            nm[new_zero_nz] = 0.0  # dds.py:1380-1383
+        r.normed_means = full(nm, fill=0.0)  # all-zero genes have normed mean 0 (dds.py:708)
+        r.mom_dispersions = full(H["mom"])
+        r.genewise_dispersions = full(gw)
+        r.genewise_converged = full(H["gconv"].astype(float))
+        r.fitted_dispersions = full(fit) if coeffs is not None else np.full(G, r.mean_disp)
+        r.MAP_dispersions = full(np.clip(H["map"], self.min_disp, self.max_disp))
+        r.MAP_converged = full(H["mconv"].astype(float))
+        r.outlier_genes = full(H["outl"].astype(bool), fill=False)
+        r.dispersions = full(disp)
+        r.LFC = full(beta)
+        r.LFC_converged = full(H["lconv"].astype(float))
+        r.replaced = full(replaced_nz, fill=False)
+        r.refitted = full(refitted_nz, fill=False)
+        r.new_all_zeroes = full(new_zero_nz, fill=False)
+        # ---- cooks_outlier (dds.py:1066-1110)
+        any_use, any_use_nr = H["any_use"].astype(bool), H["any_use_nr"].astype(bool)
+        co_nz = np.where(refitted_nz, any_use_nr, any_use) if (self.refit_cooks and refitted_nz.any()) else any_use
+        r.cooks_outlier = full(co_nz & H["few_above"].astype(bool), fill=False)
+        pv, st, se = H["p"], H["stat"], H["se"]
+        if new_zero_nz.any():  # ds.py:357-360
+            pv, st, se = pv.copy(), st.copy(), se.copy()
+            se[new_zero_nz], st[new_zero_nz], pv[new_zero_nz] = 0.0, 0.0, 1.0
+        r.pvalue, r.stat, r.lfcSE = full(pv), full(st), full(se)
+        t9 = tick(); T["assemble"] = t9 - t8
+        T["total"] = t9 - t0
         if not self.keep_cooks:
             self.layers = {}
         return r
@@ -492,6 +612,7 @@ class DeseqPipeline:
         for _cap, ptr in self._pool_free + self._pool_used:
             self.ctx.free(ptr)
         self._pool_free, self._pool_used = [], []
+        self._pinned.close()
 
     def __del__(self):
         try:

@@ -81,9 +81,63 @@ struct IrlsOut {
     int fallback;  // 1: IRLS diverged (|beta| > max_beta or maxiter) -> gene needs irls_rescue_gene
 };
 
-// initial beta (:349-357) and sum(logbinom), the mu-independent part of the NLL
+// initial beta (:349-357) and sum(logbinom), the mu-independent part of the NLL:
+//   cst = sum[ lgamma(y+a) - lgamma(y+1) ] - N lgamma(a) = -sum[ (lgamma(a) - lgamma(y+a)) + log(y!) ]
+// The gamma differences come from the wave memo of the dispersion kernel (lane k evaluates the
+// count k once, counts >= 64 take the Stirling formula), log(y!) from the 256-entry table.  cst only
+// enters the deviance's denominator |dev| + 0.1 (it cancels in dev - old_dev), so ulp-level
+// differences from scipy's gammaln are immaterial.
 template <class Wv, int P>
 DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) b0[j] = 0.0;
+    double lga, dga_unused, tab_dl, tab_dd;
+    lgamma_digamma<false>(a, lga, dga_unused);
+    lgamma_digamma_diff<Wv, false>(Wv::lane(), a, lga, 0.0, tab_dl, tab_dd);
+    double c = 0.0;
+    for (int base = 0; base < A.N; base += Wv::W) {  // wave-uniform trip count (cross-lane memo reads)
+        const int n = base + Wv::lane();
+        const bool valid = n < A.N;
+        const int yi = valid ? A.y[n] : 0;
+        const double yv = (double)yi;
+        const bool in_tab = yi < Wv::W;
+        double dl = Wv::from_lane(tab_dl, in_tab ? yi : 0);
+        if (Wv::any(!in_tab)) {
+            double dl2, dd2;
+            lgamma_digamma_diff<Wv, false>(in_tab ? 64 : yi, a, lga, 0.0, dl2, dd2);
+            dl = in_tab ? dl : dl2;
+        }
+        const bool in_fact = yi < kLgammaIntN;
+        double lf = kLgammaInt[in_fact ? yi : 0];
+        if (Wv::any(!in_fact)) {
+            const double z = in_fact ? 300.0 : yv + 1.0;
+            const double big = (z - 0.5) * flog(z) - z + kHalfLog2Pi + stirling_tail(frcp(z));
+            lf = in_fact ? lf : big;
+        }
+        c -= valid ? dl + lf : 0.0;
+        if (valid) {
+            if (A.full_rank) {
+                // library log and true division: beta_init decides, on ill-conditioned genes, whether
+                // IRLS diverges (and the gene goes to the rescue) exactly as it does in the reference
+                const double ly = log(yv / A.sf[n] + 0.1);
+#pragma unroll
+                for (int j = 0; j < P; ++j) b0[j] += A.pinvXt[j * A.ldx + n] * ly;
+            } else {
+                b0[0] += log(yv / A.sf[n]);
+            }
+        }
+    }
+    cst = Wv::sum(c);
+    Wv::template sum_n<P>(b0);
+    if (!A.full_rank) b0[0] = b0[0] / (double)A.N;
+}
+
+// The same quantities with the reference's own arithmetic for cst (two lgamma evaluations per
+// sample, utils.py:218-222).  The rescue of a diverged gene minimises f = nlogterm - cst + s with
+// L-BFGS-B, whose line search and stopping tests react to the rounding of f itself on these
+// ill-conditioned genes, so there cst is kept bit-for-bit what the parity tests were pinned on.
+template <class Wv, int P>
+DSQ_HD void irls_init_exact(const IrlsArgs& A, double a, double (&b0)[P], double& cst) {
 #pragma unroll
     for (int j = 0; j < P; ++j) b0[j] = 0.0;
     double c = 0.0;
@@ -234,7 +288,7 @@ DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double
     out.converged = 0; out.iters = 0; out.fallback = 1;
     const double a = 1.0 / A.disp;
     double cst, b0[P];
-    irls_init<Wv, P>(A, a, b0, cst);
+    irls_init_exact<Wv, P>(A, a, b0, cst);
     const double nlogterm = A.N * a * log(A.disp);
 #pragma unroll
     for (int j = 0; j < P; ++j) { Wk.x[j] = b0[j]; Wk.l[j] = A.min_beta; Wk.u[j] = A.max_beta; Wk.nbd[j] = 2; }

@@ -9,7 +9,10 @@ namespace dsq {
 
 // wide designs: ask for 2 waves/SIMD (a few spilled accumulators cost less than running one
 // wave per SIMD with nothing to overlap its fp64 dependency chains)
-constexpr int irls_min_waves(int p) { return p <= 5 ? 1 : 2; }
+#ifndef DSQ_IRLS_WAVES_P2
+#define DSQ_IRLS_WAVES_P2 4
+#endif
+constexpr int irls_min_waves(int p) { return p <= 2 ? DSQ_IRLS_WAVES_P2 : (p <= 5 ? 1 : 2); }
 
 template <int P>
 __global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,

@@ -61,13 +61,21 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
         const int npad = (N + 63) & ~63;
         double* ms = stage + (size_t)w * (npad + npad / 2);
         int32_t* ys = (int32_t*)(ms + npad);
-        for (int n = threadIdx.x & 63; n < npad; n += 64) {  // lane n%64 later reads exactly what it wrote
-            const bool valid = n < N;
-            const int yv = valid ? yg[n] : 0;
-            ms[n] = valid ? mg[n] : 0.0;
-            ys[n] = yv;
-            maxc = yv > maxc ? yv : maxc;
-        }
+        // Whole 1-KiB pieces of the two rows go global -> LDS directly (gfx950 LDS-DMA: 16 B per lane,
+        // destination = wave-uniform base + lane * 16, no staging registers, all pieces in flight at
+        // once); the ragged end and the zero padding go through registers.
+        const int lane = threadIdx.x & 63;
+        const int full_d = N / 128, full_i = N / 256;  // pieces of 128 doubles / 256 ints
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        for (int c = 0; c < full_d; ++c)
+            __builtin_amdgcn_global_load_lds((glb_void*)(mg + c * 128 + lane * 2), (lds_void*)(ms + c * 128), 16, 0, 0);
+        for (int c = 0; c < full_i; ++c)
+            __builtin_amdgcn_global_load_lds((glb_void*)(yg + c * 256 + lane * 4), (lds_void*)(ys + c * 256), 16, 0, 0);
+        for (int n = full_d * 128 + lane; n < npad; n += 64) ms[n] = n < N ? mg[n] : 0.0;
+        for (int n = full_i * 256 + lane; n < npad; n += 64) ys[n] = n < N ? yg[n] : 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed
+        for (int n = lane; n < npad; n += 64) maxc = ys[n] > maxc ? ys[n] : maxc;
         yg = ys;
         mg = ms;
     } else {

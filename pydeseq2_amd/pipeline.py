@@ -84,10 +84,13 @@ class _PinnedPool:
         self.ctx, self.free, self.closed = ctx, [], False
 
     def take(self, nbytes):
-        for k, (cap, ptr) in enumerate(self.free):
-            if cap >= nbytes:
-                self.free.pop(k)
-                return _PinnedSlab(self, cap, ptr)
+        best = None
+        for k, (cap, ptr) in enumerate(self.free):  # best fit; a small request must not eat the big slab
+            if nbytes <= cap <= 2 * nbytes + 65536 and (best is None or cap < self.free[best][0]):
+                best = k
+        if best is not None:
+            cap, ptr = self.free.pop(best)
+            return _PinnedSlab(self, cap, ptr)
         p = _vp()
         self.ctx.call("dsq_host_alloc", C.c_size_t(int(nbytes)), C.byref(p))
         return _PinnedSlab(self, int(nbytes), p.value)
@@ -289,23 +292,29 @@ class DeseqPipeline:
     def _fetch(self, slab, names=None):
         """Device slab -> numpy views over a pinned host slab (dict name -> array)."""
         Gs, off = slab["_Gs"], slab["_off"]
-        host = self._host_slab(slab["_total"])
+        width = lambda k: Gs * (8 * self.P if k == "beta" else (8 if k in self._F64 else 1))  # noqa: E731
         if names is None:
+            host, hoff = self._host_slab(slab["_total"]), off
             self.ctx.call("dsq_d2h_async", _vp(host.ptr), _vp(slab["_base"]), C.c_size_t(slab["_total"]))
             names = list(self._F64) + ["beta"] + list(self._U8)
-        else:
+        else:  # a few vectors: a compact host buffer of their own
+            hoff, o = {}, 0
             for k in names:
-                nb = Gs * (8 * self.P if k == "beta" else (8 if k in self._F64 else 1))
-                self.ctx.call("dsq_d2h_async", _vp(host.ptr + off[k]), _vp(slab["_base"] + off[k]), C.c_size_t(nb))
+                hoff[k] = o
+                o += (width(k) + 63) // 64 * 64
+            host = self._host_slab(o)
+            for k in names:
+                self.ctx.call("dsq_d2h_async", _vp(host.ptr + hoff[k]), _vp(slab["_base"] + off[k]),
+                              C.c_size_t(width(k)))
         self.ctx.sync()
         out = {}
         for k in names:
             if k == "beta":
-                out[k] = host.view(off[k], Gs * self.P, np.float64).reshape(Gs, self.P)
+                out[k] = host.view(hoff[k], Gs * self.P, np.float64).reshape(Gs, self.P)
             elif k in self._F64:
-                out[k] = host.view(off[k], Gs, np.float64)
+                out[k] = host.view(hoff[k], Gs, np.float64)
             else:
-                out[k] = host.view(off[k], Gs, np.uint8)
+                out[k] = host.view(hoff[k], Gs, np.uint8)
         return out
 
     # ------------------------------------------------------------------ stages (device in, device out)

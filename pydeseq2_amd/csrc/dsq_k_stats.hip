@@ -859,11 +859,16 @@ __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __
     }
 }
 
-// ---- multi-workgroup variant (cooperative launch) for large gene sets (the all-gathered vectors of
-// the multi-GPU layout): same leader / helper protocol, but the data passes are spread over
-// kTrendGridBlocks workgroups that meet at grid-wide barriers; per-wave partials go through global
-// memory and are combined by the leader in a fixed order.
-constexpr int kTrendGridBlocks = 32;
+// ---- multi-workgroup variant (cooperative launch) for large gene sets: the data passes are spread
+// over kTrendGridBlocks workgroups.  EVERY workgroup's wave 0 runs the same deterministic optimiser
+// on the same combined sums (bit-identical: one slot per workgroup, combined in a fixed order), so a
+// pass needs no parameter broadcast and only ONE grid-wide barrier: partials -> slot -> barrier ->
+// every leader combines all slots.  Slots are double-buffered by pass parity (a workgroup can run at
+// most one pass ahead of the slowest reader).
+#ifndef DSQ_TREND_GRID_BLOCKS
+#define DSQ_TREND_GRID_BLOCKS 32
+#endif
+constexpr int kTrendGridBlocks = DSQ_TREND_GRID_BLOCKS;
 
 struct TrendGridMem {  // device global memory (zeroed before every launch)
     double a0, a1;
@@ -871,8 +876,8 @@ struct TrendGridMem {  // device global memory (zeroed before every launch)
     unsigned int arrive;  // monotonic arrival counter of the grid barrier
     unsigned int timeout; // set if a spin ever exceeds its bound (never observed; avoids a hung GPU)
     int pad;
-    double part[64][3];  // one slot per workgroup (kTrendGridBlocks <= 64)
-    int ipart[64][3];
+    double part[2][64][3];  // [pass parity][workgroup] (kTrendGridBlocks <= 64)
+    int ipart[2][64][3];
 };
 
 // Grid-wide barrier on one monotonic counter (MI355X_MICROARCH.md "barrier-counter", ~3 us at 32
@@ -902,6 +907,8 @@ __device__ __forceinline__ void trend_grid_barrier(TrendGridMem* Gm, unsigned in
 struct TrendBlockScratch {
     double part[kTrendWaves][3];
     int ipart[kTrendWaves][3];
+    double a0, a1;  // mailbox of this workgroup: its leader wave -> its helper waves
+    int cmd;
 };
 
 struct GridTrendOps {
@@ -913,9 +920,10 @@ struct GridTrendOps {
     __device__ void wri(int* p, int v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ double rd(const double* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ int rdi(const int* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    // every thread of every workgroup calls work() once per command: wave partials -> LDS ->
-    // one slot per workgroup in global memory (agent-scope atomics on both sides: the per-XCD L2s
-    // are not coherent for plain accesses)
+    int phase = 0;
+    // every thread of every workgroup calls work() once per pass: wave partials -> LDS -> one slot
+    // per workgroup in global memory (agent-scope atomics on both sides: the per-XCD L2s are not
+    // coherent for plain accesses) -> the one grid-wide barrier of the pass
     __device__ void work(int cmd, double a0, double a1) {
         const int w = threadIdx.x >> 6;
         const int tid = blockIdx.x * (64 * kTrendWaves) + threadIdx.x, NT = gridDim.x * 64 * kTrendWaves;
@@ -939,29 +947,31 @@ struct GridTrendOps {
             KSum s;
             int c = 0;
             for (int q = 0; q < kTrendWaves; ++q) { s.add(B->part[q][threadIdx.x]); c += B->ipart[q][threadIdx.x]; }
-            wr(&Gm->part[blockIdx.x][threadIdx.x], s.value());
-            wri(&Gm->ipart[blockIdx.x][threadIdx.x], c);
+            wr(&Gm->part[phase][blockIdx.x][threadIdx.x], s.value());
+            wri(&Gm->ipart[phase][blockIdx.x][threadIdx.x], c);
         }
-        __syncthreads();
+        trend_grid_barrier(Gm, target);
+        phase ^= 1;
     }
-    __device__ void post(int cmd, double a0, double a1) {  // leader wave only
-        if ((threadIdx.x & 63) == 0) { wr(&Gm->a0, a0); wr(&Gm->a1, a1); wri(&Gm->cmd, cmd); }
-        trend_grid_barrier(Gm, target);  // A
+    __device__ void post(int cmd, double a0, double a1) {  // wave 0 of every workgroup
+        if ((threadIdx.x & 63) == 0) { B->a0 = a0; B->a1 = a1; B->cmd = cmd; }
+        __syncthreads();  // mailbox visible to this workgroup's helper waves
         work(cmd, a0, a1);
-        trend_grid_barrier(Gm, target);  // B
     }
-    // leader wave: lane b fetches workgroup b's slot, butterfly-combine (fixed order)
+    // leader wave: lane b fetches workgroup b's slot of the pass just completed, butterfly-combine
+    // (fixed order => every workgroup's leader gets the bit-identical totals)
     __device__ void combine(double& s, double& g0, double& g1, int& cf, int& c0, int& c1) {
         const int b = threadIdx.x & 63;
         const bool on = b < (int)gridDim.x;
+        const int ph = phase ^ 1;
         KSum ks, k0, k1;
-        ks.s = on ? rd(&Gm->part[b][0]) : 0.0;
-        k0.s = on ? rd(&Gm->part[b][1]) : 0.0;
-        k1.s = on ? rd(&Gm->part[b][2]) : 0.0;
+        ks.s = on ? rd(&Gm->part[ph][b][0]) : 0.0;
+        k0.s = on ? rd(&Gm->part[ph][b][1]) : 0.0;
+        k1.s = on ? rd(&Gm->part[ph][b][2]) : 0.0;
         s = DeviceWave::sum_comp(ks); g0 = DeviceWave::sum_comp(k0); g1 = DeviceWave::sum_comp(k1);
-        cf = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][0]) : 0);
-        c0 = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][1]) : 0);
-        c1 = DeviceWave::sumi(on ? rdi(&Gm->ipart[b][2]) : 0);
+        cf = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][0]) : 0);
+        c0 = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][1]) : 0);
+        c1 = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][2]) : 0);
     }
     __device__ int init_keep() {
         post(3, 0.0, 0.0);
@@ -996,21 +1006,22 @@ __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit_grid(const doubl
     ops.Gm = Gm;
     ops.B = &Bs;
     ops.target = gridDim.x;
-    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 0) {
+    if ((threadIdx.x >> 6) == 0) {  // the leader wave of every workgroup runs the optimiser
         const TrendOut o = trend_fit_core(ops, W);
         if (threadIdx.x == 0) {
-            out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
-            out5[4] = (double)o.n_kept;
-            __hip_atomic_store(&Gm->cmd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {
+                out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
+                out5[4] = (double)o.n_kept;
+            }
+            Bs.cmd = 0;
         }
-        trend_grid_barrier(Gm, ops.target);  // A (release the helpers)
+        __syncthreads();  // release this workgroup's helper waves
     } else {
         for (;;) {
-            trend_grid_barrier(Gm, ops.target);  // A
-            const int cmd = ops.rdi(&Gm->cmd);
-            if (cmd == 0 || ops.rdi((const int*)&Gm->timeout) != 0) break;
-            ops.work(cmd, ops.rd(&Gm->a0), ops.rd(&Gm->a1));
-            trend_grid_barrier(Gm, ops.target);  // B
+            __syncthreads();  // wait for the leader's next command
+            const int cmd = Bs.cmd;
+            if (cmd == 0) break;
+            ops.work(cmd, Bs.a0, Bs.a1);
         }
     }
 }

@@ -48,6 +48,24 @@ struct LdsSorter {
         }
         return L;
     }
+    // buf[0..n) bitonic (here: decreasing then increasing), buf[n..L) = +inf from the preceding sort:
+    // the final merge phase of the network alone leaves it ascending
+    __device__ __forceinline__ void merge(double* buf, int n) const {
+        int L = 1;
+        while (L < n) L <<= 1;
+        const int lane = threadIdx.x & 63;
+        wave_sync();
+        for (int j = L >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < (L >> 1); i += 64) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const double a = buf[lo], b = buf[hi];
+                const bool gt = (a > b) || (a != a && b == b);
+                if (gt) { buf[lo] = b; buf[hi] = a; }
+            }
+            wave_sync();
+        }
+    }
 };
 
 // ------------------------------------------------------------------ transposes

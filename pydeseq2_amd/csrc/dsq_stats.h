@@ -241,13 +241,14 @@ DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu,
         const int L = sorter(scratch, n);
         (void)L;
         const double tm = range_sum<Wv>(scratch, nt, n - nt) / (double)(n - 2 * nt);
-        // trimmed mean of squared errors
+        // trimmed mean of squared errors.  The buffer holds the normalised counts in ascending order,
+        // so (v - tm)^2 taken in place is a decreasing-then-increasing (bitonic) sequence: one bitonic
+        // MERGE (log2 L stages) sorts it, instead of a second full sort (log2 L (log2 L + 1) / 2 stages).
         for (int k = Wv::lane(); k < n; k += Wv::W) {
-            const int sidx = C.whole ? k : C.cell_index[beg + k];
-            const double d = (double)y[sidx] / sf[sidx] - tm;
+            const double d = scratch[k] - tm;
             scratch[k] = d * d;
         }
-        sorter(scratch, n);
+        sorter.merge(scratch, n);
         const double tv = scales[cls] * (range_sum<Wv>(scratch, nt, n - nt) / (double)(n - 2 * nt));
         vmax = (tv > vmax || tv != tv) ? tv : vmax;
     }

@@ -27,6 +27,7 @@ struct HostSorter {
         std::sort(buf, buf + n);
         return n;
     }
+    void merge(double* buf, int n) const { std::sort(buf, buf + n); }
 };
 }  // namespace
 

@@ -234,6 +234,8 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* device-to-device copy on the context's stream */
+int dsq_d2d(dsq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* page-locked host memory + asynchronous copies on the context's stream (complete at dsq_sync) */
 int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out);
 int dsq_host_free(dsq_ctx* ctx, void* p);

@@ -502,6 +502,10 @@ int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d
     return DSQ_OK;
 }
 
+int dsq_d2d(dsq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (bytes) DSQ_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return DSQ_OK;
+}
 int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out) {
     DSQ_CHECK_ARG(out != nullptr, "null output pointer");
     DSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));

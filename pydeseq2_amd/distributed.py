@@ -194,36 +194,51 @@ class DistDeseqPipeline(DeseqPipeline):
         return d_sf
 
     def _gather_trend_inputs(self, Gn):
-        """All-gather (raw genewise dispersion, normalised mean) of every rank, NaN padded to G."""
+        """All-gather (raw genewise dispersion, normalised mean) of every rank on the device: two
+        [world][G] vectors, NaN where a rank has fewer than G non-zero genes (the trend and prior
+        kernels skip NaNs)."""
         d_gw, d_nm = self._last_gw_dev
         G, W = self.G, self.comm.world
-        gw, nm = trend_inputs_padded(self._down(d_gw, Gn), self._down(d_nm, Gn), G)
-        d_send = self._up(np.concatenate([gw, nm]))
-        d_all = self._pooled((2 * G * W,), np.float64)
-        self.comm.allgather(d_send, d_all)
-        allv = self._down(d_all, 2 * G * W).reshape(W, 2, G)
-        gw_all = np.ascontiguousarray(allv[:, 0, :].reshape(-1))
-        nm_all = np.ascontiguousarray(allv[:, 1, :].reshape(-1))
-        self._gathered = (gw_all, nm_all)
-        return gw_all, nm_all
+        out = []
+        for d_src in (d_gw, d_nm):
+            d_send = self._pooled((G,), np.float64)
+            if Gn < G:
+                self.ctx.memset(d_send.ptr, 0xFF, 8 * G)  # all-ones bit pattern: a quiet NaN
+            self.ctx.call("dsq_d2d", _vp(d_send.ptr), _vp(d_src.ptr), C.c_size_t(8 * Gn))
+            d_all = self._pooled((G * W,), np.float64)
+            self.comm.allgather(d_send, d_all)
+            out.append(d_all)
+        self._gathered = tuple(out)
+        return self._gathered
 
     def _fit_trend(self, Gn):
-        gw_all, nm_all = self._gather_trend_inputs(Gn)
-        return self._run_trend_kernel(self._up(gw_all), self._up(nm_all), len(gw_all))
+        d_gw_all, d_nm_all = self._gather_trend_inputs(Gn)
+        return self._run_trend_kernel(d_gw_all, d_nm_all, self.G * self.comm.world)
 
     def _mean_trend(self, Gn):
         if self._gathered is None:
             self._gather_trend_inputs(Gn)
-        gw_all = np.clip(self._gathered[0], self.min_disp, self.max_disp)
+        gw_all = self._down(self._gathered[0], self.G * self.comm.world)
+        gw_all = np.clip(gw_all[~np.isnan(gw_all)], self.min_disp, self.max_disp)
         return _trend.mean_trend(gw_all, self.min_disp)
 
     def _prior(self, Gn, d_fit, r):
-        gw_all, nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(Gn)
-        ok = ~np.isnan(nm_all)
-        gwc = np.clip(gw_all[ok], self.min_disp, self.max_disp)
+        """MAD prior over the genes of ALL ranks (dds.py:866-884), on the gathered device vectors."""
+        from scipy.special import polygamma
+
+        d_gw_all, d_nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(Gn)
+        n_all = self.G * self.comm.world
         if r.disp_function_type == "parametric":
-            fitted = r.trend_coeffs[0] + r.trend_coeffs[1] / nm_all[ok]
+            a0, a1 = float(r.trend_coeffs[0]), float(r.trend_coeffs[1])
         else:
-            fitted = np.full(ok.sum(), r.mean_disp)
+            a0, a1 = float(r.mean_disp), 0.0
+        d_fit_all = self._pooled((n_all,), np.float64)
+        self.ctx.call("dsq_dev_trend_eval", _vp(d_nm_all.ptr), n_all, C.c_double(a0), C.c_double(a1),
+                      _vp(d_fit_all.ptr))
+        sq = C.c_double()
+        d_work = self._pooled((n_all,), np.float64)
+        self._k("prior_mad", n_all, "dsq_dev_prior_mad", _vp(d_gw_all.ptr), _vp(d_fit_all.ptr), n_all,
+                C.c_double(self.min_disp), C.c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
         self._gathered = None
-        return _trend.dispersion_prior(gwc, fitted, self.N, self.P, self.min_disp)
+        sq = float(sq.value)
+        return sq, float(np.maximum(sq - polygamma(1, (self.N - self.P) / 2), 0.25))

@@ -260,3 +260,73 @@ def test_distributed_pipeline_world1_equals_single():
     assert_close(res_d.dispersions, res_s.dispersions, 1e-10, 0, "disp")
     assert_close(res_d.pvalue, res_s.pvalue, 1e-9, 1e-300, "p")
     comm.close()
+
+
+def test_distributed_pipeline_two_ranks_threads():
+    """Two gene shards run as two ranks (threads, one context each on the same GPU) through
+    DistDeseqPipeline with a host-staged communicator: every rank must reproduce its slice of the
+    single-GPU result on the whole matrix (size-factor radix protocol, NaN-padded all-gather of the
+    trend inputs, trend + prior over the genes of all ranks)."""
+    import threading
+
+    import pydeseq2_amd
+    from pydeseq2_amd._lib import Context
+    from pydeseq2_amd.distributed import DistDeseqPipeline
+
+    G, N, W = 1400, 40, 2
+    counts, X = orc.synth_counts(G, N, "2level", 11)
+    counts[:, 3] = 0  # a gene without counts in rank 0's shard: its vectors are NaN padded
+    res_full = pydeseq2_amd.DeseqPipeline(counts, X, device=0).deseq2()
+
+    barrier = threading.Barrier(W)
+    slots = [None] * W
+
+    class ThreadComm:
+        def __init__(self, ctx, rank):
+            self.ctx, self.rank, self.world = ctx, rank, W
+
+        def _exchange(self, host):
+            slots[self.rank] = host
+            barrier.wait()
+            got = list(slots)
+            barrier.wait()
+            return got
+
+        def allreduce_sum(self, darr):
+            n = darr.nbytes // darr.dtype.itemsize
+            host = np.empty(n, dtype=darr.dtype)
+            self.ctx.d2h(host, darr.ptr)
+            self.ctx.h2d(darr.ptr, np.sum(self._exchange(host), axis=0).astype(darr.dtype))
+            return darr
+
+        def allgather(self, dsend, drecv):
+            host = np.empty(dsend.nbytes // 8, dtype=np.float64)
+            self.ctx.d2h(host, dsend.ptr)
+            self.ctx.h2d(drecv.ptr, np.concatenate(self._exchange(host)))
+            return drecv
+
+    out, errs = [None] * W, []
+
+    def run(rank):
+        try:
+            ctx = Context(0)
+            sl = slice(rank * G // W, (rank + 1) * G // W)
+            pipe = DistDeseqPipeline(np.ascontiguousarray(counts[:, sl]), X, comm=ThreadComm(ctx, rank), ctx=ctx)
+            out[rank] = pipe.deseq2()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    for rank in range(W):
+        sl = slice(rank * G // W, (rank + 1) * G // W)
+        r = out[rank]
+        assert_close(r.size_factors, res_full.size_factors, 1e-14, 0, "sf")
+        assert_close(r.trend_coeffs, res_full.trend_coeffs, 1e-9, 0, "trend")
+        assert abs(r.prior_disp_var - res_full.prior_disp_var) < 1e-10
+        assert_close(r.dispersions, res_full.dispersions[sl], 1e-7, 0, "disp")
+        assert_close(r.LFC, res_full.LFC[sl], 1e-6, 1e-10, "LFC")
+        assert_close(r.pvalue, res_full.pvalue[sl], 1e-6, 1e-300, "p")

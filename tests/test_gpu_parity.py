@@ -147,6 +147,18 @@ def test_pipeline_vs_oracle(G, N, design, seed):
         assert ref.replaced.sum() >= 2 and (res.replaced == ref.replaced).all()
 
 
+def test_pipeline_vs_oracle_many_samples():
+    """C5-shaped case (N = 2500, two categorical + three continuous covariates): rows too long for the
+    LDS staging, so the dispersion kernel runs its streaming (unstaged, masked) variant, IRLS supplies
+    mu_hat, Cook's sorts over the whole gene (no design cells with replicates)."""
+    import pydeseq2_amd
+
+    counts, X = orc.synth_counts(160, 2500, "mixed", 5)
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    ref = orc.deseq2(counts, X, n_jobs=8)
+    _compare(res, ref)
+
+
 def test_cooks_layer_vs_oracle():
     import pydeseq2_amd
 

@@ -546,7 +546,8 @@ __global__ __launch_bounds__(64 * WPB) void k_cooks(const int32_t* __restrict__ 
                                                     const double* __restrict__ hat,
                                                     const int32_t* __restrict__ cell_offsets,
                                                     const int32_t* __restrict__ cell_index, int n_cells,
-                                                    int whole, int cap, const uint8_t* __restrict__ flags,
+                                                    int whole, int cap, int stride,
+                                                    const uint8_t* __restrict__ flags,
                                                     int N, int G, int P, double cutoff,
                                                     double* __restrict__ cooks,
                                                     double* __restrict__ robust_disp,
@@ -558,11 +559,14 @@ __global__ __launch_bounds__(64 * WPB) void k_cooks(const int32_t* __restrict__ 
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * WPB + w;
     if (g >= G) return;
-    double* scratch = lds + (size_t)w * cap;
+    // per wave: cap doubles of values (+ 2 * kTrimBins histogram counters when cells are large enough
+    // to be handled by selection; `stride` is the per-wave segment in doubles)
+    double* scratch = lds + (size_t)w * stride;
+    unsigned int* hist = (unsigned int*)(scratch + cap);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
     const CooksOut o = cooks_gene<DeviceWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
                                               hat + (size_t)g * ldn, C, flags, N, P, cutoff, scratch,
-                                              LdsSorter(), cooks ? cooks + (size_t)g * ldn : nullptr);
+                                              hist, LdsSorter(), cooks ? cooks + (size_t)g * ldn : nullptr);
     if ((threadIdx.x & 63) == 0) {
         robust_disp[g] = o.robust_disp;
         any_all[g] = (uint8_t)o.any_gt_all;
@@ -584,9 +588,11 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
                         int P, double cutoff, double* cooks, double* robust_disp, uint8_t* any_all,
                         uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above) {
     if (G <= 0) return hipSuccess;
-    const int cap = next_pow2(whole ? N : max_cell);
-    const size_t per_wave = (size_t)cap * sizeof(double);
-    if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // > 20480 samples in one cell
+    const int biggest = whole ? N : max_cell;  // sorted cells need power-of-two room, selected ones do not
+    const int cap = biggest <= kTrimSortMax ? next_pow2(biggest) : ((biggest + 15) & ~15);
+    const int stride = cap + (biggest <= kTrimSortMax ? 0 : kTrimBins);
+    const size_t per_wave = (size_t)stride * sizeof(double);
+    if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // > ~20000 samples in one cell
 #define DSQ_COOKS_LAUNCH(WPB)                                                                          \
     do {                                                                                               \
         if (per_wave * WPB > 48 * 1024) {                                                              \
@@ -595,7 +601,7 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
             (void)hipGetLastError();                                                                   \
         }                                                                                              \
         hipLaunchKernelGGL(k_cooks<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, \
-                           y, ldn, sf, mu, hat, cell_offsets, cell_index, n_cells, whole, cap, flags, \
+                           y, ldn, sf, mu, hat, cell_offsets, cell_index, n_cells, whole, cap, stride, flags, \
                            N, G, P, cutoff, cooks, robust_disp, any_all, any_use, any_use_nr,         \
                            few_above);                                                                \
     } while (0)

@@ -63,6 +63,23 @@ struct DeviceWave {
         }
         return v;
     }
+    // exclusive prefix sum over the lanes
+    static __device__ __forceinline__ int excl_scan_i(int v) {
+        int s = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(s, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) s += o;
+        }
+        return s - v;
+    }
+    // wave-private LDS histogram cell += 1; the segment is touched by this wave only
+    static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }
     // value held by lane `src` (all lanes must be active); src in [0, 64)
     static __device__ __forceinline__ double from_lane(double v, int src) { return __shfl(v, src, 64); }
@@ -97,6 +114,9 @@ struct HostWave {
     static inline double max(double v) { return v; }
     static inline int sumi(int v) { return v; }
     static inline int maxi(int v) { return v; }
+    static inline int excl_scan_i(int) { return 0; }
+    static inline void hist_add(unsigned int* cell) { *cell += 1u; }
+    static inline void sync() {}
     static inline bool any(bool p) { return p; }
     static inline double from_lane(double v, int) { return v; }
     static inline double uniform(double v) { return v; }

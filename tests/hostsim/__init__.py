@@ -275,3 +275,11 @@ def flog(x):
     a, b, c = np.empty_like(x), np.empty_like(x), np.empty_like(x)
     lib().hs_flog(_p(x, C.c_double), C.c_int(x.size), _p(a, C.c_double), _p(b, C.c_double), _p(c, C.c_double))
     return a, b, c
+
+
+def trimmed_sum(buf, nt):
+    """sum(sorted(buf)[nt : len - nt]) through the device's selection routine (host instantiation)."""
+    b = np.ascontiguousarray(buf, dtype=np.float64)
+    f = lib().hs_trimmed_sum
+    f.restype = C.c_double
+    return float(f(_p(b, C.c_double), C.c_int(len(b)), C.c_int(int(nt))))

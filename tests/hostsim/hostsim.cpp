@@ -159,17 +159,23 @@ int hs_wald(const double* mu, int ldn, const double* sf, const double* Xt, int l
     return 0;
 }
 
+double hs_trimmed_sum(const double* buf, int n, int nt) {
+    std::vector<unsigned int> hist(2 * kTrimBins);
+    return trimmed_sum_select<HostWave>(buf, n, nt, hist.data());
+}
+
 int hs_cooks(const int32_t* y, int ldn, const double* sf, const double* mu, const double* H,
              const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
              const uint8_t* flags, int N, int G, int P_, double cutoff, double* cooks,
              double* robust_disp, uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr,
              uint8_t* few_above) {
     std::vector<double> scratch(N + 8);
+    std::vector<unsigned int> hist(2 * kTrimBins);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
     for (int g = 0; g < G; ++g) {
         CooksOut o = cooks_gene<HostWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
                                           H + (size_t)g * ldn, C, flags, N, P_, cutoff,
-                                          scratch.data(), HostSorter(),
+                                          scratch.data(), hist.data(), HostSorter(),
                                           cooks ? cooks + (size_t)g * ldn : nullptr);
         robust_disp[g] = o.robust_disp; any_all[g] = o.any_gt_all; any_use[g] = o.any_gt_use;
         any_use_nr[g] = o.any_gt_use_nr; few_above[g] = o.few_above;

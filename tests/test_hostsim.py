@@ -227,3 +227,24 @@ def test_lbfgsb_dense_matches_scipy():
         x, f, ok, nfev, nit, st = hs.lbfgsb_dense(fg, x0, bounds)
         assert ok == res.success and nit == res.nit
         assert np.max(np.abs(x - res.x)) <= 1e-7 * max(1, np.max(np.abs(res.x)))
+
+
+def test_trimmed_sum_by_selection_matches_sort():
+    """Radix-select trimmed sums (Cook's robust variance) == sum of the sorted slice, incl. heavy ties,
+    negative values, tiny ranges that share all leading bytes, and every trim count."""
+    rng = np.random.default_rng(12)
+    cases = []
+    for n in (1, 2, 3, 7, 24, 100, 500, 1000):
+        cases.append(rng.integers(0, 6, n) / 1.37)                       # heavy ties
+        cases.append(rng.normal(0, 1, n) * 10 ** rng.uniform(-3, 6))      # mixed signs
+        cases.append(1000.0 + rng.uniform(0, 1e-9, n))                    # shared leading bytes
+        cases.append(np.full(n, 3.25))                                    # all equal
+        cases.append(rng.negative_binomial(2, 0.01, n) / rng.uniform(0.5, 2, n))
+    for v in cases:
+        n = len(v)
+        for nt in sorted({0, n // 8, n // 4, n // 3, (n - 1) // 2}):
+            if n - 2 * nt < 1:
+                continue
+            ref = np.sort(v)[nt:n - nt].sum()
+            got = hs.trimmed_sum(v, nt)
+            assert abs(got - ref) <= 1e-12 * max(1.0, np.abs(v).sum()), (n, nt, got, ref)

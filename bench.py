@@ -45,10 +45,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def synth_fast(G, N, design, seed):
-    """Same generator as oracle.synth_counts, float32 mu to keep it quick."""
-    from oracle import nbglm_oracle as orc
+    """SURVEY §8(d) generator (pydeseq2_amd/synth.py)."""
+    from pydeseq2_amd.synth import synth_counts
 
-    return orc.synth_counts(G, N, design, seed)
+    return synth_counts(G, N, design, seed)
 
 
 def cpu_baseline(counts, X, n_sample, n_jobs):

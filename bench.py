@@ -42,6 +42,7 @@ CONFIGS = {
     "c5": (60000, 5000, "mixed"),  # not a default bench line: host generation alone takes minutes
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (256 CU x 128 flop/clk x 2.4 GHz)
 
 
 def synth_fast(G, N, design, seed):
@@ -65,6 +66,39 @@ def cpu_baseline(counts, X, n_sample, n_jobs):
         orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
         dt = time.perf_counter() - t
     return sub.shape[1] / dt, dt
+
+
+class GlooHostComm:
+    """Harness-only fallback transport (same allreduce_sum / allgather interface as RcclComm): stages the
+    small exchange buffers (<= 2 MB) through the host and torch.distributed/gloo.  Used only if the RCCL
+    communicator cannot be brought up on some rank; the JSON line then says so."""
+
+    def __init__(self, ctx, dist, rank, world):
+        self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+
+    def allreduce_sum(self, darr):
+        import torch
+
+        n = darr.nbytes // darr.dtype.itemsize
+        host = np.empty(n, dtype=darr.dtype)
+        self.ctx.d2h(host, darr.ptr)
+        t = torch.from_numpy(host.view(np.int32) if host.dtype == np.uint32 else host)
+        self.dist.all_reduce(t)
+        self.ctx.h2d(darr.ptr, host)
+        return darr
+
+    def allgather(self, dsend, drecv):
+        import torch
+
+        host = np.empty(dsend.nbytes // 8, dtype=np.float64)
+        self.ctx.d2h(host, dsend.ptr)
+        out = [torch.empty(len(host), dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, torch.from_numpy(host))
+        self.ctx.h2d(drecv.ptr, np.concatenate([o.numpy() for o in out]))
+        return drecv
+
+    def close(self):
+        pass
 
 
 def main():
@@ -105,12 +139,28 @@ def main():
     if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
         from pydeseq2_amd.distributed import DistDeseqPipeline, RcclComm
 
-        box = [RcclComm.unique_id(ctx) if rank == 0 else None]
+        transport = "rccl"
+        try:
+            box = [RcclComm.unique_id(ctx) if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(box, src=0)
+            comm = RcclComm(ctx, box[0], rank, world)
+            ok = 1
+        except Exception as e:  # noqa: BLE001 - any bring-up failure falls back, loudly
+            print(f"[bench] rank {rank}: RCCL bring-up failed: {e}", file=sys.stderr)
+            comm, ok = None, 0
         if dist is not None:
-            dist.broadcast_object_list(box, src=0)
-        comm = RcclComm(ctx, box[0], rank, world)
+            import torch
+
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm, transport = GlooHostComm(ctx, dist, rank, world), "gloo-host-fallback (RCCL bring-up failed)"
+        elif comm is None:
+            raise RuntimeError("RCCL communicator could not be created")
         pipe = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True)
     else:
+        transport = None
         pipe = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
 
     def barrier():
@@ -141,9 +191,9 @@ def main():
     barrier()
     klog_timed = pipe.kernel_log
     # one extra, untimed step with per-stage event timing (synchronises after every stage)
-    pipe.time_kernels, pipe.kernel_log = True, {}
+    pipe.time_kernels, pipe.collect_nfev, pipe.kernel_log = True, True, {}
     res_prof = pipe.deseq2(profile=True)
-    klog_prof, pipe.time_kernels = pipe.kernel_log, False
+    klog_prof, pipe.time_kernels, pipe.collect_nfev = pipe.kernel_log, False, False
     barrier()
 
     if rank != 0:
@@ -166,7 +216,18 @@ def main():
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     big = [(ms, g) for ms, g in launches if g > 0.5 * G]
     stage_ms = {k: round(float(np.sum([ms for ms, _ in v])), 3) for k, v in klog_prof.items()
-                if k not in ("k_alpha", "grid_fallback_genes")}
+                if k not in ("k_alpha", "grid_fallback_genes", "nfev")}
+    # companion bound: the fit is fp64-ALU work, ~250 flop per sample and evaluation
+    # (lgamma + digamma differences, 3 logs, Cox-Reid sums); evaluations counted by the kernel itself
+    nfev_full = [e for e, g in klog_prof.get("nfev", []) if g > 0.5 * G]
+    evals = float(np.mean(nfev_full)) if nfev_full else None
+    full_ms = float(np.mean([ms for ms, _ in big])) if big else None
+    valu = None
+    if evals and full_ms:
+        tflops = evals * N * 250.0 / (full_ms * 1e-3) / 1e12
+        valu = {"bound": "fp64_valu", "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4), "evaluations_per_gene": round(evals / G, 2),
+                "flop_per_sample_eval": 250}
     n_fallback = float(np.sum([x for x, _ in klog.get("grid_fallback_genes", [])])) / args.steps
     roofline = {
         "bound": "hbm", "kernel": "k_alpha (dispersion MLE/MAP, one gene per wavefront)",
@@ -177,6 +238,7 @@ def main():
         "full_launch_ms": round(float(np.mean([ms for ms, _ in big])), 4) if big else None,
         "pipeline_algorithmic_GBps": round(G * 104.0 * N / (dt / args.steps) / 1e9, 2),
         "kernel_ms_per_step": stage_ms, "grid_fallback_genes_per_step": n_fallback,
+        "companion": valu,
     }
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(traffic_file):
@@ -205,7 +267,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.config}: {G} genes x {N} samples per GPU, design {design} "
                                f"(p={X.shape[1]}), NB counts (SURVEY 8d generator)",
-                   "genes_per_gpu": G, "samples": N, "p": int(X.shape[1]),
+                   "genes_per_gpu": G, "samples": N, "p": int(X.shape[1]), "collectives": transport,
                    "device": info["name"], "arch": info["arch"]},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -181,6 +181,7 @@ class DeseqPipeline:
         self._work = None
         self.layers = {}
         self.time_kernels = False
+        self.collect_nfev = False  # profiling aid: log the L-BFGS-B evaluation count of every dispersion launch
         self.kernel_log = {}
         self._pool_free, self._pool_used = [], []
         self._pinned = _PinnedPool(ctx_)
@@ -336,18 +337,26 @@ class DeseqPipeline:
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                     _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
         d_mu.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
+        d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
         self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
                 D.ldx, self.N, Gs, self.P, _vp(S["mom"].ptr), c_double(self.min_disp), c_double(self.max_disp),
-                c_double(1.0), 1, 0, _vp(S["gw"].ptr), _vp(S["gconv"].ptr), None, _vp(d_mu.nll_const.ptr), 1)
+                c_double(1.0), 1, 0, _vp(S["gw"].ptr), _vp(S["gconv"].ptr),
+                _vp(d_nfev.ptr) if d_nfev else None, _vp(d_mu.nll_const.ptr), 1)
+        if d_nfev:
+            self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
         return d_mu
 
     def _stage_map(self, d_y, d_mu, Gs, prior_var, squared_logres, S):
         """MAP dispersions (dds.py:886-935) from S[fit] -> S[map (raw), mconv], then the final
         dispersions S[disp] and the dispersion-outlier flags S[outl]."""
+        d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
         self._k("alpha_map", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
                 self.design.ldx, self.N, Gs, self.P, _vp(S["fit"].ptr), c_double(self.min_disp),
-                c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(S["map"].ptr), _vp(S["mconv"].ptr), None,
+                c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(S["map"].ptr), _vp(S["mconv"].ptr),
+                _vp(d_nfev.ptr) if d_nfev else None,
                 *((_vp(d_mu.nll_const.ptr), 2) if getattr(d_mu, "nll_const", None) is not None else (None, 0)))
+        if d_nfev:
+            self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
         self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
                       c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
                       _vp(S["disp"].ptr), _vp(S["outl"].ptr))

@@ -194,6 +194,18 @@ def main():
     pipe.time_kernels, pipe.collect_nfev, pipe.kernel_log = True, True, {}
     res_prof = pipe.deseq2(profile=True)
     klog_prof, pipe.time_kernels, pipe.collect_nfev = pipe.kernel_log, False, False
+    # summary tail (Cook's filter, independent filtering + BH): outside `value`
+    from pydeseq2_amd.summary import summary as summary_tail
+
+    cvec = np.zeros(X.shape[1])
+    cvec[-1] = 1.0
+    summary_tail(res_prof, cvec, ctx=ctx)
+    ctx.sync()
+    t_sum = time.perf_counter()
+    for _ in range(3):
+        sres = summary_tail(res_prof, cvec, ctx=ctx)
+    ctx.sync()
+    t_sum = (time.perf_counter() - t_sum) / 3
     barrier()
 
     if rank != 0:
@@ -273,6 +285,9 @@ def main():
         "cpu_baseline": cpu,
         "stage_wall_ms_profiled_step": {k: round(v * 1e3, 3) for k, v in res_prof.timings.items()},
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+        "summary_tail": {"ms": round(t_sum * 1e3, 3), "rejections_at_0.05": int(np.nansum(sres["padj"] < 0.05)),
+                         "cutoff_index": int(sres["info"]["j"]),
+                         "note": "padj with independent filtering on the device (not part of value)"},
     }
     print(json.dumps(out))
     if dist is not None:

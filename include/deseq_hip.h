@@ -234,6 +234,20 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* Adjusted p-values of DeseqStats.summary() (ds.py:486-542).
+ * prepare: sorts the p-values once, derives the 50 baseMean cut-offs (np.quantile of base_mean at
+ *   theta = linspace(mean(base_mean == 0), 0.95 or 1, 50)), assigns every gene the number of cut-offs it
+ *   passes (d_bins) and counts the BH rejections (adjusted p < alpha) of each of the 50 passes.
+ *   h_out200 = theta[50], cutoffs[50], num_rej[50], m[50]; *h_n_valid = genes with a p-value.
+ *   d_pvalue already carries the Cook's filter (NaN for outlier genes, ds.py:543-549).
+ * finish: BH-adjusted p-values of pass j scattered to gene order (NaN for genes outside the pass);
+ *   j = -1 is plain BH over all genes with a p-value (ds.py:529-542).
+ * The lowess choice of j (ds.py:512-525, 50 points) is host code (pydeseq2_amd/summary.py). */
+int dsq_dev_padj_prepare(dsq_ctx* ctx, const double* d_base_mean, const double* d_pvalue, int n, double alpha,
+                         unsigned long long* d_sorted_p, int32_t* d_sorted_idx, uint8_t* d_bins,
+                         double* h_out200, int* h_n_valid);
+int dsq_dev_padj_finish(dsq_ctx* ctx, const unsigned long long* d_sorted_p, const int32_t* d_sorted_idx,
+                        const uint8_t* d_bins, int n, int n_valid, int j, double* d_padj);
 /* device-to-device copy on the context's stream */
 int dsq_d2d(dsq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* page-locked host memory + asynchronous copies on the context's stream (complete at dsq_sync) */

@@ -850,6 +850,83 @@ def p_value_adjustment(pvalue):
     return padj
 
 
+def lowess(features, targets, frac=2.0 / 3.0, iters=3):
+    """Robust locally weighted regression, restating utils.lowess (utils.py:1379-1442) line by line."""
+    features = np.asarray(features, dtype=float)
+    targets = np.asarray(targets, dtype=float)
+    n = len(features)
+    r = int(np.ceil(frac * n))
+    h = np.maximum(np.array([np.sort(np.abs(features - features[i]))[r] for i in range(n)]), 1e-12)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        w = np.clip(np.abs(np.nan_to_num((features[:, None] - features[None, :]) / h)), 0.0, 1.0)
+    w = (1 - w**3) ** 3
+    yest = np.zeros(n)
+    delta = np.ones(n)
+    for _ in range(iters):
+        for i in range(n):
+            weights = delta * w[:, i]
+            b = np.array([np.sum(weights * targets), np.sum(weights * targets * features)])
+            A = np.array([[np.sum(weights), np.sum(weights * features)],
+                          [np.sum(weights * features), np.sum(weights * features * features)]])
+            beta = np.linalg.lstsq(A, b, rcond=None)[0]
+            yest[i] = beta[0] + beta[1] * features[i]
+        residuals = targets - yest
+        s = np.median(np.abs(residuals))
+        if s == 0:
+            delta = (np.abs(residuals) > 0).astype(float)
+        else:
+            delta = np.clip(residuals / (6.0 * s), -1, 1)
+        delta = (1 - delta**2) ** 2
+    return yest
+
+
+def independent_filtering(base_mean, pvalue, alpha=0.05):
+    """DeseqStats._independent_filtering (ds.py:486-527) -> (padj, info).
+
+    50 candidate baseMean cut-offs (quantiles theta of base_mean), BH over the genes above each one,
+    lowess-smoothed number of rejections picks the cut-off; padj is the BH column of that cut-off.
+    """
+    base_mean = np.asarray(base_mean, dtype=float)
+    pvalue = np.asarray(pvalue, dtype=float)
+    G = len(base_mean)
+    lower_quantile = np.mean(base_mean == 0)
+    upper_quantile = 0.95 if lower_quantile < 0.95 else 1
+    theta = np.linspace(lower_quantile, upper_quantile, 50)
+    cutoffs = np.quantile(base_mean, theta)
+    result = np.full((G, len(theta)), np.nan)
+    for i, cutoff in enumerate(cutoffs):
+        use = (base_mean >= cutoff) & (~np.isnan(pvalue))
+        if use.any():
+            result[use, i] = bh_adjust(pvalue[use])
+    with np.errstate(invalid="ignore"):
+        num_rej = (result < alpha).sum(0).astype(int)
+    lowess_res = lowess(theta, num_rej, frac=1 / 5)
+    if num_rej.max() <= 10:
+        j = 0
+    else:
+        residual = num_rej[num_rej > 0] - lowess_res[num_rej > 0]
+        thresh = lowess_res.max() - np.sqrt(np.mean(residual**2))
+        j = int(np.where(num_rej > thresh)[0][0]) if np.any(num_rej > thresh) else 0
+    return result[:, j], dict(theta=theta, cutoffs=cutoffs, num_rej=num_rej, lowess=lowess_res, j=j)
+
+
+def summary(res, contrast, alpha=0.05, cooks_filter=True, independent_filter=True):
+    """DeseqStats.summary() after the Wald test (ds.py:266-286): Cook's filtering of the p-values
+    (ds.py:543-549), adjusted p-values, and the result columns (log2 scale for the LFCs)."""
+    contrast = np.asarray(contrast, dtype=float)
+    pvalue = np.array(res.pvalue, dtype=float)
+    if cooks_filter:
+        pvalue[np.asarray(res.cooks_outlier, dtype=bool)] = np.nan
+    base_mean = np.asarray(res.normed_means, dtype=float)
+    if independent_filter:
+        padj, info = independent_filtering(base_mean, pvalue, alpha)
+    else:
+        padj, info = p_value_adjustment(pvalue), {}
+    return dict(baseMean=base_mean, log2FoldChange=np.asarray(res.LFC) @ contrast / np.log(2),
+                lfcSE=np.asarray(res.lfcSE) / np.log(2), stat=np.asarray(res.stat), pvalue=pvalue, padj=padj,
+                info=info)
+
+
 # --------------------------------------------------------------------------
 # synthetic inputs                                SURVEY.md §8(d) / BASELINE.md §3
 # --------------------------------------------------------------------------

@@ -9,5 +9,6 @@ GPU only: importing works anywhere, every computation requires libdeseq_hip.so a
 from ._lib import Context, DsqError  # noqa: F401
 from .inference import HipInference  # noqa: F401
 from .pipeline import DeseqPipeline, deseq2  # noqa: F401
+from . import summary  # noqa: F401  (module: summary.summary(res, contrast) = DeseqStats.summary() tail)
 
 __version__ = "0.1.0"

@@ -27,6 +27,8 @@ struct dsq_ctx {
     size_t list_cap = 0;
     void* d_trend_grid = nullptr; // global-memory mailbox of the multi-workgroup trend fit
     double* d_lsf = nullptr;      // log(size factors) of the current IRLS call (grown on demand)
+    void* d_sum = nullptr;        // workspace of the adjusted-p-value kernels (grown on demand)
+    size_t sum_cap = 0, sum_sort_bytes = 0;
     size_t lsf_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
@@ -258,6 +260,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_list) (void)hipFree(ctx->d_list);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
+    if (ctx->d_sum) (void)hipFree(ctx->d_sum);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
@@ -499,6 +502,59 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst) {
     DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, d_src, d_idx, n_idx, width, d_dst));
+    return DSQ_OK;
+}
+
+// ---- adjusted p-values (ds.py:486-542).  Workspace layout inside ctx->d_sum for n genes:
+//   [sort temp][work 4n u64][rank n i32][out 200 f64][counters 4 i32]
+namespace {
+struct SumWs { void* sort_tmp; void* work; int* rank; double* out; int* counters; };
+hipError_t sum_workspace(dsq_ctx* ctx, int n, SumWs& w) {
+    const size_t sort_b = (dsq::summary_sort_temp_bytes(n) + 255) & ~(size_t)255;
+    const size_t work_b = (size_t)n * 4 * 8, rank_b = (((size_t)n * 4) + 255) & ~(size_t)255;
+    const size_t total = sort_b + work_b + rank_b + 200 * 8 + 64;
+    if (total > ctx->sum_cap) {
+        if (ctx->d_sum) (void)hipFree(ctx->d_sum);
+        ctx->d_sum = nullptr; ctx->sum_cap = 0;
+        hipError_t e = hipMalloc(&ctx->d_sum, total);
+        if (e != hipSuccess) return e;
+        ctx->sum_cap = total;
+    }
+    ctx->sum_sort_bytes = sort_b;
+    char* p = (char*)ctx->d_sum;
+    w.sort_tmp = p; p += sort_b;
+    w.work = p; p += work_b;
+    w.rank = (int*)p; p += rank_b;
+    w.out = (double*)p; p += 200 * 8;
+    w.counters = (int*)p;
+    return hipSuccess;
+}
+}  // namespace
+
+int dsq_dev_padj_prepare(dsq_ctx* ctx, const double* d_base_mean, const double* d_pvalue, int n, double alpha,
+                         unsigned long long* d_sorted_p, int32_t* d_sorted_idx, uint8_t* d_bins,
+                         double* h_out200, int* h_n_valid) {
+    DSQ_CHECK_ARG(n >= 1, "no genes");
+    SumWs w;
+    DSQ_HIP(sum_workspace(ctx, n, w));
+    DSQ_HIP(dsq::launch_padj_prepare(ctx->stream, d_base_mean, d_pvalue, n, alpha, w.sort_tmp, ctx->sum_sort_bytes,
+                                     w.work, d_sorted_p, d_sorted_idx, d_bins, w.out, w.counters));
+    int cnt[4] = {0, 0, 0, 0};
+    DSQ_HIP(hipMemcpyAsync(cnt, w.counters, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    DSQ_HIP(dsq::launch_padj_numrej(ctx->stream, d_sorted_p, d_sorted_idx, d_bins, cnt[1], alpha, w.out));
+    DSQ_HIP(hipMemcpyAsync(h_out200, w.out, 200 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    *h_n_valid = cnt[1];
+    return DSQ_OK;
+}
+
+int dsq_dev_padj_finish(dsq_ctx* ctx, const unsigned long long* d_sorted_p, const int32_t* d_sorted_idx,
+                        const uint8_t* d_bins, int n, int n_valid, int j, double* d_padj) {
+    DSQ_CHECK_ARG(n >= 1 && n_valid >= 0 && n_valid <= n && j >= -1 && j < 50, "bad pass / sizes");
+    SumWs w;
+    DSQ_HIP(sum_workspace(ctx, n, w));
+    DSQ_HIP(dsq::launch_padj_finish(ctx->stream, d_sorted_p, d_sorted_idx, d_bins, n, n_valid, j, w.rank, d_padj));
     return DSQ_OK;
 }
 

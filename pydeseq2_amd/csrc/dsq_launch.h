@@ -69,6 +69,15 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero);
 hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
                                   int n_idx, int ncols, double* dst);
+// ---- dsq_k_summary.hip (adjusted p-values of DeseqStats.summary())
+size_t summary_sort_temp_bytes(int n);
+hipError_t launch_padj_prepare(hipStream_t st, const double* base_mean, const double* pvalue, int n, double alpha,
+                               void* sort_tmp, size_t sort_tmp_bytes, void* work, unsigned long long* sorted_p,
+                               int* sorted_idx, unsigned char* bins, double* out200, int* counters);
+hipError_t launch_padj_numrej(hipStream_t st, const unsigned long long* sorted_p, const int* sorted_idx,
+                              const unsigned char* bins, int n_valid, double alpha, double* out200);
+hipError_t launch_padj_finish(hipStream_t st, const unsigned long long* sorted_p, const int* sorted_idx,
+                              const unsigned char* bins, int n, int n_valid, int j, int* rank_tmp, double* padj);
 hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted);
 hipError_t launch_select_disp(hipStream_t st, const double* gw_raw, const double* map_raw, const double* fitted,
                               int n, double min_disp, double max_disp, double two_sd, double* disp,

@@ -1,0 +1,105 @@
+"""``DeseqStats.summary()`` after the Wald test (pydeseq2/ds.py:266-286, 486-549) on the device.
+
+Cook's filtering of the p-values, Benjamini-Hochberg adjustment with (or without) independent
+filtering, and the result columns.  The 50 BH passes of the reference's independent filtering
+collapse into one device sort plus prefix counts (csrc/dsq_k_summary.hip); only the lowess choice of
+the cut-off — a 50-point smoother — runs on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, DeviceArray
+
+_vp = C.c_void_p
+
+
+def lowess(x, y, frac=2.0 / 3.0, iters=3):
+    """Robust locally weighted linear regression with tricube weights (what utils.lowess computes,
+    utils.py:1379-1442), vectorised over the evaluation points.
+
+    Bandwidth h_i = distance to the ceil(frac*n)-th nearest x (index r of the sorted distances, which
+    include the point itself), weights (1 - |d/h|^3)^3, ``iters`` passes with bisquare robustness
+    weights from the residuals / (6 * median |residual|).  Each local fit is the minimum-norm solution
+    of its 2x2 weighted normal equations (``numpy.linalg.lstsq`` in the reference, a pseudo-inverse here).
+    """
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    n = len(x)
+    r = int(np.ceil(frac * n))
+    dist = np.abs(x[:, None] - x[None, :])
+    h = np.maximum(np.sort(dist, axis=0)[r], 1e-12)  # per evaluation point (column)
+    w = np.clip(np.nan_to_num(dist / h[None, :]), 0.0, 1.0)  # w[j, i]: point j seen from evaluation point i
+    w = (1 - w**3) ** 3
+    est = np.zeros(n)
+    delta = np.ones(n)
+    for _ in range(iters):
+        wt = delta[:, None] * w  # [point j, evaluation i]
+        s0, s1, s2 = wt.sum(0), (wt * x[:, None]).sum(0), (wt * (x * x)[:, None]).sum(0)
+        t0, t1 = (wt * y[:, None]).sum(0), (wt * (y * x)[:, None]).sum(0)
+        A = np.stack([np.stack([s0, s1], -1), np.stack([s1, s2], -1)], -2)  # [i, 2, 2]
+        beta = np.einsum("ijk,ik->ij", np.linalg.pinv(A, rcond=2 * np.finfo(float).eps), np.stack([t0, t1], -1))
+        est = beta[:, 0] + beta[:, 1] * x
+        res = y - est
+        s = np.median(np.abs(res))
+        delta = (np.abs(res) > 0).astype(float) if s == 0 else np.clip(res / (6.0 * s), -1, 1)
+        delta = (1 - delta**2) ** 2
+    return est
+
+
+def choose_cutoff(theta, num_rej):
+    """Index of the baseMean cut-off to use (ds.py:512-525)."""
+    num_rej = np.asarray(num_rej, dtype=int)
+    fit = lowess(theta, num_rej, frac=1 / 5)
+    if num_rej.max() <= 10:
+        return 0, fit
+    pos = num_rej > 0
+    residual = num_rej[pos] - fit[pos]
+    thresh = fit.max() - np.sqrt(np.mean(residual**2))
+    above = np.nonzero(num_rej > thresh)[0]
+    return (int(above[0]) if len(above) else 0), fit
+
+
+def adjusted_pvalues(ctx: Context, base_mean, pvalue, alpha=0.05, independent_filter=True):
+    """padj for all genes (NaN where the gene has no p-value or falls below the chosen cut-off)."""
+    base_mean = np.ascontiguousarray(base_mean, dtype=np.float64)
+    pvalue = np.ascontiguousarray(pvalue, dtype=np.float64)
+    G = len(base_mean)
+    d_bm, d_p = DeviceArray.from_host(ctx, base_mean), DeviceArray.from_host(ctx, pvalue)
+    d_sp, d_si = DeviceArray(ctx, (G,), np.uint64), DeviceArray(ctx, (G,), np.int32)
+    d_bins, d_padj = DeviceArray(ctx, (G,), np.uint8), DeviceArray(ctx, (G,), np.float64)
+    out = (C.c_double * 200)()
+    n_valid = C.c_int(0)
+    ctx.call("dsq_dev_padj_prepare", _vp(d_bm.ptr), _vp(d_p.ptr), G, C.c_double(alpha), _vp(d_sp.ptr),
+             _vp(d_si.ptr), _vp(d_bins.ptr), out, C.byref(n_valid))
+    o = np.array(out[:]).reshape(4, 50)
+    info = dict(theta=o[0], cutoffs=o[1], num_rej=o[2].astype(int), m=o[3].astype(int), n_valid=n_valid.value)
+    if independent_filter:
+        j, fit = choose_cutoff(info["theta"], info["num_rej"])
+        info.update(j=j, lowess=fit)
+    else:
+        j = -1
+    ctx.call("dsq_dev_padj_finish", _vp(d_sp.ptr), _vp(d_si.ptr), _vp(d_bins.ptr), G, n_valid.value, int(j),
+             _vp(d_padj.ptr))
+    return d_padj.to_host(), info
+
+
+def summary(res, contrast, alpha=0.05, cooks_filter=True, independent_filter=True, ctx: Context | None = None,
+            device: int = 0):
+    """Result columns of ``DeseqStats.summary()`` from a :class:`DeseqResult` (log2 scale for the LFCs).
+
+    Returns a dict with baseMean, log2FoldChange, lfcSE, stat, pvalue, padj (+ ``info``: thetas, cut-offs,
+    rejections per cut-off, the chosen index).
+    """
+    ctx = ctx if ctx is not None else Context(device)
+    contrast = np.asarray(contrast, dtype=float)
+    pvalue = np.array(res.pvalue, dtype=float)
+    if cooks_filter:  # ds.py:543-549
+        pvalue[np.asarray(res.cooks_outlier, dtype=bool)] = np.nan
+    base_mean = np.asarray(res.normed_means, dtype=float)
+    padj, info = adjusted_pvalues(ctx, base_mean, pvalue, alpha, independent_filter)
+    return dict(baseMean=base_mean, log2FoldChange=np.asarray(res.LFC) @ contrast / np.log(2),
+                lfcSE=np.asarray(res.lfcSE) / np.log(2), stat=np.asarray(res.stat), pvalue=pvalue, padj=padj,
+                info=info)

@@ -183,6 +183,28 @@ def main():
     X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
     kat_case("p8", synth(48, N, X, 13), X, ut, gs, pp, di)
 
+    # lowess known answers (summary tail): the reference's utils.lowess on the shapes
+    # _independent_filtering feeds it (50 thetas vs rejection counts) plus generic cases
+    from scipy.stats import false_discovery_control
+
+    rng = np.random.default_rng(21)
+    lw = {}
+    for k in range(6):
+        n = 50 if k < 4 else 37
+        x = np.linspace(rng.uniform(0, 0.2), 0.95, n) if k < 4 else np.sort(rng.uniform(0, 1, n))
+        if k < 4:
+            y = np.round(np.maximum(800 * np.exp(-((x - 0.4) / 0.5) ** 2) + rng.normal(0, 15, n), 0))
+            if k == 3:
+                y[:] = 7.0
+        else:
+            y = np.sin(4 * x) + rng.normal(0, 0.2, n)
+        lw[f"x{k}"], lw[f"y{k}"] = x, y
+        lw[f"f{k}"] = np.array(1 / 5 if k < 4 else 2 / 3)
+        lw[f"out{k}"] = ut.lowess(x, y, frac=float(lw[f"f{k}"]))
+    pv = rng.uniform(0, 1, 500) ** 3
+    lw["bh_in"], lw["bh_out"] = pv, false_discovery_control(pv, method="bh")
+    np.savez(os.path.join(HERE, "kat_lowess.npz"), **lw)
+
     # R fixtures (data files) copied verbatim
     for sub, files in {
         "single_factor": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",

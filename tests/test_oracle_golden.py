@@ -1,6 +1,8 @@
 """The oracle (oracle/nbglm_oracle.py) against (i) vectors produced by the unmodified
 reference kernels (tests/golden/kat_*.npz, see make_golden.py) and (ii) the reference's
 own R-DESeq2 fixtures at the reference's own tolerances (tests/test_pydeseq2.py:932-942)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -168,3 +170,30 @@ def test_r_wide():
     c[ci] = 1
     res = orc.deseq2(counts.to_numpy(), X, contrast=c)
     _check_res(res, counts, r_csv("wide", "r_test_res.csv"), ci, 0.02)
+
+
+# ---------------------------------------------------------------- summary tail
+def test_lowess_and_bh_match_reference():
+    """Restated utils.lowess (utils.py:1379-1442) and BH against vectors produced by the unmodified
+    reference / scipy (tests/golden/make_golden.py)."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_lowess.npz"))
+    for i in range(6):
+        out = orc.lowess(k[f"x{i}"], k[f"y{i}"], frac=float(k[f"f{i}"]))
+        np.testing.assert_allclose(out, k[f"out{i}"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(orc.bh_adjust(k["bh_in"]), k["bh_out"], rtol=1e-14)
+
+
+def test_r_single_factor_summary_padj():
+    """DeseqStats.summary() columns incl. independent filtering against R (tests/test_pydeseq2.py:94-118)."""
+    counts, X, names = _run_r_case("synthetic", ["condition"])
+    res = orc.deseq2(counts.to_numpy(), X, contrast=[0, 1])
+    r_res = r_csv("single_factor", "r_test_res.csv")
+    s = orc.summary(res, [0, 1])
+    assert max_rel_err(s["log2FoldChange"], r_res["log2FoldChange"].to_numpy()) < 0.02
+    assert max_rel_err(s["lfcSE"], r_res["lfcSE"].to_numpy()) < 0.02
+    assert max_rel_err(s["baseMean"], r_res["baseMean"].to_numpy()) < 0.02
+    assert (np.isnan(s["padj"]) == r_res["padj"].isna().to_numpy()).all()
+    assert max_rel_err(s["padj"], r_res["padj"].to_numpy()) < 0.02
+    s2 = orc.summary(res, [0, 1], independent_filter=False)
+    r_noif = r_csv("single_factor", "r_test_res_no_independent_filtering.csv")
+    assert max_rel_err(s2["padj"], r_noif["padj"].to_numpy()) < 0.02

@@ -206,6 +206,15 @@ def main():
         sres = summary_tail(res_prof, cvec, ctx=ctx)
     ctx.sync()
     t_sum = (time.perf_counter() - t_sum) / 3
+    # apeGLM LFC shrinkage of the tested coefficient: outside `value`
+    from pydeseq2_amd.summary import lfc_shrink
+
+    lfc_shrink(pipe, res_prof, X.shape[1] - 1)
+    ctx.sync()
+    t_shr = time.perf_counter()
+    shr = lfc_shrink(pipe, res_prof, X.shape[1] - 1)
+    ctx.sync()
+    t_shr = time.perf_counter() - t_shr
     barrier()
 
     if rank != 0:
@@ -288,6 +297,9 @@ def main():
         "summary_tail": {"ms": round(t_sum * 1e3, 3), "rejections_at_0.05": int(np.nansum(sres["padj"] < 0.05)),
                          "cutoff_index": int(sres["info"]["j"]),
                          "note": "padj with independent filtering on the device (not part of value)"},
+        "lfc_shrink": {"ms": round(t_shr * 1e3, 3), "prior_scale": round(float(shr[3]), 6),
+                       "converged_fraction": round(float(np.nanmean(shr[2])), 5),
+                       "note": "apeGLM MAP LFC of the last coefficient, all genes (not part of value)"},
     }
     print(json.dumps(out))
     if dist is not None:

@@ -234,6 +234,19 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* apeGLM MAP log-fold changes: Inference.lfc_shrink_nbinom_glm (inference.py:306-362,
+ * default_inference.py:232-264 -> utils.nbinomGLM, utils.py:990-1142).  size = 1/dispersion [G],
+ * offset = log(size factors) [N]; outputs beta [G][P], inv_hessian [G][P][P] (the reference's matrix,
+ * incl. its broadcast prior curvature), converged [G] (L-BFGS-B success; for P == 2 a failed gene has
+ * already been re-fitted by the reference's grid search). */
+int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                                  const double* design, const double* size, const double* offset, int N, int G,
+                                  int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
+                                  double* beta_out, double* inv_hessian_out, uint8_t* converged);
+int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                       int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                       double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                       uint8_t* d_converged);
 /* Adjusted p-values of DeseqStats.summary() (ds.py:486-542).
  * prepare: sorts the p-values once, derives the 50 baseMean cut-offs (np.quantile of base_mean at
  *   theta = linspace(mean(base_mean == 0), 0.95 or 1, 50)), assigns every gene the number of cut-offs it

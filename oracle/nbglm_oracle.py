@@ -850,6 +850,116 @@ def p_value_adjustment(pvalue):
     return padj
 
 
+# --------------------------------------------------------------------------
+# apeGLM LFC shrinkage                      SURVEY.md §8(f)-2
+# --------------------------------------------------------------------------
+
+
+def nbinom_fn(beta, X, counts, size, offset, prior_no_shrink_scale, prior_scale, shrink_index=1):
+    """NB negative log-likelihood + apeGLM prior (utils.py:1145-1207)."""
+    p = X.shape[-1]
+    shrink_mask = np.zeros(p)
+    shrink_mask[shrink_index] = 1
+    no_shrink_mask = np.ones(p) - shrink_mask
+    xbeta = X @ beta
+    prior = ((beta * no_shrink_mask) ** 2 / (2 * prior_no_shrink_scale**2)).sum() + np.log1p(
+        (beta[shrink_index] / prior_scale) ** 2)
+    nll = (counts * xbeta - (counts + size) * np.logaddexp(xbeta + offset, np.log(size))).sum(0)
+    return prior - nll
+
+
+def grid_fit_shrink_beta(counts, offset, X, size, prior_no_shrink_scale, prior_scale, scale_cnst,
+                         grid_length=60, min_beta=-30, max_beta=30):
+    """Two-level 2-D grid search (grid_search.py:224-320); its loss always shrinks coefficient 1."""
+    def loss(b):
+        return nbinom_fn(b, X, counts, size, offset, prior_no_shrink_scale, prior_scale) / scale_cnst
+
+    xg = np.linspace(min_beta, max_beta, grid_length)
+    yg = np.linspace(min_beta, max_beta, grid_length)
+    ll = np.array([[loss(np.array([x, y])) for y in yg] for x in xg])
+    i, j = np.unravel_index(np.argmin(ll, axis=None), ll.shape)
+    delta = xg[1] - xg[0]
+    fx = np.linspace(xg[i] - delta, xg[i] + delta, grid_length)
+    fy = np.linspace(yg[j] - delta, yg[j] + delta, grid_length)
+    ll = np.array([[loss(np.array([x, y])) for y in fy] for x in fx])
+    i, j = np.unravel_index(np.argmin(ll, axis=None), ll.shape)
+    return np.array([fx[i], fy[j]])
+
+
+def nbinom_glm_gene(X, counts, size, offset, prior_no_shrink_scale, prior_scale, shrink_index=1):
+    """utils.nbinomGLM (utils.py:990-1142) with optimizer='L-BFGS-B': (beta, inv_hessian, converged).
+
+    Kept as in the reference: the Hessian adds ``np.diag(h)`` where ``h`` is already a diagonal matrix,
+    i.e. the VECTOR of prior curvatures is broadcast onto every row (utils.py:1099-1110)."""
+    p = X.shape[-1]
+    shrink_mask = np.zeros(p)
+    shrink_mask[shrink_index] = 1
+    no_shrink_mask = np.ones(p) - shrink_mask
+    beta_init = np.ones(p) * 0.1 * (-1) ** (np.arange(p))
+    cnst = np.maximum(nbinom_fn(np.zeros(p), X, counts, size, offset, prior_no_shrink_scale, prior_scale,
+                                shrink_index), 1)
+
+    def f(beta):
+        return nbinom_fn(beta, X, counts, size, offset, prior_no_shrink_scale, prior_scale, shrink_index) / cnst
+
+    def df(beta):
+        xbeta = X @ beta
+        d_neg_prior = (beta * no_shrink_mask / prior_no_shrink_scale**2
+                       + 2 * beta * shrink_mask / (prior_scale**2 + beta[shrink_index] ** 2))
+        d_nll = (counts - (counts + size) / (1 + size * np.exp(-xbeta - offset))) @ X
+        return (d_neg_prior - d_nll) / cnst
+
+    def ddf(beta, c=1):
+        xbeta = X @ beta
+        e = np.exp(xbeta + offset)
+        frac = (counts + size) * size * e / (size + e) ** 2
+        h11 = 1 / prior_no_shrink_scale**2
+        h22 = 2 * (prior_scale**2 - beta[shrink_index] ** 2) / (prior_scale**2 + beta[shrink_index] ** 2) ** 2
+        h = np.diag(no_shrink_mask * h11 + shrink_mask * h22)
+        return 1 / c * ((X.T * frac) @ X + np.diag(h))
+
+    res = minimize(f, beta_init, jac=df, method="L-BFGS-B", options={"ftol": 1e-8, "gtol": 1e-8})
+    beta, converged = res.x, res.success
+    if not converged and p == 2:
+        beta = grid_fit_shrink_beta(counts, offset, X, size, prior_no_shrink_scale, prior_scale, cnst)
+    return beta, np.linalg.inv(ddf(beta, 1)), converged
+
+
+def fit_prior_var(lfc, se, min_var=1e-6, max_var=400.0):
+    """DeseqStats._fit_prior_var (ds.py:551-590): zero of the moment-matching equation."""
+    from scipy.optimize import root_scalar
+
+    keep = ~np.isnan(lfc)
+    S, D = lfc[keep] ** 2, se[keep] ** 2
+
+    def objective(a):
+        coeff = 1 / (2 * (a + D) ** 2)
+        return ((S - D) * coeff).sum() / coeff.sum() - a
+
+    if objective(min_var) < 0:
+        return min_var
+    return root_scalar(objective, bracket=(min_var, max_var)).root
+
+
+def lfc_shrink(counts, X, res, coeff_idx, adapt=True):
+    """DeseqStats.lfc_shrink (ds.py:363-447) on a DeseqResult: shrunken (LFC column, lfcSE, converged).
+
+    ``res.lfcSE`` must come from the Wald test of the same coefficient (contrast = unit vector)."""
+    counts = np.asarray(counts)
+    nz = np.asarray(res.non_zero, dtype=bool)
+    size = 1.0 / res.dispersions
+    offset = np.log(res.size_factors)
+    prior_scale = 1
+    if adapt:
+        prior_scale = np.minimum(np.sqrt(fit_prior_var(res.LFC[:, coeff_idx], res.lfcSE)), 1)
+    lfc, se = res.LFC[:, coeff_idx].copy(), np.array(res.lfcSE, dtype=float)
+    conv = np.full(len(nz), np.nan)
+    for g in np.nonzero(nz)[0]:
+        b, ih, cv = nbinom_glm_gene(X, counts[:, g], size[g], offset, 15, prior_scale, coeff_idx)
+        lfc[g], se[g], conv[g] = b[coeff_idx], np.sqrt(np.abs(ih[coeff_idx, coeff_idx])), cv
+    return lfc, se, conv, float(prior_scale)
+
+
 def lowess(features, targets, frac=2.0 / 3.0, iters=3):
     """Robust locally weighted regression, restating utils.lowess (utils.py:1379-1442) line by line."""
     features = np.asarray(features, dtype=float)

@@ -486,6 +486,17 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
     return DSQ_OK;
 }
 
+int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                       int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                       double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                       uint8_t* d_converged) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
+    DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
+                               prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged));
+    return DSQ_OK;
+}
+
 int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1, double* d_fitted) {
     DSQ_HIP(dsq::launch_trend_eval(ctx->stream, d_normed_means, n, a0, a1, d_fitted));
     return DSQ_OK;
@@ -704,6 +715,36 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
                         conv.as<uint8_t>(), nullptr)))
         return rc;
     DSQ_HIP(hipMemcpyAsync(alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                                  const double* design, const double* size, const double* offset, int N, int G,
+                                  int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
+                                  double* beta_out, double* inv_hessian_out, uint8_t* converged) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf y, sz, off, b, ih, conv;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    if ((rc = upload_vec(ctx, size, (size_t)G * sizeof(double), sz))) return rc;
+    if ((rc = upload_vec(ctx, offset, (size_t)N * sizeof(double), off))) return rc;
+    DSQ_HIP(b.alloc((size_t)G * P * sizeof(double)));
+    DSQ_HIP(ih.alloc((size_t)G * P * P * sizeof(double)));
+    DSQ_HIP(conv.alloc((size_t)G));
+    if ((rc = dsq_dev_lfc_shrink(ctx, y.as<int32_t>(), ldn, off.as<double>(), D.Xt.as<double>(), D.ldx, N, G, P,
+                                 sz.as<double>(), prior_no_shrink_scale, prior_scale, shrink_index, b.as<double>(),
+                                 ih.as<double>(), conv.as<uint8_t>())))
+        return rc;
+    DSQ_HIP(hipMemcpyAsync(beta_out, b.p, (size_t)G * P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(inv_hessian_out, ih.p, (size_t)G * P * P * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     return DSQ_OK;

@@ -1,0 +1,43 @@
+// dsq_k_shrink.hip — apeGLM MAP log-fold-change kernel (gfx950): one gene per wavefront, the n-dim
+// L-BFGS-B workspace (12-15 KB) in wave-private LDS.  Algorithmic HBM traffic per gene: 4N bytes of
+// counts per objective evaluation (re-reads hit L2), 8 p + 8 p^2 + 1 bytes written.
+#include "dsq_dispatch.h"
+#include "dsq_launch.h"
+#include "dsq_shrink.h"
+
+namespace dsq {
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_shrink(const int32_t* __restrict__ y, int ldn,
+                                                   const double* __restrict__ offset,
+                                                   const double* __restrict__ Xt, int ldx, int N, int G,
+                                                   const double* __restrict__ size, double sigma0, double sigma,
+                                                   int shrink_index, double* __restrict__ beta,
+                                                   double* __restrict__ invh, uint8_t* __restrict__ conv) {
+    __shared__ ShrinkWork<P> work[kWavesPerBlock];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * kWavesPerBlock + w;
+    if (g >= G) return;
+    ShrinkArgs A;
+    A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
+    double b[P];
+    const int ok = shrink_gene<DeviceWave, P>(A, work[w], b, invh ? invh + (size_t)g * P * P : nullptr);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
+        conv[g] = (uint8_t)ok;
+    }
+}
+
+hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx,
+                         int N, int G, int P_, const double* size, double sigma0, double sigma, int shrink_index,
+                         double* beta, double* invh, uint8_t* conv) {
+    if (G <= 0) return hipSuccess;
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_shrink<P>, grid, block, 0, st, y, ldn, offset, Xt, ldx, N, G, size,
+                                          sigma0, sigma, shrink_index, beta, invh, conv))
+    return hipGetLastError();
+}
+
+}  // namespace dsq

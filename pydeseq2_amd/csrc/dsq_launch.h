@@ -69,6 +69,10 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero);
 hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
                                   int n_idx, int ncols, double* dst);
+// ---- dsq_k_shrink.hip (apeGLM MAP LFC)
+hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx,
+                         int N, int G, int P, const double* size, double sigma0, double sigma, int shrink_index,
+                         double* beta, double* invh, uint8_t* conv);
 // ---- dsq_k_summary.hip (adjusted p-values of DeseqStats.summary())
 size_t summary_sort_temp_bytes(int n);
 hipError_t launch_padj_prepare(hipStream_t st, const double* base_mean, const double* pvalue, int n, double alpha,

@@ -1,0 +1,218 @@
+// dsq_shrink.h — apeGLM MAP log-fold-change per gene, one gene per wave.
+//
+// Replaces pydeseq2/utils.py:990-1142 (nbinomGLM), :1145-1207 (nbinomFn) and
+// pydeseq2/grid_search.py:224-320 (grid_fit_shrink_beta):
+//   f(beta)   = [ prior(beta) - nll(beta) ] / cnst,          cnst = max(f_raw(0), 1)
+//   nll       = sum_n  y_n eta_n - (y_n + size) logaddexp(eta_n + offset_n, log size),   eta = X beta
+//   prior     = sum_{j != s} beta_j^2 / (2 sigma0^2) + log1p((beta_s / sigma)^2)
+//   grad      = [ beta_j / sigma0^2 (j != s),  2 beta_s / (sigma^2 + beta_s^2) (j == s) ]
+//               - sum_n [ y_n - (y_n + size) / (1 + size exp(-eta_n - offset_n)) ] x_n        , / cnst
+// minimised with the unbounded L-BFGS-B (scipy options ftol = gtol = 1e-8) from
+// beta_0 = 0.1 (-1)^j; on failure and p == 2 the reference's two-level 60 x 60 grid; then the inverse
+// of the Hessian  X^T diag(frac) X + diag(h)  at the solution (unscaled), frac = (y + size) size e /
+// (size + e)^2,  e = exp(eta + offset).
+#pragma once
+#include "dsq_alpha.h"  // linspace_at
+#include "dsq_lbfgsb.h"
+#include "dsq_linalg.h"
+#include "dsq_wave.h"
+
+namespace dsq {
+
+struct ShrinkArgs {
+    const int32_t* y;      // [N]
+    const double* offset;  // [N] log size factors
+    const double* Xt;      // [P][ldx]
+    int ldx, N;
+    double size;           // 1 / dispersion
+    double sigma0, sigma;  // prior_no_shrink_scale, prior_scale
+    int shrink_index;
+};
+
+template <int P>
+struct ShrinkWork {  // wave-private LDS on the device
+    LbfgsbWork<P> lb;
+    double x[P], l[P], u[P];
+    int nbd[P];
+};
+
+// numpy.logaddexp(a, b)
+DSQ_HD double logaddexp_np(double a, double b) {
+    if (a == b) return a + 0.69314718055994530942;
+    const double d = a - b;
+    if (d > 0) return a + log1p(exp(-d));
+    if (d <= 0) return b + log1p(exp(d));
+    return a + b;  // NaN
+}
+
+// prior - nll (unscaled) and, if g != nullptr, its gradient
+template <class Wv, int P>
+DSQ_HD double shrink_fn(const ShrinkArgs& A, const double (&b)[P], double* g) {
+    const double lsz = log(A.size);
+    double s = 0.0, gr[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) gr[j] = 0.0;
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const double yv = (double)A.y[n];
+        double x[P];
+        double eta = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * b[j]; }
+        const double eo = eta + A.offset[n];
+        s += yv * eta - (yv + A.size) * logaddexp_np(eo, lsz);
+        if (g != nullptr) {
+            const double gk = yv - (yv + A.size) / (1.0 + A.size * exp(-eta - A.offset[n]));
+#pragma unroll
+            for (int j = 0; j < P; ++j) gr[j] += gk * x[j];
+        }
+    }
+    s = Wv::sum(s);
+    double prior = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+        if (j != A.shrink_index) prior += (b[j] * b[j]) / (2.0 * A.sigma0 * A.sigma0);
+    double bs = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) bs = (j == A.shrink_index) ? b[j] : bs;
+    const double q = bs / A.sigma;
+    prior += log1p(q * q);
+    if (g != nullptr) {
+        Wv::template sum_n<P>(gr);
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double dp = (j == A.shrink_index) ? 2.0 * b[j] / (A.sigma * A.sigma + bs * bs)
+                                                    : b[j] / (A.sigma0 * A.sigma0);
+            g[j] = dp - gr[j];
+        }
+    }
+    return prior - s;
+}
+
+// grid_fit_shrink_beta (grid_search.py:224-320), P == 2 (the reference's loss uses shrink_index = 1)
+template <class Wv>
+DSQ_HD void grid_fit_shrink2(const ShrinkArgs& A0, double cnst, double (&beta)[2], int grid_length = 60,
+                             double min_beta = -30.0, double max_beta = 30.0) {
+    ShrinkArgs A = A0;
+    A.shrink_index = 1;
+    double xlo = min_beta, xhi = max_beta, ylo = min_beta, yhi = max_beta;
+    for (int level = 0; level < 2; ++level) {
+        double best = 0.0;
+        int bi = 0, bj = 0;
+        bool best_nan = false, first = true;
+        for (int i = 0; i < grid_length; ++i) {
+            for (int j = 0; j < grid_length; ++j) {
+                const double bb[2] = {linspace_at(xlo, xhi, grid_length, i), linspace_at(ylo, yhi, grid_length, j)};
+                const double v = shrink_fn<Wv, 2>(A, bb, nullptr) / cnst;
+                const bool isn = (v != v);
+                if (first || (!best_nan && (isn || v < best))) { best = v; bi = i; bj = j; best_nan = isn; first = false; }
+            }
+        }
+        const double cx = linspace_at(xlo, xhi, grid_length, bi), cy = linspace_at(ylo, yhi, grid_length, bj);
+        if (level == 0) {
+            const double delta = linspace_at(xlo, xhi, grid_length, 1) - linspace_at(xlo, xhi, grid_length, 0);
+            xlo = cx - delta; xhi = cx + delta; ylo = cy - delta; yhi = cy + delta;
+        } else {
+            beta[0] = cx; beta[1] = cy;
+        }
+    }
+}
+
+// beta[P] (out), inv_hessian[P*P] row-major (out); returns scipy's res.success
+template <class Wv, int P>
+DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P], double* inv_hessian) {
+    constexpr int T = Tri<P>::N;
+    double zero[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) zero[j] = 0.0;
+    const double f0 = shrink_fn<Wv, P>(A, zero, nullptr);
+    const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
+    const double cn = (f0 != f0) ? f0 : cnst;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        Wk.x[j] = (j & 1) ? -0.1 : 0.1;
+        Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+    }
+    auto fg = [&](const double* xb, double& f, double* g) {
+        double b[P], gg[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] = xb[j];
+        f = shrink_fn<Wv, P>(A, b, gg) / cn;
+#pragma unroll
+        for (int j = 0; j < P; ++j) g[j] = gg[j] / cn;
+    };
+    // scipy: factr = ftol / eps, pgtol = gtol
+    const LbfgsbResult res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+#pragma unroll
+    for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
+    if (!res.success && P == 2) {
+        if constexpr (P == 2) grid_fit_shrink2<Wv>(A, cn, beta);
+    }
+    // Hessian (cnst = 1) and its inverse (numpy.linalg.inv)
+    double M[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) M[k] = 0.0;
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const double yv = (double)A.y[n];
+        double x[P];
+        double eta = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
+        const double e = exp(eta + A.offset[n]);
+        const double fr = (yv + A.size) * A.size * e / ((A.size + e) * (A.size + e));
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const double xw = x[i] * fr;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[tri(i, j)] += xw * x[j];
+        }
+    }
+    Wv::template sum_n<T>(M);
+    double bs = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) bs = (j == A.shrink_index) ? beta[j] : bs;
+    // prior curvature h_j.  The reference adds it as  X^T F X + np.diag(h)  where h is ALREADY a diagonal
+    // matrix, so np.diag(h) is the 1-D vector of its diagonal and numpy broadcasting adds h_j to EVERY
+    // row of column j (utils.py:1099-1110).  Reproduced as is: the returned "inverse Hessian" (and the
+    // shrunken lfcSE derived from it, ds.py:424-433) is the inverse of that non-symmetric matrix.
+    double hd[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const double s2 = A.sigma * A.sigma, b2 = bs * bs;
+        hd[j] = (j == A.shrink_index) ? 2.0 * (s2 - b2) / ((s2 + b2) * (s2 + b2)) : 1.0 / (A.sigma0 * A.sigma0);
+    }
+    if (inv_hessian != nullptr) {
+        // general inverse by Gauss-Jordan with partial pivoting on the full p x p matrix
+        double Hm[P][P], Iv[P][P];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                Hm[i][j] = M[tri(i > j ? i : j, i > j ? j : i)] + hd[j];
+                Iv[i][j] = (i == j) ? 1.0 : 0.0;
+            }
+        for (int c = 0; c < P; ++c) {
+            int pv = c;
+            double mx = fabs(Hm[c][c]);
+            for (int r = c + 1; r < P; ++r)
+                if (fabs(Hm[r][c]) > mx) { mx = fabs(Hm[r][c]); pv = r; }
+            if (pv != c)
+                for (int k = 0; k < P; ++k) {
+                    double t = Hm[c][k]; Hm[c][k] = Hm[pv][k]; Hm[pv][k] = t;
+                    t = Iv[c][k]; Iv[c][k] = Iv[pv][k]; Iv[pv][k] = t;
+                }
+            const double d = 1.0 / Hm[c][c];
+            for (int k = 0; k < P; ++k) { Hm[c][k] *= d; Iv[c][k] *= d; }
+            for (int r = 0; r < P; ++r) {
+                if (r == c) continue;
+                const double fct = Hm[r][c];
+                for (int k = 0; k < P; ++k) { Hm[r][k] -= fct * Hm[c][k]; Iv[r][k] -= fct * Iv[c][k]; }
+            }
+        }
+        if (Wv::lane() == 0)
+            for (int i = 0; i < P; ++i)
+                for (int j = 0; j < P; ++j) inv_hessian[i * P + j] = Iv[i][j];
+    }
+    return res.success ? 1 : 0;
+}
+
+}  // namespace dsq

@@ -189,9 +189,21 @@ class HipInference:
         tgt = np.asarray(getattr(targets, "values", targets), dtype=np.float64)
         return gamma_glm_fit(cov, tgt)
 
-    # ------------------------------------------------------------------ apeGLM (next row)
+    # ------------------------------------------------------------------ apeGLM shrinkage
     def lfc_shrink_nbinom_glm(self, design_matrix, counts, size, offset, prior_no_shrink_scale, prior_scale,
                               optimizer, shrink_index):
-        """``Inference.lfc_shrink_nbinom_glm`` (inference.py:310-362) is outside the
-        deseq2() -> Wald hot path and is not built yet."""
-        raise NotImplementedError("apeGLM LFC shrinkage is not part of the deseq2()->Wald hot path yet")
+        """See ``Inference.lfc_shrink_nbinom_glm`` (inference.py:306-362, default_inference.py:232-264).
+        Returns (beta G x p, inv_hessian G x p x p, converged G)."""
+        if optimizer != "L-BFGS-B":
+            raise NotImplementedError("HipInference implements the L-BFGS-B apeGLM fit only")
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        P = X.shape[1]
+        sz, off = _vec(size), _vec(offset)
+        beta, invh, conv = np.empty((G, P)), np.empty((G, P, P)), np.empty(G, dtype=np.uint8)
+        self.ctx.call("dsq_inf_lfc_shrink_nbinom_glm", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data),
+                      _vp(sz.ctypes.data), _vp(off.ctypes.data), N, G, P, c_double(prior_no_shrink_scale),
+                      c_double(prior_scale), int(shrink_index), _vp(beta.ctypes.data), _vp(invh.ctypes.data),
+                      _vp(conv.ctypes.data))
+        return beta, invh, conv.astype(bool)

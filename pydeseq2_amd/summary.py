@@ -103,3 +103,47 @@ def summary(res, contrast, alpha=0.05, cooks_filter=True, independent_filter=Tru
     return dict(baseMean=base_mean, log2FoldChange=np.asarray(res.LFC) @ contrast / np.log(2),
                 lfcSE=np.asarray(res.lfcSE) / np.log(2), stat=np.asarray(res.stat), pvalue=pvalue, padj=padj,
                 info=info)
+
+
+# ------------------------------------------------------------------ apeGLM LFC shrinkage
+def fit_prior_var(lfc, se, min_var=1e-6, max_var=400.0):
+    """Prior variance of the apeGLM model from the MLE LFCs and their standard errors: the zero of the
+    moment-matching equation of ``DeseqStats._fit_prior_var`` (ds.py:551-590)."""
+    from scipy.optimize import root_scalar
+
+    keep = ~np.isnan(lfc)
+    s2, d2 = np.asarray(lfc, dtype=float)[keep] ** 2, np.asarray(se, dtype=float)[keep] ** 2
+
+    def moment_gap(a):
+        wgt = 1 / (2 * (a + d2) ** 2)
+        return ((s2 - d2) * wgt).sum() / wgt.sum() - a
+
+    if moment_gap(min_var) < 0:
+        return min_var
+    return root_scalar(moment_gap, bracket=(min_var, max_var)).root
+
+
+def lfc_shrink(pipe, res, coeff_idx, adapt=True, prior_no_shrink_scale=15.0):
+    """``DeseqStats.lfc_shrink`` (ds.py:363-447) on the pipeline's device-resident counts.
+
+    ``res`` is the DeseqResult of ``pipe.deseq2(contrast=unit vector of coeff_idx)`` (its lfcSE feeds the
+    adaptive prior).  Returns (shrunken LFC of the coefficient [G], its SE [G], converged [G] with NaN
+    for all-zero genes, prior_scale)."""
+    ctx, N, G, P = pipe.ctx, pipe.N, pipe.G, pipe.P
+    prior_scale = 1.0
+    if adapt:
+        prior_scale = float(min(np.sqrt(fit_prior_var(res.LFC[:, coeff_idx], res.lfcSE)), 1.0))
+    nz = np.asarray(res.non_zero, dtype=bool)
+    disp = np.where(nz, res.dispersions, 1.0)  # all-zero genes are fitted too (cheap) and masked below
+    d_size = DeviceArray.from_host(ctx, 1.0 / disp)
+    d_off = DeviceArray.from_host(ctx, np.log(res.size_factors))
+    d_beta, d_ih = DeviceArray(ctx, (G, P), np.float64), DeviceArray(ctx, (G, P * P), np.float64)
+    d_conv = DeviceArray(ctx, (G,), np.uint8)
+    ctx.call("dsq_dev_lfc_shrink", _vp(pipe.d_y.ptr), pipe.ldn, _vp(d_off.ptr), _vp(pipe.d_Xt.ptr), pipe.design.ldx,
+             N, G, P, _vp(d_size.ptr), C.c_double(prior_no_shrink_scale), C.c_double(prior_scale), int(coeff_idx),
+             _vp(d_beta.ptr), _vp(d_ih.ptr), _vp(d_conv.ptr))
+    beta, ih = d_beta.to_host(), d_ih.to_host().reshape(G, P, P)
+    lfc = np.where(nz, beta[:, coeff_idx], res.LFC[:, coeff_idx])
+    se = np.where(nz, np.sqrt(np.abs(ih[:, coeff_idx, coeff_idx])), res.lfcSE)
+    conv = np.where(nz, d_conv.to_host().astype(float), np.nan)
+    return lfc, se, conv, prior_scale

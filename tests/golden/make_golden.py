@@ -183,6 +183,22 @@ def main():
     X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
     kat_case("p8", synth(48, N, X, 13), X, ut, gs, pp, di)
 
+    # apeGLM MAP LFC known answers: the reference's utils.nbinomGLM per gene
+    sh = {}
+    for case, sidx in (("p2", 1), ("p4", 3), ("p8", 1)):
+        k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
+        counts, X, sf = k["counts"], k["X"], k["sf"]
+        size = 1.0 / np.clip(k["map_alpha"], 1e-8, max(10, counts.shape[0]))
+        G = min(counts.shape[1], 40)
+        for tag, ps in (("a", 1.0), ("b", 0.3)):
+            r = [ut.nbinomGLM(X, counts[:, i], size[i], np.log(sf), 15, ps, "L-BFGS-B", sidx) for i in range(G)]
+            sh[f"{case}{tag}_beta"] = np.stack([x[0] for x in r])
+            sh[f"{case}{tag}_invh"] = np.stack([x[1] for x in r])
+            sh[f"{case}{tag}_conv"] = np.array([x[2] for x in r], dtype=bool)
+            sh[f"{case}{tag}_scale"] = np.array(ps)
+        sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
+    np.savez(os.path.join(HERE, "kat_shrink.npz"), **sh)
+
     # lowess known answers (summary tail): the reference's utils.lowess on the shapes
     # _independent_filtering feeds it (50 thetas vs rejection counts) plus generic cases
     from scipy.stats import false_discovery_control
@@ -210,11 +226,13 @@ def main():
         "single_factor": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
                           "r_test_res_mean_curve.csv", "r_test_res_no_independent_filtering.csv",
                           "r_test_res_greater.csv", "r_test_res_less.csv",
-                          "r_test_res_greaterAbs.csv", "r_test_res_lessAbs.csv"],
+                          "r_test_res_greaterAbs.csv", "r_test_res_lessAbs.csv",
+                          "r_test_lfc_shrink_res.csv", "r_test_lfc_shrink_no_apeAdapt_res.csv"],
         "multi_factor": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
-                         "r_test_res_outliers.csv"],
+                         "r_test_res_outliers.csv", "r_test_lfc_shrink_res.csv"],
         "continuous": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
-                       "r_test_res_outliers.csv", "test_counts.csv", "test_metadata.csv"],
+                       "r_test_res_outliers.csv", "r_test_lfc_shrink_res.csv", "test_counts.csv",
+                       "test_metadata.csv"],
         "wide": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
                  "test_counts.csv", "test_metadata.csv"],
     }.items():

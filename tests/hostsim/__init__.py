@@ -283,3 +283,20 @@ def trimmed_sum(buf, nt):
     f = lib().hs_trimmed_sum
     f.restype = C.c_double
     return float(f(_p(b, C.c_double), C.c_int(len(b)), C.c_int(int(nt))))
+
+
+def shrink(counts, X, size, offset, prior_no_shrink_scale, prior_scale, shrink_index):
+    """apeGLM MAP fit (nbinomGLM) through the device templates: (beta G x p, inv_hessian G x p x p, converged)."""
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, _, _ = design_pack(X)
+    P = Xt.shape[0]
+    sz = np.ascontiguousarray(size, dtype=np.float64)
+    off = np.ascontiguousarray(offset, dtype=np.float64)
+    beta, invh, conv = np.empty((G, P)), np.empty((G, P, P)), np.empty(G, np.uint8)
+    rc = lib().hs_shrink(_p(y, C.c_int32), C.c_int(N), _p(off, C.c_double), _p(Xt, C.c_double), C.c_int(N),
+                         C.c_int(N), C.c_int(G), C.c_int(P), _p(sz, C.c_double), C.c_double(prior_no_shrink_scale),
+                         C.c_double(prior_scale), C.c_int(shrink_index), _p(beta, C.c_double),
+                         _p(invh, C.c_double), _p(conv, C.c_uint8))
+    assert rc == 0
+    return beta, invh, conv.astype(bool)

@@ -17,6 +17,7 @@
 #include "dsq_lbfgsb.h"
 #include "dsq_lbfgsb_dense.h"
 #include "dsq_stats.h"
+#include "dsq_shrink.h"
 #include "dsq_trend.h"
 
 using namespace dsq;
@@ -107,6 +108,23 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
         conv[g] = (uint8_t)o.converged;
         if (iters) iters[g] = o.iters;
         if (fallback) fallback[g] = (uint8_t)o.fallback;
+    })
+    return 0;
+}
+
+int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx, int N, int G, int P_,
+              const double* size, double sigma0, double sigma, int shrink_index, double* beta /*[G][P]*/,
+              double* invh /*[G][P][P]*/, uint8_t* conv) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        ShrinkArgs A;
+        A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
+        A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
+        static ShrinkWork<P> Wk;
+        std::memset(&Wk, 0, sizeof(Wk));
+        double b[P];
+        conv[g] = (uint8_t)shrink_gene<HostWave, P>(A, Wk, b, invh + (size_t)g * P * P);
+        for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
     })
     return 0;
 }

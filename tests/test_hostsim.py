@@ -1,5 +1,7 @@
 """The per-gene device templates (pydeseq2_amd/csrc/dsq_*.h), instantiated on the host
 (tests/hostsim), against the reference's own kernels (golden KATs) and against scipy."""
+import os
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -248,3 +250,19 @@ def test_trimmed_sum_by_selection_matches_sort():
             ref = np.sort(v)[nt:n - nt].sum()
             got = hs.trimmed_sum(v, nt)
             assert abs(got - ref) <= 1e-12 * max(1.0, np.abs(v).sum()), (n, nt, got, ref)
+
+
+@pytest.mark.parametrize("case", ["p2", "p4", "p8"])
+def test_apeglm_shrinkage_templates_match_reference(case):
+    """shrink_gene (unbounded n-dim L-BFGS-B with ftol = gtol = 1e-8, apeGLM objective, the reference's
+    Hessian incl. its broadcasting quirk) against outputs of the unmodified utils.nbinomGLM."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink.npz"))
+    kk = load_kat(case)
+    G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
+    for tag in "ab":
+        b, ih, cv = hs.shrink(kk["counts"][:, :G], kk["X"], k[f"{case}_size"], np.log(kk["sf"]), 15.0,
+                              float(k[f"{case}{tag}_scale"]), sidx)
+        assert (cv == k[f"{case}{tag}_conv"]).all()
+        np.testing.assert_allclose(b, k[f"{case}{tag}_beta"], rtol=1e-6, atol=1e-9)
+        scale = np.abs(k[f"{case}{tag}_invh"]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-8

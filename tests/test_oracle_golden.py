@@ -197,3 +197,35 @@ def test_r_single_factor_summary_padj():
     s2 = orc.summary(res, [0, 1], independent_filter=False)
     r_noif = r_csv("single_factor", "r_test_res_no_independent_filtering.csv")
     assert max_rel_err(s2["padj"], r_noif["padj"].to_numpy()) < 0.02
+
+
+# ---------------------------------------------------------------- apeGLM shrinkage
+@pytest.mark.parametrize("case", ["p2", "p4"])
+def test_nbinom_glm_matches_reference(case):
+    """Restated utils.nbinomGLM against outputs of the unmodified reference (kat_shrink.npz)."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink.npz"))
+    kk = load_kat(case)
+    sidx = int(k[f"{case}_sidx"])
+    for tag in "ab":
+        for g in range(0, int(k[f"{case}_G"]), 3):
+            b, ih, cv = orc.nbinom_glm_gene(kk["X"], kk["counts"][:, g], k[f"{case}_size"][g], np.log(kk["sf"]), 15,
+                                            float(k[f"{case}{tag}_scale"]), sidx)
+            np.testing.assert_allclose(b, k[f"{case}{tag}_beta"][g], rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(ih, k[f"{case}{tag}_invh"][g], rtol=1e-8, atol=1e-12)
+            assert cv == k[f"{case}{tag}_conv"][g]
+
+
+@pytest.mark.parametrize("adapt,fn", [(True, "r_test_lfc_shrink_res.csv"),
+                                      (False, "r_test_lfc_shrink_no_apeAdapt_res.csv")])
+def test_r_lfc_shrink_single_factor(adapt, fn):
+    """tests/test_pydeseq2.py:256-341: start from R's size factors, dispersions, LFC and SE."""
+    counts, X, names = _run_r_case("synthetic", ["condition"])
+    res = orc.deseq2(counts.to_numpy(), X, contrast=[0, 1])
+    r_res = r_csv("single_factor", "r_test_res.csv")
+    res.size_factors = r_csv("single_factor", "r_test_size_factors.csv")["x"].to_numpy()
+    res.dispersions = r_csv("single_factor", "r_test_dispersions.csv")["x"].to_numpy()
+    res.LFC[:, 1] = r_res["log2FoldChange"].to_numpy() * np.log(2)
+    res.lfcSE = r_res["lfcSE"].to_numpy() * np.log(2)
+    lfc, se, conv, scale = orc.lfc_shrink(counts.to_numpy(), X, res, 1, adapt=adapt)
+    r_shr = r_csv("single_factor", fn)
+    assert max_rel_err(lfc / np.log(2), r_shr["log2FoldChange"].to_numpy()) < 0.02

@@ -9,6 +9,7 @@ GPU only: importing works anywhere, every computation requires libdeseq_hip.so a
 from ._lib import Context, DsqError  # noqa: F401
 from .inference import HipInference  # noqa: F401
 from .pipeline import DeseqPipeline, deseq2  # noqa: F401
+from .api import DeseqDataSet, DeseqStats  # noqa: F401  (AnnData-free facade with the reference's user-level names)
 from . import summary  # noqa: F401  (module: summary.summary(res, contrast) = DeseqStats.summary() tail)
 
 __version__ = "0.1.0"

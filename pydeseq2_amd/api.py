@@ -1,0 +1,224 @@
+"""AnnData-free façade with the reference's user-level surface.
+
+``DeseqDataSet`` / ``DeseqStats`` mirror the parts of ``pydeseq2.dds.DeseqDataSet`` and
+``pydeseq2.ds.DeseqStats`` a typical analysis touches — constructor arguments, ``deseq2()``,
+``summary()``, ``lfc_shrink()``, and the field names written by the path (``obs["size_factors"]``,
+``var["dispersions"]``, ``varm["LFC"]``, ``uns["trend_coeffs"]``, ``results_df`` …) —
+on top of the device pipeline, without ``anndata`` or ``formulaic``.  Designs are additive formulas
+of metadata columns (``"~group + condition"``; object/category columns are treatment-coded with the
+first sorted level as reference, numeric columns enter as they are) or an explicit design matrix.
+"""
+from __future__ import annotations
+
+import re
+
+import numpy as np
+import pandas as pd
+
+from . import summary as _summary
+from ._lib import Context
+from .pipeline import DeseqPipeline
+
+
+def build_design(metadata: pd.DataFrame, design) -> pd.DataFrame:
+    """Design matrix for an additive formula (same columns and names ``formulaic`` produces for it:
+    ``Intercept``, ``factor[T.level]`` …, continuous covariates under their own name)."""
+    if isinstance(design, pd.DataFrame):
+        return design.astype(float)
+    if not isinstance(design, str):
+        X = np.asarray(design, dtype=float)
+        return pd.DataFrame(X, index=metadata.index, columns=[f"x{j}" for j in range(X.shape[1])])
+    rhs = design.strip()
+    if not rhs.startswith("~"):
+        raise ValueError("design must be a formula starting with '~' (e.g. '~condition') or a matrix")
+    terms = [t.strip() for t in rhs[1:].split("+") if t.strip()]
+    cols = {}
+    intercept = True
+    for t in terms:
+        if t == "1":
+            continue
+        if t in ("0", "-1"):
+            intercept = False
+            continue
+        if not re.fullmatch(r"[A-Za-z_][A-Za-z0-9_.]*", t):
+            raise NotImplementedError(f"only additive formulas of metadata columns are supported (term {t!r})")
+        if t not in metadata.columns:
+            raise KeyError(f"design term {t!r} is not a metadata column")
+        col = metadata[t]
+        if col.isna().any():
+            raise ValueError("NaNs are not allowed in the design factors.")
+        if col.dtype.kind in "OUSb" or str(col.dtype) == "category":
+            levels = sorted(col.astype(str).unique())
+            for lv in levels[1:]:
+                cols[f"{t}[T.{lv}]"] = (col.astype(str) == lv).to_numpy().astype(float)
+        else:
+            cols[t] = col.to_numpy().astype(float)
+    out = pd.DataFrame(cols, index=metadata.index)
+    if intercept:
+        out.insert(0, "Intercept", 1.0)
+    return out
+
+
+class DeseqDataSet:
+    """Counts + metadata + design, fitted on the GPU (cf. ``pydeseq2.dds.DeseqDataSet``, dds.py:206-340)."""
+
+    def __init__(self, *, counts: pd.DataFrame, metadata: pd.DataFrame, design="~condition", refit_cooks=True,
+                 min_mu=0.5, min_disp=1e-8, max_disp=10.0, beta_tol=1e-8, min_replicates=7, fit_type="parametric",
+                 device=0, ctx: Context | None = None, quiet=True):
+        if not isinstance(counts, pd.DataFrame):
+            counts = pd.DataFrame(np.asarray(counts))
+        if counts.shape[0] != metadata.shape[0]:
+            raise ValueError("counts (samples x genes) and metadata disagree on the number of samples")
+        if counts.isna().any().any():
+            raise ValueError("NaNs are not allowed in the count matrix.")
+        self.obs = metadata.loc[counts.index].copy() if set(counts.index) == set(metadata.index) else metadata.copy()
+        self.obs_names, self.var_names = counts.index, counts.columns
+        self.X = counts.to_numpy()
+        self.n_obs, self.n_vars = self.X.shape
+        self.design = design
+        dm = build_design(self.obs, design)
+        self.obsm = {"design_matrix": dm}
+        self.var = pd.DataFrame(index=self.var_names)
+        self.varm, self.layers, self.uns = {}, _LazyLayers(self), {}
+        self.refit_cooks, self.fit_type, self.quiet = refit_cooks, fit_type, quiet
+        self._pipe = DeseqPipeline(self.X, dm.to_numpy(), ctx=ctx, device=device, min_mu=min_mu, min_disp=min_disp,
+                                   max_disp=max_disp, refit_cooks=refit_cooks, min_replicates=min_replicates,
+                                   beta_tol=beta_tol, fit_type=fit_type)
+        self._res = None
+
+    # ------------------------------------------------------------------ the pipeline
+    def deseq2(self):
+        """Size factors, dispersions, LFCs, Cook's outliers and their refit (dds.py:516-562)."""
+        r = self._res = self._pipe.deseq2()
+        v, cols = self.var, self.obsm["design_matrix"].columns
+        self.obs["size_factors"] = r.size_factors
+        v["non_zero"], v["_normed_means"] = r.non_zero, r.normed_means
+        v["_MoM_dispersions"], v["genewise_dispersions"] = r.mom_dispersions, r.genewise_dispersions
+        v["_genewise_converged"], v["fitted_dispersions"] = r.genewise_converged, r.fitted_dispersions
+        v["MAP_dispersions"], v["_MAP_converged"] = r.MAP_dispersions, r.MAP_converged
+        v["dispersions"], v["_outlier_genes"] = r.dispersions, r.outlier_genes
+        v["_LFC_converged"], v["replaced"], v["refitted"] = r.LFC_converged, r.replaced, r.refitted
+        v["_pvalue_cooks_outlier"] = r.cooks_outlier
+        self.varm["LFC"] = pd.DataFrame(r.LFC, index=self.var_names, columns=cols)
+        self.uns["disp_function_type"] = r.disp_function_type
+        if r.trend_coeffs is not None:
+            self.uns["trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
+        if r.mean_disp is not None:
+            self.uns["mean_disp"] = r.mean_disp
+        self.uns["_squared_logres"], self.uns["prior_disp_var"] = r.squared_logres, r.prior_disp_var
+        return self
+
+    def cooks_outlier(self) -> pd.Series:
+        return pd.Series(np.asarray(self._res.cooks_outlier, dtype=bool), index=self.var_names)
+
+    @property
+    def non_zero_genes(self):
+        return self.var_names[np.asarray(self.var["non_zero"], dtype=bool)]
+
+
+class _LazyLayers(dict):
+    """N x G layers stay on the device until asked for (``normed_counts``, ``_mu_LFC``, ``_hat_diagonals``,
+    ``cooks``)."""
+
+    def __init__(self, dds):
+        super().__init__()
+        self._dds = dds
+
+    def __missing__(self, key):
+        dds = self._dds
+        if dds._res is None:
+            raise KeyError(key)
+        if key == "normed_counts":
+            val = dds.X / np.asarray(dds.obs["size_factors"])[:, None]
+        else:
+            name = {"_mu_LFC": "mu_LFC", "_hat_diagonals": "hat_diagonals", "cooks": "cooks"}.get(key)
+            if name is None:
+                raise KeyError(key)
+            val = dds._pipe.layer(name)
+        self[key] = val
+        return val
+
+
+class DeseqStats:
+    """Wald tests, adjusted p-values and LFC shrinkage (cf. ``pydeseq2.ds.DeseqStats``, ds.py:110-447)."""
+
+    def __init__(self, dds: DeseqDataSet, contrast, alpha=0.05, cooks_filter=True, independent_filter=True,
+                 lfc_null=0.0, alt_hypothesis=None, quiet=True):
+        if dds._res is None:
+            raise AttributeError("Please run deseq2() on the DeseqDataSet first.")
+        self.dds, self.alpha = dds, alpha
+        self.cooks_filter, self.independent_filter = cooks_filter, independent_filter
+        self.lfc_null, self.alt_hypothesis, self.quiet = lfc_null, alt_hypothesis, quiet
+        self.design_matrix = dds.obsm["design_matrix"]
+        self.LFC = dds.varm["LFC"].copy()
+        self.base_mean = dds.var["_normed_means"].copy()
+        self.contrast = contrast
+        self.contrast_vector = self._contrast_vector(contrast)
+        self.shrunk_LFCs = False
+
+    def _contrast_vector(self, contrast) -> np.ndarray:
+        cols = list(self.design_matrix.columns)
+        if isinstance(contrast, np.ndarray) or (len(contrast) == len(cols) and not isinstance(contrast[0], str)):
+            return np.asarray(contrast, dtype=float)
+        factor, tested, ref = (str(c) for c in contrast)
+        if factor not in self.dds.obs.columns:
+            raise KeyError(f"The contrast variable ('{factor}') should be one of the design factors.")
+        levels = sorted(self.dds.obs[factor].astype(str).unique())
+        if tested not in levels or ref not in levels:
+            raise KeyError(f"The contrast levels ({tested}, {ref}) should be levels of '{factor}': {levels}.")
+        v = np.zeros(len(cols))
+        for lv, sign in ((tested, 1.0), (ref, -1.0)):
+            name = f"{factor}[T.{lv}]"
+            if name in cols:  # the reference level of the factor has no column: it is the intercept
+                v[cols.index(name)] = sign
+        return v
+
+    def run_wald_test(self):
+        r = self.dds._res
+        pv, st, se = self.dds._pipe.wald(r, self.contrast_vector, self.lfc_null, self.alt_hypothesis)
+        idx = self.dds.var_names
+        self.p_values, self.statistics, self.SE = pd.Series(pv, index=idx), pd.Series(st, index=idx), pd.Series(se, index=idx)
+
+    def summary(self, **kwargs) -> pd.DataFrame:
+        """Wald test, Cook's filtering, adjusted p-values; returns and stores ``results_df`` (ds.py:219-299)."""
+        self.lfc_null = kwargs.get("lfc_null", self.lfc_null)
+        self.alt_hypothesis = kwargs.get("alt_hypothesis", self.alt_hypothesis)
+        self.run_wald_test()
+        pv = self.p_values.to_numpy().copy()
+        if self.cooks_filter:
+            pv[self.dds.cooks_outlier().to_numpy()] = np.nan
+        self.p_values = pd.Series(pv, index=self.dds.var_names)
+        padj, self._padj_info = _summary.adjusted_pvalues(self.dds._pipe.ctx, self.base_mean.to_numpy(), pv, self.alpha,
+                                                          self.independent_filter)
+        self.padj = pd.Series(padj, index=self.dds.var_names)
+        df = pd.DataFrame(index=self.dds.var_names)
+        df["baseMean"] = self.base_mean
+        df["log2FoldChange"] = self.LFC.to_numpy() @ self.contrast_vector / np.log(2)
+        df["lfcSE"] = self.SE / np.log(2)
+        df["stat"], df["pvalue"], df["padj"] = self.statistics, self.p_values, self.padj
+        self.results_df = df
+        return df
+
+    def lfc_shrink(self, coeff: str, adapt: bool = True) -> pd.DataFrame:
+        """apeGLM shrinkage of one LFC column, p-values unchanged (ds.py:363-447)."""
+        if coeff not in self.LFC.columns:
+            raise KeyError(f"The coeff argument '{coeff}' should be one the LFC columns. "
+                           f"The available LFC coeffs are {self.LFC.columns[1:]}.")
+        j = self.LFC.columns.get_loc(coeff)
+        if not hasattr(self, "SE"):
+            self.run_wald_test()
+        r = self.dds._res
+        work = type(r)(**{k: getattr(r, k) for k in r.__dataclass_fields__})
+        work.LFC, work.lfcSE = self.LFC.to_numpy().copy(), self.SE.to_numpy()
+        work.size_factors = np.asarray(self.dds.obs["size_factors"], dtype=float)
+        work.dispersions = np.asarray(self.dds.var["dispersions"], dtype=float)
+        lfc, se, conv, self.prior_scale = _summary.lfc_shrink(self.dds._pipe, work, j, adapt=adapt)
+        self.LFC.iloc[:, j] = lfc
+        self.SE = pd.Series(se, index=self.dds.var_names)
+        self._LFC_shrink_converged = pd.Series(conv, index=self.dds.var_names)
+        self.shrunk_LFCs = True
+        if hasattr(self, "results_df"):
+            self.results_df["log2FoldChange"] = self.LFC.iloc[:, j] / np.log(2)
+            self.results_df["lfcSE"] = self.SE / np.log(2)
+            return self.results_df
+        return None

@@ -625,6 +625,32 @@ class DeseqPipeline:
             self.layers = {}
         return r
 
+    def wald(self, res: DeseqResult, contrast, lfc_null=0.0, alt_hypothesis=None):
+        """Wald test only (ds.py:303-360) on the dispersions / LFCs of ``res`` (e.g. another contrast or
+        alternative hypothesis after ``deseq2()``).  Returns (pvalue, stat, lfcSE), NaN for all-zero genes."""
+        if alt_hypothesis not in ALT:
+            raise KeyError(alt_hypothesis)
+        if lfc_null < 0 and alt_hypothesis in {"greaterAbs", "lessAbs"}:
+            raise ValueError(f"The alternative hypothesis being {alt_hypothesis}, please provide a "
+                             f"positive lfc_null value (got {lfc_null}).")
+        G, N, P, D = self.G, self.N, self.P, self.design
+        contrast = np.ascontiguousarray(contrast, dtype=np.float64)
+        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
+        ctx = self.ctx
+        d_sf = DeviceArray.from_host(ctx, np.ascontiguousarray(res.size_factors, dtype=np.float64))
+        d_beta = DeviceArray.from_host(ctx, np.ascontiguousarray(res.LFC, dtype=np.float64))
+        d_disp = DeviceArray.from_host(ctx, np.ascontiguousarray(res.dispersions, dtype=np.float64))
+        d_out = DeviceArray(ctx, (3 * G,), np.float64)
+        ctx.call("dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P, _vp(d_disp.ptr),
+                 _vp(d_beta.ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data), c_double(np.log(2) * lfc_null),
+                 ALT[alt_hypothesis], _vp(d_out.ptr), _vp(d_out.ptr + 8 * G), _vp(d_out.ptr + 16 * G))
+        o = d_out.to_host()
+        pv, st, se = o[:G].copy(), o[G:2 * G].copy(), o[2 * G:].copy()
+        z = np.asarray(res.new_all_zeroes, dtype=bool)
+        if z.any():  # ds.py:357-360
+            se[z], st[z], pv[z] = 0.0, 0.0, 1.0
+        return pv, st, se
+
     def close(self):
         """Release the pooled device buffers."""
         for _cap, ptr in self._pool_free + self._pool_used:

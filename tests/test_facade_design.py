@@ -1,0 +1,35 @@
+"""Formula -> design matrix of the AnnData-free façade (pydeseq2_amd/api.py), CPU only."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from pydeseq2_amd.api import build_design
+from tests.helpers import load_dataset, treatment_design
+
+
+@pytest.mark.parametrize("which,factors,cont,formula", [
+    ("synthetic", ["condition"], (), "~condition"),
+    ("synthetic", ["group", "condition"], (), "~group + condition"),
+    ("continuous", ["group", "condition"], ("measurement",), "~ group + condition + measurement"),
+])
+def test_formula_designs(which, factors, cont, formula):
+    _, meta = load_dataset(which)
+    X, names = treatment_design(meta, factors, cont)
+    dm = build_design(meta, formula)
+    assert list(dm.columns) == names
+    assert np.array_equal(dm.to_numpy(), X)
+
+
+def test_formula_errors_and_matrix_input():
+    meta = pd.DataFrame({"a": ["x", "y", "x"], "b": [1.0, 2.0, np.nan]})
+    with pytest.raises(KeyError):
+        build_design(meta, "~zzz")
+    with pytest.raises(ValueError):
+        build_design(meta, "~b")
+    with pytest.raises(NotImplementedError):
+        build_design(meta, "~a:b")
+    with pytest.raises(ValueError):
+        build_design(meta, "a + b")
+    assert list(build_design(meta, "~0 + a").columns) == ["a[T.y]"]
+    M = np.ones((3, 2))
+    assert build_design(meta, M).shape == (3, 2)

@@ -234,6 +234,10 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* Variance stabilising transformation of the normalised counts (dds.py:486-514) on the
+ * sample-major matrix as uploaded: mode 0 parametric trend (a0, a1), mode 1 mean dispersion (a0). */
+int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G, const double* d_sf, int mode,
+                double a0, double a1, double* d_out);
 /* apeGLM MAP log-fold changes: Inference.lfc_shrink_nbinom_glm (inference.py:306-362,
  * default_inference.py:232-264 -> utils.nbinomGLM, utils.py:990-1142).  size = 1/dispersion [G],
  * offset = log(size factors) [N]; outputs beta [G][P], inv_hessian [G][P][P] (the reference's matrix,

@@ -851,6 +851,41 @@ def p_value_adjustment(pvalue):
 
 
 # --------------------------------------------------------------------------
+# variance stabilising transformation        SURVEY.md §8(f)-4
+# --------------------------------------------------------------------------
+
+
+def vst(counts, X, use_design=False, fit_type="parametric", min_mu=0.5, min_disp=1e-8, max_disp=10.0,
+        beta_tol=1e-8, n_jobs=1):
+    """DeseqDataSet.vst (dds.py:349-514): size factors, genewise dispersions and trend fitted with an
+    intercept-only design (or the full one), then the closed-form transform of the normalised counts.
+    Returns (vst_counts N x G, info)."""
+    counts = np.asarray(counts)
+    N, G = counts.shape
+    max_disp = max(max_disp, N)
+    Xd = np.asarray(X, dtype=float) if use_design else np.ones((N, 1))
+    sf, normed, _, _ = size_factors_ratio(counts)
+    nz = ~(counts == 0).all(axis=0)
+    nzi = np.nonzero(nz)[0]
+    _, _, gw, _ = _fit_genewise(counts[:, nzi], normed[:, nzi], sf, Xd, min_mu, min_disp, max_disp, beta_tol, n_jobs)
+    gw_all = _scatter(G, nzi, gw)
+    info = dict(size_factors=sf, genewise_dispersions=gw_all)
+    coeffs = None
+    if fit_type == "parametric":
+        coeffs, _ = fit_parametric_trend(gw, normed.mean(0)[nzi])
+    if coeffs is not None:
+        a0, a1 = coeffs
+        info["trend_coeffs"] = coeffs
+        out = np.log2((1 + a1 + 2 * a0 * normed + 2 * np.sqrt(a0 * normed * (1 + a1 + a0 * normed))) / (4 * a0))
+    else:
+        use = gw_all > 10 * min_disp
+        mean_disp = trim_mean(gw_all[use], proportiontocut=0.001)
+        info["mean_disp"] = mean_disp
+        out = (2 * np.arcsinh(np.sqrt(mean_disp * normed)) - np.log(mean_disp) - np.log(4)) / np.log(2)
+    return out, info
+
+
+# --------------------------------------------------------------------------
 # apeGLM LFC shrinkage                      SURVEY.md §8(f)-2
 # --------------------------------------------------------------------------
 

@@ -108,6 +108,32 @@ class DeseqDataSet:
         self.uns["_squared_logres"], self.uns["prior_disp_var"] = r.squared_logres, r.prior_disp_var
         return self
 
+    def vst(self, use_design: bool = False, fit_type=None):
+        """Variance stabilising transformation into ``layers["vst_counts"]`` (dds.py:349-514): dispersions
+        and trend fitted with an intercept-only design unless ``use_design``."""
+        self.vst_fit_type = fit_type if fit_type is not None else self.fit_type
+        if self.vst_fit_type not in ("parametric", "mean"):
+            raise NotImplementedError(f"Found fit_type '{self.vst_fit_type}'. Expected 'parametric' or 'mean'.")
+        p0 = self._pipe
+        X = self.obsm["design_matrix"].to_numpy() if use_design else np.ones((self.n_obs, 1))
+        pipe = p0 if use_design else DeseqPipeline(self.X, X, ctx=p0.ctx, min_mu=p0.min_mu, min_disp=p0.min_disp,
+                                                    max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type)
+        old_ft, pipe.fit_type = pipe.fit_type, self.vst_fit_type
+        try:
+            r = pipe.deseq2(stop_after_trend=True)
+        finally:
+            pipe.fit_type = old_ft
+        self.obs["size_factors"] = r.size_factors
+        self.var["vst_genewise_dispersions"] = r.genewise_dispersions
+        if r.disp_function_type == "parametric":
+            self.uns["vst_trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
+            out = p0.vst_transform(r.size_factors, trend_coeffs=r.trend_coeffs)
+        else:
+            self.vst_fit_type = "mean"
+            out = p0.vst_transform(r.size_factors, mean_disp=r.mean_disp)
+        self.layers["vst_counts"] = out
+        return out
+
     def cooks_outlier(self) -> pd.Series:
         return pd.Series(np.asarray(self._res.cooks_outlier, dtype=bool), index=self.var_names)
 

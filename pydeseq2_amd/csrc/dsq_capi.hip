@@ -497,6 +497,13 @@ int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
     return DSQ_OK;
 }
 
+int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G, const double* d_sf, int mode,
+                double a0, double a1, double* d_out) {
+    DSQ_CHECK_ARG(mode == 0 || mode == 1, "mode: 0 parametric trend, 1 mean dispersion");
+    DSQ_HIP(dsq::launch_vst(ctx->stream, d_counts_sm, count_type, N, G, d_sf, mode, a0, a1, d_out));
+    return DSQ_OK;
+}
+
 int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1, double* d_fitted) {
     DSQ_HIP(dsq::launch_trend_eval(ctx->stream, d_normed_means, n, a0, a1, d_fitted));
     return DSQ_OK;

@@ -727,6 +727,33 @@ __global__ void k_scatter_rows(const double* __restrict__ src, const int32_t* __
     dst[(size_t)idx[k] * width + c] = src[t];
 }
 
+// variance stabilising transformation of the normalised counts (dds.py:486-514), sample-major N x G:
+// mode 0: log2((1 + a1 + 2 a0 x + 2 sqrt(a0 x (1 + a1 + a0 x))) / (4 a0)),  x = count / size factor
+// mode 1: (2 asinh(sqrt(a0 x)) - log a0 - log 4) / log 2                    (a0 = mean dispersion)
+template <class T>
+__global__ void k_vst(const T* __restrict__ counts, int N, int G, const double* __restrict__ sf, int mode,
+                      double a0, double a1, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * G) return;
+    const double x = (double)counts[i] / sf[i / G];
+    double v;
+    if (mode == 0) v = log2((1.0 + a1 + 2.0 * a0 * x + 2.0 * sqrt(a0 * x * (1.0 + a1 + a0 * x))) / (4.0 * a0));
+    else v = (2.0 * asinh(sqrt(a0 * x)) - log(a0) - log(4.0)) / log(2.0);
+    out[i] = v;
+}
+
+hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int N, int G, const double* sf, int mode,
+                      double a0, double a1, double* out) {
+    if (N <= 0 || G <= 0) return hipSuccess;
+    const size_t total = (size_t)N * G;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (count_type == 1)
+        hipLaunchKernelGGL(k_vst<int64_t>, grid, block, 0, st, (const int64_t*)counts_sm, N, G, sf, mode, a0, a1, out);
+    else
+        hipLaunchKernelGGL(k_vst<int32_t>, grid, block, 0, st, (const int32_t*)counts_sm, N, G, sf, mode, a0, a1, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_trend_eval, dim3((n + 255) / 256), dim3(256), 0, st, nm, n, a0, a1, fitted);

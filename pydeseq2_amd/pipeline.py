@@ -417,7 +417,8 @@ class DeseqPipeline:
         return sq, float(np.maximum(sq - polygamma(1, (self.N - self.P) / 2), 0.25))
 
     # ------------------------------------------------------------------ the pipeline
-    def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False) -> DeseqResult:
+    def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False,
+               stop_after_trend=False) -> DeseqResult:
         """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald.
 
         The per-gene vectors stay in HBM from the first kernel to the Wald test; the host sees
@@ -493,6 +494,21 @@ class DeseqPipeline:
             r.disp_function_type = "mean"
             r.mean_disp = self._mean_trend(Gn)
             a0, a1 = float(r.mean_disp), 0.0
+        if stop_after_trend:  # vst_fit (dds.py:384-438): size factors, genewise dispersions, trend
+            Hh = self._fetch(S, ["nm", "mom", "gw", "gconv"])
+
+            def fullv(v, fill=np.nan):
+                if all_nz:
+                    return np.array(v, dtype=float)
+                out = np.full(G, fill)
+                out[nzi] = v
+                return out
+
+            r.normed_means = fullv(Hh["nm"], 0.0)
+            r.mom_dispersions = fullv(Hh["mom"])
+            r.genewise_dispersions = fullv(np.clip(Hh["gw"], self.min_disp, self.max_disp))
+            r.genewise_converged = fullv(Hh["gconv"].astype(float))
+            return r
         ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(a0), c_double(a1), _vp(S["fit"].ptr))
         if (N - P) <= 3:
             warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
@@ -624,6 +640,19 @@ class DeseqPipeline:
         if not self.keep_cooks:
             self.layers = {}
         return r
+
+    def vst_transform(self, size_factors, trend_coeffs=None, mean_disp=None):
+        """Variance-stabilised counts N x G (dds.py:440-514) from the resident raw counts."""
+        ctx = self.ctx
+        d_sf = DeviceArray.from_host(ctx, np.ascontiguousarray(size_factors, dtype=np.float64))
+        d_out = DeviceArray(ctx, (self.N, self.G), np.float64)
+        if trend_coeffs is not None:
+            mode, a0, a1 = 0, float(trend_coeffs[0]), float(trend_coeffs[1])
+        else:
+            mode, a0, a1 = 1, float(mean_disp), 0.0
+        ctx.call("dsq_dev_vst", _vp(self.d_raw.ptr), self._count_type, self.N, self.G, _vp(d_sf.ptr), mode,
+                 c_double(a0), c_double(a1), _vp(d_out.ptr))
+        return d_out.to_host()
 
     def wald(self, res: DeseqResult, contrast, lfc_null=0.0, alt_hypothesis=None):
         """Wald test only (ds.py:303-360) on the dispersions / LFCs of ``res`` (e.g. another contrast or

@@ -68,3 +68,21 @@ def test_multi_factor_and_continuous():
     df = DeseqStats(dds, contrast=contrast).summary()
     _almost(df, r_csv("continuous", "r_test_res.csv"), 0.04, cols=("log2FoldChange", "pvalue"))
     assert dds.layers["cooks"].shape == counts.shape and dds.layers["normed_counts"].shape == counts.shape
+
+
+@pytest.mark.parametrize("use_design,fit_type,fn", [(False, None, "r_vst.csv"), (True, None, "r_vst_with_design.csv"),
+                                                    (False, "mean", "r_mean_vst.csv")])
+def test_vst(use_design, fit_type, fn):
+    """tests/test_pydeseq2.py:761-805 + the oracle restatement on the same inputs."""
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition")
+    out = dds.vst(use_design=use_design, fit_type=fit_type)
+    r_vst = r_csv("single_factor", fn).T.to_numpy()
+    assert np.max(np.abs(r_vst - out) / r_vst) < 0.02
+    ref, _ = orc.vst(counts.to_numpy(), dds.obsm["design_matrix"].to_numpy(), use_design=use_design,
+                     fit_type=fit_type or "parametric")
+    np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-9)
+    assert dds.layers["vst_counts"].shape == counts.shape

@@ -229,3 +229,15 @@ def test_r_lfc_shrink_single_factor(adapt, fn):
     lfc, se, conv, scale = orc.lfc_shrink(counts.to_numpy(), X, res, 1, adapt=adapt)
     r_shr = r_csv("single_factor", fn)
     assert max_rel_err(lfc / np.log(2), r_shr["log2FoldChange"].to_numpy()) < 0.02
+
+
+# ---------------------------------------------------------------- VST
+@pytest.mark.parametrize("use_design,fit_type,fn", [(False, "parametric", "r_vst.csv"),
+                                                    (True, "parametric", "r_vst_with_design.csv"),
+                                                    (False, "mean", "r_mean_vst.csv")])
+def test_r_vst(use_design, fit_type, fn):
+    """tests/test_pydeseq2.py:761-805."""
+    counts, X, _ = _run_r_case("synthetic", ["condition"])
+    out, _ = orc.vst(counts.to_numpy(), X, use_design=use_design, fit_type=fit_type)
+    r_vst = r_csv("single_factor", fn).T.to_numpy()
+    assert np.max(np.abs(r_vst - out) / r_vst) < 0.02

@@ -234,6 +234,12 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* "poscounts" size factors (dds.py:655-680): log geometric means over the positive counts
+ * (zeros contribute 0 to the mean over all samples) and the usable-gene mask (finite, > 0); feed both to
+ * dsq_dev_size_factors (which leaves a sample's zero counts out of its median) and divide the result by its
+ * geometric mean.  d_gene_mask of dsq_dev_size_factors also serves `control_genes`. */
+int dsq_dev_logmeans_poscounts(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, double* d_logmeans,
+                               uint8_t* d_usable);
 /* Variance stabilising transformation of the normalised counts (dds.py:486-514) on the
  * sample-major matrix as uploaded: mode 0 parametric trend (a0, a1), mode 1 mean dispersion (a0). */
 int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G, const double* d_sf, int mode,

@@ -66,6 +66,35 @@ def size_factors_ratio(counts: np.ndarray):
     return sf, counts / sf[:, None], lm, keep
 
 
+def size_factors_control(counts, control_mask):
+    """Median-of-ratios size factors restricted to control genes (dds.py:640-650, 692-703)."""
+    lm, keep = logmeans_and_filter(counts)
+    keep = keep & np.asarray(control_mask, dtype=bool)
+    with np.errstate(divide="ignore"):
+        lc = np.log(counts)
+    return np.exp(np.median(lc[:, keep] - lm[keep], axis=1))
+
+
+def size_factors_poscounts(counts, control_mask=None):
+    """``fit_size_factors(fit_type="poscounts")`` (dds.py:655-680): geometric means over the positive
+    counts only, per-sample median over the positive entries of the usable genes, normalised to a
+    geometric mean of 1."""
+    counts = np.asarray(counts)
+    log_counts = np.zeros_like(counts, dtype=float)
+    np.log(counts, out=log_counts, where=counts != 0)
+    logmeans = log_counts.mean(0)
+    mask = (~np.isinf(logmeans)) & (logmeans > 0)
+    if control_mask is not None:
+        mask = mask & np.asarray(control_mask, dtype=bool)
+
+    def one(x):
+        m = np.logical_and(mask, x > 0)
+        return np.exp(np.median(np.log(x[m]) - logmeans[m]))
+
+    sf = np.apply_along_axis(one, 1, counts)
+    return sf / np.exp(np.mean(np.log(sf)))
+
+
 # --------------------------------------------------------------------------
 # a3/a4  method-of-moments initial dispersions    utils.py:814-885, dds.py:1140-1162
 # --------------------------------------------------------------------------

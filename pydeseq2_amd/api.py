@@ -64,7 +64,7 @@ class DeseqDataSet:
 
     def __init__(self, *, counts: pd.DataFrame, metadata: pd.DataFrame, design="~condition", refit_cooks=True,
                  min_mu=0.5, min_disp=1e-8, max_disp=10.0, beta_tol=1e-8, min_replicates=7, fit_type="parametric",
-                 device=0, ctx: Context | None = None, quiet=True):
+                 size_factors_fit_type="ratio", control_genes=None, device=0, ctx: Context | None = None, quiet=True):
         if not isinstance(counts, pd.DataFrame):
             counts = pd.DataFrame(np.asarray(counts))
         if counts.shape[0] != metadata.shape[0]:
@@ -81,9 +81,15 @@ class DeseqDataSet:
         self.var = pd.DataFrame(index=self.var_names)
         self.varm, self.layers, self.uns = {}, _LazyLayers(self), {}
         self.refit_cooks, self.fit_type, self.quiet = refit_cooks, fit_type, quiet
+        if control_genes is not None:  # names, integer positions or a boolean mask (dds.py:640-650)
+            cg = np.asarray(control_genes)
+            control_genes = self.var_names.get_indexer(cg) if cg.dtype.kind in "OUS" else cg
+            if cg.dtype.kind in "OUS" and (np.asarray(control_genes) < 0).any():
+                raise KeyError("control_genes: unknown gene name")
         self._pipe = DeseqPipeline(self.X, dm.to_numpy(), ctx=ctx, device=device, min_mu=min_mu, min_disp=min_disp,
                                    max_disp=max_disp, refit_cooks=refit_cooks, min_replicates=min_replicates,
-                                   beta_tol=beta_tol, fit_type=fit_type)
+                                   beta_tol=beta_tol, fit_type=fit_type, size_factors_fit_type=size_factors_fit_type,
+                                   control_genes=control_genes)
         self._res = None
 
     # ------------------------------------------------------------------ the pipeline
@@ -106,6 +112,16 @@ class DeseqDataSet:
         if r.mean_disp is not None:
             self.uns["mean_disp"] = r.mean_disp
         self.uns["_squared_logres"], self.uns["prior_disp_var"] = r.squared_logres, r.prior_disp_var
+        return self
+
+    def fit_size_factors(self, fit_type=None):
+        """Size factors only (dds.py:600-708): ``"ratio"`` (median of ratios) or ``"poscounts"``."""
+        if fit_type is not None:
+            if fit_type not in ("ratio", "poscounts"):
+                raise NotImplementedError("fit_type: 'ratio' or 'poscounts' ('iterative' is not built)")
+            self._pipe.size_factors_fit_type = fit_type
+        r = self._pipe.deseq2(stop_after_size_factors=True)
+        self.obs["size_factors"] = r.size_factors
         return self
 
     def vst(self, use_design: bool = False, fit_type=None):

@@ -377,6 +377,12 @@ int dsq_dev_logmeans(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, do
     return DSQ_OK;
 }
 
+int dsq_dev_logmeans_poscounts(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, double* d_logmeans,
+                               uint8_t* d_usable) {
+    DSQ_HIP(dsq::launch_logmeans_pos(ctx->stream, d_y, ldn, N, G, d_logmeans, d_usable));
+    return DSQ_OK;
+}
+
 int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                          const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
                          double* d_size_factors) {

@@ -164,6 +164,33 @@ __global__ __launch_bounds__(kBlock) void k_logmeans(const int32_t* __restrict__
     }
 }
 
+// "poscounts" log geometric means (dds.py:655-662): mean over ALL samples of log(count), zero counts
+// contributing 0; usable = finite and > 0
+__global__ __launch_bounds__(kBlock) void k_logmeans_pos(const int32_t* __restrict__ y, int ldn, int N, int G,
+                                                         double* __restrict__ logmeans,
+                                                         uint8_t* __restrict__ usable) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int32_t* yr = y + (size_t)g * ldn;
+    double s = 0.0;
+    for (int n = threadIdx.x & 63; n < N; n += 64) {
+        const int v = yr[n];
+        if (v != 0) s += log((double)v);
+    }
+    s = DeviceWave::sum(s) / (double)N;
+    if ((threadIdx.x & 63) == 0) {
+        logmeans[g] = s;
+        usable[g] = (uint8_t)((s > 0.0 && s != INFINITY) ? 1 : 0);
+    }
+}
+
+hipError_t launch_logmeans_pos(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
+                               uint8_t* usable) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_logmeans_pos, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, N, G, logmeans, usable);
+    return hipGetLastError();
+}
+
 hipError_t launch_logmeans(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
                            uint8_t* nonzero) {
     if (G <= 0) return hipSuccess;
@@ -194,7 +221,10 @@ __global__ __launch_bounds__(256) void k_ratio_keys(const SrcT* __restrict__ cou
         const double lm = logmeans[g];
         const bool use = (lm != -INFINITY) && (lm == lm) && (mask == nullptr || mask[g] != 0);
         unsigned long long k = ~0ull;
-        if (use) k = f64_key(log((double)counts[(size_t)n * G + g]) - lm);
+        // a zero count never occurs among the genes of the default mode (their logmean is -inf); in
+        // "poscounts" mode the sample's zero entries are left out of its median (dds.py:668-671)
+        const double c = (double)counts[(size_t)n * G + g];
+        if (use && c > 0.0) k = f64_key(log(c) - lm);
         keys[(size_t)n * G + g] = k;
     }
 }

@@ -181,6 +181,9 @@ class DistDeseqPipeline(DeseqPipeline):
 
     def __init__(self, counts, design_matrix, *, comm, **kw):
         super().__init__(counts, design_matrix, **kw)
+        if self.size_factors_fit_type != "ratio" or self._control_mask is not None:
+            raise NotImplementedError("the gene-sharded pipeline implements the default median-of-ratios size "
+                                      "factors only")
         self.comm = comm
         self._gathered = None
 

@@ -136,7 +136,7 @@ class DeseqPipeline:
 
     def __init__(self, counts, design_matrix, *, ctx: Context | None = None, device: int = 0, min_mu=0.5,
                  min_disp=1e-8, max_disp=10.0, refit_cooks=True, min_replicates=7, beta_tol=1e-8,
-                 fit_type="parametric", keep_cooks=True):
+                 fit_type="parametric", keep_cooks=True, size_factors_fit_type="ratio", control_genes=None):
         self.ctx = ctx if ctx is not None else Context(device)
         counts = np.asarray(counts)
         if counts.ndim != 2:
@@ -161,6 +161,15 @@ class DeseqPipeline:
         self.refit_cooks, self.min_replicates = bool(refit_cooks), int(min_replicates)
         self.beta_tol, self.fit_type = float(beta_tol), fit_type
         self.keep_cooks = keep_cooks
+        if size_factors_fit_type not in ("ratio", "poscounts"):
+            raise NotImplementedError("size_factors_fit_type: 'ratio' (median of ratios) or 'poscounts'; the "
+                                      "'iterative' mode (dds.py:1460-1548) is not built")
+        self.size_factors_fit_type = size_factors_fit_type
+        self._control_mask = None
+        if control_genes is not None:  # boolean mask or integer indices (dds.py:640-650)
+            m = np.zeros(self.G if hasattr(self, "G") else counts.shape[1], dtype=np.uint8)
+            m[np.asarray(control_genes)] = 1
+            self._control_mask = m
         self.ldn = pad16(self.N)
         self._count_type = I32 if counts.dtype == np.int32 else I64
         ctx_ = self.ctx
@@ -381,8 +390,22 @@ class DeseqPipeline:
         if self._work is None:
             self._work = DeviceArray(self.ctx, (self.N * self.G,), np.float64)
         d_sf = self._dvec(self.N)
+        d_mask = None
+        if self.size_factors_fit_type == "poscounts":  # dds.py:655-680
+            d_lm, d_use = self._dvec(self.G), self._dvec(self.G, np.uint8)
+            self.ctx.call("dsq_dev_logmeans_poscounts", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_lm.ptr),
+                          _vp(d_use.ptr))
+            d_mask = d_use
+            if self._control_mask is not None:
+                d_mask = self._up(self._down(d_use, self.G, np.uint8) & self._control_mask, np.uint8)
+        elif self._control_mask is not None:
+            d_mask = self._up(self._control_mask, np.uint8)
         self._k("size_factors", self.G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, self.N,
-                self.G, _vp(d_lm.ptr), None, _vp(self._work.ptr), _vp(d_sf.ptr))
+                self.G, _vp(d_lm.ptr), _vp(d_mask.ptr) if d_mask is not None else None, _vp(self._work.ptr),
+                _vp(d_sf.ptr))
+        if self.size_factors_fit_type == "poscounts":  # normalise to a geometric mean of 1
+            sf = self._down(d_sf, self.N)
+            d_sf = self._up(sf / np.exp(np.mean(np.log(sf))))
         return d_sf
 
     def _fit_trend(self, Gn):
@@ -418,7 +441,7 @@ class DeseqPipeline:
 
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False,
-               stop_after_trend=False) -> DeseqResult:
+               stop_after_trend=False, stop_after_size_factors=False) -> DeseqResult:
         """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald.
 
         The per-gene vectors stay in HBM from the first kernel to the Wald test; the host sees
@@ -457,6 +480,8 @@ class DeseqPipeline:
         non_zero = self._down(d_nz, G, np.uint8).astype(bool)
         r.size_factors, r.non_zero = sf, non_zero
         self.d_sf = d_sf
+        if stop_after_size_factors:
+            return r
         Gn = int(non_zero.sum())
         all_nz = Gn == G
         nzi = None if all_nz else np.nonzero(non_zero)[0]

@@ -86,3 +86,28 @@ def test_vst(use_design, fit_type, fn):
                      fit_type=fit_type or "parametric")
     np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-9)
     assert dds.layers["vst_counts"].shape == counts.shape
+
+
+def test_size_factor_modes():
+    """tests/test_pydeseq2.py:56-91: poscounts vs R, control genes, and both against the oracle."""
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    c = counts.to_numpy()
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition").fit_size_factors("poscounts")
+    r_sf = r_csv("single_factor", "r_test_size_factors_poscount.csv")["sizeFactor"].to_numpy()
+    np.testing.assert_array_almost_equal(dds.obs["size_factors"], r_sf)
+    np.testing.assert_allclose(dds.obs["size_factors"], orc.size_factors_poscounts(c), rtol=1e-12)
+    expect = c[:, 3] / np.exp(np.log(c[:, 3]).mean())
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition", control_genes=["gene4"]).fit_size_factors()
+    np.testing.assert_array_almost_equal(dds.obs["size_factors"], expect)
+    dds.fit_size_factors(fit_type="poscounts")
+    np.testing.assert_array_almost_equal(dds.obs["size_factors"], expect)
+    # zeros in the matrix: poscounts uses the positive entries only
+    z = c.copy()
+    z[::3, ::2] = 0
+    import pandas as pd
+    dds = DeseqDataSet(counts=pd.DataFrame(z, index=counts.index, columns=counts.columns), metadata=meta,
+                       design="~condition", size_factors_fit_type="poscounts").fit_size_factors()
+    np.testing.assert_allclose(dds.obs["size_factors"], orc.size_factors_poscounts(z), rtol=1e-12)

@@ -241,3 +241,16 @@ def test_r_vst(use_design, fit_type, fn):
     out, _ = orc.vst(counts.to_numpy(), X, use_design=use_design, fit_type=fit_type)
     r_vst = r_csv("single_factor", fn).T.to_numpy()
     assert np.max(np.abs(r_vst - out) / r_vst) < 0.02
+
+
+def test_r_size_factors_poscounts_and_control_genes():
+    """tests/test_pydeseq2.py:56-91."""
+    counts, X, _ = _run_r_case("synthetic", ["condition"])
+    c = counts.to_numpy()
+    r_sf = r_csv("single_factor", "r_test_size_factors_poscount.csv")["sizeFactor"].to_numpy()
+    np.testing.assert_array_almost_equal(orc.size_factors_poscounts(c), r_sf)
+    mask = np.zeros(c.shape[1], dtype=bool)
+    mask[3] = True  # "gene4"
+    expect = c[:, 3] / np.exp(np.log(c[:, 3]).mean())
+    np.testing.assert_array_almost_equal(orc.size_factors_control(c, mask), expect)
+    np.testing.assert_array_almost_equal(orc.size_factors_poscounts(c, mask), expect)

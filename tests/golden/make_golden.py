@@ -237,6 +237,8 @@ def main():
                        "test_metadata.csv"],
         "wide": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
                  "test_counts.csv", "test_metadata.csv"],
+        "large_counts": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
+                         "r_test_lfc_shrink_res.csv"],
     }.items():
         dst = os.path.join(HERE, f"r_{sub}")
         os.makedirs(dst, exist_ok=True)

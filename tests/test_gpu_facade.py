@@ -111,3 +111,43 @@ def test_size_factor_modes():
     dds = DeseqDataSet(counts=pd.DataFrame(z, index=counts.index, columns=counts.columns), metadata=meta,
                        design="~condition", size_factors_fit_type="poscounts").fit_size_factors()
     np.testing.assert_allclose(dds.obs["size_factors"], orc.size_factors_poscounts(z), rtol=1e-12)
+
+
+def _shrink_from_r(dds, sub, coeff, contrast):
+    """The reference's shrinkage tests start from R's size factors, dispersions, LFC column 1 and SE."""
+    from pydeseq2_amd.api import DeseqStats
+
+    r_res = r_csv(sub, "r_test_res.csv")
+    dds.obs["size_factors"] = r_csv(sub, "r_test_size_factors.csv").squeeze().to_numpy()
+    dds.var["dispersions"] = r_csv(sub, "r_test_dispersions.csv").squeeze().to_numpy()
+    dds.varm["LFC"].iloc[:, 1] = r_res["log2FoldChange"].to_numpy() * np.log(2)
+    ds = DeseqStats(dds, contrast=contrast)
+    ds.summary()
+    ds.SE = r_res["lfcSE"] * np.log(2)
+    shr = ds.lfc_shrink(coeff=coeff)
+    r_shr = r_csv(sub, "r_test_lfc_shrink_res.csv")
+    return ((r_shr["log2FoldChange"] - shr["log2FoldChange"]).abs() / r_shr["log2FoldChange"].abs()).max()
+
+
+def test_lfc_shrink_multi_factor_continuous_and_large_counts():
+    """tests/test_pydeseq2.py:367-430, 470-509, 566-622."""
+    import pandas as pd
+
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~group + condition").deseq2()
+    assert _shrink_from_r(dds, "multi_factor", "condition[T.B]", ["condition", "B", "A"]) < 0.02
+    counts, meta = load_dataset("continuous")
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~group + condition + measurement").deseq2()
+    cv = np.zeros(dds.obsm["design_matrix"].shape[1])
+    cv[-1] = 1
+    assert _shrink_from_r(dds, "continuous", "measurement", cv) < 0.02
+    counts = pd.DataFrame(
+        [[25, 405, 1355, 12558, 489843], [28, 480, 2144, 13844, 514571], [12, 690, 1919, 15632, 564106],
+         [31, 420, 1684, 11513, 556380], [34, 278, 3849, 11577, 412551], [19, 249, 3086, 7296, 295565],
+         [17, 491, 4089, 13805, 280945], [15, 251, 2785, 10492, 214062]],
+        index=["A1", "A2", "A3", "A4", "B1", "B2", "B3", "B4"], columns=["g1", "g2", "g3", "g4", "g5"])
+    meta = pd.DataFrame({"condition": list("AAAABBBB")}, index=counts.index)
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition").deseq2()
+    assert _shrink_from_r(dds, "large_counts", "condition[T.B]", ["condition", "B", "A"]) < 0.02

@@ -234,6 +234,18 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,
                              double* d_dst);
+/* "iterative" size factors (dds.py:1460-1548).  The Powell search over the log size factors
+ * is host code (scipy, as in the reference); the device supplies its objective: per-gene NLL of the counts
+ * under mu_hat * scale_n (dsq_dev_nll_scaled; the alpha-only part once per outer iteration,
+ * dsq_dev_nll_const), and the reference's start values for the dispersion fit, i.e. the method-of-moments
+ * estimate on the RAW counts (d_ones = normalising size factors of 1) with mean(1/size factor) of the
+ * current size factors (dsq_dev_mom_raw). */
+int dsq_dev_mom_raw(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_ones, const double* d_sf,
+                    const double* d_Xt, const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp,
+                    double max_disp, double* d_normed_mean, double* d_mom);
+int dsq_dev_nll_const(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, const double* d_disp, double* d_cst);
+int dsq_dev_nll_scaled(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, int N, int G,
+                       const double* d_disp, const double* d_scale, const double* d_cst, double* d_nll);
 /* "poscounts" size factors (dds.py:655-680): log geometric means over the positive counts
  * (zeros contribute 0 to the mean over all samples) and the usable-gene mask (finite, > 0); feed both to
  * dsq_dev_size_factors (which leaves a sample's zero counts out of its median) and divide the result by its

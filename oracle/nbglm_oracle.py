@@ -66,6 +66,57 @@ def size_factors_ratio(counts: np.ndarray):
     return sf, counts / sf[:, None], lm, keep
 
 
+def nb_nll_genes(counts, mu, alpha):
+    """Per-gene NLL, array-alpha branch of utils.nb_nll (utils.py:216-226): counts, mu N x G, alpha [G]."""
+    a1 = 1 / alpha
+    logbinom = gammaln(counts + a1) - gammaln(counts + 1) - gammaln(a1)
+    return (a1 * np.log(alpha) - logbinom + (counts + a1) * np.log(mu + a1) - counts * np.log(mu)).sum(0)
+
+
+def size_factors_iterative(counts, niter=10, quant=0.95, min_mu=0.5, min_disp=1e-8, max_disp=10.0, beta_tol=1e-8,
+                           n_jobs=1):
+    """``DeseqDataSet._fit_iterate_size_factors`` (dds.py:1460-1548): alternate dispersion fits with an
+    intercept-only design (mean trend) and a Powell search over the log size factors on the NLL summed
+    over the genes below its 0.95 quantile.  As in the reference, the method-of-moments start values are
+    computed on the RAW counts throughout (``layers["normed_counts"]`` is only refreshed at the end)."""
+    counts = np.asarray(counts)
+    N, G = counts.shape
+    max_disp = max(max_disp, N)
+    X1 = np.ones((N, 1))
+    sf = np.ones(N)
+    nz = ~(counts == 0).all(axis=0)
+    nzi = np.nonzero(nz)[0]
+    c_nz = counts[:, nzi]
+    for i in range(niter):
+        _, mu_hat, gw, _ = _fit_genewise(c_nz, c_nz.astype(float), sf, X1, min_mu, min_disp, max_disp, beta_tol, n_jobs)
+        use = gw > 10 * min_disp
+        if not use.any():
+            break
+        mean_disp = trim_mean(gw[use], proportiontocut=0.001)
+        fitted = np.full(len(nzi), mean_disp)
+        sq, prior_var = dispersion_prior(gw, fitted, N, 1, min_disp)
+        mp, _ = alpha_mle(c_nz, X1, mu_hat, fitted, min_disp, max_disp, prior_disp_var=float(prior_var), cr_reg=True,
+                          prior_reg=True, n_jobs=n_jobs)
+        disp = np.clip(mp, min_disp, max_disp)
+        out = np.log(gw) > np.log(fitted) + 2 * np.sqrt(sq)
+        disp[out] = gw[out]
+        old_sf = sf.copy()
+        base = mu_hat / old_sf[:, None]
+
+        def objective(p):
+            s = np.exp(p - np.mean(p))
+            nll = nb_nll_genes(c_nz, base * s[:, None], disp)
+            return np.sum(nll[nll < np.quantile(nll, quant)])
+
+        res = minimize(objective, np.log(old_sf), method="Powell")
+        sf = np.exp(res.x - np.mean(res.x))
+        if not res.success:
+            break
+        if (i > 1) and np.sum((np.log(old_sf) - np.log(sf)) ** 2) < 1e-4:
+            break
+    return sf
+
+
 def size_factors_control(counts, control_mask):
     """Median-of-ratios size factors restricted to control genes (dds.py:640-650, 692-703)."""
     lm, keep = logmeans_and_filter(counts)
@@ -677,8 +728,15 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
     T = r.timings
     t0 = time.perf_counter()
 
-    # -- size factors (dds.py:692-708)
-    sf, normed, _, _ = size_factors_ratio(counts)
+    # -- size factors (dds.py:692-708); iterative mode when every gene contains a zero (dds.py:682-690)
+    if (counts == 0).any(0).all():
+        warnings.warn("Every gene contains at least one zero, cannot compute log geometric means. "
+                      "Switching to iterative mode.", UserWarning, stacklevel=2)
+        sf = size_factors_iterative(counts, min_mu=min_mu, min_disp=min_disp, max_disp=max_disp, beta_tol=beta_tol,
+                                    n_jobs=n_jobs)
+        normed = counts / sf[:, None]
+    else:
+        sf, normed, _, _ = size_factors_ratio(counts)
     r.size_factors = sf
     r.normed_means = normed.mean(0)
     T["size_factors"] = time.perf_counter() - t0

@@ -117,8 +117,8 @@ class DeseqDataSet:
     def fit_size_factors(self, fit_type=None):
         """Size factors only (dds.py:600-708): ``"ratio"`` (median of ratios) or ``"poscounts"``."""
         if fit_type is not None:
-            if fit_type not in ("ratio", "poscounts"):
-                raise NotImplementedError("fit_type: 'ratio' or 'poscounts' ('iterative' is not built)")
+            if fit_type not in ("ratio", "poscounts", "iterative"):
+                raise ValueError("fit_type: 'ratio', 'poscounts' or 'iterative'")
             self._pipe.size_factors_fit_type = fit_type
         r = self._pipe.deseq2(stop_after_size_factors=True)
         self.obs["size_factors"] = r.size_factors

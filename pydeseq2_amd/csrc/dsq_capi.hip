@@ -402,6 +402,28 @@ int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, c
     return DSQ_OK;
 }
 
+int dsq_dev_mom_raw(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_ones, const double* d_sf,
+                    const double* d_Xt, const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp,
+                    double max_disp, double* d_normed_mean, double* d_mom) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(N != P, "The number of samples and the number of design variables are equal, i.e., "
+                          "there are no replicates to estimate the dispersion.");
+    DSQ_HIP(dsq::launch_mom(ctx->stream, d_y, ldn, d_ones, d_Xt, d_pinvXt, ldx, N, G, P, min_disp, max_disp,
+                            d_normed_mean, nullptr, nullptr, d_mom, ctx->d_scratch + 8, d_sf));
+    return DSQ_OK;
+}
+
+int dsq_dev_nll_const(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, const double* d_disp, double* d_cst) {
+    DSQ_HIP(dsq::launch_nll_const(ctx->stream, d_y, ldn, N, G, d_disp, d_cst));
+    return DSQ_OK;
+}
+
+int dsq_dev_nll_scaled(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, int N, int G,
+                       const double* d_disp, const double* d_scale, const double* d_cst, double* d_nll) {
+    DSQ_HIP(dsq::launch_nll_scaled(ctx->stream, d_y, d_mu, ldn, N, G, d_disp, d_scale, d_cst, d_nll));
+    return DSQ_OK;
+}
+
 int dsq_dev_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                    const double* d_pinvXt, int ldx, int N, int G, int P, double min_mu, double* d_mu) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");

@@ -434,9 +434,11 @@ __global__ __launch_bounds__(kBlock) void k_mom(const int32_t* __restrict__ y, i
 hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
                       const double* pinvXt, int ldx, int N, int G, int P_, double min_disp,
                       double max_disp, double* normed_mean, double* rough, double* moments,
-                      double* mom, double* d_scalar) {
+                      double* mom, double* d_scalar, const double* sf_moments) {
     if (G <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf, N, d_scalar);
+    // sf_moments: the size factors whose mean reciprocal enters the moments estimate when they differ
+    // from the ones the counts are normalised with (iterative size factors, dds.py:1149-1156 there)
+    hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf_moments ? sf_moments : sf, N, d_scalar);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
                                           (const double*)d_scalar, min_disp, max_disp, normed_mean, rough,
@@ -770,6 +772,55 @@ __global__ void k_vst(const T* __restrict__ counts, int N, int G, const double* 
     if (mode == 0) v = log2((1.0 + a1 + 2.0 * a0 * x + 2.0 * sqrt(a0 * x * (1.0 + a1 + a0 * x))) / (4.0 * a0));
     else v = (2.0 * asinh(sqrt(a0 * x)) - log(a0) - log(4.0)) / log(2.0);
     out[i] = v;
+}
+
+// ---- iterative size factors (dds.py:1460-1548): per-gene NLL under rescaled size factors
+// cst[g] = N a log(alpha) - sum_n [ lgamma(y+a) - lgamma(y+1) - lgamma(a) ]   (alpha-only part, utils.py:216-226)
+__global__ __launch_bounds__(kBlock) void k_nll_const(const int32_t* __restrict__ y, int ldn, int N, int G,
+                                                      const double* __restrict__ disp, double* __restrict__ cst) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const double alpha = disp[g], a = 1.0 / alpha;
+    const int32_t* yr = y + (size_t)g * ldn;
+    double s = 0.0;
+    for (int n = threadIdx.x & 63; n < N; n += 64) {
+        const double yv = (double)yr[n];
+        s += lgamma_pos(yv + a) - lgamma_pos(yv + 1.0);
+    }
+    s = DeviceWave::sum(s);
+    if ((threadIdx.x & 63) == 0) cst[g] = (double)N * a * log(alpha) - (s - (double)N * lgamma_pos(a));
+}
+
+// nll[g] = cst[g] + sum_n (y + a) log(mu scale_n + a) - y log(mu scale_n)
+__global__ __launch_bounds__(kBlock) void k_nll_scaled(const int32_t* __restrict__ y, const double* __restrict__ mu,
+                                                       int ldn, int N, int G, const double* __restrict__ disp,
+                                                       const double* __restrict__ scale,
+                                                       const double* __restrict__ cst, double* __restrict__ nll) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const double a = 1.0 / disp[g];
+    const int32_t* yr = y + (size_t)g * ldn;
+    const double* mr = mu + (size_t)g * ldn;
+    double s = 0.0;
+    for (int n = threadIdx.x & 63; n < N; n += 64) {
+        const double yv = (double)yr[n], m = mr[n] * scale[n];
+        s += (yv + a) * log(m + a) - yv * log(m);
+    }
+    s = DeviceWave::sum(s);
+    if ((threadIdx.x & 63) == 0) nll[g] = cst[g] + s;
+}
+
+hipError_t launch_nll_const(hipStream_t st, const int32_t* y, int ldn, int N, int G, const double* disp, double* cst) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nll_const, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, N, G, disp, cst);
+    return hipGetLastError();
+}
+hipError_t launch_nll_scaled(hipStream_t st, const int32_t* y, const double* mu, int ldn, int N, int G,
+                             const double* disp, const double* scale, const double* cst, double* nll) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nll_scaled, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, mu, ldn, N, G, disp, scale, cst,
+                       nll);
+    return hipGetLastError();
 }
 
 hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int N, int G, const double* sf, int mode,

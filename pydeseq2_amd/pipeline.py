@@ -161,9 +161,8 @@ class DeseqPipeline:
         self.refit_cooks, self.min_replicates = bool(refit_cooks), int(min_replicates)
         self.beta_tol, self.fit_type = float(beta_tol), fit_type
         self.keep_cooks = keep_cooks
-        if size_factors_fit_type not in ("ratio", "poscounts"):
-            raise NotImplementedError("size_factors_fit_type: 'ratio' (median of ratios) or 'poscounts'; the "
-                                      "'iterative' mode (dds.py:1460-1548) is not built")
+        if size_factors_fit_type not in ("ratio", "poscounts", "iterative"):
+            raise ValueError("size_factors_fit_type: 'ratio' (median of ratios), 'poscounts' or 'iterative'")
         self.size_factors_fit_type = size_factors_fit_type
         self._control_mask = None
         if control_genes is not None:  # boolean mask or integer indices (dds.py:640-650)
@@ -241,6 +240,10 @@ class DeseqPipeline:
         if arr.size:
             self.ctx.h2d(d.ptr, arr)
         return d
+
+    def _down_nonzero(self):
+        """Mask of genes with at least one count (cached by deseq2() before the iterative size factors)."""
+        return self._nz_cache
 
     def _down(self, darr, n, dtype=np.float64):
         out = np.empty(int(n), dtype=dtype)
@@ -441,7 +444,7 @@ class DeseqPipeline:
 
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False,
-               stop_after_trend=False, stop_after_size_factors=False) -> DeseqResult:
+               stop_after_trend=False, stop_after_size_factors=False, size_factors=None) -> DeseqResult:
         """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald.
 
         The per-gene vectors stay in HBM from the first kernel to the Wald test; the host sees
@@ -471,12 +474,30 @@ class DeseqPipeline:
         # ---- size factors (dds.py:692-708)
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
         self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
-        d_sf = self._size_factors(d_lm)
-        sf = self._down(d_sf, N)
-        if np.isnan(sf).any():
-            raise NotImplementedError(
-                "Every gene contains at least one zero: the reference switches to iterative size "
-                "factors (dds.py:682-690), which is outside the hot path built here.")
+        if size_factors is None and self.size_factors_fit_type != "iterative":
+            d_sf = self._size_factors(d_lm)
+            sf = self._down(d_sf, N)
+            if np.isnan(sf).any():  # dds.py:682-690
+                warnings.warn("Every gene contains at least one zero, cannot compute log geometric means. "
+                              "Switching to iterative mode.", UserWarning, stacklevel=2)
+                size_factors = "iterative"
+        if size_factors is None and self.size_factors_fit_type == "iterative":
+            size_factors = "iterative"
+        if size_factors is not None:
+            if isinstance(size_factors, str):
+                from .sizefactors import iterative_size_factors
+
+                if type(self) is not DeseqPipeline:
+                    raise NotImplementedError("iterative size factors are not built for the gene-sharded pipeline")
+
+                self._nz_cache = self._down(d_nz, G, np.uint8).astype(bool)
+                size_factors = iterative_size_factors(self)
+                self._pool_reset()
+                d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
+                self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr),
+                        _vp(d_nz.ptr))
+            sf = np.ascontiguousarray(size_factors, dtype=np.float64)
+            d_sf = self._up(sf)
         non_zero = self._down(d_nz, G, np.uint8).astype(bool)
         r.size_factors, r.non_zero = sf, non_zero
         self.d_sf = d_sf

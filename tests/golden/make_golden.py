@@ -229,7 +229,7 @@ def main():
                           "r_test_res_greaterAbs.csv", "r_test_res_lessAbs.csv",
                           "r_test_lfc_shrink_res.csv", "r_test_lfc_shrink_no_apeAdapt_res.csv",
                           "r_vst.csv", "r_vst_with_design.csv", "r_mean_vst.csv",
-                          "r_test_size_factors_poscount.csv"],
+                          "r_test_size_factors_poscount.csv", "r_iterative_size_factors.csv"],
         "multi_factor": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",
                          "r_test_res_outliers.csv", "r_test_lfc_shrink_res.csv"],
         "continuous": ["r_test_size_factors.csv", "r_test_dispersions.csv", "r_test_res.csv",

@@ -151,3 +151,31 @@ def test_lfc_shrink_multi_factor_continuous_and_large_counts():
     meta = pd.DataFrame({"condition": list("AAAABBBB")}, index=counts.index)
     dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition").deseq2()
     assert _shrink_from_r(dds, "large_counts", "condition[T.B]", ["condition", "B", "A"]) < 0.02
+
+
+def test_iterative_size_factors():
+    """tests/test_pydeseq2.py:344-364 + the automatic switch when every gene contains a zero (dds.py:682-690)."""
+    import warnings
+
+    import pydeseq2_amd
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition").fit_size_factors("iterative")
+    r = r_csv("single_factor", "r_iterative_size_factors.csv").squeeze().to_numpy()
+    assert np.max(np.abs(r - dds.obs["size_factors"]) / np.abs(r)) < 0.02
+    ref = orc.size_factors_iterative(counts.to_numpy())
+    np.testing.assert_allclose(dds.obs["size_factors"], ref, rtol=1e-4)
+    # every gene with a zero -> deseq2() switches by itself
+    c, X = orc.synth_counts(60, 24, "2level", 21)
+    c[np.arange(60) % 24, np.arange(60)] = 0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = pydeseq2_amd.deseq2(c, X, device=0)
+        ref = orc.deseq2(c, X, n_jobs=2)
+    assert any("iterative" in str(x.message) for x in w)
+    np.testing.assert_allclose(res.size_factors, ref.size_factors, rtol=1e-4)
+    ok = ~np.isnan(ref.dispersions)
+    np.testing.assert_allclose(res.dispersions[ok], ref.dispersions[ok], rtol=5e-3)
+    np.testing.assert_allclose(res.LFC[ok], ref.LFC[ok], rtol=5e-3, atol=1e-4)

@@ -254,3 +254,11 @@ def test_r_size_factors_poscounts_and_control_genes():
     expect = c[:, 3] / np.exp(np.log(c[:, 3]).mean())
     np.testing.assert_array_almost_equal(orc.size_factors_control(c, mask), expect)
     np.testing.assert_array_almost_equal(orc.size_factors_poscounts(c, mask), expect)
+
+
+def test_r_iterative_size_factors():
+    """tests/test_pydeseq2.py:344-364."""
+    counts, X, _ = _run_r_case("synthetic", ["condition"])
+    sf = orc.size_factors_iterative(counts.to_numpy())
+    r = r_csv("single_factor", "r_iterative_size_factors.csv").squeeze().to_numpy()
+    assert np.max(np.abs(r - sf) / np.abs(r)) < 0.02

@@ -649,6 +649,8 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
     return DSQ_OK;
 }
 
+size_t dsq_prior_mad_work_doubles(int n) { return dsq::prior_mad_work_doubles(n); }
+
 int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitted, int n, double min_disp,
                       double max_disp, double* d_work, double* h_squared_logres) {
     double* d_out = ctx->d_scratch + 1600;

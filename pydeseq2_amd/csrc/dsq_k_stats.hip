@@ -370,10 +370,134 @@ __global__ __launch_bounds__(1024) void k_prior_mad(const double* __restrict__ g
     }
 }
 
+// ---- the same two medians for LARGE gene sets (the gathered vectors of the multi-GPU layout: world x G
+// genes): one workgroup reading hundreds of thousands of keys 12 times is bandwidth-starved, so the
+// radix passes become wide kernels (LDS-privatised histograms flushed to a global one) alternating with
+// a 2-wave pick kernel; state lives in global memory.  Same digits, same tie handling as block_median.
+struct MedGlobal {
+    unsigned int hist[2][2048];
+    unsigned long long prefix[2];
+    unsigned int rank[2];
+    unsigned int M;
+    unsigned int pad;
+    double result;
+};
+
+__global__ void k_prior_res(const double* __restrict__ gw_raw, const double* __restrict__ fitted, int n,
+                            double min_disp, double max_disp, double* __restrict__ res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double g = dmin(dmax(gw_raw[i], min_disp), max_disp);
+    res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
+}
+
+__global__ void k_med_zero(MedGlobal* S) {
+    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&S->hist[0][0])[i] = 0;
+    if (threadIdx.x == 0) { S->prefix[0] = 0; S->prefix[1] = 0; S->rank[0] = 0; S->rank[1] = 0; S->M = 0; }
+}
+
+// ABS: keys of |res - center| (center = result of the previous median), else keys of res; NaN skipped
+template <bool ABS>
+__global__ __launch_bounds__(1024) void k_med_hist(const double* __restrict__ res, int n,
+                                                   const MedGlobal* __restrict__ prev, int pass, MedGlobal* S) {
+    __shared__ unsigned int h[2][2048];
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    const int shift = shifts[pass];
+    const int nbins = pass == 5 ? 512 : 2048;
+    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long p0 = S->prefix[0], p1 = S->prefix[1];
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
+    const double center = ABS ? prev->result : 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double r = res[i];
+        if (r != r) continue;
+        const unsigned long long k = f64_key(ABS ? fabs(r - center) : r);
+        const unsigned int d = (unsigned int)(k >> shift) & (unsigned int)(nbins - 1);
+        if (pass == 0) {
+            atomicAdd(&h[0][d], 1u);
+        } else {
+            if ((k & himask) == p0) atomicAdd(&h[0][d], 1u);
+            if ((k & himask) == p1) atomicAdd(&h[1][d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) {
+        const unsigned int c = (&h[0][0])[i];
+        if (c) atomicAdd(&(&S->hist[0][0])[i], c);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_med_pick(MedGlobal* S, int pass) {
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    const int shift = shifts[pass];
+    const int nbins = pass == 5 ? 512 : 2048;
+    const int tid = threadIdx.x;
+    if (pass == 0) {
+        if (tid < 64) {
+            unsigned int c = 0;
+            for (int k = tid; k < 2048; k += 64) c += S->hist[0][k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (tid == 0) { S->M = c; S->rank[0] = c ? (c - 1) / 2 : 0; S->rank[1] = c / 2; }
+        }
+        __syncthreads();
+    }
+    const int w = tid >> 6;
+    unsigned int r = S->rank[w];
+    const int d = pick_digit(S->hist[pass == 0 ? 0 : w], nbins, r);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        S->rank[w] = r;
+        S->prefix[w] |= ((unsigned long long)d << shift);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * 2048; i += blockDim.x) (&S->hist[0][0])[i] = 0;  // ready for the next pass
+    if (pass == 5 && tid == 0) {
+        const unsigned int M = S->M;
+        const double v0 = key_f64(S->prefix[0]), v1 = key_f64(S->prefix[1]);
+        S->result = (M == 0) ? NAN : (((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0);
+    }
+}
+
+__global__ void k_prior_finish(const MedGlobal* S1, const MedGlobal* S2, double* out) {
+    const double m = S2->result / 0.67448975019608171;  // norm.ppf(0.75)
+    out[0] = m * m;
+    out[1] = (double)S1->M;
+}
+
+constexpr int kPriorWideMin = 32768;  // below this one workgroup is faster (launch latency)
+
+// res_scratch: n doubles (+ 2 * sizeof(MedGlobal) bytes when n >= kPriorWideMin: see prior_mad_work_doubles)
+size_t prior_mad_work_doubles(int n) {
+    return (size_t)n + (n >= kPriorWideMin ? (2 * sizeof(MedGlobal) + 7) / 8 + 8 : 0);
+}
+
 hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
                             double max_disp, double* res_scratch, double* out2) {
-    hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, gw_raw, fitted, n, min_disp, max_disp,
-                       res_scratch, out2);
+    if (n < kPriorWideMin) {
+        hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, gw_raw, fitted, n, min_disp, max_disp,
+                           res_scratch, out2);
+        return hipGetLastError();
+    }
+    MedGlobal* S1 = (MedGlobal*)(res_scratch + (((size_t)n + 7) & ~(size_t)7));
+    MedGlobal* S2 = S1 + 1;
+    const int blocks = (n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_prior_res, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, fitted, n, min_disp, max_disp,
+                       res_scratch);
+    hipLaunchKernelGGL(k_med_zero, dim3(1), dim3(1024), 0, st, S1);
+    hipLaunchKernelGGL(k_med_zero, dim3(1), dim3(1024), 0, st, S2);
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(k_med_hist<false>, dim3(blocks), dim3(1024), 0, st, (const double*)res_scratch, n,
+                           (const MedGlobal*)S1, pass, S1);
+        hipLaunchKernelGGL(k_med_pick, dim3(1), dim3(128), 0, st, S1, pass);
+    }
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(k_med_hist<true>, dim3(blocks), dim3(1024), 0, st, (const double*)res_scratch, n,
+                           (const MedGlobal*)S1, pass, S2);
+        hipLaunchKernelGGL(k_med_pick, dim3(1), dim3(128), 0, st, S2, pass);
+    }
+    hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(1), 0, st, (const MedGlobal*)S1, (const MedGlobal*)S2, out2);
     return hipGetLastError();
 }
 

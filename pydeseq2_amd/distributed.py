@@ -239,7 +239,7 @@ class DistDeseqPipeline(DeseqPipeline):
         self.ctx.call("dsq_dev_trend_eval", _vp(d_nm_all.ptr), n_all, C.c_double(a0), C.c_double(a1),
                       _vp(d_fit_all.ptr))
         sq = C.c_double()
-        d_work = self._pooled((n_all,), np.float64)
+        d_work = self._pooled((self.ctx.lib.dsq_prior_mad_work_doubles(int(n_all)),), np.float64)
         self._k("prior_mad", n_all, "dsq_dev_prior_mad", _vp(d_gw_all.ptr), _vp(d_fit_all.ptr), n_all,
                 C.c_double(self.min_disp), C.c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
         self._gathered = None

@@ -436,7 +436,7 @@ class DeseqPipeline:
 
         d_gw, _ = self._last_gw_dev
         sq = C.c_double()
-        d_work = self._dvec(Gn)
+        d_work = self._dvec(self.ctx.lib.dsq_prior_mad_work_doubles(int(Gn)))
         self._k("prior_mad", Gn, "dsq_dev_prior_mad", _vp(d_gw.ptr), _vp(d_fit.ptr), Gn,
                 c_double(self.min_disp), c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
         sq = float(sq.value)

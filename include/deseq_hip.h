@@ -176,7 +176,9 @@ int dsq_dev_logmeans(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, do
                      uint8_t* d_nonzero);
 /* preprocessing.deseq2_norm_transform (preprocessing.py:59-102): per-sample median over the
  * genes with finite logmeans (and d_gene_mask[g] != 0 if given) of log(count) - logmeans.
- * d_counts_sm: sample-major counts [N][G] of `count_type`; d_work: N*G doubles scratch. */
+ * d_counts_sm: sample-major counts [N][G] of `count_type`; d_work: dsq_size_factors_work_doubles(N, G)
+ * doubles of scratch (order-preserving keys of the usable genes only + their index list). */
+size_t dsq_size_factors_work_doubles(int N, int G);
 int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                          const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
                          double* d_size_factors);

@@ -383,6 +383,8 @@ int dsq_dev_logmeans_poscounts(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N,
     return DSQ_OK;
 }
 
+size_t dsq_size_factors_work_doubles(int N, int G) { return dsq::size_factors_work_doubles(N, G); }
+
 int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                          const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
                          double* d_size_factors) {

@@ -501,21 +501,86 @@ hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* 
     return hipGetLastError();
 }
 
+// ---- compacted variant: only the usable genes (finite logmean, mask) get keys.  With ~1000 samples
+// most genes contain a zero somewhere (75 % in the benchmark data), so the key matrix and the six radix
+// passes over it shrink accordingly.  idx[j] = j-th usable gene, *count = their number.
+__global__ __launch_bounds__(1024) void k_sf_compact(const double* __restrict__ logmeans,
+                                                     const uint8_t* __restrict__ mask, int G,
+                                                     int* __restrict__ idx, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    if (threadIdx.x == 0) base_sh = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int g0 = 0; g0 < G; g0 += 1024) {
+        const int g = g0 + threadIdx.x;
+        bool use = false;
+        if (g < G) {
+            const double lm = logmeans[g];
+            use = (lm != -INFINITY) && (lm == lm) && (mask == nullptr || mask[g] != 0);
+        }
+        const unsigned long long b = __ballot(use);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int off = base_sh;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        if (use) idx[off + before] = g;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int q = 0; q < 16; ++q) t += wsum[q];
+            base_sh += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base_sh;
+}
+
+template <class SrcT>
+__global__ __launch_bounds__(256) void k_ratio_keys_c(const SrcT* __restrict__ counts, int N, int G,
+                                                      const double* __restrict__ logmeans,
+                                                      const int* __restrict__ idx, const int* __restrict__ count,
+                                                      unsigned long long* __restrict__ keys) {
+    const int n = blockIdx.y, Gu = *count;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Gu; j += gridDim.x * 256) {
+        const int g = idx[j];
+        const double c = (double)counts[(size_t)n * G + g];
+        keys[(size_t)n * Gu + j] = (c > 0.0) ? f64_key(log(c) - logmeans[g]) : ~0ull;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_row_median_c(const unsigned long long* __restrict__ keys, int N,
+                                                       const int* __restrict__ count, double* __restrict__ sf) {
+    __shared__ MedianShared S;
+    const int n = blockIdx.x, Gu = *count;
+    const unsigned long long* row = keys + (size_t)n * Gu;
+    double med;
+    unsigned int M;
+    block_median([&](int g) { return row[g]; }, Gu, S, med, M);
+    if (threadIdx.x == 0) sf[n] = (M == 0) ? NAN : exp(med);
+}
+
+// work: N*G u64 keys (worst case) followed by G + 2 ints (dsq_size_factors_work_doubles)
+size_t size_factors_work_doubles(int N, int G) { return (size_t)N * G + (size_t)G / 2 + 8; }
+
 hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
                                const double* logmeans, const uint8_t* gene_mask, double* work,
                                double* sf) {
     if (N <= 0 || G <= 0) return hipSuccess;
+    unsigned long long* keys = (unsigned long long*)work;
+    int* idx = (int*)(work + (size_t)N * G);
+    int* count = idx + G;
+    hipLaunchKernelGGL(k_sf_compact, dim3(1), dim3(1024), 0, st, logmeans, gene_mask, G, idx, count);
     const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
     if (count_type == 1)
-        hipLaunchKernelGGL((k_ratio_keys<int64_t>), dim3(gx, N), dim3(256), 0, st,
-                           (const int64_t*)counts_sm, N, G, logmeans, gene_mask,
-                           (unsigned long long*)work);
+        hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
+                           logmeans, (const int*)idx, (const int*)count, keys);
     else
-        hipLaunchKernelGGL((k_ratio_keys<int32_t>), dim3(gx, N), dim3(256), 0, st,
-                           (const int32_t*)counts_sm, N, G, logmeans, gene_mask,
-                           (unsigned long long*)work);
-    hipLaunchKernelGGL(k_row_median, dim3(N), dim3(1024), 0, st, (const unsigned long long*)work, N, G,
-                       sf);
+        hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
+                           logmeans, (const int*)idx, (const int*)count, keys);
+    hipLaunchKernelGGL(k_row_median_c, dim3(N), dim3(1024), 0, st, (const unsigned long long*)keys, N,
+                       (const int*)count, sf);
     return hipGetLastError();
 }
 

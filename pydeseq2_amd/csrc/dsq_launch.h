@@ -88,6 +88,7 @@ hipError_t launch_padj_finish(hipStream_t st, const unsigned long long* sorted_p
 hipError_t launch_logmeans_pos(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
                                uint8_t* usable);
 size_t prior_mad_work_doubles(int n);
+size_t size_factors_work_doubles(int N, int G);
 hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int N, int G, const double* sf, int mode,
                       double a0, double a1, double* out);
 hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted);

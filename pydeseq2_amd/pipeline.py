@@ -391,7 +391,8 @@ class DeseqPipeline:
     def _size_factors(self, d_lm):
         """Median-of-ratios size factors on the device (preprocessing.py:59-102) -> device array [N]."""
         if self._work is None:
-            self._work = DeviceArray(self.ctx, (self.N * self.G,), np.float64)
+            self._work = DeviceArray(self.ctx, (self.ctx.lib.dsq_size_factors_work_doubles(self.N, self.G),),
+                                     np.float64)
         d_sf = self._dvec(self.N)
         d_mask = None
         if self.size_factors_fit_type == "poscounts":  # dds.py:655-680

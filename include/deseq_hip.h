@@ -313,6 +313,11 @@ int dsq_comm_allgather(dsq_ctx* ctx, const void* d_send, void* d_recv, size_t by
  * d_hist: 2*N*256 u32. */
 int dsq_dev_sf_keys(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                     const double* d_logmeans, const uint8_t* d_gene_mask, void* d_keys);
+/* same, but only for the usable genes (finite logmean, mask): keys [N][*h_n_usable]; the following passes
+ * then take G = *h_n_usable.  d_idx_work: G + 2 ints. */
+int dsq_dev_sf_keys_compact(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                            const double* d_logmeans, const uint8_t* d_gene_mask, int32_t* d_idx_work, void* d_keys,
+                            int* h_n_usable);
 int dsq_dev_sf_count(dsq_ctx* ctx, const void* d_keys, int N, int G, uint32_t* d_counts);
 int dsq_dev_sf_init(dsq_ctx* ctx, const uint32_t* d_total, int N, void* d_prefix, uint32_t* d_rank);
 int dsq_dev_sf_hist(dsq_ctx* ctx, const void* d_keys, int N, int G, const void* d_prefix, int shift,

@@ -949,6 +949,18 @@ int dsq_dev_sf_keys(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N
                                 (unsigned long long*)d_keys));
     return DSQ_OK;
 }
+int dsq_dev_sf_keys_compact(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                            const double* d_logmeans, const uint8_t* d_gene_mask, int32_t* d_idx_work, void* d_keys,
+                            int* h_n_usable) {
+    DSQ_HIP(dsq::launch_sf_compact(ctx->stream, d_logmeans, d_gene_mask, G, d_idx_work));
+    int gu = 0;
+    DSQ_HIP(hipMemcpyAsync(&gu, d_idx_work + G, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(dsq::launch_sf_keys_compact(ctx->stream, d_counts_sm, count_type, N, G, d_logmeans, d_idx_work,
+                                        (unsigned long long*)d_keys));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    *h_n_usable = gu;
+    return DSQ_OK;
+}
 int dsq_dev_sf_count(dsq_ctx* ctx, const void* d_keys, int N, int G, uint32_t* d_counts) {
     DSQ_HIP(dsq::launch_sf_count(ctx->stream, (const unsigned long long*)d_keys, N, G, d_counts));
     return DSQ_OK;

@@ -1458,6 +1458,22 @@ hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type,
                            G, logmeans, gene_mask, keys);
     return hipGetLastError();
 }
+// compacted keys for the distributed protocol: idx_work = G + 2 ints; keys [N][*count]
+hipError_t launch_sf_compact(hipStream_t st, const double* logmeans, const uint8_t* gene_mask, int G, int* idx_work) {
+    hipLaunchKernelGGL(k_sf_compact, dim3(1), dim3(1024), 0, st, logmeans, gene_mask, G, idx_work, idx_work + G);
+    return hipGetLastError();
+}
+hipError_t launch_sf_keys_compact(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                                  const double* logmeans, const int* idx_work, unsigned long long* keys) {
+    const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
+    if (count_type == 1)
+        hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
+                           logmeans, idx_work, idx_work + G, keys);
+    else
+        hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
+                           logmeans, idx_work, idx_work + G, keys);
+    return hipGetLastError();
+}
 hipError_t launch_sf_count(hipStream_t st, const unsigned long long* keys, int N, int G, unsigned int* counts) {
     hipLaunchKernelGGL(k_sf_count, dim3(N), dim3(256), 0, st, keys, N, G, counts);
     return hipGetLastError();

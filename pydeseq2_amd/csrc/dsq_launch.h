@@ -88,6 +88,9 @@ hipError_t launch_padj_finish(hipStream_t st, const unsigned long long* sorted_p
 hipError_t launch_logmeans_pos(hipStream_t st, const int32_t* y, int ldn, int N, int G, double* logmeans,
                                uint8_t* usable);
 size_t prior_mad_work_doubles(int n);
+hipError_t launch_sf_compact(hipStream_t st, const double* logmeans, const uint8_t* gene_mask, int G, int* idx_work);
+hipError_t launch_sf_keys_compact(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
+                                  const double* logmeans, const int* idx_work, unsigned long long* keys);
 size_t size_factors_work_doubles(int N, int G);
 hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int N, int G, const double* sf, int mode,
                       double a0, double a1, double* out);

@@ -146,23 +146,27 @@ class _DeviceSfOps:
     def __init__(self, pipe: DeseqPipeline, d_lm):
         self.p, ctx = pipe, pipe.ctx
         N, G = pipe.N, pipe.G
+        # keys only for this rank's usable genes (finite logmean): [N][Gu]
         self.d_keys = pipe._pooled((N * G,), np.uint64)
-        ctx.call("dsq_dev_sf_keys", _vp(pipe.d_raw.ptr), pipe._count_type, N, G, _vp(d_lm.ptr), None,
-                 _vp(self.d_keys.ptr))
+        d_idx = pipe._pooled((G + 2,), np.int32)
+        gu = C.c_int(0)
+        ctx.call("dsq_dev_sf_keys_compact", _vp(pipe.d_raw.ptr), pipe._count_type, N, G, _vp(d_lm.ptr), None,
+                 _vp(d_idx.ptr), _vp(self.d_keys.ptr), C.byref(gu))
+        self.Gu = int(gu.value)
         self.d_cnt = pipe._pooled((N,), np.uint32)
         self.d_prefix = pipe._pooled((2 * N,), np.uint64)
         self.d_rank = pipe._pooled((2 * N,), np.uint32)
         self.d_hist = pipe._pooled((2 * N * 256,), np.uint32)
 
     def count(self):
-        self.p.ctx.call("dsq_dev_sf_count", _vp(self.d_keys.ptr), self.p.N, self.p.G, _vp(self.d_cnt.ptr))
+        self.p.ctx.call("dsq_dev_sf_count", _vp(self.d_keys.ptr), self.p.N, self.Gu, _vp(self.d_cnt.ptr))
         return self.d_cnt
 
     def init(self, total):
         self.p.ctx.call("dsq_dev_sf_init", _vp(total.ptr), self.p.N, _vp(self.d_prefix.ptr), _vp(self.d_rank.ptr))
 
     def hist(self, shift):
-        self.p.ctx.call("dsq_dev_sf_hist", _vp(self.d_keys.ptr), self.p.N, self.p.G, _vp(self.d_prefix.ptr),
+        self.p.ctx.call("dsq_dev_sf_hist", _vp(self.d_keys.ptr), self.p.N, self.Gu, _vp(self.d_prefix.ptr),
                         int(shift), _vp(self.d_hist.ptr))
         return self.d_hist
 

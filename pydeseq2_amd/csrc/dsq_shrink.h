@@ -36,16 +36,11 @@ struct ShrinkWork {  // wave-private LDS on the device
     int nbd[P];
 };
 
-// numpy.logaddexp(a, b)
-DSQ_HD double logaddexp_np(double a, double b) {
-    if (a == b) return a + 0.69314718055994530942;
-    const double d = a - b;
-    if (d > 0) return a + log1p(exp(-d));
-    if (d <= 0) return b + log1p(exp(d));
-    return a + b;  // NaN
-}
-
-// prior - nll (unscaled) and, if g != nullptr, its gradient
+// prior - nll (unscaled) and, if g != nullptr, its gradient.
+// With d = eta + offset - log(size) and e = exp(-|d|) (one exponential per sample):
+//   logaddexp(eta + offset, log size) = max(.) + log1p(e)                      (numpy's formula)
+//   (y + size) / (1 + size exp(-eta - offset)) = (y + size) / (1 + exp(-d)) = (y + size) * (d > 0 ? 1 : e) / (1 + e)
+// so the likelihood and its gradient share the exponential, one lean log1p and one reciprocal.
 template <class Wv, int P>
 DSQ_HD double shrink_fn(const ShrinkArgs& A, const double (&b)[P], double* g) {
     const double lsz = log(A.size);
@@ -59,9 +54,12 @@ DSQ_HD double shrink_fn(const ShrinkArgs& A, const double (&b)[P], double* g) {
 #pragma unroll
         for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * b[j]; }
         const double eo = eta + A.offset[n];
-        s += yv * eta - (yv + A.size) * logaddexp_np(eo, lsz);
+        const double d = eo - lsz;
+        const double e = exp(-fabs(d));
+        const double lae = (d > 0 ? eo : lsz) + flog1p(e);
+        s += yv * eta - (yv + A.size) * lae;
         if (g != nullptr) {
-            const double gk = yv - (yv + A.size) / (1.0 + A.size * exp(-eta - A.offset[n]));
+            const double gk = yv - (yv + A.size) * ((d > 0 ? 1.0 : e) * frcp(1.0 + e));
 #pragma unroll
             for (int j = 0; j < P; ++j) gr[j] += gk * x[j];
         }

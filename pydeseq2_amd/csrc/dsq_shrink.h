@@ -14,6 +14,7 @@
 #pragma once
 #include "dsq_alpha.h"  // linspace_at
 #include "dsq_lbfgsb.h"
+#include "dsq_lbfgsb_dense.h"
 #include "dsq_linalg.h"
 #include "dsq_wave.h"
 
@@ -29,9 +30,17 @@ struct ShrinkArgs {
     int shrink_index;
 };
 
+// up to 4 coefficients the dense-matrix L-BFGS-B (same iterates, a fraction of the scalar work and of
+// the workspace) replaces the compact-form one
+constexpr int kShrinkDenseMax = 4;
+template <int P, bool DENSE = (P <= kShrinkDenseMax)>
+struct ShrinkLb { typedef LbfgsbWork<P> type; };
+template <int P>
+struct ShrinkLb<P, true> { typedef LbfgsbDenseWork<P> type; };
+
 template <int P>
 struct ShrinkWork {  // wave-private LDS on the device
-    LbfgsbWork<P> lb;
+    typename ShrinkLb<P>::type lb;
     double x[P], l[P], u[P];
     int nbd[P];
 };
@@ -139,7 +148,11 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
         for (int j = 0; j < P; ++j) g[j] = gg[j] / cn;
     };
     // scipy: factr = ftol / eps, pgtol = gtol
-    const LbfgsbResult res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    LbfgsbResult res;
+    if constexpr (P <= kShrinkDenseMax)
+        res = lbfgsb_dense<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    else
+        res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
 #pragma unroll
     for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
     if (!res.success && P == 2) {

@@ -190,6 +190,16 @@ class DistDeseqPipeline(DeseqPipeline):
                                       "factors only")
         self.comm = comm
         self._gathered = None
+        # ranks may own different numbers of genes: the gathered vectors are padded to the largest shard
+        d_g = self._pooled_once((1,), np.float64, float(self.G))
+        d_all = DeviceArray(self.ctx, (comm.world,), np.float64)
+        comm.allgather(d_g, d_all)
+        self.Gpad = int(d_all.to_host().max())
+
+    def _pooled_once(self, shape, dtype, value):
+        arr = DeviceArray(self.ctx, shape, dtype)
+        self.ctx.h2d(arr.ptr, np.full(shape, value, dtype=dtype))
+        return arr
 
     def _size_factors(self, d_lm):
         ops = _DeviceSfOps(self, d_lm)
@@ -202,10 +212,10 @@ class DistDeseqPipeline(DeseqPipeline):
 
     def _gather_trend_inputs(self, Gn):
         """All-gather (raw genewise dispersion, normalised mean) of every rank on the device: two
-        [world][G] vectors, NaN where a rank has fewer than G non-zero genes (the trend and prior
-        kernels skip NaNs)."""
+        [world][Gpad] vectors (Gpad = largest shard), NaN beyond a rank's non-zero genes (the trend and
+        prior kernels skip NaNs)."""
         d_gw, d_nm = self._last_gw_dev
-        G, W = self.G, self.comm.world
+        G, W = self.Gpad, self.comm.world
         out = []
         for d_src in (d_gw, d_nm):
             d_send = self._pooled((G,), np.float64)
@@ -220,12 +230,12 @@ class DistDeseqPipeline(DeseqPipeline):
 
     def _fit_trend(self, Gn):
         d_gw_all, d_nm_all = self._gather_trend_inputs(Gn)
-        return self._run_trend_kernel(d_gw_all, d_nm_all, self.G * self.comm.world)
+        return self._run_trend_kernel(d_gw_all, d_nm_all, self.Gpad * self.comm.world)
 
     def _mean_trend(self, Gn):
         if self._gathered is None:
             self._gather_trend_inputs(Gn)
-        gw_all = self._down(self._gathered[0], self.G * self.comm.world)
+        gw_all = self._down(self._gathered[0], self.Gpad * self.comm.world)
         gw_all = np.clip(gw_all[~np.isnan(gw_all)], self.min_disp, self.max_disp)
         return _trend.mean_trend(gw_all, self.min_disp)
 
@@ -234,7 +244,7 @@ class DistDeseqPipeline(DeseqPipeline):
         from scipy.special import polygamma
 
         d_gw_all, d_nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(Gn)
-        n_all = self.G * self.comm.world
+        n_all = self.Gpad * self.comm.world
         if r.disp_function_type == "parametric":
             a0, a1 = float(r.trend_coeffs[0]), float(r.trend_coeffs[1])
         else:

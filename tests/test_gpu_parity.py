@@ -290,6 +290,7 @@ def test_distributed_pipeline_two_ranks_threads():
     counts[:, 3] = 0  # a gene without counts in rank 0's shard: its vectors are NaN padded
     res_full = pydeseq2_amd.DeseqPipeline(counts, X, device=0).deseq2()
 
+    cuts = [0, 600, G]  # unequal shards: the gathered vectors are padded to the larger one
     barrier = threading.Barrier(W)
     slots = [None] * W
 
@@ -322,7 +323,7 @@ def test_distributed_pipeline_two_ranks_threads():
     def run(rank):
         try:
             ctx = Context(0)
-            sl = slice(rank * G // W, (rank + 1) * G // W)
+            sl = slice(cuts[rank], cuts[rank + 1])
             pipe = DistDeseqPipeline(np.ascontiguousarray(counts[:, sl]), X, comm=ThreadComm(ctx, rank), ctx=ctx)
             out[rank] = pipe.deseq2()
         except Exception as e:  # pragma: no cover
@@ -334,7 +335,7 @@ def test_distributed_pipeline_two_ranks_threads():
     [t.join(120) for t in ts]
     assert not errs, errs
     for rank in range(W):
-        sl = slice(rank * G // W, (rank + 1) * G // W)
+        sl = slice(cuts[rank], cuts[rank + 1])
         r = out[rank]
         assert_close(r.size_factors, res_full.size_factors, 1e-14, 0, "sf")
         assert_close(r.trend_coeffs, res_full.trend_coeffs, 1e-9, 0, "trend")

@@ -193,6 +193,8 @@ class DeseqPipeline:
         self.kernel_log = {}
         self._pool_free, self._pool_used = [], []
         self._pinned = _PinnedPool(ctx_)
+        # Cook's cutoff F.ppf(0.99, p, N - p) (dds.py:1073, 1324): a scipy call of ~0.1 ms, off the step's path
+        self._cooks_cutoff = float(f_dist.ppf(0.99, self.P, self.N - self.P)) if self.N > self.P else float("nan")
         ctx_.sync()
 
     # ------------------------------------------------------------------ helpers
@@ -573,7 +575,7 @@ class DeseqPipeline:
         t5 = tick(); T["LFC"] = t5 - t4
 
         # ---- Cook's (dds.py:986-1040)
-        cutoff = float(f_dist.ppf(0.99, P, N - P))
+        cutoff = self._cooks_cutoff
         d_cooks = self._dmat(Gn)
         flag_names = ["any_all", "any_use", "any_use_nr", "few_above"]
         self._k("cooks", Gn, "dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),

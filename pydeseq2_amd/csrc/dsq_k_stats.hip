@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_logmeans_pos(const int32_t* __restri
     double s = 0.0;
     for (int n = threadIdx.x & 63; n < N; n += 64) {
         const int v = yr[n];
-        if (v != 0) s += log((double)v);
+        if (v != 0) s += log_count(v);
     }
     s = DeviceWave::sum(s) / (double)N;
     if ((threadIdx.x & 63) == 0) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_ratio_keys(const SrcT* __restrict__ cou
         // a zero count never occurs among the genes of the default mode (their logmean is -inf); in
         // "poscounts" mode the sample's zero entries are left out of its median (dds.py:668-671)
         const double c = (double)counts[(size_t)n * G + g];
-        if (use && c > 0.0) k = f64_key(log(c) - lm);
+        if (use && c > 0.0) k = f64_key((c < 256.0 ? kLogInt[(int)c] : flog(c)) - lm);
         keys[(size_t)n * G + g] = k;
     }
 }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_ratio_keys_c(const SrcT* __restrict__ c
     for (int j = blockIdx.x * 256 + threadIdx.x; j < Gu; j += gridDim.x * 256) {
         const int g = idx[j];
         const double c = (double)counts[(size_t)n * G + g];
-        keys[(size_t)n * Gu + j] = (c > 0.0) ? f64_key(log(c) - logmeans[g]) : ~0ull;
+        keys[(size_t)n * Gu + j] = (c > 0.0) ? f64_key((c < 256.0 ? kLogInt[(int)c] : flog(c)) - logmeans[g]) : ~0ull;
     }
 }
 

@@ -177,6 +177,9 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
+            for bufs in self.__dict__.pop("_padj_buffers", {}).values():  # cached work buffers (summary.py)
+                for b in bufs:
+                    b.free()
             self.lib.dsq_destroy(self.h)
             self.h = _vp()
 

@@ -504,37 +504,23 @@ hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* 
 // ---- compacted variant: only the usable genes (finite logmean, mask) get keys.  With ~1000 samples
 // most genes contain a zero somewhere (75 % in the benchmark data), so the key matrix and the six radix
 // passes over it shrink accordingly.  idx[j] = j-th usable gene, *count = their number.
-__global__ __launch_bounds__(1024) void k_sf_compact(const double* __restrict__ logmeans,
-                                                     const uint8_t* __restrict__ mask, int G,
-                                                     int* __restrict__ idx, int* __restrict__ count) {
-    __shared__ int wsum[16];
-    __shared__ int base_sh;
-    if (threadIdx.x == 0) base_sh = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int g0 = 0; g0 < G; g0 += 1024) {
-        const int g = g0 + threadIdx.x;
-        bool use = false;
-        if (g < G) {
-            const double lm = logmeans[g];
-            use = (lm != -INFINITY) && (lm == lm) && (mask == nullptr || mask[g] != 0);
-        }
-        const unsigned long long b = __ballot(use);
-        const int before = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[w] = __popcll(b);
-        __syncthreads();
-        int off = base_sh;
-        for (int q = 0; q < w; ++q) off += wsum[q];
-        if (use) idx[off + before] = g;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int q = 0; q < 16; ++q) t += wsum[q];
-            base_sh += t;
-        }
-        __syncthreads();
+__global__ __launch_bounds__(256) void k_sf_compact(const double* __restrict__ logmeans,
+                                                    const uint8_t* __restrict__ mask, int G,
+                                                    int* __restrict__ idx, int* __restrict__ count) {
+    // one atomic per wave reserves a slot range; the order of idx is irrelevant (only medians over the
+    // usable genes are taken), so no scan is needed.  *count must be zero at launch.
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    bool use = false;
+    if (g < G) {
+        const double lm = logmeans[g];
+        use = (lm != -INFINITY) && (lm == lm) && (mask == nullptr || mask[g] != 0);
     }
-    if (threadIdx.x == 0) *count = base_sh;
+    const unsigned long long b = __ballot(use);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(count, __popcll(b));
+    base = __shfl(base, 0, 64);
+    if (use) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = g;
 }
 
 template <class SrcT>
@@ -571,7 +557,9 @@ hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_
     unsigned long long* keys = (unsigned long long*)work;
     int* idx = (int*)(work + (size_t)N * G);
     int* count = idx + G;
-    hipLaunchKernelGGL(k_sf_compact, dim3(1), dim3(1024), 0, st, logmeans, gene_mask, G, idx, count);
+    hipError_t e0 = hipMemsetAsync(count, 0, sizeof(int), st);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(k_sf_compact, dim3((G + 255) / 256), dim3(256), 0, st, logmeans, gene_mask, G, idx, count);
     const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
     if (count_type == 1)
         hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
@@ -1460,7 +1448,10 @@ hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type,
 }
 // compacted keys for the distributed protocol: idx_work = G + 2 ints; keys [N][*count]
 hipError_t launch_sf_compact(hipStream_t st, const double* logmeans, const uint8_t* gene_mask, int G, int* idx_work) {
-    hipLaunchKernelGGL(k_sf_compact, dim3(1), dim3(1024), 0, st, logmeans, gene_mask, G, idx_work, idx_work + G);
+    hipError_t e0 = hipMemsetAsync(idx_work + G, 0, sizeof(int), st);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(k_sf_compact, dim3((G + 255) / 256), dim3(256), 0, st, logmeans, gene_mask, G, idx_work,
+                       idx_work + G);
     return hipGetLastError();
 }
 hipError_t launch_sf_keys_compact(hipStream_t st, const void* counts_sm, int count_type, int N, int G,

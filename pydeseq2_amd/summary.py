@@ -39,9 +39,20 @@ def lowess(x, y, frac=2.0 / 3.0, iters=3):
         wt = delta[:, None] * w  # [point j, evaluation i]
         s0, s1, s2 = wt.sum(0), (wt * x[:, None]).sum(0), (wt * (x * x)[:, None]).sum(0)
         t0, t1 = (wt * y[:, None]).sum(0), (wt * (y * x)[:, None]).sum(0)
-        A = np.stack([np.stack([s0, s1], -1), np.stack([s1, s2], -1)], -2)  # [i, 2, 2]
-        beta = np.einsum("ijk,ik->ij", np.linalg.pinv(A, rcond=2 * np.finfo(float).eps), np.stack([t0, t1], -1))
-        est = beta[:, 0] + beta[:, 1] * x
+        # 2x2 normal equations: Cramer's rule where they are well conditioned, minimum-norm solution
+        # (what numpy.linalg.lstsq returns in the reference) for the degenerate ones
+        det = s0 * s2 - s1 * s1
+        good = np.abs(det) > 1e-10 * np.maximum(np.abs(s0 * s2), 1e-300)
+        safe = np.where(good, det, 1.0)
+        b0 = np.where(good, (t0 * s2 - t1 * s1) / safe, 0.0)
+        b1 = np.where(good, (s0 * t1 - s1 * t0) / safe, 0.0)
+        if not good.all():
+            bad = np.nonzero(~good)[0]
+            A = np.stack([np.stack([s0[bad], s1[bad]], -1), np.stack([s1[bad], s2[bad]], -1)], -2)
+            sol = np.einsum("ijk,ik->ij", np.linalg.pinv(A, rcond=2 * np.finfo(float).eps),
+                            np.stack([t0[bad], t1[bad]], -1))
+            b0[bad], b1[bad] = sol[:, 0], sol[:, 1]
+        est = b0 + b1 * x
         res = y - est
         s = np.median(np.abs(res))
         delta = (np.abs(res) > 0).astype(float) if s == 0 else np.clip(res / (6.0 * s), -1, 1)
@@ -67,9 +78,16 @@ def adjusted_pvalues(ctx: Context, base_mean, pvalue, alpha=0.05, independent_fi
     base_mean = np.ascontiguousarray(base_mean, dtype=np.float64)
     pvalue = np.ascontiguousarray(pvalue, dtype=np.float64)
     G = len(base_mean)
-    d_bm, d_p = DeviceArray.from_host(ctx, base_mean), DeviceArray.from_host(ctx, pvalue)
-    d_sp, d_si = DeviceArray(ctx, (G,), np.uint64), DeviceArray(ctx, (G,), np.int32)
-    d_bins, d_padj = DeviceArray(ctx, (G,), np.uint8), DeviceArray(ctx, (G,), np.float64)
+    # device buffers are kept per context and gene count (hipMalloc / hipFree cost more than the kernels)
+    cache = ctx.__dict__.setdefault("_padj_buffers", {})
+    if G not in cache:
+        cache.clear()
+        cache[G] = (DeviceArray(ctx, (G,), np.float64), DeviceArray(ctx, (G,), np.float64),
+                    DeviceArray(ctx, (G,), np.uint64), DeviceArray(ctx, (G,), np.int32),
+                    DeviceArray(ctx, (G,), np.uint8), DeviceArray(ctx, (G,), np.float64))
+    d_bm, d_p, d_sp, d_si, d_bins, d_padj = cache[G]
+    ctx.h2d(d_bm.ptr, base_mean)
+    ctx.h2d(d_p.ptr, pvalue)
     out = (C.c_double * 200)()
     n_valid = C.c_int(0)
     ctx.call("dsq_dev_padj_prepare", _vp(d_bm.ptr), _vp(d_p.ptr), G, C.c_double(alpha), _vp(d_sp.ptr),

@@ -371,3 +371,39 @@ def test_prior_mad_kernel_vs_numpy(n):
     res = np.log(g[ok]) - np.log(fit[ok])
     mad = np.median(np.abs(res - np.median(res))) / 0.67448975019608171
     assert abs(sq.value - mad**2) <= 1e-12 * mad**2
+
+
+def test_full_size_c3_properties():
+    """The benchmark configuration itself (BASELINE.json configs[2]: 60 000 genes x 1000 samples, p = 2):
+    run-to-run determinism (bit-identical results), Wald consistency, and the oracle's per-gene kernels
+    (genewise MLE, MAP, IRLS LFC) on a random gene subset with the pipeline's own cross-gene quantities."""
+    import pydeseq2_amd
+    from scipy.stats import norm
+
+    counts, X = orc.synth_counts(60000, 1000, "2level", 2)
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0)
+    res = pipe.deseq2()
+    res2 = pipe.deseq2()
+    for f in ("size_factors", "genewise_dispersions", "MAP_dispersions", "dispersions", "LFC", "pvalue"):
+        a, b = getattr(res, f), getattr(res2, f)
+        assert np.array_equal(a, b, equal_nan=True), f  # idempotent and deterministic
+    nz = res.non_zero
+    ok = nz & ~np.isnan(res.pvalue)
+    assert np.isfinite(res.dispersions[nz]).all()
+    z = res.LFC[ok, 1] / res.lfcSE[ok]
+    assert np.allclose(z, res.stat[ok], rtol=1e-9, atol=1e-12)
+    assert np.allclose(res.pvalue[ok], 2 * norm.sf(np.abs(res.stat[ok])), rtol=1e-9, atol=1e-300)
+    sel = np.sort(np.random.default_rng(3).choice(np.nonzero(nz & ~res.replaced)[0], 160, replace=False))
+    c = counts[:, sel]
+    mu = orc.lin_reg_mu(c, res.size_factors, X, 0.5)
+    a, cv = orc.alpha_mle(c, X, mu, res.mom_dispersions[sel], 1e-8, 1000.0, n_jobs=8)
+    same = cv & (res.genewise_converged[sel] == 1)
+    assert same.mean() > 0.97
+    assert_close(res.genewise_dispersions[sel][same], np.clip(a, 1e-8, 1000.0)[same], RTOL, 0, "genewise")
+    m, mc = orc.alpha_mle(c, X, mu, res.fitted_dispersions[sel], 1e-8, 1000.0, prior_disp_var=res.prior_disp_var,
+                          cr_reg=True, prior_reg=True, n_jobs=8)
+    same = mc & (res.MAP_converged[sel] == 1)
+    assert same.mean() > 0.97
+    assert_close(res.MAP_dispersions[sel][same], np.clip(m, 1e-8, 1000.0)[same], RTOL, 0, "MAP")
+    beta, _, _, bc = orc.irls(c, res.size_factors, X, res.dispersions[sel], 0.5, 1e-8)
+    assert_close(res.LFC[sel][bc], beta[bc], RTOL, 1e-8, "LFC")

@@ -20,9 +20,11 @@ from ._lib import Context
 from .pipeline import DeseqPipeline
 
 
-def build_design(metadata: pd.DataFrame, design) -> pd.DataFrame:
+def build_design(metadata: pd.DataFrame, design, ref_level=None) -> pd.DataFrame:
     """Design matrix for an additive formula (same columns and names ``formulaic`` produces for it:
-    ``Intercept``, ``factor[T.level]`` …, continuous covariates under their own name)."""
+    ``Intercept``, ``factor[T.level]`` …, continuous covariates under their own name).
+    ``ref_level = [factor, level]`` makes ``level`` the reference of ``factor`` instead of its first
+    sorted level."""
     if isinstance(design, pd.DataFrame):
         return design.astype(float)
     if not isinstance(design, str):
@@ -49,6 +51,11 @@ def build_design(metadata: pd.DataFrame, design) -> pd.DataFrame:
             raise ValueError("NaNs are not allowed in the design factors.")
         if col.dtype.kind in "OUSb" or str(col.dtype) == "category":
             levels = sorted(col.astype(str).unique())
+            if ref_level is not None and ref_level[0] == t:
+                if str(ref_level[1]) not in levels:
+                    raise KeyError(f"ref_level: {ref_level[1]!r} is not a level of {t!r}")
+                levels.remove(str(ref_level[1]))
+                levels.insert(0, str(ref_level[1]))
             for lv in levels[1:]:
                 cols[f"{t}[T.{lv}]"] = (col.astype(str) == lv).to_numpy().astype(float)
         else:
@@ -62,9 +69,20 @@ def build_design(metadata: pd.DataFrame, design) -> pd.DataFrame:
 class DeseqDataSet:
     """Counts + metadata + design, fitted on the GPU (cf. ``pydeseq2.dds.DeseqDataSet``, dds.py:206-340)."""
 
-    def __init__(self, *, counts: pd.DataFrame, metadata: pd.DataFrame, design="~condition", refit_cooks=True,
+    def __init__(self, *, counts: pd.DataFrame, metadata: pd.DataFrame, design="~condition", design_factors=None,
+                 continuous_factors=None, ref_level=None, refit_cooks=True,
                  min_mu=0.5, min_disp=1e-8, max_disp=10.0, beta_tol=1e-8, min_replicates=7, fit_type="parametric",
-                 size_factors_fit_type="ratio", control_genes=None, device=0, ctx: Context | None = None, quiet=True):
+                 size_factors_fit_type="ratio", control_genes=None, device=0, ctx: Context | None = None, quiet=True,
+                 n_cpus=None, inference=None, low_memory=False):
+        # n_cpus / inference / low_memory: accepted for signature compatibility (dds.py:206-229); the engine
+        # is the GPU pipeline.  design_factors (+ continuous_factors): the reference's older way to spell
+        # an additive design.
+        if design_factors is not None:
+            fac = [design_factors] if isinstance(design_factors, str) else list(design_factors)
+            design = "~" + " + ".join(fac)
+            for cf in continuous_factors or []:
+                metadata = metadata.copy()
+                metadata[cf] = metadata[cf].astype(float)
         if not isinstance(counts, pd.DataFrame):
             counts = pd.DataFrame(np.asarray(counts))
         if counts.shape[0] != metadata.shape[0]:
@@ -76,7 +94,7 @@ class DeseqDataSet:
         self.X = counts.to_numpy()
         self.n_obs, self.n_vars = self.X.shape
         self.design = design
-        dm = build_design(self.obs, design)
+        dm = build_design(self.obs, design, ref_level)
         self.obsm = {"design_matrix": dm}
         self.var = pd.DataFrame(index=self.var_names)
         self.varm, self.layers, self.uns = {}, _LazyLayers(self), {}
@@ -185,10 +203,10 @@ class DeseqStats:
     """Wald tests, adjusted p-values and LFC shrinkage (cf. ``pydeseq2.ds.DeseqStats``, ds.py:110-447)."""
 
     def __init__(self, dds: DeseqDataSet, contrast, alpha=0.05, cooks_filter=True, independent_filter=True,
-                 lfc_null=0.0, alt_hypothesis=None, quiet=True):
+                 prior_LFC_var=None, lfc_null=0.0, alt_hypothesis=None, inference=None, quiet=True, n_cpus=None):
         if dds._res is None:
             raise AttributeError("Please run deseq2() on the DeseqDataSet first.")
-        self.dds, self.alpha = dds, alpha
+        self.dds, self.alpha, self.prior_LFC_var = dds, alpha, prior_LFC_var
         self.cooks_filter, self.independent_filter = cooks_filter, independent_filter
         self.lfc_null, self.alt_hypothesis, self.quiet = lfc_null, alt_hypothesis, quiet
         self.design_matrix = dds.obsm["design_matrix"]

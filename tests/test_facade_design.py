@@ -33,3 +33,13 @@ def test_formula_errors_and_matrix_input():
     assert list(build_design(meta, "~0 + a").columns) == ["a[T.y]"]
     M = np.ones((3, 2))
     assert build_design(meta, M).shape == (3, 2)
+
+
+def test_ref_level_and_design_factors():
+    meta = pd.DataFrame({"condition": ["A", "B", "C", "A", "B", "C"], "x": [1, 2, 3, 4, 5, 6]})
+    dm = build_design(meta, "~condition", ref_level=["condition", "B"])
+    assert list(dm.columns) == ["Intercept", "condition[T.A]", "condition[T.C]"]
+    assert dm["condition[T.A]"].tolist() == [1, 0, 0, 1, 0, 0]
+    with pytest.raises(KeyError):
+        build_design(meta, "~condition", ref_level=["condition", "Z"])
+    assert list(build_design(meta, "~condition + x").columns) == ["Intercept", "condition[T.B]", "condition[T.C]", "x"]

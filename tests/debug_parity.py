@@ -1,4 +1,7 @@
-"""Developer tool: stage-by-stage max relative differences GPU pipeline vs oracle."""
+"""Developer tool (test infrastructure): stage-by-stage max relative differences GPU pipeline vs oracle.
+
+    python tests/debug_parity.py <genes> <samples> <2level|3factor|mixed> <seed>
+"""
 import sys
 
 import numpy as np

@@ -972,6 +972,21 @@ def vst(counts, X, use_design=False, fit_type="parametric", min_mu=0.5, min_disp
     return out, info
 
 
+def vst_transform_new(counts_new, counts_train, info):
+    """``vst_transform(counts)`` for new samples (dds.py:471-514): size factors from the training
+    logmeans / usable genes (preprocessing.py:59-102), then the fitted closed form."""
+    lm, keep = logmeans_and_filter(np.asarray(counts_train))
+    counts_new = np.asarray(counts_new)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sf = np.exp(np.median((np.log(counts_new) - lm)[:, keep], axis=1))
+    normed = counts_new / sf[:, None]
+    if "trend_coeffs" in info:
+        a0, a1 = info["trend_coeffs"]
+        return np.log2((1 + a1 + 2 * a0 * normed + 2 * np.sqrt(a0 * normed * (1 + a1 + a0 * normed))) / (4 * a0))
+    md = info["mean_disp"]
+    return (2 * np.arcsinh(np.sqrt(md * normed)) - np.log(md) - np.log(4)) / np.log(2)
+
+
 # --------------------------------------------------------------------------
 # apeGLM LFC shrinkage                      SURVEY.md §8(f)-2
 # --------------------------------------------------------------------------

@@ -146,12 +146,22 @@ class DeseqDataSet:
         """Variance stabilising transformation into ``layers["vst_counts"]`` (dds.py:349-514): dispersions
         and trend fitted with an intercept-only design unless ``use_design``."""
         self.vst_fit_type = fit_type if fit_type is not None else self.fit_type
+        self.vst_fit(use_design=use_design)
+        self.layers["vst_counts"] = self.vst_transform()
+        return self.layers["vst_counts"]
+
+    def vst_fit(self, use_design: bool = False):
+        """Fit the transformation (dds.py:384-438): size factors, genewise dispersions and trend; keeps the
+        training log geometric means so that new samples can be transformed later."""
+        if not hasattr(self, "vst_fit_type"):
+            self.vst_fit_type = self.fit_type
         if self.vst_fit_type not in ("parametric", "mean"):
             raise NotImplementedError(f"Found fit_type '{self.vst_fit_type}'. Expected 'parametric' or 'mean'.")
         p0 = self._pipe
         X = self.obsm["design_matrix"].to_numpy() if use_design else np.ones((self.n_obs, 1))
         pipe = p0 if use_design else DeseqPipeline(self.X, X, ctx=p0.ctx, min_mu=p0.min_mu, min_disp=p0.min_disp,
-                                                    max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type)
+                                                    max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type,
+                                                    size_factors_fit_type=p0.size_factors_fit_type)
         old_ft, pipe.fit_type = pipe.fit_type, self.vst_fit_type
         try:
             r = pipe.deseq2(stop_after_trend=True)
@@ -161,12 +171,23 @@ class DeseqDataSet:
         self.var["vst_genewise_dispersions"] = r.genewise_dispersions
         if r.disp_function_type == "parametric":
             self.uns["vst_trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
-            out = p0.vst_transform(r.size_factors, trend_coeffs=r.trend_coeffs)
+            self._vst_params = dict(trend_coeffs=r.trend_coeffs)
         else:
             self.vst_fit_type = "mean"
-            out = p0.vst_transform(r.size_factors, mean_disp=r.mean_disp)
-        self.layers["vst_counts"] = out
-        return out
+            self._vst_params = dict(mean_disp=r.mean_disp)
+        with np.errstate(divide="ignore"):  # preprocessing.deseq2_norm_fit on the training counts
+            self.logmeans = np.log(self.X).mean(0)
+        self.filtered_genes = ~np.isinf(self.logmeans)
+        return self
+
+    def vst_transform(self, counts=None) -> np.ndarray:
+        """Apply the fitted transformation (dds.py:440-514) to the dataset's own counts, or to new samples
+        (``counts``: samples x genes), whose size factors come from the TRAINING log geometric means."""
+        if "size_factors" not in self.obs or not hasattr(self, "_vst_params"):
+            raise RuntimeError("The vst_fit method should be called prior to vst_transform.")
+        if counts is None:
+            return self._pipe.vst_transform(self.obs["size_factors"].to_numpy(), **self._vst_params)
+        return self._pipe.vst_transform_new(np.asarray(counts), self.logmeans, self.filtered_genes, **self._vst_params)
 
     def cooks_outlier(self) -> pd.Series:
         return pd.Series(np.asarray(self._res.cooks_outlier, dtype=bool), index=self.var_names)

@@ -703,6 +703,32 @@ class DeseqPipeline:
                  c_double(a0), c_double(a1), _vp(d_out.ptr))
         return d_out.to_host()
 
+    def vst_transform_new(self, counts, logmeans, filtered, trend_coeffs=None, mean_disp=None):
+        """Variance-stabilised NEW samples (M x G): their size factors are the medians of
+        log(count) - training logmeans over the training-usable genes (preprocessing.py:59-102 as called from
+        dds.py:471-484), then the same closed form."""
+        from ._lib import I32, I64
+
+        ctx = self.ctx
+        counts = np.ascontiguousarray(counts if counts.dtype in (np.int32, np.int64) else counts.astype(np.int64))
+        M, G = counts.shape
+        if G != self.G:
+            raise ValueError("new counts must have the genes of the fitted dataset")
+        ct = I32 if counts.dtype == np.int32 else I64
+        d_c = DeviceArray.from_host(ctx, counts)
+        lm = np.where(np.asarray(filtered, dtype=bool), np.asarray(logmeans, dtype=float), -np.inf)
+        d_lm = DeviceArray.from_host(ctx, np.ascontiguousarray(lm))
+        d_work = DeviceArray(ctx, (ctx.lib.dsq_size_factors_work_doubles(M, G),), np.float64)
+        d_sf = DeviceArray(ctx, (M,), np.float64)
+        ctx.call("dsq_dev_size_factors", _vp(d_c.ptr), ct, M, G, _vp(d_lm.ptr), None, _vp(d_work.ptr), _vp(d_sf.ptr))
+        d_out = DeviceArray(ctx, (M, G), np.float64)
+        if trend_coeffs is not None:
+            mode, a0, a1 = 0, float(trend_coeffs[0]), float(trend_coeffs[1])
+        else:
+            mode, a0, a1 = 1, float(mean_disp), 0.0
+        ctx.call("dsq_dev_vst", _vp(d_c.ptr), ct, M, G, _vp(d_sf.ptr), mode, c_double(a0), c_double(a1), _vp(d_out.ptr))
+        return d_out.to_host()
+
     def wald(self, res: DeseqResult, contrast, lfc_null=0.0, alt_hypothesis=None):
         """Wald test only (ds.py:303-360) on the dispersions / LFCs of ``res`` (e.g. another contrast or
         alternative hypothesis after ``deseq2()``).  Returns (pvalue, stat, lfcSE), NaN for all-zero genes."""

@@ -179,3 +179,24 @@ def test_iterative_size_factors():
     ok = ~np.isnan(ref.dispersions)
     np.testing.assert_allclose(res.dispersions[ok], ref.dispersions[ok], rtol=5e-3)
     np.testing.assert_allclose(res.LFC[ok], ref.LFC[ok], rtol=5e-3, atol=1e-4)
+
+
+def test_vst_train_test_split():
+    """tests/test_pydeseq2.py:826-929: fit on samples 25..75, transform 0..25 with the training logmeans."""
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    train, test = counts[25:75], counts[0:25]
+    dds = DeseqDataSet(counts=train, metadata=meta[25:75], design="~condition")
+    with pytest.raises(RuntimeError):
+        dds.vst_transform(test.to_numpy())
+    dds.vst_fit()
+    assert "vst_trend_coeffs" in dds.uns and "size_factors" in dds.obs
+    out = dds.vst_transform(test.to_numpy())
+    assert isinstance(out, np.ndarray) and out.shape == (25, 10)
+    _, info = orc.vst(train.to_numpy(), dds.obsm["design_matrix"].to_numpy())
+    ref = orc.vst_transform_new(test.to_numpy(), train.to_numpy(), info)
+    np.testing.assert_allclose(out, ref, rtol=1e-6)
+    # the dataset's own samples: same as vst()
+    np.testing.assert_allclose(dds.vst_transform(), dds.vst(), rtol=1e-12)

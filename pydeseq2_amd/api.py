@@ -4,9 +4,9 @@
 ``pydeseq2.ds.DeseqStats`` a typical analysis touches — constructor arguments, ``deseq2()``,
 ``summary()``, ``lfc_shrink()``, and the field names written by the path (``obs["size_factors"]``,
 ``var["dispersions"]``, ``varm["LFC"]``, ``uns["trend_coeffs"]``, ``results_df`` …) —
-on top of the device pipeline, without ``anndata`` or ``formulaic``.  Designs are additive formulas
-of metadata columns (``"~group + condition"``; object/category columns are treatment-coded with the
-first sorted level as reference, numeric columns enter as they are) or an explicit design matrix.
+on top of the device pipeline, without ``anndata`` or ``formulaic``.  Designs are formulas of metadata
+columns (``"~group + condition"``, ``"~group*condition"``; object/category columns are treatment-coded
+with the first sorted level as reference, numeric columns enter as they are) or an explicit design matrix.
 """
 from __future__ import annotations
 
@@ -21,8 +21,10 @@ from .pipeline import DeseqPipeline
 
 
 def build_design(metadata: pd.DataFrame, design, ref_level=None) -> pd.DataFrame:
-    """Design matrix for an additive formula (same columns and names ``formulaic`` produces for it:
-    ``Intercept``, ``factor[T.level]`` …, continuous covariates under their own name).
+    """Design matrix for a formula of metadata columns: main effects (same columns and names ``formulaic``
+    produces: ``Intercept``, ``factor[T.level]`` …, continuous covariates under their own name) and
+    interactions ``a:b`` / ``a*b`` (products of the main-effect columns, named ``a[T.x]:b[T.y]``, after all
+    main effects).
     ``ref_level = [factor, level]`` makes ``level`` the reference of ``factor`` instead of its first
     sorted level."""
     if isinstance(design, pd.DataFrame):
@@ -33,33 +35,56 @@ def build_design(metadata: pd.DataFrame, design, ref_level=None) -> pd.DataFrame
     rhs = design.strip()
     if not rhs.startswith("~"):
         raise ValueError("design must be a formula starting with '~' (e.g. '~condition') or a matrix")
-    terms = [t.strip() for t in rhs[1:].split("+") if t.strip()]
+    terms = []
+    for t in (s.strip() for s in rhs[1:].split("+")):
+        if not t:
+            continue
+        if "*" in t:  # a*b = a + b + a:b
+            parts = [s.strip() for s in t.split("*")]
+            terms.extend(parts)
+            terms.append(":".join(parts))
+        else:
+            terms.append(t)
+    # main effects first, then interactions by degree (the order formulaic uses), duplicates dropped
+    seen, ordered = set(), []
+    for t in sorted(terms, key=lambda s: s.count(":")):
+        if t not in seen:
+            seen.add(t)
+            ordered.append(t)
+
+    def expand(name):
+        """Columns of one variable: treatment-coded levels of a factor or the numeric covariate itself."""
+        if not re.fullmatch(r"[A-Za-z_][A-Za-z0-9_.]*", name):
+            raise NotImplementedError(f"unsupported design term {name!r}: terms are metadata columns, their "
+                                      f"interactions (a:b, a*b), 0/1 for the intercept")
+        if name not in metadata.columns:
+            raise KeyError(f"design term {name!r} is not a metadata column")
+        col = metadata[name]
+        if col.isna().any():
+            raise ValueError("NaNs are not allowed in the design factors.")
+        if col.dtype.kind in "OUSb" or str(col.dtype) == "category":
+            levels = sorted(col.astype(str).unique())
+            if ref_level is not None and ref_level[0] == name:
+                if str(ref_level[1]) not in levels:
+                    raise KeyError(f"ref_level: {ref_level[1]!r} is not a level of {name!r}")
+                levels.remove(str(ref_level[1]))
+                levels.insert(0, str(ref_level[1]))
+            return [(f"{name}[T.{lv}]", (col.astype(str) == lv).to_numpy().astype(float)) for lv in levels[1:]]
+        return [(name, col.to_numpy().astype(float))]
+
     cols = {}
     intercept = True
-    for t in terms:
+    for t in ordered:
         if t == "1":
             continue
         if t in ("0", "-1"):
             intercept = False
             continue
-        if not re.fullmatch(r"[A-Za-z_][A-Za-z0-9_.]*", t):
-            raise NotImplementedError(f"only additive formulas of metadata columns are supported (term {t!r})")
-        if t not in metadata.columns:
-            raise KeyError(f"design term {t!r} is not a metadata column")
-        col = metadata[t]
-        if col.isna().any():
-            raise ValueError("NaNs are not allowed in the design factors.")
-        if col.dtype.kind in "OUSb" or str(col.dtype) == "category":
-            levels = sorted(col.astype(str).unique())
-            if ref_level is not None and ref_level[0] == t:
-                if str(ref_level[1]) not in levels:
-                    raise KeyError(f"ref_level: {ref_level[1]!r} is not a level of {t!r}")
-                levels.remove(str(ref_level[1]))
-                levels.insert(0, str(ref_level[1]))
-            for lv in levels[1:]:
-                cols[f"{t}[T.{lv}]"] = (col.astype(str) == lv).to_numpy().astype(float)
-        else:
-            cols[t] = col.to_numpy().astype(float)
+        combos = [("", np.ones(len(metadata)))]
+        for var in t.split(":"):
+            combos = [((a + ":" if a else "") + b, va * vb) for a, va in combos for b, vb in expand(var.strip())]
+        for name, v in combos:
+            cols[name] = v
     out = pd.DataFrame(cols, index=metadata.index)
     if intercept:
         out.insert(0, "Intercept", 1.0)

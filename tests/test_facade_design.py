@@ -27,7 +27,7 @@ def test_formula_errors_and_matrix_input():
     with pytest.raises(ValueError):
         build_design(meta, "~b")
     with pytest.raises(NotImplementedError):
-        build_design(meta, "~a:b")
+        build_design(meta, "~log(b)")
     with pytest.raises(ValueError):
         build_design(meta, "a + b")
     assert list(build_design(meta, "~0 + a").columns) == ["a[T.y]"]
@@ -43,3 +43,14 @@ def test_ref_level_and_design_factors():
     with pytest.raises(KeyError):
         build_design(meta, "~condition", ref_level=["condition", "Z"])
     assert list(build_design(meta, "~condition + x").columns) == ["Intercept", "condition[T.B]", "condition[T.C]", "x"]
+
+
+def test_interactions():
+    meta = pd.DataFrame({"g": list("XXYYXXYY"), "c": list("ABABABAB"), "x": np.arange(8.0)})
+    dm = build_design(meta, "~g*c")
+    assert list(dm.columns) == ["Intercept", "g[T.Y]", "c[T.B]", "g[T.Y]:c[T.B]"]
+    assert np.array_equal(dm["g[T.Y]:c[T.B]"], dm["g[T.Y]"] * dm["c[T.B]"])
+    dm2 = build_design(meta, "~g + c + g:x")
+    assert list(dm2.columns) == ["Intercept", "g[T.Y]", "c[T.B]", "g[T.Y]:x"]
+    assert np.array_equal(dm2["g[T.Y]:x"], dm2["g[T.Y]"] * meta["x"])
+    assert np.linalg.matrix_rank(dm.to_numpy()) == 4

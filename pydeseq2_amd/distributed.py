@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import ctypes as C
 import socket
-import struct
 import time
 
 import numpy as np

@@ -14,7 +14,6 @@ from typing import Literal
 
 import numpy as np
 
-from . import _lib
 from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context
 
 _vp, c_int, c_double = C.c_void_p, C.c_int, C.c_double

@@ -102,3 +102,21 @@ def test_gpu_invalid_inputs_raise():
         pydeseq2_amd.DeseqPipeline(counts, Xn, device=0)
     with pytest.raises(ValueError):  # N == p: no replicates (utils.py:839-844)
         pydeseq2_amd.deseq2(counts[:2], X[:2] + np.array([[0, 0], [0, 1.0]]) * 0 + np.eye(2), device=0)
+
+
+@pytest.mark.gpu
+def test_input_dtypes_and_layouts_give_identical_results():
+    """int64 / int32 / integer-valued float64 counts, C- or F-ordered: the same bits come out (the
+    reference casts with ``.astype(int)``, dds.py:245-249)."""
+    import pydeseq2_amd
+    from oracle import nbglm_oracle as orc
+
+    counts, X = orc.synth_counts(300, 40, "2level", 17)
+    base = pydeseq2_amd.deseq2(counts, X, device=0)
+    for variant in (counts.astype(np.int32), counts.astype(np.float64), np.asfortranarray(counts),
+                    np.asfortranarray(counts.astype(np.int32))):
+        r = pydeseq2_amd.deseq2(variant, X, device=0)
+        for f in ("size_factors", "dispersions", "LFC", "pvalue"):
+            assert np.array_equal(getattr(r, f), getattr(base, f), equal_nan=True), (variant.dtype, f)
+    with pytest.raises(ValueError):
+        pydeseq2_amd.deseq2(counts + 0.5, X, device=0)

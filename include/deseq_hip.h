@@ -182,6 +182,11 @@ size_t dsq_size_factors_work_doubles(int N, int G);
 int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                          const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
                          double* d_size_factors);
+/* dsq_dev_mom + dsq_dev_lin_mu fused for the designs that take the linear-model mu_hat (#cells == p,
+ * dds.py:747-756): two sweeps over a gene's counts instead of four, bit-identical outputs. */
+int dsq_dev_mom_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                       const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                       double min_mu, double* d_normed_mean, double* d_mom, double* d_mu);
 /* utils.fit_rough_dispersions + fit_moments_dispersions + dds.py:1157-1162 and
  * var["_normed_means"] (dds.py:708) */
 int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,

@@ -404,6 +404,17 @@ int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, c
     return DSQ_OK;
 }
 
+int dsq_dev_mom_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                       const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                       double min_mu, double* d_normed_mean, double* d_mom, double* d_mu) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(N != P, "The number of samples and the number of design variables are equal, i.e., "
+                          "there are no replicates to estimate the dispersion.");
+    DSQ_HIP(dsq::launch_mom_lin_mu(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, min_disp, max_disp,
+                                   min_mu, d_normed_mean, d_mom, d_mu, ctx->d_scratch + 8));
+    return DSQ_OK;
+}
+
 int dsq_dev_mom_raw(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_ones, const double* d_sf,
                     const double* d_Xt, const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp,
                     double max_disp, double* d_normed_mean, double* d_mom) {

@@ -624,6 +624,36 @@ hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* s
 }
 
 template <int P>
+__global__ __launch_bounds__(kBlock) void k_mom_lin_mu(const int32_t* __restrict__ y, int ldn,
+                                                       const double* __restrict__ sf,
+                                                       const double* __restrict__ Xt,
+                                                       const double* __restrict__ pinvXt, int ldx, int N, int G,
+                                                       const double* __restrict__ s_mean_inv, double min_disp,
+                                                       double max_disp, double min_mu,
+                                                       double* __restrict__ normed_mean, double* __restrict__ mom,
+                                                       double* __restrict__ mu) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const MomOut o = mom_lin_mu_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
+                                                    min_disp, max_disp, min_mu, mu + (size_t)g * ldn);
+    if ((threadIdx.x & 63) == 0) {
+        normed_mean[g] = o.normed_mean;
+        mom[g] = o.mom;
+    }
+}
+
+hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                             const double* pinvXt, int ldx, int N, int G, int P_, double min_disp, double max_disp,
+                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf, N, d_scalar);
+    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
+                                          (const double*)d_scalar, min_disp, max_disp, min_mu, normed_mean, mom, mu))
+    return hipGetLastError();
+}
+
+template <int P>
 __global__ __launch_bounds__(kBlock) void k_lin_mu(const int32_t* __restrict__ y, int ldn,
                                                    const double* __restrict__ sf,
                                                    const double* __restrict__ Xt,

@@ -52,6 +52,9 @@ hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* s
                       const double* pinvXt, int ldx, int N, int G, int P, double min_disp,
                       double max_disp, double* normed_mean, double* rough, double* moments,
                       double* mom, double* d_scalar, const double* sf_moments = nullptr);
+hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                             const double* pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar);
 hipError_t launch_nll_const(hipStream_t st, const int32_t* y, int ldn, int N, int G, const double* disp, double* cst);
 hipError_t launch_nll_scaled(hipStream_t st, const int32_t* y, const double* mu, int ldn, int N, int G,
                              const double* disp, const double* scale, const double* cst, double* nll);

@@ -337,14 +337,15 @@ class DeseqPipeline:
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
         unclipped), gconv]; returns the device mu_hat matrix."""
         D = self.design
-        self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr),
-                D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp), _vp(S["nm"].ptr),
-                None, None, _vp(S["mom"].ptr))
         d_mu = self._dmat(Gs)
-        if D.linear_mu:  # dds.py:747-756
-            self._k("lin_mu", Gs, "dsq_dev_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
-                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_mu), _vp(d_mu.ptr))
+        if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
+            self._k("mom_lin_mu", Gs, "dsq_dev_mom_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
+                    c_double(self.min_mu), _vp(S["nm"].ptr), _vp(S["mom"].ptr), _vp(d_mu.ptr))
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
+            self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
+                    _vp(S["nm"].ptr), None, None, _vp(S["mom"].ptr))
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
             self._k("irls_mu", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),

@@ -129,6 +129,20 @@ def mom(counts, sf, X, min_disp, max_disp):
     return dict(normed_mean=o[0], rough=o[1], moments=o[2], mom=o[3])
 
 
+def mom_lin_mu(counts, sf, X, min_disp, max_disp, min_mu):
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, _ = design_pack(X)
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    nm, mom_, mu = np.empty(G), np.empty(G), np.empty((G, N))
+    rc = lib().hs_mom_lin_mu(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double),
+                             _p(pinv, C.c_double), C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]),
+                             C.c_double(min_disp), C.c_double(max_disp), C.c_double(min_mu), _p(nm, C.c_double),
+                             _p(mom_, C.c_double), _p(mu, C.c_double))
+    assert rc == 0
+    return dict(normed_mean=nm, mom=mom_, mu=mu.T)
+
+
 def lin_mu(counts, sf, X, min_mu):
     y = gene_major(counts)
     G, N = y.shape

@@ -162,6 +162,21 @@ int hs_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, con
     return 0;
 }
 
+int hs_mom_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt, int ldx,
+                  int N, int G, int P_, double min_disp, double max_disp, double min_mu, double* normed_mean,
+                  double* mom, double* mu) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    double smi = 0;
+    for (int n = 0; n < N; ++n) smi += 1.0 / sf[n];
+    smi /= N;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        MomOut o = mom_lin_mu_gene<HostWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, smi, min_disp,
+                                                max_disp, min_mu, mu + (size_t)g * ldn);
+        normed_mean[g] = o.normed_mean; mom[g] = o.mom;
+    })
+    return 0;
+}
+
 int hs_wald(const double* mu, int ldn, const double* sf, const double* Xt, int ldx, int N, int G,
             int P_, const double* disp, const double* beta, const double* ridge,
             const double* contrast, double lfc_null, int alt, double* pval, double* stat,

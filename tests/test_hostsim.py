@@ -61,7 +61,12 @@ def test_sizefactor_mom_linmu(case):
     assert_close(m["moments"], k["moments"], 1e-11, 1e-14, "moments")
     assert_close(m["mom"], k["mom"], 1e-9, 0, "mom")
     assert_close(m["normed_mean"], k["normed"].mean(0), 1e-13, 0, "normed mean")
-    assert_close(hs.lin_mu(k["counts"], k["sf"], k["X"], 0.5), k["lin_mu"], 1e-10, 0, "lin mu")
+    lin = hs.lin_mu(k["counts"], k["sf"], k["X"], 0.5)
+    assert_close(lin, k["lin_mu"], 1e-10, 0, "lin mu")
+    # the fused MoM + linear mu_hat template does the same arithmetic in the same order
+    f = hs.mom_lin_mu(k["counts"], k["sf"], k["X"], 1e-8, max(10, N), 0.5)
+    assert np.array_equal(f["mom"], m["mom"]) and np.array_equal(f["normed_mean"], m["normed_mean"])
+    assert np.array_equal(f["mu"], lin)
 
 
 @pytest.mark.parametrize("case", CASES)

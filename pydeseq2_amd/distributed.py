@@ -142,15 +142,15 @@ def exchange_unique_id(ctx: Context, rank: int, world: int, addr: str, port: int
 
 # ------------------------------------------------------------------ device passes of the median
 class _DeviceSfOps:
-    def __init__(self, pipe: DeseqPipeline, d_lm):
+    def __init__(self, pipe: DeseqPipeline, d_lm, d_mask=None):
         self.p, ctx = pipe, pipe.ctx
         N, G = pipe.N, pipe.G
-        # keys only for this rank's usable genes (finite logmean): [N][Gu]
+        # keys only for this rank's usable genes (finite logmean, inside the mask if there is one): [N][Gu]
         self.d_keys = pipe._pooled((N * G,), np.uint64)
         d_idx = pipe._pooled((G + 2,), np.int32)
         gu = C.c_int(0)
-        ctx.call("dsq_dev_sf_keys_compact", _vp(pipe.d_raw.ptr), pipe._count_type, N, G, _vp(d_lm.ptr), None,
-                 _vp(d_idx.ptr), _vp(self.d_keys.ptr), C.byref(gu))
+        ctx.call("dsq_dev_sf_keys_compact", _vp(pipe.d_raw.ptr), pipe._count_type, N, G, _vp(d_lm.ptr),
+                 _vp(d_mask.ptr) if d_mask is not None else None, _vp(d_idx.ptr), _vp(self.d_keys.ptr), C.byref(gu))
         self.Gu = int(gu.value)
         self.d_cnt = pipe._pooled((N,), np.uint32)
         self.d_prefix = pipe._pooled((2 * N,), np.uint64)
@@ -184,9 +184,9 @@ class DistDeseqPipeline(DeseqPipeline):
 
     def __init__(self, counts, design_matrix, *, comm, **kw):
         super().__init__(counts, design_matrix, **kw)
-        if self.size_factors_fit_type != "ratio" or self._control_mask is not None:
-            raise NotImplementedError("the gene-sharded pipeline implements the default median-of-ratios size "
-                                      "factors only")
+        if self.size_factors_fit_type == "iterative":
+            raise NotImplementedError("the gene-sharded pipeline implements the median-of-ratios size factors "
+                                      "('ratio', 'poscounts', control genes); the iterative mode is single-GPU")
         self.comm = comm
         self._gathered = None
         # ranks may own different numbers of genes: the gathered vectors are padded to the largest shard
@@ -201,13 +201,16 @@ class DistDeseqPipeline(DeseqPipeline):
         return arr
 
     def _size_factors(self, d_lm):
-        ops = _DeviceSfOps(self, d_lm)
+        # log means and masks are per gene (local; `control_genes` index this rank's genes); the medians over
+        # the genes of all ranks come from the shared radix protocol; every rank ends with the same factors
+        d_lm, d_mask = self._sf_inputs(d_lm)
+        ops = _DeviceSfOps(self, d_lm, d_mask)
         if self.time_kernels:
             self.ctx.timer_start()
         d_sf = median_select_protocol(ops, self.comm.allreduce_sum)
         if self.time_kernels:
             self.kernel_log.setdefault("size_factors_dist", []).append((self.ctx.timer_stop(), self.G))
-        return d_sf
+        return self._sf_finish(d_sf)
 
     def _gather_trend_inputs(self, Gn):
         """All-gather (raw genewise dispersion, normalised mean) of every rank on the device: two

@@ -397,8 +397,18 @@ class DeseqPipeline:
             self._work = DeviceArray(self.ctx, (self.ctx.lib.dsq_size_factors_work_doubles(self.N, self.G),),
                                      np.float64)
         d_sf = self._dvec(self.N)
+        d_lm, d_mask = self._sf_inputs(d_lm)
+        self._k("size_factors", self.G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, self.N,
+                self.G, _vp(d_lm.ptr), _vp(d_mask.ptr) if d_mask is not None else None, _vp(self._work.ptr),
+                _vp(d_sf.ptr))
+        return self._sf_finish(d_sf)
+
+    def _sf_inputs(self, d_lm):
+        """(log means, gene mask or None) the median of ratios runs on: the plain log means of the genes
+        without zeros, or — "poscounts", dds.py:655-680 — the log geometric means over the positive counts;
+        restricted to the control genes when there are any (dds.py:631-653)."""
         d_mask = None
-        if self.size_factors_fit_type == "poscounts":  # dds.py:655-680
+        if self.size_factors_fit_type == "poscounts":
             d_lm, d_use = self._dvec(self.G), self._dvec(self.G, np.uint8)
             self.ctx.call("dsq_dev_logmeans_poscounts", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_lm.ptr),
                           _vp(d_use.ptr))
@@ -407,9 +417,9 @@ class DeseqPipeline:
                 d_mask = self._up(self._down(d_use, self.G, np.uint8) & self._control_mask, np.uint8)
         elif self._control_mask is not None:
             d_mask = self._up(self._control_mask, np.uint8)
-        self._k("size_factors", self.G, "dsq_dev_size_factors", _vp(self.d_raw.ptr), self._count_type, self.N,
-                self.G, _vp(d_lm.ptr), _vp(d_mask.ptr) if d_mask is not None else None, _vp(self._work.ptr),
-                _vp(d_sf.ptr))
+        return d_lm, d_mask
+
+    def _sf_finish(self, d_sf):
         if self.size_factors_fit_type == "poscounts":  # normalise to a geometric mean of 1
             sf = self._down(d_sf, self.N)
             d_sf = self._up(sf / np.exp(np.mean(np.log(sf))))

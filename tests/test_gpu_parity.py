@@ -274,7 +274,8 @@ def test_distributed_pipeline_world1_equals_single():
     comm.close()
 
 
-def test_distributed_pipeline_two_ranks_threads():
+@pytest.mark.parametrize("sf_mode", ["ratio", "poscounts+control"])
+def test_distributed_pipeline_two_ranks_threads(sf_mode):
     """Two gene shards run as two ranks (threads, one context each on the same GPU) through
     DistDeseqPipeline with a host-staged communicator: every rank must reproduce its slice of the
     single-GPU result on the whole matrix (size-factor radix protocol, NaN-padded all-gather of the
@@ -288,9 +289,17 @@ def test_distributed_pipeline_two_ranks_threads():
     G, N, W = 1400, 40, 2
     counts, X = orc.synth_counts(G, N, "2level", 11)
     counts[:, 3] = 0  # a gene without counts in rank 0's shard: its vectors are NaN padded
-    res_full = pydeseq2_amd.DeseqPipeline(counts, X, device=0).deseq2()
-
     cuts = [0, 600, G]  # unequal shards: the gathered vectors are padded to the larger one
+    kw_full, kw_rank = {}, [{}, {}]
+    if sf_mode != "ratio":  # poscounts log means restricted to control genes, which live on both ranks
+        counts[::3, 10:900:7] = 0
+        control = np.r_[np.arange(20, 500, 3), np.arange(700, 1300, 2)]
+        kw_full = dict(size_factors_fit_type="poscounts", control_genes=control)
+        kw_rank = [dict(size_factors_fit_type="poscounts",
+                        control_genes=control[(control >= cuts[r]) & (control < cuts[r + 1])] - cuts[r])
+                   for r in range(W)]
+    res_full = pydeseq2_amd.DeseqPipeline(counts, X, device=0, **kw_full).deseq2()
+
     barrier = threading.Barrier(W)
     slots = [None] * W
 
@@ -324,7 +333,8 @@ def test_distributed_pipeline_two_ranks_threads():
         try:
             ctx = Context(0)
             sl = slice(cuts[rank], cuts[rank + 1])
-            pipe = DistDeseqPipeline(np.ascontiguousarray(counts[:, sl]), X, comm=ThreadComm(ctx, rank), ctx=ctx)
+            pipe = DistDeseqPipeline(np.ascontiguousarray(counts[:, sl]), X, comm=ThreadComm(ctx, rank), ctx=ctx,
+                                     **kw_rank[rank])
             out[rank] = pipe.deseq2()
         except Exception as e:  # pragma: no cover
             errs.append(e)

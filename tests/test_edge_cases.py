@@ -4,7 +4,6 @@ is checked on CPU; the HIP engine is checked against the oracle on the GPU (-m g
 import warnings
 
 import numpy as np
-import pandas as pd
 import pytest
 
 from oracle import nbglm_oracle as orc

@@ -6,7 +6,6 @@ line search fails at rounding-noise level (reference falls back to a quantised g
 counted and bounded separately."""
 import numpy as np
 import pytest
-from scipy.stats import f as f_dist
 
 from oracle import nbglm_oracle as orc
 from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design

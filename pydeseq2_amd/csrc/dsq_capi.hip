@@ -671,6 +671,7 @@ int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitt
     double out2[2];
     DSQ_HIP(hipMemcpyAsync(out2, d_out, sizeof(out2), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (out2[1] < 0.0) return fail(ctx, DSQ_ERR_HIP, "prior MAD: grid barrier timed out");
     *h_squared_logres = out2[0];
     return DSQ_OK;
 }

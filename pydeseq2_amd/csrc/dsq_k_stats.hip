@@ -468,9 +468,139 @@ __global__ void k_prior_finish(const MedGlobal* S1, const MedGlobal* S2, double*
 
 constexpr int kPriorWideMin = 32768;  // below this one workgroup is faster (launch latency)
 
+// Grid-wide barrier on one monotonic counter (MI355X_MICROARCH.md "barrier-counter", ~3 us at 32
+// workgroups vs ~45 us measured for cooperative_groups::grid.sync()): agent-scope release before
+// the arrival, relaxed polling with s_sleep, agent-scope acquire after; all words exchanged across
+// workgroups are agent-scope atomics on both sides.  Launches are cooperative so all workgroups are
+// resident; a bounded spin sets *timeout instead of hanging the GPU (never observed).
+__device__ __forceinline__ void grid_barrier(unsigned int* arrive, unsigned int* timeout, unsigned int& target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 200000000u) {
+                __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    target += gridDim.x;
+}
+
+// ---- the wide medians as ONE cooperative launch: the 12 radix passes are separated by grid barriers
+// instead of kernel boundaries (28 launches of a few microseconds each were mostly launch gaps).  Per
+// pass: LDS-privatised digit histograms -> agent-scope atomics into a global histogram -> barrier ->
+// EVERY workgroup picks the digit from the same global histogram (identical state everywhere, no
+// broadcast, one barrier per pass).  Three global histograms rotate: pass p fills buffer p % 3 while
+// buffer (p + 1) % 3 — last read before barrier p - 1 — is cleared for the next pass.
+struct PriorGridMem {
+    unsigned int arrive, timeout, pad[14];
+    unsigned int hist[3][2 * 2048];
+};
+
+__global__ __launch_bounds__(1024) void k_prior_mad_grid(const double* __restrict__ gw_raw,
+                                                         const double* __restrict__ fitted, int n, double min_disp,
+                                                         double max_disp, double* __restrict__ res, PriorGridMem* Gm,
+                                                         double* __restrict__ out) {
+    __shared__ MedianShared S;
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    const int tid = threadIdx.x;
+    const int gtid = blockIdx.x * 1024 + tid, gstride = gridDim.x * 1024;
+    unsigned int target = gridDim.x;
+    // residuals of the elements this thread re-reads in every pass (thread-private: no barrier needed)
+    for (int i = gtid; i < n; i += gstride) {
+        const double g = dmin(dmax(gw_raw[i], min_disp), max_disp);
+        res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
+    }
+    double center = 0.0, med = 0.0;
+    unsigned int M1 = 0;
+    int gp = 0;
+    for (int which = 0; which < 2; ++which) {
+        for (int pass = 0; pass < 6; ++pass, ++gp) {
+            const int shift = shifts[pass];
+            const int nbins = pass == 5 ? 512 : 2048;
+            unsigned int* gh = Gm->hist[gp % 3];
+            for (int i = tid; i < 2 * 2048; i += 1024) (&S.hist[0][0])[i] = 0;
+            __syncthreads();
+            const unsigned long long p0 = pass ? S.prefix[0] : 0ull, p1 = pass ? S.prefix[1] : 0ull;
+            const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
+            for (int i = gtid; i < n; i += gstride) {
+                const double r = res[i];
+                if (r != r) continue;
+                const unsigned long long kk = f64_key(which ? fabs(r - center) : r);
+                const unsigned int d = (unsigned int)(kk >> shift) & (unsigned int)(nbins - 1);
+                if (pass == 0) {
+                    atomicAdd(&S.hist[0][d], 1u);
+                } else {
+                    if ((kk & himask) == p0) atomicAdd(&S.hist[0][d], 1u);
+                    if ((kk & himask) == p1) atomicAdd(&S.hist[1][d], 1u);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < 2 * 2048; i += 1024) {
+                const unsigned int c = (&S.hist[0][0])[i];
+                if (c) __hip_atomic_fetch_add(&gh[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (gp >= 2) {
+                unsigned int* nxt = Gm->hist[(gp + 1) % 3];
+                for (int i = gtid; i < 2 * 2048; i += gstride)
+                    __hip_atomic_store(&nxt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            grid_barrier(&Gm->arrive, &Gm->timeout, target);
+            for (int i = tid; i < 2 * 2048; i += 1024)
+                (&S.hist[0][0])[i] = __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (pass == 0) {
+                if (tid < 64) {  // total count and the two target ranks
+                    unsigned int c = 0;
+                    for (int k = tid; k < 2048; k += 64) c += S.hist[0][k];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                    if (tid == 0) {
+                        S.M = c;
+                        S.rank[0] = c ? (c - 1) / 2 : 0;
+                        S.rank[1] = c / 2;
+                        S.prefix[0] = 0ull;
+                        S.prefix[1] = 0ull;
+                    }
+                }
+                __syncthreads();
+            }
+            const int w = tid >> 6;
+            if (w < 2) {
+                unsigned int r = S.rank[w];
+                const int d = pick_digit(S.hist[pass == 0 ? 0 : w], nbins, r);
+                if ((tid & 63) == 0) {
+                    S.rank[w] = r;
+                    S.prefix[w] |= ((unsigned long long)d << shift);
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned int M = S.M;
+        const double v0 = key_f64(S.prefix[0]), v1 = key_f64(S.prefix[1]);
+        med = (M == 0) ? NAN : (((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0);
+        if (which == 0) { center = med; M1 = M; }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        const bool timed_out = __hip_atomic_load(&Gm->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const double m = med / 0.67448975019608171;  // norm.ppf(0.75)
+        out[0] = timed_out ? NAN : m * m;
+        out[1] = timed_out ? -1.0 : (double)M1;
+    }
+}
+
 // res_scratch: n doubles (+ 2 * sizeof(MedGlobal) bytes when n >= kPriorWideMin: see prior_mad_work_doubles)
 size_t prior_mad_work_doubles(int n) {
-    return (size_t)n + (n >= kPriorWideMin ? (2 * sizeof(MedGlobal) + 7) / 8 + 8 : 0);
+    const size_t state = 2 * sizeof(MedGlobal) > sizeof(PriorGridMem) ? 2 * sizeof(MedGlobal) : sizeof(PriorGridMem);
+    return (size_t)n + (n >= kPriorWideMin ? (state + 7) / 8 + 8 : 0);
 }
 
 hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
@@ -479,6 +609,19 @@ hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* 
         hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, gw_raw, fitted, n, min_disp, max_disp,
                            res_scratch, out2);
         return hipGetLastError();
+    }
+    static const bool no_grid = getenv("DSQ_PRIOR_MULTI_LAUNCH") != nullptr;
+    if (!no_grid) {  // one cooperative launch (<= 1 workgroup per CU, so all are resident)
+        PriorGridMem* gm = (PriorGridMem*)(res_scratch + (((size_t)n + 7) & ~(size_t)7));
+        hipError_t e0 = hipMemsetAsync(gm, 0, sizeof(PriorGridMem), st);
+        if (e0 != hipSuccess) return e0;
+        const int gblocks = (n + 1023) / 1024 > 256 ? 256 : (n + 1023) / 1024;
+        void* args[] = {(void*)&gw_raw, (void*)&fitted, (void*)&n,  (void*)&min_disp,
+                        (void*)&max_disp, (void*)&res_scratch, (void*)&gm, (void*)&out2};
+        if (hipLaunchCooperativeKernel((const void*)k_prior_mad_grid, dim3(gblocks), dim3(1024), args, 0, st) ==
+            hipSuccess)
+            return hipSuccess;
+        (void)hipGetLastError();  // not launchable cooperatively here: the multi-launch passes below
     }
     MedGlobal* S1 = (MedGlobal*)(res_scratch + (((size_t)n + 7) & ~(size_t)7));
     MedGlobal* S2 = S1 + 1;
@@ -1219,28 +1362,8 @@ struct TrendGridMem {  // device global memory (zeroed before every launch)
     int ipart[2][64][3];
 };
 
-// Grid-wide barrier on one monotonic counter (MI355X_MICROARCH.md "barrier-counter", ~3 us at 32
-// workgroups vs ~45 us measured for cooperative_groups::grid.sync()): agent-scope release before
-// the arrival, relaxed polling with s_sleep, agent-scope acquire after; all exchanged words are
-// agent-scope atomics on both sides.  The launch is cooperative so all workgroups are resident.
 __device__ __forceinline__ void trend_grid_barrier(TrendGridMem* Gm, unsigned int& target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&Gm->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned int spins = 0;
-        while (__hip_atomic_load(&Gm->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > 200000000u) {
-                __hip_atomic_store(&Gm->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    target += gridDim.x;
+    grid_barrier(&Gm->arrive, &Gm->timeout, target);
 }
 
 struct TrendBlockScratch {

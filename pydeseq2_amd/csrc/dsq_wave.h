@@ -34,14 +34,59 @@ struct KSum {
 };
 
 #if defined(__HIPCC__)
+// The xor butterfly of the wave reductions without the LDS crossbar (ds_bpermute): gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the wave halves / neighbouring 16-lane rows, DPP
+// row_ror:8, row_ror:4 and quad permutations do the steps inside a row.  Same partners, same order
+// (32, 16, 8, 4, 2, 1), same operand values as `v op= shfl_xor(v, m)`: bit-identical results.
+// (row_ror:4 reaches lane i +- 4 rather than i ^ 4; after the xor-8 step the values have period 8
+// inside a row, so that is the same value.)  All 64 lanes must be active, as for the shuffles.
+namespace detail {
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// (a, c): a = the value of the lower half (row) replicated, c = the value of the upper half (row)
+template <bool HALF>
+__device__ __forceinline__ void swap_i(int v, int& a, int& c) {
+    if constexpr (HALF) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        a = (int)r[0]; c = (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        a = (int)r[0]; c = (int)r[1];
+    }
+}
+template <bool HALF>
+__device__ __forceinline__ void swap_d(double v, double& a, double& c) {
+    const long long b = __double_as_longlong(v);
+    int alo, clo, ahi, chi;
+    swap_i<HALF>((int)(b & 0xffffffffll), alo, clo);
+    swap_i<HALF>((int)(b >> 32), ahi, chi);
+    a = __longlong_as_double(((long long)ahi << 32) | (unsigned int)alo);
+    c = __longlong_as_double(((long long)chi << 32) | (unsigned int)clo);
+}
+constexpr int kRor8 = 0x128, kRor4 = 0x124, kXor2 = 0x4E, kXor1 = 0xB1;
+}  // namespace detail
+
 struct DeviceWave {
     static constexpr int W = 64;
     static __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
     static __device__ __forceinline__ double sum(double v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        double a, c;
+        detail::swap_d<true>(v, a, c); v = a + c;
+        detail::swap_d<false>(v, a, c); v = a + c;
+        v += detail::dpp_d<detail::kRor8>(v);
+        v += detail::dpp_d<detail::kRor4>(v);
+        v += detail::dpp_d<detail::kXor2>(v);
+        v += detail::dpp_d<detail::kXor1>(v);
         return v;
     }
+    // (shuffles: with a NaN operand `v > o ? v : o` is not symmetric between the two partners, which the
+    // row_ror:4 step of the DPP butterfly relies on; max is not on any hot path)
     static __device__ __forceinline__ double max(double v) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -51,16 +96,23 @@ struct DeviceWave {
         return v;
     }
     static __device__ __forceinline__ int sumi(int v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        int a, c;
+        detail::swap_i<true>(v, a, c); v = a + c;
+        detail::swap_i<false>(v, a, c); v = a + c;
+        v += detail::dpp_i<detail::kRor8>(v);
+        v += detail::dpp_i<detail::kRor4>(v);
+        v += detail::dpp_i<detail::kXor2>(v);
+        v += detail::dpp_i<detail::kXor1>(v);
         return v;
     }
     static __device__ __forceinline__ int maxi(int v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const int o = __shfl_xor(v, m, 64);
-            v = v > o ? v : o;
-        }
+        int a, c;
+        detail::swap_i<true>(v, a, c); v = a > c ? a : c;
+        detail::swap_i<false>(v, a, c); v = a > c ? a : c;
+        { const int o = detail::dpp_i<detail::kRor8>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kRor4>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kXor2>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kXor1>(v); v = v > o ? v : o; }
         return v;
     }
     // exclusive prefix sum over the lanes
@@ -91,12 +143,22 @@ struct DeviceWave {
         return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     }
     static __device__ __forceinline__ double sum_comp(KSum k) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double os = __shfl_xor(k.s, m, 64);
-            const double oc = __shfl_xor(k.c, m, 64);
+        double a, c;
+        const bool up32 = (threadIdx.x & 32) != 0, up16 = (threadIdx.x & 16) != 0;
+        {
+            detail::swap_d<true>(k.s, a, c); const double os = up32 ? a : c;
+            detail::swap_d<true>(k.c, a, c); const double oc = up32 ? a : c;
             k.merge(os, oc);
         }
+        {
+            detail::swap_d<false>(k.s, a, c); const double os = up16 ? a : c;
+            detail::swap_d<false>(k.c, a, c); const double oc = up16 ? a : c;
+            k.merge(os, oc);
+        }
+        k.merge(detail::dpp_d<detail::kRor8>(k.s), detail::dpp_d<detail::kRor8>(k.c));
+        k.merge(detail::dpp_d<detail::kRor4>(k.s), detail::dpp_d<detail::kRor4>(k.c));
+        k.merge(detail::dpp_d<detail::kXor2>(k.s), detail::dpp_d<detail::kXor2>(k.c));
+        k.merge(detail::dpp_d<detail::kXor1>(k.s), detail::dpp_d<detail::kXor1>(k.c));
         return k.value();
     }
     template <int K>

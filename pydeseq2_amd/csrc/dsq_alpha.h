@@ -137,8 +137,16 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     // not enough to hide a serial  ds_read -> ds_bpermute -> use  chain per iteration).
     const int n_end = PAD ? ((A.N + Wv::W - 1) / Wv::W) * Wv::W : A.N;
     const int n_last = n_end - Wv::W + Wv::lane();  // PAD: this lane's slot of the last iteration
-    auto load_y = [&](int n) -> int { return PAD ? A.y[n < n_last ? n : n_last] : (n < A.N ? A.y[n] : 0); };
-    auto load_m = [&](int n) -> double { return PAD ? A.mu[n < n_last ? n : n_last] : (n < A.N ? A.mu[n] : 0.0); };
+    // PAD rows are this wave's LDS segment (k_alpha stages them), the others and the design are global
+    auto load_y = [&](int n) -> int {
+        if constexpr (PAD) return DSQ_AS_LDS(int32_t, A.y)[n < n_last ? n : n_last];
+        else return n < A.N ? DSQ_AS_GLOBAL(int32_t, A.y)[n] : 0;
+    };
+    auto load_m = [&](int n) -> double {
+        if constexpr (PAD) return DSQ_AS_LDS(double, A.mu)[n < n_last ? n : n_last];
+        else return n < A.N ? DSQ_AS_GLOBAL(double, A.mu)[n] : 0.0;
+    };
+    const auto Xg = DSQ_AS_GLOBAL(double, A.Xt);
     auto memo_issue = [&](int yi, double (&rl)[NB], double (&rd)[NB]) {
         const int src = yi & (Wv::W - 1);
 #pragma unroll
@@ -162,7 +170,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     double x1[P];
     if (cr_reg) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) x1[j] = A.Xt[j * A.ldx + (nl < A.N ? nl : A.N - 1)];
+        for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + (nl < A.N ? nl : A.N - 1)];
     }
     // the 4-block memo keeps 16 fetched values in flight per prefetch, which costs more registers
     // than the 168 a wave may use at 3 waves per SIMD: it fetches at the point of use instead
@@ -187,7 +195,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         if (cr_reg) {
             const int nx = nl < A.N ? nl : A.N - 1;  // padded / out-of-range samples have w = 0
 #pragma unroll
-            for (int j = 0; j < P; ++j) x1[j] = A.Xt[j * A.ldx + nx];
+            for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + nx];
         }
         double rl[NB], rd[NB];
         memo_issue(kPrefetchMemo ? y1 : yi, rl, rd);
@@ -241,7 +249,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
             const int nx = n < A.N ? n : A.N - 1;
             double x[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) x[j] = A.Xt[j * A.ldx + nx];
+            for (int j = 0; j < P; ++j) x[j] = Xg[j * A.ldx + nx];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const double xdw = x[i] * dw;
@@ -349,6 +357,8 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
                                double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
                                const double* cst_in = nullptr, double* cst_out = nullptr,
                                int memo_blocks = 1) {
+    // PAD rows are LDS-staged; the in-place grid search evaluates with PAD = false (global rows)
+    static_assert(!(RUN_GRID && PAD), "the in-place grid search expects un-staged rows");
     AlphaArgs A;
     A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = log(alpha_hat);

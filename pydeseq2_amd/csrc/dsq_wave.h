@@ -33,6 +33,17 @@ struct KSum {
     DSQ_HD double value() const { return s + c; }
 };
 
+// Pointers whose address space the compiler cannot see (they reach an out-of-line function through a
+// struct): naming it turns flat loads with 64-bit address arithmetic into ds_read / global_load with
+// immediate offsets.  Identity on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSQ_AS_LDS(T, p) ((const __attribute__((address_space(3))) T*)(p))
+#define DSQ_AS_GLOBAL(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#else
+#define DSQ_AS_LDS(T, p) (p)
+#define DSQ_AS_GLOBAL(T, p) (p)
+#endif
+
 #if defined(__HIPCC__)
 // The xor butterfly of the wave reductions without the LDS crossbar (ds_bpermute): gfx950's
 // v_permlane32_swap / v_permlane16_swap exchange the wave halves / neighbouring 16-lane rows, DPP

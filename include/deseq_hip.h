@@ -154,7 +154,8 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
  * the genes with genewise >= 100*min_disp; exact medians by radix select in one workgroup.
  * d_gw_raw: raw genewise dispersions (clipped on the fly), d_fitted: trend values, n genes,
  * d_work: dsq_prior_mad_work_doubles(n) doubles of device scratch (n residuals; for n >= 32768 the medians
- * run as multi-workgroup radix passes whose global state follows the residuals). */
+ * run as multi-workgroup radix passes — one cooperative launch with a grid barrier per pass — whose
+ * global state follows the residuals). */
 size_t dsq_prior_mad_work_doubles(int n);
 int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitted, int n,
                       double min_disp, double max_disp, double* d_work, double* h_squared_logres);

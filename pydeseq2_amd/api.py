@@ -11,6 +11,7 @@ with the first sorted level as reference, numeric columns enter as they are) or 
 from __future__ import annotations
 
 import re
+import warnings
 
 import numpy as np
 import pandas as pd
@@ -91,6 +92,23 @@ def build_design(metadata: pd.DataFrame, design, ref_level=None) -> pd.DataFrame
     return out
 
 
+def check_counts(counts) -> None:
+    """Non-negative integers only, no NaNs (what ``utils.test_valid_counts`` enforces, utils.py:110-133; same
+    messages).  Runs on the host before anything is uploaded."""
+    arr = counts.to_numpy() if isinstance(counts, pd.DataFrame) else np.asarray(counts)
+    if not np.issubdtype(arr.dtype, np.number):
+        if isinstance(counts, pd.DataFrame) and counts.isna().any().any():
+            raise ValueError("NaNs are not allowed in the count matrix.")
+        raise ValueError("The count matrix should only contain numbers.")
+    if arr.dtype.kind == "f":
+        if np.isnan(arr).any():
+            raise ValueError("NaNs are not allowed in the count matrix.")
+        if (arr % 1 != 0).any():
+            raise ValueError("The count matrix should only contain integers.")
+    if (arr < 0).any():
+        raise ValueError("The count matrix should only contain non-negative values.")
+
+
 class DeseqDataSet:
     """Counts + metadata + design, fitted on the GPU (cf. ``pydeseq2.dds.DeseqDataSet``, dds.py:206-340)."""
 
@@ -112,8 +130,7 @@ class DeseqDataSet:
             counts = pd.DataFrame(np.asarray(counts))
         if counts.shape[0] != metadata.shape[0]:
             raise ValueError("counts (samples x genes) and metadata disagree on the number of samples")
-        if counts.isna().any().any():
-            raise ValueError("NaNs are not allowed in the count matrix.")
+        check_counts(counts)
         self.obs = metadata.loc[counts.index].copy() if set(counts.index) == set(metadata.index) else metadata.copy()
         self.obs_names, self.var_names = counts.index, counts.columns
         self.X = counts.to_numpy()
@@ -121,6 +138,11 @@ class DeseqDataSet:
         self.design = design
         dm = build_design(self.obs, design, ref_level)
         self.obsm = {"design_matrix": dm}
+        if np.linalg.matrix_rank(dm.to_numpy()) < dm.shape[1]:  # dds.py:1550-1563
+            warnings.warn("The design matrix is not full rank, so the model cannot be fitted, but some operations "
+                          "like design-free VST remain possible. To perform differential expression analysis, "
+                          "please remove the design variables that are linear combinations of others.",
+                          UserWarning, stacklevel=2)
         self.var = pd.DataFrame(index=self.var_names)
         self.varm, self.layers, self.uns = {}, _LazyLayers(self), {}
         self.refit_cooks, self.fit_type, self.quiet = refit_cooks, fit_type, quiet

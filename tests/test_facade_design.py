@@ -54,3 +54,39 @@ def test_interactions():
     assert list(dm2.columns) == ["Intercept", "g[T.Y]", "c[T.B]", "g[T.Y]:x"]
     assert np.array_equal(dm2["g[T.Y]:x"], dm2["g[T.Y]"] * meta["x"])
     assert np.linalg.matrix_rank(dm.to_numpy()) == 4
+
+
+def test_count_validation_on_the_host():
+    """The reference's constructor checks (tests/test_edge_cases.py: test_nan_counts, test_numeric_counts,
+    test_integer_counts, test_non_negative_counts) run before anything touches the GPU."""
+    from pydeseq2_amd.api import DeseqDataSet, check_counts
+
+    meta = pd.DataFrame({"condition": list("ABABAB")}, index=[f"s{i}" for i in range(6)])
+    good = pd.DataFrame(np.arange(18).reshape(6, 3), index=meta.index, columns=list("xyz"))
+    check_counts(good)
+    check_counts(good.astype(float))
+    check_counts(good.to_numpy())
+    cases = {
+        "NaNs are not allowed": good.astype(float).mask(good == 4),
+        "only contain numbers": good.astype(str),
+        "only contain integers": good + 0.5,
+        "non-negative": good - 3,
+    }
+    for msg, bad in cases.items():
+        with pytest.raises(ValueError, match=msg):
+            DeseqDataSet(counts=bad, metadata=meta, design="~condition")
+    with pytest.raises(ValueError, match="number of samples"):
+        DeseqDataSet(counts=good.iloc[:4], metadata=meta, design="~condition")
+
+
+def test_rank_deficient_design_warns():
+    """tests/test_edge_cases.py::test_rank_deficient_design: a warning, not an error, at construction."""
+    from pydeseq2_amd.api import DeseqDataSet
+
+    meta = pd.DataFrame({"a": list("XXYYXXYY"), "b": list("PPQQPPQQ")}, index=[f"s{i}" for i in range(8)])
+    counts = pd.DataFrame(np.arange(16).reshape(8, 2) + 1, index=meta.index, columns=["g1", "g2"])
+    with pytest.warns(UserWarning, match="not full rank"):
+        try:
+            DeseqDataSet(counts=counts, metadata=meta, design="~a + b")
+        except Exception:  # noqa: BLE001 - without a GPU the pipeline behind the facade cannot be created
+            pass

@@ -126,12 +126,19 @@ class DeseqDataSet:
             for cf in continuous_factors or []:
                 metadata = metadata.copy()
                 metadata[cf] = metadata[cf].astype(float)
-        if not isinstance(counts, pd.DataFrame):
+        named = isinstance(counts, pd.DataFrame)
+        if not named:
             counts = pd.DataFrame(np.asarray(counts))
         if counts.shape[0] != metadata.shape[0]:
             raise ValueError("counts (samples x genes) and metadata disagree on the number of samples")
         check_counts(counts)
-        self.obs = metadata.loc[counts.index].copy() if set(counts.index) == set(metadata.index) else metadata.copy()
+        same = set(counts.index) == set(metadata.index)
+        if named and not same:  # AnnData refuses this in the reference (tests/test_edge_cases.py::test_indexes)
+            raise ValueError("The count matrix and the metadata should have the same sample index.")
+        self.obs = metadata.loc[counts.index].copy() if same else metadata.copy()
+        if isinstance(design, pd.DataFrame) and not (len(design) == len(self.obs)
+                                                       and (design.index == self.obs.index).all()):
+            raise ValueError("The design matrix and the metadata should have the same sample index.")
         self.obs_names, self.var_names = counts.index, counts.columns
         self.X = counts.to_numpy()
         self.n_obs, self.n_vars = self.X.shape

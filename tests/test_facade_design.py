@@ -90,3 +90,18 @@ def test_rank_deficient_design_warns():
             DeseqDataSet(counts=counts, metadata=meta, design="~a + b")
         except Exception:  # noqa: BLE001 - without a GPU the pipeline behind the facade cannot be created
             pass
+
+
+def test_sample_indexes_must_match():
+    """tests/test_edge_cases.py::test_indexes and ::test_matching_samples."""
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts = pd.DataFrame({"gene1": [0, 1, 55], "gene2": [4, 12, 60]}, index=["sample1", "sample2", "sample3"])
+    meta = pd.DataFrame({"condition": [0, 1, 0]}, index=["sample1", "sample2", "sample3"])
+    with pytest.raises(ValueError):
+        DeseqDataSet(counts=counts, metadata=meta.set_axis(["sample01", "sample02", "sample03"]), design="~condition")
+    for idx, rows in ((["sample1", "sample2", "sample5"], 3), (["sample1", "sample2"], 2),
+                      (["sample1", "sample2", "sample3", "sample4"], 4)):
+        dm = pd.DataFrame({"intercept": [1.0] * rows, "condition": [0, 1, 0, 0][:rows]}, index=idx)
+        with pytest.raises(ValueError):
+            DeseqDataSet(counts=counts, metadata=meta, design=dm)

@@ -292,15 +292,22 @@ class DeseqStats:
         self.shrunk_LFCs = False
 
     def _contrast_vector(self, contrast) -> np.ndarray:
+        # errors as in the reference (ds.py:172-188, tests/test_edge_cases.py::test_contrast): IndexError for a
+        # list that is too short, ValueError for unknown factors / levels and for a vector of the wrong length
         cols = list(self.design_matrix.columns)
-        if isinstance(contrast, np.ndarray) or (len(contrast) == len(cols) and not isinstance(contrast[0], str)):
-            return np.asarray(contrast, dtype=float)
-        factor, tested, ref = (str(c) for c in contrast)
+        if contrast is None:
+            raise ValueError('Default contrasts are no longer supported. The "contrast" argument must be provided.')
+        if isinstance(contrast, np.ndarray) or not isinstance(contrast[0], str):
+            v = np.asarray(contrast, dtype=float)
+            if v.shape[0] != len(cols):
+                raise ValueError("The contrast vector must have the same length as the design matrix.")
+            return v
+        factor, tested, ref = str(contrast[0]), str(contrast[1]), str(contrast[2])
         if factor not in self.dds.obs.columns:
-            raise KeyError(f"The contrast variable ('{factor}') should be one of the design factors.")
+            raise ValueError(f"The contrast variable ('{factor}') should be one of the design factors.")
         levels = sorted(self.dds.obs[factor].astype(str).unique())
         if tested not in levels or ref not in levels:
-            raise KeyError(f"The contrast levels ({tested}, {ref}) should be levels of '{factor}': {levels}.")
+            raise ValueError(f"The contrast levels ({tested}, {ref}) should be levels of '{factor}': {levels}.")
         v = np.zeros(len(cols))
         for lv, sign in ((tested, 1.0), (ref, -1.0)):
             name = f"{factor}[T.{lv}]"

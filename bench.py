@@ -112,6 +112,19 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without a launcher: re-run under torch.distributed.run, one rank per GPU
+        # (the driver launches the ranks itself and never takes this branch)
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

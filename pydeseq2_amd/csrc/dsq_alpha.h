@@ -91,9 +91,22 @@ DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double
 #else
 #define DSQ_EVAL_FN inline
 #endif
+// -DDSQ_EVAL_BYVAL (an experiment prepared for an A/B run on the GPU, off by default): the argument struct
+// and the two results travel in registers instead of through the caller's stack frame, which removes the
+// 12 flat scratch loads and 6 stores at the function's entry and exit.  The default build preprocesses to
+// exactly the code that was validated.
+#if defined(DSQ_EVAL_BYVAL)
+struct EvalOut {
+    double f, g;
+};
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+DSQ_EVAL_FN EvalOut alpha_eval_v(const AlphaArgs A, double la, bool cr_reg, bool prior_reg) {
+    double f, g;
+#else
 template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
 DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
                        double& g) {
+#endif
     constexpr int T = Tri<P>::N;
     constexpr bool kSplitDM = P >= 9;
     DSQ_PHASE(2);
@@ -281,7 +294,19 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         f += dl * dl / (2.0 * A.prior_var);
         if (GRAD) g += dl / A.prior_var;
     }
+#if defined(DSQ_EVAL_BYVAL)
+    return EvalOut{f, g};
+#endif
 }
+
+#if defined(DSQ_EVAL_BYVAL)
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f, double& g) {
+    const EvalOut o = alpha_eval_v<Wv, P, GRAD, PAD, NB>(A, la, cr_reg, prior_reg);
+    f = o.f;
+    g = o.g;
+}
+#endif
 
 // numpy.linspace(lo, hi, num)[i]
 DSQ_HD double linspace_at(double lo, double hi, int num, int i) {

@@ -65,3 +65,40 @@ def test_dispersion_fit_across_count_magnitudes(mean_log2, disp, tol):
     both = np.asarray(conv_o, bool) & np.asarray(conv_h, bool)
     assert both.mean() > 0.9
     assert np.max(np.abs(a_h - a_o)[both] / a_o[both]) < tol
+
+
+def test_trend_fit_failure_modes_and_odd_inputs():
+    """The trend-fit template agrees with the oracle's restatement of dds.py:1199-1275 on coefficients, on the
+    number of outer (re-filtering) iterations and on WHEN the fit is declared failed (flat / increasing / pure-noise
+    dispersions -> mean trend), with outliers, genes at min_disp, a handful of genes, NaN means."""
+    import warnings
+
+    rng = np.random.default_rng(0)
+    G = 400
+    nm = np.exp(rng.normal(4, 2, G))
+    true = 0.05 + 3.0 / nm
+    noisy = lambda s=0.3: true * np.exp(rng.normal(0, s, G))  # noqa: E731
+    outl = noisy()
+    outl[::17] *= 1e4
+    at_min = true.copy()
+    at_min[:200] = 1e-8
+    cases = {
+        "clean": (noisy(), nm), "few": (noisy()[:12], nm[:12]), "outliers": (outl, nm),
+        "flat": (np.full(G, 0.2) * np.exp(rng.normal(0, 0.05, G)), nm),
+        "increasing": ((0.01 + nm * 1e-3) * np.exp(rng.normal(0, 0.2, G)), nm),
+        "noise": (np.exp(rng.normal(-2, 3, G)), nm), "at_min": (at_min * np.exp(rng.normal(0, 0.3, G)), nm),
+        "nan_means": (noisy(), np.where(np.arange(G) % 9 == 0, np.nan, nm)),
+    }
+    failed = set()
+    for name, (gw, means) in cases.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            co, n_outer = orc.fit_parametric_trend(np.clip(gw, 1e-8, 100.0), means)
+        ch, ok, no = hs.trend_fit(gw, means, 1e-8, 100.0)
+        assert ok == (co is not None), name
+        assert no == n_outer, name
+        if ok:
+            assert rel(ch, co) < 1e-9, name
+        else:
+            failed.add(name)
+    assert failed == {"flat", "increasing", "noise"}

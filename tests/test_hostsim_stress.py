@@ -102,3 +102,23 @@ def test_trend_fit_failure_modes_and_odd_inputs():
         else:
             failed.add(name)
     assert failed == {"flat", "increasing", "noise"}
+
+
+@pytest.mark.parametrize("name,mean_log2,disp,design,N,scale", [
+    ("huge", 22.0, 0.01, "2level", 40, 1.0), ("tiny", -2.0, 0.5, "2level", 40, 0.3),
+    ("wide", 6.0, 0.3, "3factor", 90, 0.5), ("mixed", 7.0, 0.2, "mixed", 48, 1.0),
+    ("tight_prior", 6.0, 0.2, "2level", 30, 0.01), ("six_samples", 8.0, 0.1, "2level", 6, 1.0)])
+def test_apeglm_templates_far_from_the_benchmark_regime(name, mean_log2, disp, design, N, scale):
+    import warnings
+
+    c, X, sf = make(20, N, mean_log2, disp, 5, design)
+    G, P = c.shape[1], X.shape[1]
+    size, off = np.full(G, 1 / disp), np.log(sf)
+    bh, ih, cvh = hs.shrink(c, X, size, off, 15.0, scale, 1)
+    for g in range(G):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bo, io, cvo = orc.nbinom_glm_gene(X, c[:, g], size[g], off, 15.0, scale, 1)
+        assert bool(cvh[g]) == bool(cvo)
+        assert np.max(np.abs(bh[g] - bo) / np.maximum(np.abs(bo), 1e-6)) < 1e-8
+        assert np.max(np.abs(ih[g] - io)) / np.abs(io).max() < 1e-9

@@ -35,6 +35,7 @@ import warnings
 from dataclasses import dataclass, field
 
 import numpy as np
+from scipy.linalg import solve as sp_solve
 from scipy.optimize import minimize
 from scipy.special import gammaln, polygamma
 from scipy.stats import f as f_dist
@@ -416,7 +417,8 @@ def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=
     disp = np.asarray(disp, dtype=float)
     ridge = np.diag(np.repeat(1e-6, p))
     with np.errstate(divide="ignore"):
-        if np.linalg.matrix_rank(X) == p:  # utils.py:349-353
+        full_rank = np.linalg.matrix_rank(X) == p
+        if full_rank:  # utils.py:349-353
             Q, R = np.linalg.qr(X)
             beta_init = np.linalg.solve(R, Q.T @ np.log(counts / sf[:, None] + 0.1))
         else:  # utils.py:354-357
@@ -441,8 +443,14 @@ def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=
         bad = (np.abs(bh) > max_beta).any(1) | (iters[idx] >= maxiter)
         for k in np.nonzero(bad)[0]:
             g = idx[k]
-            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], beta_init[:, g], min_mu,
-                                   min_beta, max_beta)
+            # the rescue restarts from beta_init; its termination flag on these ill-conditioned genes reacts to
+            # the last bit of the start point, so it is recomputed per gene with the reference's own calls
+            # (utils.py:349-353: scipy.linalg.solve on the gene's vector, not the batched matrix product)
+            b0 = beta_init[:, g]
+            if full_rank:
+                with np.errstate(divide="ignore"):
+                    b0 = sp_solve(R, Q.T @ np.log(counts[:, g] / sf + 0.1))
+            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], b0, min_mu, min_beta, max_beta)
             beta[:, g] = b
             mu[:, g] = np.maximum(sf * np.exp(X @ b), min_mu)
             converged[g] = ok

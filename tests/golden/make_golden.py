@@ -44,13 +44,13 @@ def _import_reference():
     return ut, gs, pp, di
 
 
-def synth(G, N, X, seed):
+def synth(G, N, X, seed, eff=0.7):
     rng = np.random.default_rng(seed)
     p = X.shape[1]
     beta = np.zeros((p, G))
     beta[0] = rng.normal(4, 2, G)
     for j in range(1, p):
-        beta[j] = rng.normal(0, 0.7, G)
+        beta[j] = rng.normal(0, eff, G)
     disp = 4 / np.maximum(2.0 ** beta[0], 1e-3) + 0.1
     sf = np.exp(rng.normal(0, 0.2, N))
     mu = sf[:, None] * 2.0 ** (X @ beta)
@@ -162,8 +162,101 @@ def kat_case(name, counts, X, ut, gs, pp, di, n_grid=3):
           "map non-converged", int((~out["map_conv"]).sum()))
 
 
+
+def hard_cases(ut, gs):
+    """Genes on which the reference leaves its main optimiser and takes a grid search (kat_hard.npz).
+
+    * dispersion (fit_alpha_mle, utils.py:546-564): very large counts make scipy's L-BFGS-B line search end in
+      the rounding noise of the loss (success = False) -> exp(grid_fit_alpha(...));
+    * LFC (irls_solver, utils.py:374-413): IRLS diverges (|beta| > 30: a group without counts, a huge outlier)
+      and the bounded L-BFGS-B rescue terminates ABNORMALly on the min_mu kink -> grid_fit_beta(...).
+    Every candidate gene of the seeded search is kept (no selection on what any other implementation does)."""
+    import warnings
+
+    out = {}
+    N = 40
+    X = np.column_stack([np.ones(N), (np.arange(N) % 2).astype(float)])
+    rng = np.random.default_rng(77)
+    sf = np.exp(rng.normal(0, 0.2, N))
+    out["X"], out["sf"] = X, sf
+    # ---- dispersion
+    G = 600
+    b0, lfc = rng.uniform(12, 22, G), rng.normal(0, 1, G)
+    disp = 10 ** rng.uniform(-2.5, 0.0, G)
+    mu = sf[:, None] * 2.0 ** (b0[None, :] + X[:, 1:2] * lfc[None, :])
+    Y = rng.negative_binomial(1 / disp[None, :], 1 / (1 + mu * disp[None, :])).astype(np.int64)
+    Y = Y[:, Y.max(0) < 2**30]
+    normed = Y / sf[:, None]
+    mom = np.clip(np.minimum(ut.fit_rough_dispersions(normed, X), ut.fit_moments_dispersions(normed, sf)), 1e-8, 40.0)
+    mu_hat = np.stack([ut.fit_lin_mu(Y[:, g], sf, X, 0.5) for g in range(Y.shape[1])], axis=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = [ut.fit_alpha_mle(Y[:, g], X, mu_hat[:, g], mom[g], 1e-8, 40.0) for g in range(Y.shape[1])]
+    conv = np.array([x[1] for x in r], dtype=bool)
+    sel = np.r_[np.nonzero(~conv)[0][:24], np.nonzero(conv)[0][:8]]
+    out["a_counts"], out["a_mu_hat"], out["a_mom"] = Y[:, sel], mu_hat[:, sel], mom[sel]
+    out["a_alpha"] = np.array([r[g][0] for g in sel])
+    out["a_conv"] = conv[sel]
+    out["a_grid_log_alpha"] = np.array(
+        [gs.grid_fit_alpha(Y[:, g], X, mu_hat[:, g], mom[g], 1e-8, 40.0) for g in sel])
+    # ---- LFC
+    found = []
+    state = {}
+    orig = ut.minimize
+
+    def spy(*a, **k):
+        state["res"] = orig(*a, **k)
+        return state["res"]
+
+    ut.minimize = spy
+    try:
+        for trial in range(1200):
+            kind = trial % 4
+            base, lf = 2.0 ** rng.uniform(-3, 6), rng.normal(0, 3)
+            m = sf * base * np.exp(X[:, 1] * lf)
+            dtrue = 10 ** rng.uniform(-3, 1.3)
+            y = rng.negative_binomial(1 / dtrue, 1 / (1 + m * dtrue)).astype(np.int64)
+            if kind == 1:
+                y[X[:, 1] == 1] = 0
+            if kind == 2:
+                y[X[:, 1] == 0] = 0
+            if kind == 3:
+                y[rng.integers(0, N)] = int(10 ** rng.uniform(3, 7))
+            if y.sum() == 0:
+                continue
+            d = 10 ** rng.uniform(-8, 1.6)
+            state.pop("res", None)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                b, mu_, H, cv = ut.irls_solver(y, sf, X, d, 0.5, 1e-8)
+            if "res" in state and not state["res"].success:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    gb = gs.grid_fit_beta(y, sf, X, d)
+                found.append((y, d, b, mu_, H, cv, state["res"].x.copy(), gb))
+            if len(found) >= 32:
+                break
+    finally:
+        ut.minimize = orig
+    out["b_counts"] = np.stack([f[0] for f in found], axis=1)
+    out["b_disp"] = np.array([f[1] for f in found])
+    out["b_beta"] = np.stack([f[2] for f in found])
+    out["b_mu"] = np.stack([f[3] for f in found], axis=1)
+    out["b_H"] = np.stack([f[4] for f in found], axis=1)
+    out["b_conv"] = np.array([f[5] for f in found], dtype=bool)
+    out["b_rescue_x"] = np.stack([f[6] for f in found])
+    out["b_grid_beta"] = np.stack([f[7] for f in found])
+    np.savez_compressed(os.path.join(HERE, "kat_hard.npz"), **out)
+    print("hard: dispersion genes", len(sel), "non-converged", int((~out["a_conv"]).sum()),
+          "| LFC genes with a failed rescue", len(found))
+
+
 def main():
     ut, gs, pp, di = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
+        wide_cases(ut, gs, pp, di)
+        hard_cases(ut, gs)
+        return
     # case A: 2-level factor (linear-mu route), p = 2
     N = 40
     X = np.column_stack([np.ones(N), (np.arange(N) % 2).astype(float)])
@@ -182,6 +275,26 @@ def main():
     cols = [np.ones(N), (a == 1)] + [(b == k) for k in (1, 2)] + [(c == k) for k in (1, 2, 3, 4)]
     X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
     kat_case("p8", synth(48, N, X, 13), X, ut, gs, pp, di)
+
+    wide_cases(ut, gs, pp, di)
+    hard_cases(ut, gs)
+    rest_of_main(ut)
+
+
+def wide_cases(ut, gs, pp, di):
+    # cases D..G: wide designs (two categorical factors + continuous covariates): p = 10, 12 exercise the
+    # split second sweep of the register path, p = 16 and 24 the LDS path for designs beyond 12 columns
+    for pw, N, seed in ((10, 80, 14), (12, 96, 15), (16, 128, 16), (24, 168, 17)):
+        rng = np.random.default_rng(100 + pw)
+        a, b = np.arange(N) % 2, (np.arange(N) // 2) % 4
+        cols = [np.ones(N), (a == 1)] + [(b == k) for k in (1, 2, 3)]
+        while len(cols) < pw:
+            cols.append(rng.normal(0, 0.6, N))
+        X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
+        kat_case(f"p{pw}", synth(32, N, X, seed, eff=0.35), X, ut, gs, pp, di)
+
+
+def rest_of_main(ut):
 
     # apeGLM MAP LFC known answers: the reference's utils.nbinomGLM per gene
     sh = {}

@@ -9,7 +9,7 @@ import pytest
 from oracle import nbglm_oracle as orc
 from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design
 
-CASES = ["p2", "p4", "p8"]
+CASES = ["p2", "p4", "p8", "p10", "p12", "p16", "p24"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -62,6 +62,25 @@ def test_grid_beta():
     for g in range(len(k["grid_beta"])):
         b = orc.grid_fit_beta(k["counts"][:, g], k["sf"], k["X"], disp[g])
         assert np.abs(b - k["grid_beta"][g]).max() < 1e-12
+
+
+def test_hard_genes_grid_fallbacks():
+    """kat_hard.npz: genes on which the unmodified reference leaves its optimiser for a grid search
+    (fit_alpha_mle -> grid_fit_alpha, utils.py:556-564; irls_solver -> grid_fit_beta, utils.py:404-411)."""
+    k = load_kat("hard")
+    X, sf = k["X"], k["sf"]
+    a, c = orc.alpha_mle(k["a_counts"], X, k["a_mu_hat"], k["a_mom"], 1e-8, 40.0)
+    assert (c == k["a_conv"]).all() and (~c).sum() >= 10
+    assert_close(a, k["a_alpha"], 1e-12, 0, "alpha incl. the grid fallback")
+    for g in range(len(k["a_mom"])):
+        la = orc.grid_fit_alpha(k["a_counts"][:, g], X, k["a_mu_hat"][:, g], k["a_mom"][g], 1e-8, 40.0)
+        assert abs(la - k["a_grid_log_alpha"][g]) < 1e-12
+    b, mu, H, conv = orc.irls(k["b_counts"], sf, X, k["b_disp"], 0.5, 1e-8)
+    assert (conv == k["b_conv"]).all() and not conv.any()
+    assert_close(b, k["b_beta"], 1e-10, 1e-12, "beta after the grid fallback")
+    assert_close(b, k["b_grid_beta"], 1e-12, 1e-12, "= grid_fit_beta")
+    assert_close(mu, k["b_mu"], 1e-9, 1e-12, "mu")
+    assert_close(H, k["b_H"], 1e-8, 1e-12, "H")
 
 
 @pytest.mark.parametrize("case", CASES)

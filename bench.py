@@ -9,11 +9,12 @@ one-off int64 -> int32 gene-major transposition happen in DeseqPipeline.__init__
 it; the per-gene result vectors ARE copied back to the host inside it).
 
 Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py
---gpus N ...`): genes shard across ranks (every rank owns `genes` genes x all samples:
-weak scaling); the two cross-gene steps are exchanged in DistDeseqPipeline (size-factor
-medians by a distributed radix select whose per-sample digit histograms are all-reduced,
-trend/prior on all-gathered per-gene vectors).  torch.distributed is used only as the
-rendezvous / collective transport of this harness.
+--gpus N ...`): genes shard across ranks.  `--scaling weak` (default): every rank owns `genes`
+genes x all samples; `--scaling strong`: the config's genes are split over the ranks (BASELINE
+configs[2]: "60k x 1k, 1 vs 8 MI355X gene-shard").  The two cross-gene steps are exchanged in
+DistDeseqPipeline over RCCL (size-factor medians, trend/prior on all-gathered per-gene vectors).
+The harness itself is torch-free: the RCCL unique id travels over a TCP socket
+(pydeseq2_amd.distributed.exchange_unique_id), barriers and the max-over-ranks are RCCL all-gathers.
 
 Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
   roofline     — dominant kernel (dispersion MLE/MAP, k_alpha): algorithmic bytes per launch
@@ -21,6 +22,11 @@ Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objec
                  duration measured with HIP events on the launch stream, vs 8 TB/s HBM peak
   cpu_baseline — the oracle (numpy/scipy restatement of the reference, joblib over host cores)
                  timed on a bounded gene sample of the same workload.
+  parity       — the engine re-run on exactly the gene slice the oracle just computed, compared in-run
+                 (north-star tolerance 1e-5 on LFC / dispersions / p-values); the speed-up is only
+                 reported when it holds.
+  h2d_ms / value_with_h2d — the upload of the host count matrix (int64 as the reference holds it) and the
+                 one-off transposition, and the rate that includes them.
 """
 import argparse
 import json
@@ -63,42 +69,75 @@ def cpu_baseline(counts, X, n_sample, n_jobs):
         orc.deseq2(np.ascontiguousarray(counts[:, : 2 * n_jobs]), X, n_jobs=n_jobs, keep_layers=False)  # warm the pool
         sub = np.ascontiguousarray(counts[:, :n_sample])
         t = time.perf_counter()
-        orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
+        ref = orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
         dt = time.perf_counter() - t
-    return sub.shape[1] / dt, dt
+    return sub.shape[1] / dt, dt, sub, ref
 
 
-class GlooHostComm:
-    """Harness-only fallback transport (same allreduce_sum / allgather interface as RcclComm): stages the
-    small exchange buffers (<= 2 MB) through the host and torch.distributed/gloo.  Used only if the RCCL
-    communicator cannot be brought up on some rank; the JSON line then says so."""
+PARITY_TOL = {"dispersions": 1e-5, "LFC": 1e-5, "lfcSE": 1e-5, "pvalue": 2e-5}  # p-values amplify d(stat) by |stat|
+PARITY_MAX_NOISE_FRAC = 0.002
 
-    def __init__(self, ctx, dist, rank, world):
-        self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+
+def parity_report(res, ref):
+    """Engine vs oracle on the same matrix: max relative errors over the genes on which both L-BFGS-B runs
+    agree about convergence; the genes on which they disagree (line search decided inside rounding noise:
+    one side returns its iterate, the other the quantised grid value) are counted and reported separately."""
+    def rel(a, b, floor):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        both_nan = np.isnan(a) & np.isnan(b)
+        d = np.abs(a - b) / np.maximum(np.abs(b), floor)
+        d[both_nan] = 0.0
+        d[np.isnan(d)] = np.inf  # NaN on one side only
+        return d
+
+    nz = ref.non_zero
+    with np.errstate(invalid="ignore"):
+        noisy = (res.genewise_converged != ref.genewise_converged) | (res.MAP_converged != ref.MAP_converged)
+    noisy &= nz
+    noisy |= res.refitted != ref.refitted
+    ok = ~noisy
+    errs = {
+        "dispersions": rel(res.dispersions, ref.dispersions, 1e-300),
+        "LFC": rel(res.LFC, ref.LFC, 1e-3).max(axis=1),  # |LFC| floor 1e-3 (natural log): absolute 1e-8
+        "lfcSE": rel(res.lfcSE, ref.lfcSE, 1e-300),
+        "pvalue": rel(res.pvalue, ref.pvalue, 1e-300),
+    }
+    max_rel = {k: float(v[ok].max()) if ok.any() else 0.0 for k, v in errs.items()}
+    max_noise = {k: float(v[noisy].max()) if noisy.any() else 0.0 for k, v in errs.items()}
+    untouched = nz & ~res.refitted & ~ref.refitted
+    both = untouched & (((res.genewise_converged == 0) & (ref.genewise_converged == 0))
+                        | ((res.MAP_converged == 0) & (ref.MAP_converged == 0)))
+    G = len(nz)
+    good = (all(max_rel[k] <= PARITY_TOL[k] for k in PARITY_TOL)
+            and noisy.sum() <= max(2, PARITY_MAX_NOISE_FRAC * G)
+            and float(np.max(np.abs(res.size_factors - ref.size_factors) / ref.size_factors)) < 1e-12
+            and bool((res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()))
+    return {"genes": int(G), "tolerance": PARITY_TOL, "max_rel": {k: float(f"{v:.3e}") for k, v in max_rel.items()},
+            "n_noise_genes": int(noisy.sum()), "frac_noise": round(float(noisy.sum()) / G, 6),
+            "max_rel_noise": {k: float(f"{v:.3e}") for k, v in max_noise.items()},
+            "n_grid_on_both_sides": int(both.sum()),
+            "size_factors_max_rel": float(f"{np.max(np.abs(res.size_factors - ref.size_factors) / ref.size_factors):.3e}"),
+            "ok": bool(good)}
+
+
+class _TimedComm:
+    """Wraps a communicator for the profiled step: HIP-event time of every collective on the engine's stream."""
+
+    def __init__(self, comm, ctx, log):
+        self.comm, self.ctx, self.log = comm, ctx, log
+        self.rank, self.world = comm.rank, comm.world
+
+    def _timed(self, name, fn, *a):
+        self.ctx.timer_start()
+        out = fn(*a)
+        self.log.append((name, self.ctx.timer_stop()))
+        return out
 
     def allreduce_sum(self, darr):
-        import torch
-
-        n = darr.nbytes // darr.dtype.itemsize
-        host = np.empty(n, dtype=darr.dtype)
-        self.ctx.d2h(host, darr.ptr)
-        t = torch.from_numpy(host.view(np.int32) if host.dtype == np.uint32 else host)
-        self.dist.all_reduce(t)
-        self.ctx.h2d(darr.ptr, host)
-        return darr
+        return self._timed("allreduce", self.comm.allreduce_sum, darr)
 
     def allgather(self, dsend, drecv):
-        import torch
-
-        host = np.empty(dsend.nbytes // 8, dtype=np.float64)
-        self.ctx.d2h(host, dsend.ptr)
-        out = [torch.empty(len(host), dtype=torch.float64) for _ in range(self.world)]
-        self.dist.all_gather(out, torch.from_numpy(host))
-        self.ctx.h2d(drecv.ptr, np.concatenate([o.numpy() for o in out]))
-        return drecv
-
-    def close(self):
-        pass
+        return self._timed("allgather", self.comm.allgather, dsend, drecv)
 
 
 def main():
@@ -107,9 +146,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--genes", type=int, default=0, help="override genes per GPU")
+    ap.add_argument("--genes", type=int, default=0, help="override the config's gene count")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns the config's genes; strong: they are split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the summary-tail / shrinkage / c4-parity extras")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -128,59 +170,60 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    G, N, design = CONFIGS[args.config]
+    G_cfg, N, design = CONFIGS[args.config]
     if args.genes:
-        G = args.genes
-
-    dist = None
-    if world > 1:
-        # control plane of this harness only (barrier, max-over-ranks, unique-id broadcast);
-        # the data-path collectives are RCCL calls made by the product through its C ABI
-        import torch.distributed as dist
-
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        G_cfg = args.genes
+    # genes owned by this rank
+    if args.scaling == "strong" and world > 1:
+        cuts = np.linspace(0, G_cfg, world + 1).astype(int)
+        G = int(cuts[rank + 1] - cuts[rank])
+        G_total = G_cfg
+    else:
+        G, G_total = G_cfg, G_cfg * world
 
     import pydeseq2_amd
     from pydeseq2_amd._lib import Context
+    from pydeseq2_amd.distributed import DistDeseqPipeline, TcpControl, bring_up_comm
 
+    # control plane of this harness (unique-id broadcast, barriers, max-over-ranks): a TCP star on rank 0;
+    # the data-path collectives are RCCL calls the product makes through its C ABI
+    control = TcpControl(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                         int(os.environ.get("MASTER_PORT", "29500")))
     ctx = Context(local_rank)
     info = ctx.device_info()
-    t_gen = time.perf_counter()
-    counts, X = synth_fast(G, N, design, seed=1000 * rank + {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config])
-    t_gen = time.perf_counter() - t_gen
-
-    if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
-        from pydeseq2_amd.distributed import DistDeseqPipeline, RcclComm
-
-        transport = "rccl"
-        try:
-            box = [RcclComm.unique_id(ctx) if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(box, src=0)
-            comm = RcclComm(ctx, box[0], rank, world)
-            ok = 1
-        except Exception as e:  # noqa: BLE001 - any bring-up failure falls back, loudly
-            print(f"[bench] rank {rank}: RCCL bring-up failed: {e}", file=sys.stderr)
-            comm, ok = None, 0
-        if dist is not None:
-            import torch
-
-            flag = torch.tensor([ok])
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                comm, transport = GlooHostComm(ctx, dist, rank, world), "gloo-host-fallback (RCCL bring-up failed)"
-        elif comm is None:
-            raise RuntimeError("RCCL communicator could not be created")
-        pipe = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True)
+    seed0 = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config]
+    if args.scaling == "strong" and world > 1:
+        # one matrix for the whole job, every rank keeps its block of genes (same generator call: deterministic)
+        counts_all, X = synth_fast(G_total, N, design, seed=seed0)
+        counts = np.ascontiguousarray(counts_all[:, cuts[rank]:cuts[rank + 1]])
+        del counts_all
     else:
-        transport = None
-        pipe = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
+        counts, X = synth_fast(G, N, design, seed=1000 * rank + seed0)
+
+    transport = None
+    comm = None
+    if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
+        comm, transport = bring_up_comm(ctx, control)
+        if transport != "rccl":
+            print(f"[bench] rank {rank}: {transport}", file=sys.stderr)
+
+    def make_pipe():
+        if comm is not None:
+            return DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True)
+        return pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
 
     def barrier():
         ctx.sync()  # hipStreamSynchronize on the engine's stream (it owns all device work)
-        if dist is not None:
-            dist.barrier()
-            ctx.sync()
+        control.barrier()
+        ctx.sync()
+
+    # ---- upload (host int64 N x G -> HBM, narrowed to int32, + gene-major transposition): timed on its own
+    make_pipe().close()  # first construction pays one-off allocations (pinned staging buffers, code objects)
+    barrier()
+    t_up = time.perf_counter()
+    pipe = make_pipe()
+    ctx.sync()
+    h2d_s = control.max_float(time.perf_counter() - t_up)
 
     for _ in range(args.warmup):
         res = pipe.deseq2()
@@ -194,77 +237,77 @@ def main():
     for _ in range(args.steps):
         res = pipe.deseq2()
     ctx.sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = control.max_float(time.perf_counter() - t0)
     barrier()
     klog_timed = pipe.kernel_log
     # one extra, untimed step with per-stage event timing (synchronises after every stage)
+    coll_log = []
+    if comm is not None:
+        pipe.comm = _TimedComm(comm, ctx, coll_log)
     pipe.time_kernels, pipe.collect_nfev, pipe.kernel_log = True, True, {}
     res_prof = pipe.deseq2(profile=True)
     klog_prof, pipe.time_kernels, pipe.collect_nfev = pipe.kernel_log, False, False
+    if comm is not None:
+        pipe.comm = comm
     # extras outside `value` (a failure here must not cost the bench line): summary tail (SURVEY 8(f)-1:
     # Cook's filter, independent filtering + BH) and apeGLM LFC shrinkage of the tested coefficient (8(f)-2)
     extras = {}
-    try:
-        from pydeseq2_amd.summary import lfc_shrink
-        from pydeseq2_amd.summary import summary as summary_tail
+    if not args.no_extras:
+        try:
+            from pydeseq2_amd.summary import lfc_shrink
+            from pydeseq2_amd.summary import summary as summary_tail
 
-        cvec = np.zeros(X.shape[1])
-        cvec[-1] = 1.0
-        summary_tail(res_prof, cvec, ctx=ctx)
-        ctx.sync()
-        t_sum = time.perf_counter()
-        for _ in range(3):
-            sres = summary_tail(res_prof, cvec, ctx=ctx)
-        ctx.sync()
-        t_sum = (time.perf_counter() - t_sum) / 3
-        extras["summary_tail"] = {"ms": round(t_sum * 1e3, 3), "rejections_at_0.05": int(np.nansum(sres["padj"] < 0.05)),
-                                  "cutoff_index": int(sres["info"]["j"]),
-                                  "note": "padj with independent filtering on the device (not part of value)"}
-        lfc_shrink(pipe, res_prof, X.shape[1] - 1)
-        ctx.sync()
-        t_shr = time.perf_counter()
-        shr = lfc_shrink(pipe, res_prof, X.shape[1] - 1)
-        ctx.sync()
-        t_shr = time.perf_counter() - t_shr
-        extras["lfc_shrink"] = {"ms": round(t_shr * 1e3, 3), "prior_scale": round(float(shr[3]), 6),
-                                "converged_fraction": round(float(np.nanmean(shr[2])), 5),
-                                "note": "apeGLM MAP LFC of the last coefficient, all genes (not part of value)"}
-    except Exception as e:  # noqa: BLE001
-        extras["extras_error"] = repr(e)
+            cvec = np.zeros(X.shape[1])
+            cvec[-1] = 1.0
+            summary_tail(res_prof, cvec, ctx=ctx)
+            ctx.sync()
+            t_sum = time.perf_counter()
+            for _ in range(3):
+                sres = summary_tail(res_prof, cvec, ctx=ctx)
+            ctx.sync()
+            t_sum = (time.perf_counter() - t_sum) / 3
+            extras["summary_tail"] = {"ms": round(t_sum * 1e3, 3),
+                                      "rejections_at_0.05": int(np.nansum(sres["padj"] < 0.05)),
+                                      "cutoff_index": int(sres["info"]["j"]),
+                                      "note": "padj with independent filtering on the device (not part of value)"}
+            lfc_shrink(pipe, res_prof, X.shape[1] - 1)
+            ctx.sync()
+            t_shr = time.perf_counter()
+            shr = lfc_shrink(pipe, res_prof, X.shape[1] - 1)
+            ctx.sync()
+            t_shr = time.perf_counter() - t_shr
+            extras["lfc_shrink"] = {"ms": round(t_shr * 1e3, 3), "prior_scale": round(float(shr[3]), 6),
+                                    "converged_fraction": round(float(np.nanmean(shr[2])), 5),
+                                    "note": "apeGLM MAP LFC of the last coefficient, all genes (not part of value)"}
+        except Exception as e:  # noqa: BLE001
+            extras["extras_error"] = repr(e)
     barrier()
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        control.barrier()  # rank 0 finishes its CPU baseline before anybody tears the job down
+        control.close()
         return
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * G / (dt / args.steps)
+    value = G_total / (dt / args.steps)
 
-    # ---- roofline of the dominant kernel (both dispersion launches use k_alpha)
+    # ---- roofline of the dominant kernel (both dispersion launches use k_alpha).  Algorithmic bytes, launch
+    # duration and measured HBM traffic all refer to ONE FULL-SIZE launch (the two tiny launches on the genes
+    # refitted after outlier replacement are listed separately, so that the rocprofv3 per-kernel average of the
+    # same command, which mixes both, can still be reproduced from avg_launch_ms_all)
     klog = klog_timed
-    # every k_alpha launch of the timed region (2 per step on all genes + 2 tiny ones on the genes
-    # refitted after outlier replacement), so that avg_launch_ms is directly comparable with the
-    # per-kernel average of `rocprofv3 --kernel-trace --stats` of the same command
     launches = list(klog.get("k_alpha", []))
-    mean_ms = float(np.mean([ms for ms, _ in launches]))
-    genes_per_launch = float(np.mean([g for _, g in launches]))
-    alg_bytes = genes_per_launch * 12.0 * N + genes_per_launch * 17.0
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     big = [(ms, g) for ms, g in launches if g > 0.5 * G]
+    full_ms = float(np.mean([ms for ms, _ in big]))
+    genes_full = float(np.mean([g for _, g in big]))
+    alg_bytes = genes_full * (12.0 * N + 17.0)
+    achieved = alg_bytes / (full_ms * 1e-3) / 1e9
     stage_ms = {k: round(float(np.sum([ms for ms, _ in v])), 3) for k, v in klog_prof.items()
                 if k not in ("k_alpha", "grid_fallback_genes", "nfev")}
     # companion bound: the fit is fp64-ALU work, ~250 flop per sample and evaluation
     # (lgamma + digamma differences, 3 logs, Cox-Reid sums); evaluations counted by the kernel itself
     nfev_full = [e for e, g in klog_prof.get("nfev", []) if g > 0.5 * G]
     evals = float(np.mean(nfev_full)) if nfev_full else None
-    full_ms = float(np.mean([ms for ms, _ in big])) if big else None
     valu = None
     if evals and full_ms:
         tflops = evals * N * 250.0 / (full_ms * 1e-3) / 1e12
@@ -273,12 +316,12 @@ def main():
                 "flop_per_sample_eval": 250}
     n_fallback = float(np.sum([x for x, _ in klog.get("grid_fallback_genes", [])])) / args.steps
     roofline = {
-        "bound": "hbm", "kernel": "k_alpha (dispersion MLE/MAP, one gene per wavefront)",
+        "bound": "hbm", "kernel": "k_alpha (dispersion MLE/MAP, one gene per wavefront), full-size launches",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(mean_ms, 4),
-        "launches_timed": len(launches),
-        "full_launch_ms": round(float(np.mean([ms for ms, _ in big])), 4) if big else None,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_ratio": None,
+        "algorithmic_bytes_per_launch": int(alg_bytes), "full_launch_ms": round(full_ms, 4),
+        "full_launches_timed": len(big),
+        "avg_launch_ms_all": round(float(np.mean([ms for ms, _ in launches])), 4), "launches_timed": len(launches),
         "pipeline_algorithmic_GBps": round(G * 104.0 * N / (dt / args.steps) / 1e9, 2),
         "kernel_ms_per_step": stage_ms, "grid_fallback_genes_per_step": n_fallback,
         "companion": valu,
@@ -286,45 +329,77 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(traffic_file):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get("k_alpha_hbm_bytes_per_launch")
+            tj = json.load(open(traffic_file))
+            roofline["traffic"] = tj.get("k_alpha_hbm_bytes_per_launch")
+            roofline["traffic_source"] = tj.get("source")
+            if roofline["traffic"]:
+                roofline["traffic_ratio"] = round(roofline["traffic"] / alg_bytes, 3)
         except Exception:
             pass
 
-    # ---- CPU baseline on a bounded sample of the same workload
-    cpu = None
+    # ---- CPU baseline on a bounded sample of the same workload + in-run parity on that very slice
+    cpu, parity = None, None
     if not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         n_jobs = min(cores, 64)
         n_sample = args.cpu_sample or {"c2": 20000, "c3": 8000, "c4": 8000, "c5": 1500}[args.config]
         n_sample = min(n_sample, G)
         try:
-            v, secs = cpu_baseline(counts, X, n_sample, n_jobs)
+            v, secs, sub, ref = cpu_baseline(counts, X, n_sample, n_jobs)
             cpu = {"value": round(v, 1), "unit": "genes/s", "cores": n_jobs, "kind": "port",
                    "sample": f"oracle (numpy/scipy restatement of the reference incl. scipy L-BFGS-B per gene, "
                              f"joblib/loky workers warmed up) on the first {n_sample} genes x {N} samples of the "
                              f"same matrix, {secs:.1f} s"}
-        except Exception as e:  # noqa: BLE001 - the GPU measurement above stands on its own
-            print(f"[bench] cpu_baseline failed: {e!r}", file=sys.stderr)
-            cpu = None
+            ref_slice = os.path.join(ROOT, "profiles", "cpu_reference_slice.json")
+            if os.path.exists(ref_slice):  # the unmodified reference kernels, timed on the build box (tools/)
+                cpu["reference_slice"] = json.load(open(ref_slice)).get(args.config)
+            psub = pydeseq2_amd.DeseqPipeline(sub, X, ctx=ctx)
+            parity = parity_report(psub.deseq2(), ref)
+            parity["slice"] = f"first {n_sample} genes of the benchmark matrix (the cpu_baseline sample)"
+            psub.close()
+            if not args.no_extras and args.config == "c3":
+                # the p = 8 configuration (BASELINE configs[3]) on a slice of its own, same check
+                from oracle import nbglm_oracle as orc
 
+                c4, X4 = synth_fast(2000, CONFIGS["c4"][1], CONFIGS["c4"][2], seed=3)
+                ref4 = orc.deseq2(c4, X4, n_jobs=n_jobs, keep_layers=False)
+                p4 = pydeseq2_amd.DeseqPipeline(c4, X4, ctx=ctx)
+                extras["parity_c4"] = parity_report(p4.deseq2(), ref4)
+                extras["parity_c4"]["slice"] = "2000 genes x 500 samples, design 3factor (p=8), seed 3"
+                p4.close()
+        except Exception as e:  # noqa: BLE001 - the GPU measurement above stands on its own
+            print(f"[bench] cpu_baseline / parity failed: {e!r}", file=sys.stderr)
+    parity_ok = bool(parity and parity["ok"] and extras.get("parity_c4", {"ok": True})["ok"])
+    if parity is not None and not parity_ok:
+        print("[bench] PARITY CHECK FAILED - no speed-up is reported", file=sys.stderr)
+
+    coll_ms = round(float(sum(ms for _, ms in coll_log)), 3) if comm is not None else None
     out = {
         "metric": "genes/sec end-to-end deseq2() (size factors->dispersion->IRLS->Wald)",
         "value": round(value, 1), "unit": "genes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {G} genes x {N} samples per GPU, design {design} "
-                               f"(p={X.shape[1]}), NB counts (SURVEY 8d generator)",
-                   "genes_per_gpu": G, "samples": N, "p": int(X.shape[1]), "collectives": transport,
-                   "device": info["name"], "arch": info["arch"]},
+        "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {G_total} genes x {N} samples in total ({G} per GPU, "
+                               f"{args.scaling} scaling), design {design} (p={X.shape[1]}), NB counts "
+                               f"(SURVEY 8d generator)",
+                   "genes_per_gpu": G, "genes_total": G_total, "samples": N, "p": int(X.shape[1]),
+                   "collectives": transport, "device": info["name"], "arch": info["arch"]},
+        "h2d_ms": round(h2d_s * 1e3, 3),
+        "value_with_h2d": round(G_total / (dt / args.steps + h2d_s), 1),
+        "h2d_note": f"host int64 {N} x {G} ({counts.nbytes / 1e6:.0f} MB per GPU) -> int32 in HBM through pinned "
+                    "staging chunks + gene-major transposition; value_with_h2d = genes / (one upload + one step)",
+        "collective_ms_per_step": coll_ms,
+        "collectives_per_step": len(coll_log) if comm is not None else None,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity": parity,
         "stage_wall_ms_profiled_step": {k: round(v * 1e3, 3) for k, v in res_prof.timings.items()},
-        "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+        "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if (cpu and parity_ok) else None,
     }
     out.update(extras)
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    control.barrier()
+    control.close()
 
 
 if __name__ == "__main__":

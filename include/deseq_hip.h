@@ -132,6 +132,27 @@ int dsq_inf_fit_rough_dispersions(dsq_ctx* ctx, const double* normed, int layout
 int dsq_inf_fit_moments_dispersions(dsq_ctx* ctx, const double* normed, int layout,
                                     const double* size_factors, int N, int G, double* alpha_out);
 
+/* Inference.dispersion_trend_gamma_glm (inference.py:284-308; default_inference.py:200-230): ONE gamma-GLM
+ * fit targets ~ a0 + a1 * covariates (L-BFGS-B from (1, 1), lower bound 1e-12, scipy defaults; NaN entries
+ * are skipped as numpy.nanmean does) run on the device.  coeffs2 = (a0, a1) (intercept first),
+ * predictions[n] = a0 + a1 * covariates (may be NULL), *converged = scipy's res.success. */
+int dsq_inf_dispersion_trend_gamma_glm(dsq_ctx* ctx, const double* covariates, const double* targets, int n,
+                                       double* coeffs2, double* predictions, int* converged);
+
+/* grid_search.grid_fit_alpha (grid_search.py:54-142) — what utils.fit_alpha_mle falls back to when its
+ * L-BFGS-B run reports success == False (utils.py:556-564) — for EVERY gene of the batch, on the production
+ * kernels of that fallback (100 wavefronts per gene and grid level).  Returns log(alpha) like the reference
+ * (Cox-Reid term on, no prior: the reference passes six positional arguments only). */
+int dsq_inf_grid_fit_alpha(dsq_ctx* ctx, const void* counts, int count_type, int count_layout, const double* design,
+                           const double* mu, int mu_layout, int N, int G, int P, double min_disp, double max_disp,
+                           double* log_alpha_out);
+/* grid_search.grid_fit_beta (grid_search.py:145-221) — the P == 2 fallback of utils.irls_solver when IRLS
+ * diverged and the bounded L-BFGS-B rescue failed too (utils.py:404-411): two-level grid_length x grid_length
+ * search on [min_beta, max_beta]^2.  design: N x 2.  beta_out[G*2]. */
+int dsq_inf_grid_fit_beta(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                          const double* size_factors, const double* design, const double* disp, int N, int G,
+                          double min_mu, int grid_length, double min_beta, double max_beta, double* beta_out);
+
 /* Loss and gradient of the 2-coefficient gamma GLM of
  * Inference.dispersion_trend_gamma_glm (inference.py:284-308; default_inference.py:200-230):
  *   loss = mean(t/m + log m), m = a0 + a1*cov ; grad as default_inference.py:213-217.
@@ -293,6 +314,12 @@ int dsq_dev_padj_prepare(dsq_ctx* ctx, const double* d_base_mean, const double* 
                          double* h_out200, int* h_n_valid);
 int dsq_dev_padj_finish(dsq_ctx* ctx, const unsigned long long* d_sorted_p, const int32_t* d_sorted_idx,
                         const uint8_t* d_bins, int n, int n_valid, int j, double* d_padj);
+/* Host count matrix (int32 or int64, any layout: n_elems consecutive elements) -> int32 device buffer with the
+ * same element order.  int64 is narrowed on the host by a few threads into two page-locked staging chunks
+ * whose DMA overlaps the narrowing of the next chunk (half the PCIe bytes of the int64 matrix, no pageable
+ * staging).  *h_bad = 1 if a value is negative or >= 2^31.  Synchronous on return. */
+int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size_t n_elems, int32_t* d_dst,
+                          int* h_bad);
 /* device-to-device copy on the context's stream */
 int dsq_d2d(dsq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* page-locked host memory + asynchronous copies on the context's stream (complete at dsq_sync) */

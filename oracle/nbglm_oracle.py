@@ -506,7 +506,7 @@ def mean_trend(genewise: np.ndarray, min_disp: float) -> float:
     return float(trim_mean(sel, proportiontocut=0.001))
 
 
-def fit_parametric_trend(genewise_nz: np.ndarray, normed_means_nz: np.ndarray):
+def fit_parametric_trend(genewise_nz: np.ndarray, normed_means_nz: np.ndarray, glm=None):
     """Iterated gamma-GLM trend over non-zero genes (dds.py:1199-1275).
 
     Returns (coeffs[2] or None on failure, n_outer_iterations).
@@ -520,7 +520,8 @@ def fit_parametric_trend(genewise_nz: np.ndarray, normed_means_nz: np.ndarray):
     n_it = 0
     while (coeffs > 1e-10).all() and (np.log(np.abs(coeffs / old)) ** 2).sum() >= 1e-6:
         old = coeffs
-        coeffs, pred, conv = trend_gamma_glm(cov_all[sel], genewise_nz[sel])
+        coeffs, pred, conv = (glm or trend_gamma_glm)(cov_all[sel], genewise_nz[sel])
+        coeffs = np.asarray(coeffs)
         n_it += 1
         if not conv or (coeffs <= 1e-10).any():
             return None, n_it
@@ -702,27 +703,70 @@ class DeseqResult:
     timings: dict = field(default_factory=dict)
 
 
-def _fit_genewise(counts_nz, normed_nz, sf, X, min_mu, min_disp, max_disp, beta_tol, n_jobs):
+class _OracleInference:
+    """The oracle's own kernels behind the reference's ``Inference`` method names and keyword arguments
+    (inference.py:9-362), so that ``deseq2(..., inference=obj)`` can drive any other implementation of that
+    interface in ``DeseqDataSet``'s call order (dds.py:713-984, ds.py:303-360) — tests use it to run the
+    engine's ``HipInference`` plug-in under the reference's orchestration."""
+
+    def __init__(self, n_jobs=1):
+        self.n_jobs = n_jobs
+
+    def fit_rough_dispersions(self, normed_counts, design_matrix):
+        return rough_dispersions(normed_counts, design_matrix)
+
+    def fit_moments_dispersions(self, normed_counts, size_factors):
+        return moments_dispersions(normed_counts, size_factors)
+
+    def lin_reg_mu(self, counts, size_factors, design_matrix, min_mu):
+        return lin_reg_mu(counts, size_factors, design_matrix, min_mu)
+
+    def irls(self, counts, size_factors, design_matrix, disp, min_mu, beta_tol, **kw):
+        return irls(counts, size_factors, design_matrix, disp, min_mu, beta_tol)
+
+    def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
+                  cr_reg=True, prior_reg=False, **kw):
+        return alpha_mle(counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=prior_disp_var,
+                         cr_reg=cr_reg, prior_reg=prior_reg, n_jobs=self.n_jobs)
+
+    def dispersion_trend_gamma_glm(self, covariates, targets):
+        return trend_gamma_glm(np.asarray(covariates), np.asarray(targets))
+
+    def wald_test(self, design_matrix, disp, lfc, mu, ridge_factor, contrast, lfc_null, alt_hypothesis=None):
+        return wald_test(design_matrix, disp, lfc, mu, ridge_factor, contrast, lfc_null, alt_hypothesis)
+
+
+def _fit_genewise(counts_nz, normed_nz, sf, X, min_mu, min_disp, max_disp, beta_tol, n_jobs, inf=None):
     """MoM -> mu_hat -> genewise alpha on non-zero genes (dds.py:713-797)."""
-    mom = mom_dispersions(normed_nz, X, sf, min_disp, max_disp)
+    inf = inf if inf is not None else _OracleInference(n_jobs)
+    # dds.py:1149-1162: rough and moments estimates through the plug-in, min / clip on the host
+    rde = inf.fit_rough_dispersions(normed_nz, X)
+    mde = inf.fit_moments_dispersions(normed_nz, sf)
+    mom = np.clip(np.minimum(rde, mde), min_disp, max_disp)
     n_cells = len(np.unique(X, axis=0))
     if n_cells == X.shape[1]:  # dds.py:747-756
-        mu_hat = lin_reg_mu(counts_nz, sf, X, min_mu)
+        mu_hat = inf.lin_reg_mu(counts=counts_nz, size_factors=sf, design_matrix=X, min_mu=min_mu)
     else:  # dds.py:757-765
-        _, mu_hat, _, _ = irls(counts_nz, sf, X, mom, min_mu, beta_tol)
-    gw, conv = alpha_mle(counts_nz, X, mu_hat, mom, min_disp, max_disp, n_jobs=n_jobs)
+        _, mu_hat, _, _ = inf.irls(counts=counts_nz, size_factors=sf, design_matrix=X, disp=mom, min_mu=min_mu,
+                                   beta_tol=beta_tol)
+    gw, conv = inf.alpha_mle(counts=counts_nz, design_matrix=X, mu=mu_hat, alpha_hat=mom, min_disp=min_disp,
+                             max_disp=max_disp)
     return mom, mu_hat, np.clip(gw, min_disp, max_disp), conv
 
 
 def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0,
            refit_cooks=True, min_replicates=7, beta_tol=1e-8, fit_type="parametric",
-           lfc_null=0.0, alt_hypothesis=None, n_jobs=1, keep_layers=True):
+           lfc_null=0.0, alt_hypothesis=None, n_jobs=1, keep_layers=True, inference=None):
     """End-to-end restatement of ``DeseqDataSet.deseq2()`` + ``DeseqStats.run_wald_test()``.
 
     Follows dds.py:516-562 step by step, then ds.py:303-360.  ``counts`` is
     N x G non-negative integers, ``X`` the N x p design matrix (intercept first).
+    ``inference``: an object with the reference's ``Inference`` interface (inference.py:9-362) that
+    replaces the oracle's own per-gene kernels, as ``DeseqDataSet(inference=...)`` does (dds.py:323-336).
     """
     import time
+
+    inf = inference if inference is not None else _OracleInference(n_jobs)
 
     counts = np.asarray(counts)
     X = np.asarray(X, dtype=float)
@@ -756,7 +800,7 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
     r.non_zero = nz
     c_nz = counts[:, nzi]
     mom, mu_hat, gw, gconv = _fit_genewise(c_nz, normed[:, nzi], sf, X, min_mu, min_disp,
-                                           max_disp, beta_tol, n_jobs)
+                                           max_disp, beta_tol, n_jobs, inf)
     r.mom_dispersions = _scatter(G, nzi, mom)
     r.genewise_dispersions = _scatter(G, nzi, gw)
     r.genewise_converged = _scatter(G, nzi, gconv.astype(float))
@@ -768,7 +812,7 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
     t = time.perf_counter()
     coeffs = None
     if fit_type == "parametric":
-        coeffs, _ = fit_parametric_trend(gw, r.normed_means[nzi])
+        coeffs, _ = fit_parametric_trend(gw, r.normed_means[nzi], glm=inf.dispersion_trend_gamma_glm)
         if coeffs is None:
             warnings.warn("The dispersion trend curve fitting did not converge. "
                           "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
@@ -790,9 +834,8 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
 
     # -- MAP (dds.py:886-935)
     t = time.perf_counter()
-    mp, mconv = alpha_mle(c_nz, X, mu_hat, fitted[nzi], min_disp, max_disp,
-                          prior_disp_var=r.prior_disp_var, cr_reg=True, prior_reg=True,
-                          n_jobs=n_jobs)
+    mp, mconv = inf.alpha_mle(counts=c_nz, design_matrix=X, mu=mu_hat, alpha_hat=fitted[nzi], min_disp=min_disp,
+                              max_disp=max_disp, prior_disp_var=r.prior_disp_var, cr_reg=True, prior_reg=True)
     r.MAP_dispersions = _scatter(G, nzi, np.clip(mp, min_disp, max_disp))
     r.MAP_converged = _scatter(G, nzi, mconv.astype(float))
     disp = r.MAP_dispersions.copy()
@@ -805,7 +848,8 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
 
     # -- LFC (dds.py:937-984)
     t = time.perf_counter()
-    beta, mu, Hd, lconv = irls(c_nz, sf, X, disp[nzi], min_mu, beta_tol)
+    beta, mu, Hd, lconv = inf.irls(counts=c_nz, size_factors=sf, design_matrix=X, disp=disp[nzi], min_mu=min_mu,
+                                   beta_tol=beta_tol)
     r.LFC = _rows(G, p, nzi, beta)
     r.LFC_converged = _scatter(G, nzi, lconv.astype(float))
     T["LFC"] = time.perf_counter() - t
@@ -849,20 +893,22 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
                     rf = rp[~naz]
                     s_c = sub[:, ~naz]
                     s_n = s_c / sf[:, None]
+                    inf1 = inference if inference is not None else _OracleInference(1)
                     _, s_mu, s_gw, _ = _fit_genewise(s_c, s_n, sf, X, min_mu, min_disp,
-                                                     max_disp, beta_tol, 1)
+                                                     max_disp, beta_tol, 1, inf1)
                     s_means = s_n.mean(0)
                     if r.disp_function_type == "parametric":
                         s_fit = r.trend_coeffs[0] + r.trend_coeffs[1] / s_means
                     else:
                         s_fit = np.full(len(rf), r.mean_disp)
-                    s_map, _ = alpha_mle(s_c, X, s_mu, s_fit, min_disp, max_disp,
-                                         prior_disp_var=r.prior_disp_var, cr_reg=True,
-                                         prior_reg=True, n_jobs=1)
+                    s_map, _ = inf1.alpha_mle(counts=s_c, design_matrix=X, mu=s_mu, alpha_hat=s_fit,
+                                              min_disp=min_disp, max_disp=max_disp,
+                                              prior_disp_var=r.prior_disp_var, cr_reg=True, prior_reg=True)
                     s_disp = np.clip(s_map, min_disp, max_disp)
                     s_out = np.log(s_gw) > np.log(s_fit) + 2 * np.sqrt(r.squared_logres)
                     s_disp[s_out] = s_gw[s_out]
-                    s_beta, _, _, _ = irls(s_c, sf, X, s_disp, min_mu, beta_tol)
+                    s_beta, _, _, _ = inf1.irls(counts=s_c, size_factors=sf, design_matrix=X, disp=s_disp,
+                                                min_mu=min_mu, beta_tol=beta_tol)
                     r.normed_means[rf] = s_means
                     r.LFC[rf, :] = s_beta
                     r.genewise_dispersions[rf] = s_gw
@@ -890,8 +936,9 @@ def deseq2(counts, X, contrast=None, *, min_mu=0.5, min_disp=1e-8, max_disp=10.0
     with np.errstate(invalid="ignore", over="ignore"):
         mu_w = np.exp(X @ r.LFC.T) * sf[:, None]
     ridge = np.diag(np.repeat(1e-6, p))
-    pv, st, se = wald_test(X, r.dispersions, r.LFC, mu_w, ridge, np.asarray(contrast, float),
-                           np.log(2) * lfc_null, alt_hypothesis)
+    pv, st, se = inf.wald_test(design_matrix=X, disp=r.dispersions, lfc=r.LFC, mu=mu_w, ridge_factor=ridge,
+                               contrast=np.asarray(contrast, float), lfc_null=np.log(2) * lfc_null,
+                               alt_hypothesis=alt_hypothesis)
     if refit_cooks and r.replaced.sum() > 0:
         z = r.new_all_zeroes
         se[z], st[z], pv[z] = 0.0, 0.0, 1.0

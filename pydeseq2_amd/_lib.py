@@ -74,6 +74,11 @@ def load():
           c_int, _vp, _vp, _vp)
     proto("dsq_inf_fit_rough_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, c_int, _vp)
     proto("dsq_inf_fit_moments_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    proto("dsq_inf_dispersion_trend_gamma_glm", _vp, _vp, _vp, c_int, _vp, _vp, C.POINTER(c_int))
+    proto("dsq_inf_grid_fit_alpha", _vp, _vp, c_int, c_int, _vp, _vp, c_int, c_int, c_int, c_int, c_double, c_double,
+          _vp)
+    proto("dsq_inf_grid_fit_beta", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_double, c_int, c_double,
+          c_double, _vp)
     proto("dsq_dev_trend_loss_grad", _vp, _vp, _vp, _vp, c_int, c_double, c_double, C.POINTER(c_double),
           C.POINTER(c_double))
     proto("dsq_dev_trend_fit", _vp, _vp, _vp, c_int, c_double, c_double, _vp, C.POINTER(c_double),
@@ -108,6 +113,7 @@ def load():
     proto("dsq_dev_padj_prepare", _vp, _vp, _vp, c_int, c_double, _vp, _vp, _vp, _vp, C.POINTER(c_int))
     proto("dsq_dev_padj_finish", _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp)
     proto("dsq_d2d", _vp, _vp, _vp, c_size_t)
+    proto("dsq_upload_counts_i32", _vp, _vp, c_int, c_size_t, _vp, C.POINTER(c_int))
     proto("dsq_host_alloc", _vp, c_size_t, C.POINTER(_vp))
     proto("dsq_host_free", _vp, _vp)
     proto("dsq_d2h_async", _vp, _vp, _vp, c_size_t)
@@ -150,6 +156,7 @@ EXPORTS = [
     "dsq_comm_allreduce_sum", "dsq_comm_allgather", "dsq_dev_sf_keys", "dsq_dev_sf_count", "dsq_dev_sf_init",
     "dsq_dev_sf_hist", "dsq_dev_sf_pick", "dsq_dev_sf_finish", "dsq_dev_trend_eval", "dsq_dev_select_dispersions",
     "dsq_dev_scatter_rows_f64", "dsq_d2d", "dsq_dev_mom_lin_mu", "dsq_dev_sf_keys_compact", "dsq_prior_mad_work_doubles", "dsq_size_factors_work_doubles", "dsq_dev_mom_raw", "dsq_dev_nll_const", "dsq_dev_nll_scaled", "dsq_dev_logmeans_poscounts", "dsq_dev_vst", "dsq_inf_lfc_shrink_nbinom_glm", "dsq_dev_lfc_shrink", "dsq_dev_padj_prepare", "dsq_dev_padj_finish", "dsq_host_alloc", "dsq_host_free", "dsq_d2h_async", "dsq_h2d_async",
+    "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",
 ]
 
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/deseq_hip.h"
@@ -30,6 +31,8 @@ struct dsq_ctx {
     void* d_sum = nullptr;        // workspace of the adjusted-p-value kernels (grown on demand)
     size_t sum_cap = 0, sum_sort_bytes = 0;
     size_t lsf_cap = 0;
+    void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -261,6 +264,10 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
     if (ctx->d_sum) (void)hipFree(ctx->d_sum);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
@@ -621,6 +628,75 @@ int dsq_d2d(dsq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     if (bytes) DSQ_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return DSQ_OK;
 }
+// Host count matrix (int64 as the reference holds it, or int32) -> int32 in HBM, same element order.
+// The matrix is cut into chunks of kStageElems elements; a few host threads narrow a chunk into one of two
+// page-locked staging buffers (checking 0 <= v < 2^31) while the DMA of the previous chunk is in flight, so
+// the PCIe link carries half the bytes of the int64 matrix and never waits for pageable-memory staging.
+extern "C++" {
+namespace {
+constexpr size_t kStageElems = (size_t)8 << 20;  // 32 MiB of int32 per chunk
+
+template <class SrcT>
+void narrow_chunk(const SrcT* src, int32_t* dst, size_t n, int n_threads, int* bad) {
+    auto work = [=](size_t lo, size_t hi, int* flag) {
+        int b = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const SrcT v = src[i];
+            b |= (v < 0) | ((long long)v > 2147483647LL);
+            dst[i] = (int32_t)v;
+        }
+        if (b) *flag = 1;
+    };
+    if (n_threads <= 1 || n < ((size_t)1 << 16)) {
+        work(0, n, bad);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<int> flags((size_t)n_threads, 0);
+    const size_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        th.emplace_back(work, lo, hi, &flags[(size_t)t]);
+    }
+    for (auto& x : th) x.join();
+    for (int f : flags)
+        if (f) *bad = 1;
+}
+}  // namespace
+}  // extern "C++"
+
+int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size_t n_elems, int32_t* d_dst,
+                          int* h_bad) {
+    DSQ_CHECK_ARG(count_type == DSQ_I32 || count_type == DSQ_I64, "count_type");
+    if (h_bad) *h_bad = 0;
+    if (n_elems == 0) return DSQ_OK;
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->stage[k]) DSQ_HIP(hipHostMalloc(&ctx->stage[k], kStageElems * sizeof(int32_t), hipHostMallocDefault));
+        if (!ctx->stage_ev[k]) DSQ_HIP(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    }
+    static const int n_threads = [] {
+        const char* e = getenv("DSQ_UPLOAD_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        return t < 1 ? 1 : (t > 16 ? 16 : t);
+    }();
+    int bad = 0;
+    size_t off = 0;
+    for (int c = 0; off < n_elems; ++c, off += kStageElems) {
+        const size_t n = n_elems - off < kStageElems ? n_elems - off : kStageElems;
+        const int k = c & 1;
+        if (c >= 2) DSQ_HIP(hipEventSynchronize(ctx->stage_ev[k]));  // the DMA out of this buffer has finished
+        int32_t* st = (int32_t*)ctx->stage[k];
+        if (count_type == DSQ_I64) narrow_chunk((const int64_t*)counts + off, st, n, n_threads, &bad);
+        else narrow_chunk((const int32_t*)counts + off, st, n, n_threads, &bad);
+        DSQ_HIP(hipMemcpyAsync(d_dst + off, st, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        DSQ_HIP(hipEventRecord(ctx->stage_ev[k], ctx->stream));
+    }
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_bad) *h_bad = bad;
+    return DSQ_OK;
+}
+
 int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out) {
     DSQ_CHECK_ARG(out != nullptr, "null output pointer");
     DSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
@@ -690,6 +766,79 @@ int dsq_dev_trend_loss_grad(dsq_ctx* ctx, const double* d_cov, const double* d_t
     *loss = s[0] / cnt;
     grad2[0] = -s[1] / cnt;
     grad2[1] = -s[2] / cnt;
+    return DSQ_OK;
+}
+
+
+// ------------------------------------------------------------------ grid searches + trend GLM as entry points
+int dsq_inf_grid_fit_alpha(dsq_ctx* ctx, const void* counts, int count_type, int count_layout, const double* design,
+                           const double* mu, int mu_layout, int N, int G, int P, double min_disp, double max_disp,
+                           double* log_alpha_out) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    if (G <= 0) return DSQ_OK;
+    const int ldn = pad16(N);
+    DevBuf y, m, a, work;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, P, D))) return rc;
+    DSQ_HIP(a.alloc((size_t)G * sizeof(double)));
+    DSQ_HIP(work.alloc((size_t)G * 102 * sizeof(double)));
+    DSQ_HIP(ensure_list(ctx, (size_t)G));
+    std::vector<int32_t> all((size_t)G);
+    for (int g = 0; g < G; ++g) all[(size_t)g] = g;
+    DSQ_HIP(hipMemcpyAsync(ctx->d_list, all.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    // the production fallback path: 100 wavefronts per gene and level (k_alpha_grid_eval / k_alpha_grid_pick)
+    DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N, P,
+                                   min_disp, max_disp, a.as<double>(), ctx->d_list, G, work.as<double>()));
+    DSQ_HIP(hipMemcpyAsync(log_alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    // the production kernel stores alpha = exp(best grid point), which is what fit_alpha_mle needs
+    // (utils.py:557); grid_fit_alpha itself returns the grid point (grid_search.py:141-142): back to the log
+    // (exp/log round trip: a few 1e-16 absolute)
+    for (int g = 0; g < G; ++g) log_alpha_out[g] = std::log(log_alpha_out[g]);
+    return DSQ_OK;
+}
+
+int dsq_inf_grid_fit_beta(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                          const double* size_factors, const double* design, const double* disp, int N, int G,
+                          double min_mu, int grid_length, double min_beta, double max_beta, double* beta_out) {
+    if (G <= 0) return DSQ_OK;
+    DSQ_CHECK_ARG(grid_length >= 2, "grid_length must be at least 2");
+    const int ldn = pad16(N);
+    DevBuf y, sf, d, b;
+    DesignDev D;
+    int rc;
+    if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
+    if ((rc = upload_design(ctx, design, N, 2, D))) return rc;
+    if ((rc = upload_vec(ctx, size_factors, (size_t)N * sizeof(double), sf))) return rc;
+    if ((rc = upload_vec(ctx, disp, (size_t)G * sizeof(double), d))) return rc;
+    DSQ_HIP(b.alloc((size_t)G * 2 * sizeof(double)));
+    DSQ_HIP(dsq::launch_grid_beta(ctx->stream, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(), D.ldx, N, G,
+                                  d.as<double>(), min_mu, min_beta, max_beta, grid_length, b.as<double>()));
+    DSQ_HIP(hipMemcpyAsync(beta_out, b.p, (size_t)G * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+int dsq_inf_dispersion_trend_gamma_glm(dsq_ctx* ctx, const double* covariates, const double* targets, int n,
+                                       double* coeffs2, double* predictions, int* converged) {
+    DSQ_CHECK_ARG(n >= 1, "no genes");
+    DevBuf cov, tgt, keep;
+    int rc;
+    if ((rc = upload_vec(ctx, covariates, (size_t)n * sizeof(double), cov))) return rc;
+    if ((rc = upload_vec(ctx, targets, (size_t)n * sizeof(double), tgt))) return rc;
+    DSQ_HIP(keep.alloc((size_t)n));
+    double* d_out = ctx->d_scratch + 1536;
+    DSQ_HIP(dsq::launch_trend_glm(ctx->stream, tgt.as<double>(), cov.as<double>(), n, keep.as<uint8_t>(), d_out));
+    double out5[5];
+    DSQ_HIP(hipMemcpyAsync(out5, d_out, sizeof(out5), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    coeffs2[0] = out5[0]; coeffs2[1] = out5[1];
+    if (converged) *converged = (int)out5[2];
+    if (predictions)  // covariates @ coeffs (default_inference.py:227)
+        for (int i = 0; i < n; ++i) predictions[i] = out5[0] + covariates[i] * out5[1];
     return DSQ_OK;
 }
 

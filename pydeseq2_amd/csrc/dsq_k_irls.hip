@@ -78,6 +78,40 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     }
 }
 
+// grid_search.grid_fit_beta (grid_search.py:145-221) for every gene of a (small) batch: the same routine the
+// rescue kernel falls back to, as a stand-alone entry point (tests pin it against the reference's output)
+__global__ __launch_bounds__(kBlock) void k_grid_beta(const int32_t* __restrict__ y, int ldn,
+                                                      const double* __restrict__ sf, const double* __restrict__ Xt,
+                                                      int ldx, int N, int G, const double* __restrict__ disp,
+                                                      double min_mu, double min_beta, double max_beta, int grid_length,
+                                                      double* __restrict__ beta) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    IrlsArgs A;
+    A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = nullptr; A.ldx = ldx; A.N = N;
+    A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = 0.0; A.min_beta = min_beta; A.max_beta = max_beta;
+    A.maxiter = 0; A.full_rank = false;
+    const double a = 1.0 / A.disp;
+    double c = 0.0;  // sum lgamma(y + a) - lgamma(y + 1) - N lgamma(a), as irls_init_exact
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+        const double yv = (double)A.y[n];
+        c += lgamma_pos(yv + a) - lgamma_pos(yv + 1.0);
+    }
+    const double cst = DeviceWave::sum(c) - N * lgamma_pos(a);
+    double b[2];
+    grid_fit_beta2<DeviceWave>(A, a, cst, b, grid_length);
+    if ((threadIdx.x & 63) == 0) { beta[2 * g] = b[0]; beta[2 * g + 1] = b[1]; }
+}
+
+hipError_t launch_grid_beta(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt, int ldx,
+                            int N, int G, const double* disp, double min_mu, double min_beta, double max_beta,
+                            int grid_length, double* beta) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_grid_beta, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, sf, Xt, ldx, N, G, disp,
+                       min_mu, min_beta, max_beta, grid_length, beta);
+    return hipGetLastError();
+}
+
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P_, int full_rank,

@@ -1317,13 +1317,13 @@ __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __
                                                                 const double* __restrict__ means, int n,
                                                                 double min_disp, double max_disp,
                                                                 uint8_t* __restrict__ keep,
-                                                                double* __restrict__ out5) {
+                                                                double* __restrict__ out5, int single) {
     __shared__ TrendShared S;
     BlockTrendOps ops;
-    ops.D = TrendData{disp, means, keep, n, min_disp, max_disp};
+    ops.D = TrendData{disp, means, keep, n, min_disp, max_disp, single};
     ops.S = &S;
     if ((threadIdx.x >> 6) == 0) {
-        const TrendOut o = trend_fit_core(ops, S.W);
+        const TrendOut o = trend_fit_core(ops, S.W, single != 0);
         if (threadIdx.x == 0) {
             out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
             out5[4] = (double)o.n_kept;
@@ -1502,7 +1502,14 @@ hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* me
                                           dim3(64 * kTrendWaves), args, 0, st);
     }
     hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, disp, means, n, min_disp, max_disp,
-                       keep, out5);
+                       keep, out5, 0);
+    return hipGetLastError();
+}
+
+// Inference.dispersion_trend_gamma_glm (inference.py:284-308): ONE gamma-GLM fit of targets ~ a0 + a1 * cov
+hipError_t launch_trend_glm(hipStream_t st, const double* targets, const double* cov, int n, uint8_t* keep,
+                            double* out5) {
+    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, targets, cov, n, 0.0, 0.0, keep, out5, 1);
     return hipGetLastError();
 }
 

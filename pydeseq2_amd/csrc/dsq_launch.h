@@ -111,6 +111,12 @@ hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const doubl
 size_t trend_grid_mem_bytes();
 hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
                             double max_disp, uint8_t* keep, double* out5, void* grid_mem, int force_grid);
+hipError_t launch_trend_glm(hipStream_t st, const double* targets, const double* cov, int n, uint8_t* keep,
+                            double* out5);
+// ---- grid searches as stand-alone entry points (grid_search.py:54-221)
+hipError_t launch_grid_beta(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt, int ldx,
+                            int N, int G, const double* disp, double min_mu, double min_beta, double max_beta,
+                            int grid_length, double* beta);
 // distributed size factors (per-pass radix select, histograms all-reduced between passes)
 hipError_t launch_sf_keys(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
                           const double* logmeans, const uint8_t* gene_mask, unsigned long long* keys);

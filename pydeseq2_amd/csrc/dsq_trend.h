@@ -37,6 +37,9 @@ struct TrendData {
     uint8_t* keep;        // scratch mask (global memory)
     int n;
     double min_disp, max_disp;
+    // raw != 0: `means` holds the covariates themselves and `disp` the targets, unclipped — the inputs of
+    // Inference.dispersion_trend_gamma_glm (inference.py:284-308), one gamma GLM without the outer loop
+    int raw = 0;
 };
 
 struct TrendPartial {
@@ -47,7 +50,7 @@ struct TrendPartial {
 DSQ_HD int trend_init_keep(const TrendData& D, int first, int stride) {
     int kept = 0;
     for (int i = first; i < D.n; i += stride) {
-        const double c = 1.0 / D.means[i];
+        const double c = D.raw ? 0.0 : 1.0 / D.means[i];
         const bool bad = (c != c) || (c == INFINITY) || (c == -INFINITY);  // dds.py:1225-1231
         D.keep[i] = bad ? 0 : 1;
         kept += bad ? 0 : 1;
@@ -60,8 +63,8 @@ DSQ_HD void trend_eval_partial(const TrendData& D, int first, int stride, double
                                TrendPartial& P) {
     for (int i = first; i < D.n; i += stride) {
         if (!D.keep[i]) continue;
-        const double cov = frcp(D.means[i]);
-        const double t = dmin(dmax(D.disp[i], D.min_disp), D.max_disp);
+        const double cov = D.raw ? D.means[i] : frcp(D.means[i]);
+        const double t = D.raw ? D.disp[i] : dmin(dmax(D.disp[i], D.min_disp), D.max_disp);
         const double mu = a0 + a1 * cov;
         const double rmu = frcp(mu);
         const double tm = t * rmu;
@@ -88,12 +91,20 @@ DSQ_HD int trend_filter(const TrendData& D, int first, int stride, double a0, do
 
 // Ops: int init_keep(); void eval(a0, a1, double& f, double* g); int filter(a0, a1)
 template <class Ops>
-DSQ_HD TrendOut trend_fit_core(Ops& ops, TrendWork& W) {
+DSQ_HD TrendOut trend_fit_core(Ops& ops, TrendWork& W, bool single = false) {
     TrendOut out;
     out.ok = 0; out.n_outer = 0; out.n_kept = 0;
     int kept = ops.init_keep();
     auto fg = [&](const double* c, double& f, double* g) { ops.eval(c[0], c[1], f, g); };
     double old0 = 0.1, old1 = 0.1, a0 = 1.0, a1 = 1.0;
+    if (single) {  // DefaultInference.dispersion_trend_gamma_glm (default_inference.py:200-230): one fit
+        W.x[0] = 1.0; W.x[1] = 1.0;
+        W.l[0] = 1e-12; W.l[1] = 1e-12; W.u[0] = 0.0; W.u[1] = 0.0;
+        W.nbd[0] = 1; W.nbd[1] = 1;
+        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, W.x, W.l, W.u, W.nbd, W.lb);
+        out.a0 = W.x[0]; out.a1 = W.x[1]; out.ok = res.success ? 1 : 0; out.n_outer = 1; out.n_kept = kept;
+        return out;
+    }
     for (;;) {
         if (!(a0 > 1e-10 && a1 > 1e-10)) break;
         const double l0 = log(fabs(a0 / old0)), l1 = log(fabs(a1 / old1));

@@ -107,37 +107,180 @@ class RcclComm:
         self.ctx.call("dsq_comm_destroy")
 
 
-def exchange_unique_id(ctx: Context, rank: int, world: int, addr: str, port: int, timeout=120.0) -> bytes:
-    """Torch-free bootstrap: rank 0 creates the RCCL unique id and serves it over TCP."""
-    if rank == 0:
-        uid = RcclComm.unique_id(ctx)
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
-        srv.listen(world)
-        for _ in range(world - 1):
-            c, _a = srv.accept()
-            c.sendall(uid)
-            c.close()
-        srv.close()
-        return uid
-    t0 = time.time()
-    while True:
+class TcpControl:
+    """Torch-free control plane of a one-process-per-GPU job (rank 0 is a star hub on a TCP socket): byte
+    all-gather, broadcast, barrier.  Carries the RCCL unique id at start-up, the barriers / max-over-ranks of
+    bench.py, and — only if RCCL cannot be brought up on some rank — the small exchange buffers themselves
+    (`HostStagedComm`).  The launcher's MASTER_PORT is usually occupied by its own rendezvous store, so the
+    hub listens on the first free port of [port + 1, port + 32) and clients find it by its greeting."""
+
+    MAGIC = b"DSQCTL01"
+
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29500, timeout: float = 180.0):
+        self.rank, self.world = rank, world
+        self.peers, self.sock = [], None
+        if world == 1:
+            return
+        ports = [port + 1 + k for k in range(31)]
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            for pt in ports:
+                try:
+                    srv.bind((addr, pt))
+                    break
+                except OSError:
+                    continue
+            else:
+                raise OSError(f"no free control port in {ports[0]}..{ports[-1]}")
+            srv.listen(world)
+            srv.settimeout(timeout)
+            peers = {}
+            while len(peers) < world - 1:
+                c, _a = srv.accept()
+                c.settimeout(timeout)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.sendall(self.MAGIC)
+                r = int.from_bytes(self._recvn(c, 4), "little")
+                peers[r] = c
+            srv.close()
+            self.peers = [peers[r] for r in range(1, world)]
+        else:
+            t0 = time.time()
+            while self.sock is None:
+                for pt in ports:
+                    try:
+                        c = socket.create_connection((addr, pt), timeout=2)
+                        c.settimeout(5)
+                        if self._recvn(c, len(self.MAGIC)) == self.MAGIC:
+                            c.settimeout(timeout)
+                            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            c.sendall(int(rank).to_bytes(4, "little"))
+                            self.sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        continue
+                if self.sock is None:
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("control plane: rank 0 not reachable")
+                    time.sleep(0.05)
+
+    @staticmethod
+    def _recvn(c, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("control plane: peer closed the connection")
+            buf += chunk
+        return bytes(buf)
+
+    @classmethod
+    def _send(cls, c, b):
+        c.sendall(len(b).to_bytes(8, "little") + b)
+
+    @classmethod
+    def _recv(cls, c):
+        return cls._recvn(c, int.from_bytes(cls._recvn(c, 8), "little"))
+
+    def allgather_bytes(self, b: bytes):
+        """Every rank contributes `b`; every rank gets the list of all contributions in rank order."""
+        if self.world == 1:
+            return [b]
+        if self.rank == 0:
+            parts = [b] + [self._recv(c) for c in self.peers]
+            blob = b"".join(len(x).to_bytes(8, "little") + x for x in parts)
+            for c in self.peers:
+                self._send(c, blob)
+            return parts
+        self._send(self.sock, b)
+        blob, parts, o = self._recv(self.sock), [], 0
+        while o < len(blob):
+            n = int.from_bytes(blob[o:o + 8], "little")
+            parts.append(blob[o + 8:o + 8 + n])
+            o += 8 + n
+        return parts
+
+    def bcast_bytes(self, b):
+        return self.allgather_bytes(b if self.rank == 0 else b"")[0]
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def max_float(self, v: float) -> float:
+        return max(float(np.frombuffer(x, dtype=np.float64)[0]) for x in self.allgather_bytes(np.float64(v).tobytes()))
+
+    def close(self):
+        for c in self.peers + ([self.sock] if self.sock is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = [], None
+
+
+class HostStagedComm:
+    """Same interface as RcclComm, but the (small) exchange buffers travel device -> host -> TcpControl -> host
+    -> device.  A fallback for a node on which RCCL cannot be initialised, and the transport of the CPU tests."""
+
+    def __init__(self, ctx, control: TcpControl):
+        self.ctx, self.control, self.rank, self.world = ctx, control, control.rank, control.world
+
+    def allreduce_sum(self, darr):
+        n = darr.nbytes // darr.dtype.itemsize
+        host = np.empty(n, dtype=darr.dtype)
+        self.ctx.d2h(host, darr.ptr)
+        parts = [np.frombuffer(x, dtype=darr.dtype) for x in self.control.allgather_bytes(host.tobytes())]
+        self.ctx.h2d(darr.ptr, np.sum(parts, axis=0).astype(darr.dtype))
+        return darr
+
+    def allgather(self, dsend, drecv):
+        host = np.empty(dsend.nbytes // dsend.dtype.itemsize, dtype=dsend.dtype)
+        self.ctx.d2h(host, dsend.ptr)
+        self.ctx.h2d(drecv.ptr, np.frombuffer(b"".join(self.control.allgather_bytes(host.tobytes())), dtype=dsend.dtype))
+        return drecv
+
+    def close(self):
+        pass
+
+
+def bring_up_comm(ctx: Context, control: TcpControl):
+    """RCCL communicator over the ranks of `control` (unique id broadcast over the control plane); if any rank
+    fails to initialise RCCL every rank falls back to the host-staged transport.  Returns (comm, transport)."""
+    uid, err = b"", ""
+    if control.rank == 0:
         try:
-            c = socket.create_connection((addr, port), timeout=5)
-            break
-        except OSError:
-            if time.time() - t0 > timeout:
-                raise
-            time.sleep(0.05)
-    buf = b""
-    while len(buf) < 128:
-        chunk = c.recv(128 - len(buf))
-        if not chunk:
-            raise ConnectionError("unique id exchange interrupted")
-        buf += chunk
-    c.close()
-    return buf
+            uid = RcclComm.unique_id(ctx)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+    uid = control.bcast_bytes(uid)
+    comm = None
+    if len(uid) == 128:
+        try:
+            comm = RcclComm(ctx, uid, control.rank, control.world)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+    oks = control.allgather_bytes(b"1" if comm is not None else b"0" + err.encode())
+    if all(x == b"1" for x in oks):
+        return comm, "rccl"
+    why = "; ".join(f"rank {r}: {x[1:].decode(errors='replace')}" for r, x in enumerate(oks) if x != b"1")
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+    return HostStagedComm(ctx, control), f"host-staged tcp fallback (RCCL bring-up failed: {why})"
+
+
+def exchange_unique_id(ctx: Context, rank: int, world: int, addr: str, port: int, timeout=120.0) -> bytes:
+    """Torch-free bootstrap kept for callers that only need the id: rank 0 creates the RCCL unique id and the
+    control plane broadcasts it."""
+    control = TcpControl(rank, world, addr, port, timeout)
+    try:
+        return control.bcast_bytes(RcclComm.unique_id(ctx) if rank == 0 else b"")
+    finally:
+        control.close()
 
 
 # ------------------------------------------------------------------ device passes of the median

@@ -178,15 +178,45 @@ class HipInference:
     def dispersion_trend_gamma_glm(self, covariates, targets):
         """See ``Inference.dispersion_trend_gamma_glm`` (inference.py:284-308).
 
-        A two-coefficient cross-gene fit (not a per-gene kernel): SURVEY §8 a8 keeps it on
-        the host.  Same objective, start point, bounds and optimiser as
-        default_inference.py:200-230.
+        Same objective, start point, bounds and optimiser as default_inference.py:200-230, run by the
+        trend kernel of the device pipeline in its one-fit mode (``dsq_inf_dispersion_trend_gamma_glm``).
+        Returns (coeffs[2] intercept first, predictions, converged).
         """
-        from .trend import gamma_glm_fit
+        cov = _vec(getattr(covariates, "values", covariates))
+        tgt = _vec(getattr(targets, "values", targets))
+        if cov.shape != tgt.shape or cov.ndim != 1:
+            raise ValueError("covariates and targets must be vectors of the same length")
+        coeffs, pred, ok = np.empty(2), np.empty(len(cov)), c_int(0)
+        self.ctx.call("dsq_inf_dispersion_trend_gamma_glm", _vp(cov.ctypes.data), _vp(tgt.ctypes.data), len(cov),
+                      _vp(coeffs.ctypes.data), _vp(pred.ctypes.data), C.byref(ok))
+        return coeffs, pred, bool(ok.value)
 
-        cov = np.asarray(getattr(covariates, "values", covariates), dtype=np.float64)
-        tgt = np.asarray(getattr(targets, "values", targets), dtype=np.float64)
-        return gamma_glm_fit(cov, tgt)
+    # ------------------------------------------------------------------ grid searches (grid_search.py)
+    def grid_fit_alpha(self, counts, design_matrix, mu, min_disp, max_disp):
+        """``grid_search.grid_fit_alpha`` (grid_search.py:54-142) for every gene: log(alpha) G."""
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        m, mlay = _matrix_arg(mu)
+        out = np.empty(G)
+        self.ctx.call("dsq_inf_grid_fit_alpha", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
+                      mlay, N, G, X.shape[1], c_double(min_disp), c_double(max_disp), _vp(out.ctypes.data))
+        return out
+
+    def grid_fit_beta(self, counts, size_factors, design_matrix, disp, min_mu=0.5, grid_length=60, min_beta=-30,
+                      max_beta=30):
+        """``grid_search.grid_fit_beta`` (grid_search.py:145-221) for every gene: beta G x 2."""
+        y, ct, lay = _counts_arg(counts)
+        N, G = y.shape
+        X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
+        if X.shape[1] != 2:
+            raise ValueError("grid_fit_beta is defined for two design columns")
+        sf, d = _vec(size_factors), _vec(disp)
+        out = np.empty((G, 2))
+        self.ctx.call("dsq_inf_grid_fit_beta", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
+                      _vp(d.ctypes.data), N, G, c_double(min_mu), int(grid_length), c_double(min_beta),
+                      c_double(max_beta), _vp(out.ctypes.data))
+        return out
 
     # ------------------------------------------------------------------ apeGLM shrinkage
     def lfc_shrink_nbinom_glm(self, design_matrix, counts, size, offset, prior_no_shrink_scale, prior_scale,

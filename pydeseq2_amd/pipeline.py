@@ -170,16 +170,20 @@ class DeseqPipeline:
             m[np.asarray(control_genes)] = 1
             self._control_mask = m
         self.ldn = pad16(self.N)
-        self._count_type = I32 if counts.dtype == np.int32 else I64
         ctx_ = self.ctx
-        # ---- resident inputs
-        self.d_raw = DeviceArray.from_host(ctx_, np.ascontiguousarray(counts))  # sample-major, as given
-        self.d_y = DeviceArray(ctx_, (self.G, self.N), np.int32, ld=self.ldn)
+        # ---- resident inputs: the sample-major matrix narrowed to int32 on its way up (pinned staging chunks,
+        # dsq_upload_counts_i32) - kept for the per-sample medians - and its gene-major transposition
+        counts = np.ascontiguousarray(counts)
+        self._count_type = I32
+        self.d_raw = DeviceArray(ctx_, (self.N, self.G), np.int32)
         bad = C.c_int(0)
-        ctx_.call("dsq_dev_counts_to_gene_major", _vp(self.d_raw.ptr), self._count_type, SAMPLE_MAJOR, self.N,
-                  self.G, _vp(self.d_y.ptr), self.ldn, C.byref(bad))
+        ctx_.call("dsq_upload_counts_i32", _vp(counts.ctypes.data), I32 if counts.dtype == np.int32 else I64,
+                  C.c_size_t(counts.size), _vp(self.d_raw.ptr), C.byref(bad))
         if bad.value:
             raise ValueError("The count matrix should only contain non-negative integers below 2^31.")
+        self.d_y = DeviceArray(ctx_, (self.G, self.N), np.int32, ld=self.ldn)
+        ctx_.call("dsq_dev_counts_to_gene_major", _vp(self.d_raw.ptr), I32, SAMPLE_MAJOR, self.N,
+                  self.G, _vp(self.d_y.ptr), self.ldn, C.byref(bad))
         D = self.design
         self.d_Xt = DeviceArray.from_host(ctx_, D.Xt)
         self.d_pinv = DeviceArray.from_host(ctx_, D.pinvXt)

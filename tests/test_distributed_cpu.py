@@ -81,3 +81,46 @@ def test_world2_gloo_protocol_matches_single_process():
         np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
         assert np.isnan(allv[:, :, -3:]).all() and not np.isnan(allv[:, :, :-3]).any()
         assert np.allclose(allv[1, 0, :-3], 0.2)
+
+
+def _tcp_worker(rank, world, port, q):
+    """Control plane of the torch-free harness (pydeseq2_amd.distributed.TcpControl) carrying the size-factor
+    protocol's histograms and the trend inputs, as HostStagedComm does for device buffers."""
+    ctl = D.TcpControl(rank, world, "127.0.0.1", port, timeout=60)
+    counts, X = orc.synth_counts(400, 20, "2level", 11)
+    shard = np.array_split(np.arange(400), world)[rank]
+    mine = counts[:, shard]
+    lm, _ = orc.logmeans_and_filter(mine)
+
+    def allreduce(x):
+        parts = [np.frombuffer(b, dtype=x.dtype).reshape(x.shape) for b in ctl.allgather_bytes(x.tobytes())]
+        return np.sum(parts, axis=0).astype(x.dtype)
+
+    sf = D.median_select_protocol(NumpySfOps(mine, lm), allreduce)
+    got = ctl.allgather_bytes(bytes([rank]) * (rank + 1))
+    uid = ctl.bcast_bytes(b"u" * 128 if rank == 0 else b"")
+    mx = ctl.max_float(1.5 * rank)
+    ctl.barrier()
+    q.put((rank, sf, got, uid, mx))
+    ctl.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tcp_control_plane_carries_the_protocol(world):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    counts, X = orc.synth_counts(400, 20, "2level", 11)
+    sf_ref = orc.size_factors_ratio(counts)[0]
+    for rank, sf, got, uid, mx in res:
+        np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
+        assert got == [bytes([r]) * (r + 1) for r in range(world)]
+        assert uid == b"u" * 128 and mx == 1.5 * (world - 1)

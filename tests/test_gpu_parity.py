@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from oracle import nbglm_oracle as orc
-from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design
+from tests.helpers import (assert_close, check_hard_dispersion_genes, check_hard_lfc_genes, load_dataset, load_kat,
+                           max_rel_err, r_csv, treatment_design)
 
 pytestmark = pytest.mark.gpu
 
@@ -61,11 +62,15 @@ def test_dispersion_kernel_every_design_width(inf, P):
         assert (rel > 1e-6).mean() <= 0.03 and rel.max() < 5e-3, (P, bool(kw), np.sort(rel)[-5:])
 
 
-@pytest.mark.parametrize("case", ["p2", "p4", "p8"])
+@pytest.mark.parametrize("case", ["p2", "p4", "p8", "p10", "p12", "p16", "p24"])
 def test_inference_vs_reference_kats(inf, case):
+    """Every Inference method on the device against the outputs of the unmodified reference kernels.
+    p = 10, 12: the split second sweep of the register path; p = 16, 24: the LDS / MFMA path for designs
+    wider than 12 columns."""
     k = load_kat(case)
     N, P = k["X"].shape
     maxd = float(max(10, N))
+    atol_a = 1e-6 if P <= 8 else 2e-6  # wide designs: see tests/test_hostsim.py::test_alpha_mle
     assert_close(inf.fit_rough_dispersions(k["normed"], k["X"]), k["rough"], 1e-9, 1e-13, "rough")
     assert_close(inf.fit_moments_dispersions(k["normed"], k["sf"]), k["moments"], 1e-10, 1e-14, "moments")
     assert_close(inf.lin_reg_mu(k["counts"], k["sf"], k["X"], 0.5), k["lin_mu"], 1e-10, 0, "lin_mu")
@@ -76,13 +81,20 @@ def test_inference_vs_reference_kats(inf, case):
     assert_close(H, k["irls_H"], 1e-8, 1e-12, "irls H")
     a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, maxd)
     assert (c == k["gw_conv"]).all()
-    assert_close(a, k["gw_alpha"], 1e-6, 0, "genewise alpha")
+    assert_close(a, k["gw_alpha"], atol_a, 0, "genewise alpha")
     a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["fitted"], 1e-8, maxd,
                          prior_disp_var=float(k["prior_var"]), cr_reg=True, prior_reg=True)
     assert (c == k["map_conv"]).all()
-    assert_close(a, k["map_alpha"], 1e-6, 0, "MAP alpha")
+    assert_close(a, k["map_alpha"], atol_a, 0, "MAP alpha")
+    ng = len(k["grid_alpha"])  # a7: the device grid-search kernels (100 waves per gene and level)
+    la = inf.grid_fit_alpha(k["counts"][:, :ng], k["X"], k["mu_hat"][:, :ng], 1e-8, maxd)
+    assert np.abs(la - k["grid_alpha"]).max() < 1e-12
+    if "grid_beta" in k:  # a11
+        gb = inf.grid_fit_beta(k["counts"][:, :ng], k["sf"], k["X"], np.clip(k["map_alpha"], 1e-8, maxd)[:ng])
+        assert np.abs(gb - k["grid_beta"]).max() < 1e-12
     disp = np.clip(k["map_alpha"], 1e-8, maxd)
     b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], disp, 0.5, 1e-8)
+    assert (conv == k["lfc_conv"]).all()
     assert_close(b, k["lfc_beta"], 1e-8, 1e-10, "lfc beta")
     mu_w = np.exp(k["X"] @ k["lfc_beta"].T) * k["sf"][:, None]
     ridge = np.diag(np.repeat(1e-6, P))
@@ -97,25 +109,47 @@ def test_inference_vs_reference_kats(inf, case):
     assert_close(coeffs, k["trend_coeffs"], 1e-10, 0, "trend")
 
 
+def test_grid_fallbacks_on_genes_where_the_reference_takes_them(inf):
+    """a7 / a11 on the device (kat_hard.npz: every gene of a seeded search on which the unmodified reference
+    left its optimiser): k_alpha_grid_eval / k_alpha_grid_pick against grid_fit_alpha, k_grid_beta and the
+    rescue kernel's fallback against grid_fit_beta, and the full entry points alpha_mle / irls on those genes."""
+    k = load_kat("hard")
+    X, sf = k["X"], k["sf"]
+    la = inf.grid_fit_alpha(k["a_counts"], X, k["a_mu_hat"], 1e-8, 40.0)
+    a, c = inf.alpha_mle(k["a_counts"], X, k["a_mu_hat"], k["a_mom"], 1e-8, 40.0)
+    check_hard_dispersion_genes(k, a, c, la)
+    gb = inf.grid_fit_beta(k["b_counts"], sf, X, k["b_disp"])
+    assert np.abs(gb - k["b_grid_beta"]).max() < 1e-12
+    b, mu, H, conv = inf.irls(k["b_counts"], sf, X, k["b_disp"], 0.5, 1e-8)
+    check_hard_lfc_genes(k, b, mu, H, conv)
+
+
 def test_rough_dispersions_n_equals_p_raises(inf):
     X = np.eye(3)
     with pytest.raises(ValueError):
         inf.fit_rough_dispersions(np.ones((3, 5)), X)
 
 
-def _compare(res, ref, frac_noise=0.004):
-    """1e-5 parity on the north-star outputs; genes where the two L-BFGS-B runs disagree on
-    convergence (line search lost in rounding noise, grid-search fallback) are excluded and
-    must be a tiny fraction."""
+def _compare(res, ref, frac_noise=0.002):
+    """1e-5 parity on the north-star outputs.  Only genes on which the two L-BFGS-B runs DISAGREE about
+    convergence (line search lost in rounding noise: one side returns its last iterate, the other the
+    quantised grid value) are excluded, and they must be a tiny fraction.  Genes on which BOTH report
+    non-convergence went through the deterministic grid search on both sides (utils.py:556-564) and must
+    agree to 1e-10 (the grid objective has no prior term, so this holds for the MAP fit as well)."""
     G = len(ref.dispersions)
     assert_close(res.size_factors, ref.size_factors, 1e-12, 0, "size factors")
     assert (res.non_zero == ref.non_zero).all()
+    nz = ref.non_zero
     with np.errstate(invalid="ignore"):
         noisy = (res.genewise_converged != ref.genewise_converged) | (res.MAP_converged != ref.MAP_converged)
-        noisy |= (ref.genewise_converged == 0) | (ref.MAP_converged == 0)
-    noisy &= ref.non_zero
+    noisy &= nz
     noisy |= res.refitted != ref.refitted
     assert noisy.sum() <= max(2, frac_noise * G), f"{noisy.sum()} noise-limited genes of {G}"
+    untouched = nz & ~res.refitted & ~ref.refitted  # refitted genes carry the dispersions of the replaced counts
+    both_gw = untouched & (res.genewise_converged == 0) & (ref.genewise_converged == 0)
+    assert_close(res.genewise_dispersions[both_gw], ref.genewise_dispersions[both_gw], 1e-10, 0, "grid genewise")
+    both_map = untouched & (res.MAP_converged == 0) & (ref.MAP_converged == 0)
+    assert_close(res.MAP_dispersions[both_map], ref.MAP_dispersions[both_map], 1e-10, 0, "grid MAP")
     ok = ~noisy
     assert (res.refitted[ok] == ref.refitted[ok]).all()
     assert (res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()
@@ -125,7 +159,7 @@ def _compare(res, ref, frac_noise=0.004):
     assert_close(res.lfcSE[ok], ref.lfcSE[ok], RTOL, 0, "lfcSE")
     # the trend is fitted on all genes, so it carries the noise genes' influence
     assert_close(res.trend_coeffs, ref.trend_coeffs, 1e-4, 0, "trend coeffs")
-    return int(noisy.sum())
+    return int(noisy.sum()), int(both_gw.sum() + both_map.sum())
 
 
 @pytest.mark.parametrize("G,N,design,seed", [(1000, 100, "2level", 1), (1500, 60, "3factor", 2),
@@ -156,6 +190,47 @@ def test_pipeline_vs_oracle_many_samples():
     res = pydeseq2_amd.deseq2(counts, X, device=0)
     ref = orc.deseq2(counts, X, n_jobs=8)
     _compare(res, ref)
+
+
+def _jobs():
+    import os
+
+    return max(1, min(64, os.cpu_count() or 1))
+
+
+@pytest.mark.parametrize("cfg,G,N,design,seed", [
+    ("c3", 2000, 1000, "2level", 2),      # BASELINE configs[2]: the benchmark's shape (LDS-staged dispersion kernel)
+    ("c4", 2000, 500, "3factor", 3),      # configs[3]: p = 8, 30 design cells, IRLS supplies mu_hat
+    ("c5-shard", 2000, 5000, "mixed", 4),  # configs[4] per-GPU shard: p = 8 with continuous covariates, long rows
+])
+def test_pipeline_vs_oracle_at_benchmark_shapes(cfg, G, N, design, seed):
+    """End-to-end 1e-5 parity against the oracle on 2000-gene slices with the benchmark configurations' sample
+    counts and designs (the per-gene kernels run the very instantiations the full-size launches use)."""
+    import pydeseq2_amd
+
+    counts, X = orc.synth_counts(G, N, design, seed)
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    ref = orc.deseq2(counts, X, n_jobs=_jobs(), keep_layers=False)
+    n_noise, n_grid = _compare(res, ref)
+    print(f"{cfg}: {n_noise} noise-limited genes, {n_grid} grid-fallback fits compared at 1e-10")
+
+
+def test_hip_inference_under_the_reference_orchestration():
+    """All Inference methods of the plug-in driven in DeseqDataSet.deseq2()'s call order with the reference's
+    keyword arguments (dds.py:713-984, ds.py:303-360; the orchestration is the oracle's restatement of it, since
+    the stock DeseqDataSet needs anndata): same results as the oracle with its own kernels."""
+    from pydeseq2_amd import HipInference
+
+    for design, G, N, seed in (("2level", 600, 60, 21), ("3factor", 400, 60, 22)):
+        counts, X = orc.synth_counts(G, N, design, seed)
+        counts[:, 9] = 0
+        if design == "2level":
+            counts[3, 10] = 200000  # live Cook's refit: the plug-in is re-entered with a sub-dataset
+        ref = orc.deseq2(counts, X, n_jobs=4)
+        res = orc.deseq2(counts, X, inference=HipInference(device=0))
+        _compare(res, ref)
+        if design == "2level":
+            assert ref.refitted.sum() >= 1 and (res.refitted == ref.refitted).all()
 
 
 def test_cooks_layer_vs_oracle():
@@ -402,17 +477,21 @@ def test_full_size_c3_properties():
     z = res.LFC[ok, 1] / res.lfcSE[ok]
     assert np.allclose(z, res.stat[ok], rtol=1e-9, atol=1e-12)
     assert np.allclose(res.pvalue[ok], 2 * norm.sf(np.abs(res.stat[ok])), rtol=1e-9, atol=1e-300)
-    sel = np.sort(np.random.default_rng(3).choice(np.nonzero(nz & ~res.replaced)[0], 160, replace=False))
+    sel = np.sort(np.random.default_rng(3).choice(np.nonzero(nz & ~res.replaced)[0], 2000, replace=False))
     c = counts[:, sel]
     mu = orc.lin_reg_mu(c, res.size_factors, X, 0.5)
-    a, cv = orc.alpha_mle(c, X, mu, res.mom_dispersions[sel], 1e-8, 1000.0, n_jobs=8)
-    same = cv & (res.genewise_converged[sel] == 1)
-    assert same.mean() > 0.97
+    a, cv = orc.alpha_mle(c, X, mu, res.mom_dispersions[sel], 1e-8, 1000.0, n_jobs=_jobs())
+    gc = res.genewise_converged[sel] == 1
+    assert (cv == gc).mean() >= 0.995
+    same = cv & gc
     assert_close(res.genewise_dispersions[sel][same], np.clip(a, 1e-8, 1000.0)[same], RTOL, 0, "genewise")
+    both = ~cv & ~gc  # grid search on both sides: deterministic
+    assert_close(res.genewise_dispersions[sel][both], np.clip(a, 1e-8, 1000.0)[both], 1e-10, 0, "genewise grid")
     m, mc = orc.alpha_mle(c, X, mu, res.fitted_dispersions[sel], 1e-8, 1000.0, prior_disp_var=res.prior_disp_var,
-                          cr_reg=True, prior_reg=True, n_jobs=8)
-    same = mc & (res.MAP_converged[sel] == 1)
-    assert same.mean() > 0.97
+                          cr_reg=True, prior_reg=True, n_jobs=_jobs())
+    gm = res.MAP_converged[sel] == 1
+    assert (mc == gm).mean() >= 0.995
+    same = mc & gm
     assert_close(res.MAP_dispersions[sel][same], np.clip(m, 1e-8, 1000.0)[same], RTOL, 0, "MAP")
     beta, _, _, bc = orc.irls(c, res.size_factors, X, res.dispersions[sel], 0.5, 1e-8)
     assert_close(res.LFC[sel][bc], beta[bc], RTOL, 1e-8, "LFC")

@@ -11,7 +11,7 @@ from scipy.stats import norm
 
 from oracle import nbglm_oracle as orc
 from tests import hostsim as hs
-from tests.helpers import assert_close, load_kat
+from tests.helpers import assert_close, check_hard_dispersion_genes, check_hard_lfc_genes, load_kat
 
 CASES = ["p2", "p4", "p8", "p10", "p12"]
 
@@ -106,6 +106,17 @@ def test_irls(case):
     _, _, _, _, it_o = orc.irls(k["counts"], k["sf"], k["X"], disp, return_iters=True)
     assert (it == it_o)[~fb.astype(bool)].all()
     assert (conv == k["lfc_conv"]).all()
+
+
+def test_grid_fallbacks_on_genes_where_the_reference_takes_them():
+    """Host instantiation of the device templates on kat_hard.npz (same assertions as the GPU test)."""
+    k = load_kat("hard")
+    a, c, _ = hs.alpha_mle(k["a_counts"], k["X"], k["a_mu_hat"], k["a_mom"], 1e-8, 40.0)
+    la = hs.grid_alpha(k["a_counts"], k["X"], k["a_mu_hat"], 1e-8, 40.0)
+    check_hard_dispersion_genes(k, a, c, la)
+    b, mu, H, conv, it, fb = hs.irls(k["b_counts"], k["sf"], k["X"], k["b_disp"])
+    assert fb.all()
+    check_hard_lfc_genes(k, b, mu, H, conv)
 
 
 @pytest.mark.parametrize("case", CASES)

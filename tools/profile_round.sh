@@ -15,7 +15,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- \
     python "$REPO/bench.py" --config "$CFG" --steps 5 --warmup 2 > "$OUT/bench_prof.log" 2> "$OUT/bench_prof.err"
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o run -- \
-        python "$REPO/bench.py" --config "$CFG" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+        python "$REPO/bench.py" --config "$CFG" --steps 1 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/pmc_$C.log" 2>&1
 done
 cd "$REPO"
 for f in $(find "$OUT" -name "*_results.db"); do echo "$f"; done

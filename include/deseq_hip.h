@@ -204,6 +204,12 @@ size_t dsq_size_factors_work_doubles(int N, int G);
 int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
                          const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
                          double* d_size_factors);
+/* The same for NEW samples normalised with the training log means (DeseqDataSet.vst_transform on new counts,
+ * dds.py:471-484 -> deseq2_norm_transform): a zero count in a usable gene is log(0) - logmean = -inf and takes
+ * part in the sample's median at the low end, as in numpy. */
+int dsq_dev_size_factors_new(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                             const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
+                             double* d_size_factors);
 /* dsq_dev_mom + dsq_dev_lin_mu fused for the designs that take the linear-model mu_hat (#cells == p,
  * dds.py:747-756): two sweeps over a gene's counts instead of four, bit-identical outputs. */
 int dsq_dev_mom_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
@@ -225,6 +231,56 @@ int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int 
                       double min_disp, double max_disp, double prior_disp_var, int cr_reg,
                       int prior_reg, double* d_alpha, uint8_t* d_converged, int32_t* d_nfev,
                       double* d_nll_const, int const_mode);
+/* Designs whose rows take few distinct values (every purely categorical design): the design's "cells".
+ * d_cell_of[ldx]: cell of every sample (0 beyond N); d_Xc[n_cells][P]: the cells' design rows;
+ * d_XX[n_cells][P(P+1)/2]: products x_i x_j of a cell's row (packed lower triangle, entry i(i+1)/2 + j).
+ * With n_cells <= 64 the dispersion and IRLS kernels accumulate per-cell weight sums instead of per-sample
+ * outer products: their per-sample work no longer depends on P (used for P >= 3).  NULL / n_cells == 0: general path. */
+typedef struct dsq_cells {
+    const int32_t* d_cell_of;
+    const double* d_Xc;
+    const double* d_XX;
+    int n_cells;
+} dsq_cells;
+/* dsq_dev_mom_lin_mu that also stores the OLS coefficients of the normalised counts, d_coef[G][P]; d_mu may then be
+ * NULL: mu_hat = max(sf * (X coef), min_mu) is rebuilt inside the dispersion kernel (dsq_dev_alpha_mle2) instead of
+ * being written once (8 N bytes per gene) and read twice. */
+int dsq_dev_mom_lin_coef(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                         const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                         double min_mu, double* d_normed_mean, double* d_mom, double* d_mu, double* d_coef);
+/* dsq_dev_alpha_mle with the optional cell path (cells) and, when d_mu == NULL, mu_hat from (d_coef, d_sf, min_mu). */
+int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu);
+/* The robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960) alone: the half of dsq_dev_cooks
+ * that depends on counts, size factors and design cells only (arguments as dsq_dev_cooks). */
+int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
+                        const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int N, int G,
+                        double* d_robust_disp);
+/* dsq_dev_irls with (a) the optional cell path, (b) the per-sample half of the Cook's stage fused into its epilogue
+ * (d_flags != NULL: d_robust_disp from dsq_dev_robust_disp in, d_cooks (nullable layer) and the four flag vectors of
+ * dsq_dev_cooks out) and (c) the Wald statistics of dsq_dev_wald (h_ridge != NULL) computed while mu is in registers.
+ * d_mu / d_hat may then be NULL: the N x G layers are not written unless asked for (dsq_dev_irls_layers rebuilds
+ * them from beta on demand). */
+int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                    const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                    double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
+                    double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
+                    const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
+                    uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
+                    const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
+                    double* d_stats, double* d_se);
+int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt, int ldx,
+                        int N, int G, int P, const double* d_disp, const double* d_beta, double min_mu, double* d_mu,
+                        double* d_hat);
+/* Side stream: work enqueued between dsq_side_begin and dsq_side_end runs on a second HIP stream that starts after
+ * everything enqueued so far and overlaps what the main stream does next; dsq_side_wait makes the main stream wait
+ * for it.  (The pipeline puts dsq_dev_robust_disp underneath the latency-bound trend / prior kernels.) */
+int dsq_side_begin(dsq_ctx* ctx);
+int dsq_side_end(dsq_ctx* ctx);
+int dsq_side_wait(dsq_ctx* ctx);
 /* d_mu / d_hat may be null.  d_iters may be null. */
 int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                  const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank,

@@ -36,10 +36,19 @@ class DesignPack:
         if self.full_rank:
             Q, R = np.linalg.qr(X)
             self.pinvXt[:, : self.N] = np.linalg.solve(R, Q.T)
-        _, inv, cnt = np.unique(X, axis=0, return_inverse=True, return_counts=True)
+        rows, inv, cnt = np.unique(X, axis=0, return_inverse=True, return_counts=True)
         inv = np.asarray(inv).reshape(-1)
         self.cell_id, self.cell_sizes = inv, cnt
         self.n_design_cells = len(cnt)
+        # cell path of the dispersion / IRLS kernels (include/deseq_hip.h, dsq_cells): per-sample cell index, the
+        # cells' design rows and their packed outer products, for designs with at most 64 distinct rows
+        self.cell_path = 4 < self.n_design_cells <= 64 and self.P >= 3
+        if self.cell_path:
+            self.cell_of = np.zeros(self.ldx, dtype=np.int32)
+            self.cell_of[: self.N] = inv
+            self.Xc = np.ascontiguousarray(rows, dtype=np.float64)
+            ii, jj = np.tril_indices(self.P)  # row-major lower triangle: entry i(i+1)/2 + j
+            self.XXc = np.ascontiguousarray(self.Xc[:, ii] * self.Xc[:, jj])
         self.linear_mu = self.n_design_cells == self.P
         size = cnt[inv]
         self.use_for_max = size >= 3

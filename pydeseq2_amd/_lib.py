@@ -23,6 +23,12 @@ c_void_p, c_int, c_double, c_size_t = C.c_void_p, C.c_int, C.c_double, C.c_size_
 _vp = c_void_p
 
 
+class DsqCells(C.Structure):
+    """dsq_cells of include/deseq_hip.h: the design's distinct rows (device pointers)."""
+
+    _fields_ = [("d_cell_of", C.c_void_p), ("d_Xc", C.c_void_p), ("d_XX", C.c_void_p), ("n_cells", C.c_int)]
+
+
 class DsqError(RuntimeError):
     """A libdeseq_hip call failed (HIP error, bad argument, out of memory)."""
 
@@ -89,6 +95,7 @@ def load():
     proto("dsq_dev_f64_to_gene_major", _vp, _vp, c_int, c_int, c_int, _vp, c_int)
     proto("dsq_dev_logmeans", _vp, _vp, c_int, c_int, c_int, _vp, _vp)
     proto("dsq_dev_size_factors", _vp, _vp, c_int, c_int, c_int, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_size_factors_new", _vp, _vp, c_int, c_int, c_int, _vp, _vp, _vp, _vp)
     proto("dsq_dev_mom", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, c_double,
           _vp, _vp, _vp, _vp)
     proto("dsq_dev_lin_mu", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, _vp)
@@ -113,6 +120,19 @@ def load():
     proto("dsq_dev_padj_prepare", _vp, _vp, _vp, c_int, c_double, _vp, _vp, _vp, _vp, C.POINTER(c_int))
     proto("dsq_dev_padj_finish", _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp)
     proto("dsq_d2d", _vp, _vp, _vp, c_size_t)
+    cells_p = C.POINTER(DsqCells)
+    proto("dsq_dev_mom_lin_coef", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_double, c_double,
+          c_double, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_alpha_mle2", _vp, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
+          c_double, c_int, c_int, _vp, _vp, _vp, _vp, c_int, cells_p, _vp, _vp, c_double)
+    proto("dsq_dev_robust_disp", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, _vp)
+    proto("dsq_dev_lfc_fit", _vp, _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, _vp, c_double,
+          c_double, c_double, c_double, c_int, _vp, _vp, _vp, _vp, _vp, cells_p, _vp, _vp, c_double, _vp, _vp, _vp,
+          _vp, _vp, _vp, _vp, c_double, c_int, _vp, _vp, _vp)
+    proto("dsq_dev_irls_layers", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, _vp, c_double, _vp, _vp)
+    proto("dsq_side_begin", _vp)
+    proto("dsq_side_end", _vp)
+    proto("dsq_side_wait", _vp)
     proto("dsq_upload_counts_i32", _vp, _vp, c_int, c_size_t, _vp, C.POINTER(c_int))
     proto("dsq_host_alloc", _vp, c_size_t, C.POINTER(_vp))
     proto("dsq_host_free", _vp, _vp)
@@ -156,6 +176,8 @@ EXPORTS = [
     "dsq_comm_allreduce_sum", "dsq_comm_allgather", "dsq_dev_sf_keys", "dsq_dev_sf_count", "dsq_dev_sf_init",
     "dsq_dev_sf_hist", "dsq_dev_sf_pick", "dsq_dev_sf_finish", "dsq_dev_trend_eval", "dsq_dev_select_dispersions",
     "dsq_dev_scatter_rows_f64", "dsq_d2d", "dsq_dev_mom_lin_mu", "dsq_dev_sf_keys_compact", "dsq_prior_mad_work_doubles", "dsq_size_factors_work_doubles", "dsq_dev_mom_raw", "dsq_dev_nll_const", "dsq_dev_nll_scaled", "dsq_dev_logmeans_poscounts", "dsq_dev_vst", "dsq_inf_lfc_shrink_nbinom_glm", "dsq_dev_lfc_shrink", "dsq_dev_padj_prepare", "dsq_dev_padj_finish", "dsq_host_alloc", "dsq_host_free", "dsq_d2h_async", "dsq_h2d_async",
+    "dsq_dev_size_factors_new", "dsq_dev_mom_lin_coef", "dsq_dev_alpha_mle2", "dsq_dev_robust_disp", "dsq_dev_lfc_fit", "dsq_dev_irls_layers",
+    "dsq_side_begin", "dsq_side_end", "dsq_side_wait",
     "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",
 ]
 

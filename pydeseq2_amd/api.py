@@ -158,6 +158,7 @@ class DeseqDataSet:
             control_genes = self.var_names.get_indexer(cg) if cg.dtype.kind in "OUS" else cg
             if cg.dtype.kind in "OUS" and (np.asarray(control_genes) < 0).any():
                 raise KeyError("control_genes: unknown gene name")
+        self._control_genes = control_genes
         self._pipe = DeseqPipeline(self.X, dm.to_numpy(), ctx=ctx, device=device, min_mu=min_mu, min_disp=min_disp,
                                    max_disp=max_disp, refit_cooks=refit_cooks, min_replicates=min_replicates,
                                    beta_tol=beta_tol, fit_type=fit_type, size_factors_fit_type=size_factors_fit_type,
@@ -215,13 +216,23 @@ class DeseqDataSet:
         X = self.obsm["design_matrix"].to_numpy() if use_design else np.ones((self.n_obs, 1))
         pipe = p0 if use_design else DeseqPipeline(self.X, X, ctx=p0.ctx, min_mu=p0.min_mu, min_disp=p0.min_disp,
                                                     max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type,
-                                                    size_factors_fit_type=p0.size_factors_fit_type)
+                                                    size_factors_fit_type=p0.size_factors_fit_type,
+                                                    control_genes=self._control_genes)
+        # size factors are fitted only when there are none yet (dds.py:397-401): after deseq2() / fit_size_factors()
+        # the transformation uses the ones the model was fitted with (control genes included)
+        have_sf = "size_factors" in self.obs
         old_ft, pipe.fit_type = pipe.fit_type, self.vst_fit_type
         try:
-            r = pipe.deseq2(stop_after_trend=True)
+            r = pipe.deseq2(stop_after_trend=True,
+                            size_factors=np.asarray(self.obs["size_factors"], dtype=float) if have_sf else None)
         finally:
             pipe.fit_type = old_ft
-        self.obs["size_factors"] = r.size_factors
+            if pipe is not p0:
+                pipe.close()
+        if pipe is p0:
+            self.layers.clear()  # the device layers of an earlier deseq2() were recycled by this run
+        if not have_sf:
+            self.obs["size_factors"] = r.size_factors
         self.var["vst_genewise_dispersions"] = r.genewise_dispersions
         if r.disp_function_type == "parametric":
             self.uns["vst_trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
@@ -316,23 +327,37 @@ class DeseqStats:
         return v
 
     def run_wald_test(self):
+        """Wald test of the CURRENT coefficients (``self.LFC``: shrunk ones after ``lfc_shrink``), ds.py:303-360."""
         r = self.dds._res
-        pv, st, se = self.dds._pipe.wald(r, self.contrast_vector, self.lfc_null, self.alt_hypothesis)
+        P = self.LFC.shape[1]
+        if self.prior_LFC_var is not None:  # ds.py:326-329
+            ridge = np.diag(1.0 / np.asarray(self.prior_LFC_var, dtype=float) ** 2)
+        else:
+            ridge = np.diag(np.repeat(1e-6, P))
+        pv, st, se = self.dds._pipe.wald(r, self.contrast_vector, self.lfc_null, self.alt_hypothesis,
+                                         lfc=self.LFC.to_numpy(), ridge=ridge)
         idx = self.dds.var_names
         self.p_values, self.statistics, self.SE = pd.Series(pv, index=idx), pd.Series(st, index=idx), pd.Series(se, index=idx)
+        self._wald_key = (self.lfc_null, self.alt_hypothesis)
+        if hasattr(self, "padj"):
+            del self.padj
 
     def summary(self, **kwargs) -> pd.DataFrame:
-        """Wald test, Cook's filtering, adjusted p-values; returns and stores ``results_df`` (ds.py:219-299)."""
+        """Wald test, Cook's filtering, adjusted p-values; returns and stores ``results_df`` (ds.py:219-299).
+        The Wald test is (re)run only when there are no p-values yet or ``lfc_null`` / ``alt_hypothesis`` change
+        (ds.py:255-264), so a summary after ``lfc_shrink`` keeps the shrunk coefficients with their standard errors."""
         self.lfc_null = kwargs.get("lfc_null", self.lfc_null)
         self.alt_hypothesis = kwargs.get("alt_hypothesis", self.alt_hypothesis)
-        self.run_wald_test()
-        pv = self.p_values.to_numpy().copy()
-        if self.cooks_filter:
-            pv[self.dds.cooks_outlier().to_numpy()] = np.nan
-        self.p_values = pd.Series(pv, index=self.dds.var_names)
-        padj, self._padj_info = _summary.adjusted_pvalues(self.dds._pipe.ctx, self.base_mean.to_numpy(), pv, self.alpha,
-                                                          self.independent_filter)
-        self.padj = pd.Series(padj, index=self.dds.var_names)
+        if not hasattr(self, "p_values") or getattr(self, "_wald_key", None) != (self.lfc_null, self.alt_hypothesis):
+            self.run_wald_test()
+        if not hasattr(self, "padj"):
+            pv = self.p_values.to_numpy().copy()
+            if self.cooks_filter:
+                pv[self.dds.cooks_outlier().to_numpy()] = np.nan
+            self.p_values = pd.Series(pv, index=self.dds.var_names)
+            padj, self._padj_info = _summary.adjusted_pvalues(self.dds._pipe.ctx, self.base_mean.to_numpy(), pv,
+                                                              self.alpha, self.independent_filter)
+            self.padj = pd.Series(padj, index=self.dds.var_names)
         df = pd.DataFrame(index=self.dds.var_names)
         df["baseMean"] = self.base_mean
         df["log2FoldChange"] = self.LFC.to_numpy() @ self.contrast_vector / np.log(2)

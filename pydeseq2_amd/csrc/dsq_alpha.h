@@ -28,6 +28,8 @@ struct AlphaArgs {
     double la_hat;      // log(alpha_hat)
     double prior_var;
     bool cr_reg, prior_reg;
+    const CellDesign* cells = nullptr;  // CELL instantiations: the design's cells ...
+    void* cell_ws = nullptr;            // ... and this wave's CellWork<P>
 };
 
 // lgamma(a) - lgamma(y + a) and digamma(a) - digamma(y + a) for a count y >= 0.
@@ -99,16 +101,16 @@ DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double
 struct EvalOut {
     double f, g;
 };
-template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
 DSQ_EVAL_FN EvalOut alpha_eval_v(const AlphaArgs A, double la, bool cr_reg, bool prior_reg) {
     double f, g;
 #else
-template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
 DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
                        double& g) {
 #endif
     constexpr int T = Tri<P>::N;
-    constexpr bool kSplitDM = P >= 9;
+    constexpr bool kSplitDM = P >= 9 && !CELL;
     DSQ_PHASE(2);
     la = Wv::uniform(la);
     const double alpha = Wv::uniform(exp(la));
@@ -139,6 +141,13 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     double M[T], dM[T];
 #pragma unroll
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
+    // CELL: per-cell sums of w and dw instead of p(p+1) accumulators per lane (dsq_linalg.h, CellDesign)
+    CellWork<P>* const Wk = CELL ? (CellWork<P>*)A.cell_ws : nullptr;
+    const int32_t* const cell_of = CELL ? A.cells->cell_of : nullptr;
+    if (CELL && cr_reg) {
+        for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) { Wk->acc[0][c] = 0.0; Wk->acc[1][c] = 0.0; }
+        Wv::sync();
+    }
     DSQ_PHASE(3);
     // PAD: y / mu are padded to a multiple of the wave width with (0, 0.0), which makes every
     // per-sample contribution exactly zero (L1 = 0, w = 0, memo[0] = 0) without masking; without PAD
@@ -181,9 +190,14 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     int y1 = load_y(nl), y2 = load_y(nl + Wv::W);
     double m1 = load_m(nl);
     double x1[P];
+    int c1 = 0;
     if (cr_reg) {
+        if constexpr (CELL) {
+            c1 = DSQ_AS_GLOBAL(int32_t, cell_of)[nl < A.N ? nl : A.N - 1];
+        } else {
 #pragma unroll
-        for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + (nl < A.N ? nl : A.N - 1)];
+            for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + (nl < A.N ? nl : A.N - 1)];
+        }
     }
     // the 4-block memo keeps 16 fetched values in flight per prefetch, which costs more registers
     // than the 168 a wave may use at 3 waves per SIMD: it fetches at the point of use instead
@@ -198,8 +212,11 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         const int yi = y1;
         const double m = m1, dl0 = dl1, dd0 = dd1;
         double x[P];
+        const int cell = c1;
+        if constexpr (!CELL) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) x[j] = x1[j];
+            for (int j = 0; j < P; ++j) x[j] = x1[j];
+        }
         // ---- issue the next iteration's reads
         nl += Wv::W;
         y1 = y2;
@@ -207,8 +224,12 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         m1 = load_m(nl);
         if (cr_reg) {
             const int nx = nl < A.N ? nl : A.N - 1;  // padded / out-of-range samples have w = 0
+            if constexpr (CELL) {
+                c1 = DSQ_AS_GLOBAL(int32_t, cell_of)[nx];
+            } else {
 #pragma unroll
-            for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + nx];
+                for (int j = 0; j < P; ++j) x1[j] = Xg[j * A.ldx + nx];
+            }
         }
         double rl[NB], rd[NB];
         memo_issue(kPrefetchMemo ? y1 : yi, rl, rd);
@@ -236,13 +257,18 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         if (cr_reg) {
             const double w = m * r1;
             const double dw = -(w * w);
+            if constexpr (CELL) {
+                Wv::cell_add(&Wk->acc[0][cell], w);
+                if (GRAD) Wv::cell_add(&Wk->acc[1][cell], dw);
+            } else {
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const double xw = x[i] * w, xdw = x[i] * dw;
+                for (int i = 0; i < P; ++i) {
+                    const double xw = x[i] * w, xdw = x[i] * dw;
 #pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    M[tri(i, j)] += xw * x[j];
-                    if (GRAD && !kSplitDM) dM[tri(i, j)] += xdw * x[j];
+                    for (int j = 0; j <= i; ++j) {
+                        M[tri(i, j)] += xw * x[j];
+                        if (GRAD && !kSplitDM) dM[tri(i, j)] += xdw * x[j];
+                    }
                 }
             }
         }
@@ -278,8 +304,31 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     g = 0.0;
     if (GRAD) g = alpha * (-(a * a * accg));
     if (cr_reg) {
-        Wv::template sum_n<T>(M);
-        if (GRAD) Wv::template sum_n<T>(dM);
+        if constexpr (CELL) {
+            // entry-parallel: lane e owns entry e of X^T W X (and of X^T dW X) and walks the cells
+            Wv::sync();
+            const CellDesign& D = *A.cells;
+            const auto XXg = DSQ_AS_GLOBAL(double, D.XX);
+            for (int e = Wv::lane(); e < T; e += Wv::W) {
+                double me = 0.0, de = 0.0;
+                for (int c = 0; c < D.C; ++c) {
+                    const double xx = XXg[c * T + e];
+                    me += xx * Wk->acc[0][c];
+                    if (GRAD) de += xx * Wk->acc[1][c];
+                }
+                Wk->ent[e] = me;
+                if (GRAD) Wk->ent[T + e] = de;
+            }
+            Wv::sync();
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                M[k] = Wk->ent[k];
+                if (GRAD) dM[k] = Wk->ent[T + k];
+            }
+        } else {
+            Wv::template sum_n<T>(M);
+            if (GRAD) Wv::template sum_n<T>(dM);
+        }
         DSQ_PHASE(5);
         chol<P>(M);
         f += 0.5 * chol_logdet<P>(M);
@@ -300,9 +349,9 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
 }
 
 #if defined(DSQ_EVAL_BYVAL)
-template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1>
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
 DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f, double& g) {
-    const EvalOut o = alpha_eval_v<Wv, P, GRAD, PAD, NB>(A, la, cr_reg, prior_reg);
+    const EvalOut o = alpha_eval_v<Wv, P, GRAD, PAD, NB, CELL>(A, la, cr_reg, prior_reg);
     f = o.f;
     g = o.g;
 }
@@ -376,12 +425,12 @@ DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
 // reference's grid search right here (host simulation / single-kernel use); otherwise only report
 // converged = 0 and the caller schedules grid_alpha_gene for the gene (device: second tiny kernel,
 // which keeps the 200-evaluation grid code out of the main kernel's register budget).
-template <class Wv, int P, bool RUN_GRID, bool PAD = false>
+template <class Wv, int P, bool RUN_GRID, bool PAD = false, bool CELL = false>
 DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
                                double alpha_hat, double min_disp, double max_disp,
                                double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
                                const double* cst_in = nullptr, double* cst_out = nullptr,
-                               int memo_blocks = 1) {
+                               int memo_blocks = 1, const CellDesign* cells = nullptr, void* cell_ws = nullptr) {
     // PAD rows are LDS-staged; the in-place grid search evaluates with PAD = false (global rows)
     static_assert(!(RUN_GRID && PAD), "the in-place grid search expects un-staged rows");
     AlphaArgs A;
@@ -389,6 +438,7 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     A.la_hat = log(alpha_hat);
     A.prior_var = prior_var;
     A.cr_reg = cr_reg; A.prior_reg = prior_reg;
+    A.cells = cells; A.cell_ws = cell_ws;
     // the constant depends on (y, mu) only: the MAP fit re-uses the one the MLE fit stored
     DSQ_PHASE(1);
     A.cst = cst_in != nullptr ? *cst_in : alpha_const<Wv>(y, mu, N);
@@ -397,9 +447,9 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     m.start(A.la_hat, lo, hi);
     while (!m.done) {
         double f, g;
-        if (memo_blocks <= 1) alpha_eval<Wv, P, true, PAD, 1>(A, m.x, cr_reg, prior_reg, f, g);
-        else if (memo_blocks == 2) alpha_eval<Wv, P, true, PAD, 2>(A, m.x, cr_reg, prior_reg, f, g);
-        else alpha_eval<Wv, P, true, PAD, 4>(A, m.x, cr_reg, prior_reg, f, g);
+        if (memo_blocks <= 1) alpha_eval<Wv, P, true, PAD, 1, CELL>(A, m.x, cr_reg, prior_reg, f, g);
+        else if (memo_blocks == 2) alpha_eval<Wv, P, true, PAD, 2, CELL>(A, m.x, cr_reg, prior_reg, f, g);
+        else alpha_eval<Wv, P, true, PAD, 4, CELL>(A, m.x, cr_reg, prior_reg, f, g);
         DSQ_PHASE(6);
         m.feed(f, g);
     }
@@ -408,7 +458,10 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     o.converged = m.success ? 1 : 0;
     o.nfev = m.nfev; o.nit = m.it; o.status = m.status;
     o.alpha = exp(m.x);
-    if (RUN_GRID && !m.success) o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
+    if (RUN_GRID && !m.success) {
+        A.cells = nullptr;  // the (rare) grid search runs the general evaluation
+        o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
+    }
     return o;
 }
 

@@ -19,6 +19,8 @@
 struct dsq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t main_stream = nullptr, side_stream = nullptr;  // `stream` is whichever of the two is current
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     float last_kernel_ms = 0.0f;  // k_alpha launch of the last dsq_*_alpha_mle call (HIP events)
     int last_n_grid = 0;          // genes that took the grid-search fallback in that call
@@ -75,7 +77,8 @@ hipError_t ensure_list(dsq_ctx* c, size_t n) {
 int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
               int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
-              double* d_nll_const = nullptr, int const_mode = DSQ_CONST_COMPUTE);
+              double* d_nll_const = nullptr, int const_mode = DSQ_CONST_COMPUTE,
+              const dsq::AlphaExtras* extras = nullptr);
 
 // RAII device buffer for the Inference-level calls
 struct DevBuf {
@@ -203,7 +206,7 @@ int download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N
 int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
               int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
-              double* d_nll_const, int const_mode) {
+              double* d_nll_const, int const_mode, const dsq::AlphaExtras* extras) {
     if (G <= 0) return DSQ_OK;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     int32_t* d_cnt = ctx->d_counter + 4;
@@ -211,7 +214,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
                               prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
-                              d_nll_const, const_mode));
+                              d_nll_const, const_mode, extras));
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t n_grid = 0;
     DSQ_HIP(hipMemcpyAsync(&n_grid, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -219,11 +222,28 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     DSQ_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->evk0, ctx->evk1));
     ctx->last_n_grid = n_grid;
     if (n_grid > 0) {
-        DevBuf work;
+        DevBuf work, ysub, musub, idx;
         DSQ_HIP(work.alloc((size_t)n_grid * 102 * sizeof(double)));
-        DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
-                                       ctx->d_list, n_grid, work.as<double>()));
-        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (extras != nullptr && extras->coef != nullptr) {
+            // no N x G mu_hat exists: rebuild the rows of the (few) fallback genes, compacted, and run the grid on them
+            DSQ_HIP(ysub.alloc((size_t)n_grid * ldn * sizeof(int32_t)));
+            DSQ_HIP(musub.alloc((size_t)n_grid * ldn * sizeof(double)));
+            DSQ_HIP(idx.alloc((size_t)n_grid * sizeof(int32_t)));
+            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub.as<int32_t>()));
+            DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
+                                             ctx->d_list, n_grid, musub.as<double>(), ldn, idx.as<int32_t>()));
+            DevBuf asub;
+            DSQ_HIP(asub.alloc((size_t)n_grid * sizeof(double)));
+            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub.as<int32_t>(), musub.as<double>(), ldn, d_Xt, ldx, N, P,
+                                           min_disp, max_disp, asub.as<double>(), idx.as<int32_t>(), n_grid,
+                                           work.as<double>()));
+            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub.as<double>(), ctx->d_list, n_grid, 1, d_alpha));
+            DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
+                                           ctx->d_list, n_grid, work.as<double>()));
+            DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
     return DSQ_OK;
 }
@@ -268,11 +288,15 @@ void dsq_destroy(dsq_ctx* ctx) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     }
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->main_stream) (void)hipStreamDestroy(ctx->main_stream);
+    else if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -400,6 +424,14 @@ int dsq_dev_size_factors(dsq_ctx* ctx, const void* d_counts_sm, int count_type, 
     return DSQ_OK;
 }
 
+int dsq_dev_size_factors_new(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G,
+                             const double* d_logmeans, const uint8_t* d_gene_mask, double* d_work,
+                             double* d_size_factors) {
+    DSQ_HIP(dsq::launch_size_factors(ctx->stream, d_counts_sm, count_type, N, G, d_logmeans, d_gene_mask,
+                                     d_work, d_size_factors, 1));
+    return DSQ_OK;
+}
+
 int dsq_dev_mom(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                 const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
                 double* d_normed_mean, double* d_rough, double* d_moments, double* d_mom) {
@@ -419,6 +451,17 @@ int dsq_dev_mom_lin_mu(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
                           "there are no replicates to estimate the dispersion.");
     DSQ_HIP(dsq::launch_mom_lin_mu(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, min_disp, max_disp,
                                    min_mu, d_normed_mean, d_mom, d_mu, ctx->d_scratch + 8));
+    return DSQ_OK;
+}
+
+int dsq_dev_mom_lin_coef(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                         const double* d_pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                         double min_mu, double* d_normed_mean, double* d_mom, double* d_mu, double* d_coef) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(N != P, "The number of samples and the number of design variables are equal, i.e., "
+                          "there are no replicates to estimate the dispersion.");
+    DSQ_HIP(dsq::launch_mom_lin_mu(ctx->stream, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, min_disp, max_disp,
+                                   min_mu, d_normed_mean, d_mom, d_mu, ctx->d_scratch + 8, d_coef));
     return DSQ_OK;
 }
 
@@ -461,11 +504,12 @@ int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int 
                      cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode);
 }
 
-int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
-                 const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
-                 double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
-                 double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+namespace {
+int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+             const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+             double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
+             double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters,
+             const dsq::IrlsExtras* extras) {
     if (G <= 0) return DSQ_OK;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     if ((size_t)N > ctx->lsf_cap) {
@@ -478,17 +522,130 @@ int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, 
     DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, sizeof(int32_t), ctx->stream));
     DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
-                             d_converged, d_iters, ctx->d_counter, ctx->d_list));
+                             d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
     int32_t n_fb = 0;
     DSQ_HIP(hipMemcpyAsync(&n_fb, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     if (n_fb > 0) {
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
-                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb));
+                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras));
         DSQ_HIP(hipStreamSynchronize(ctx->stream));
     }
     return DSQ_OK;
+}
+}  // namespace
+
+int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                 const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                 double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
+                 double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    return run_irls(ctx, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp, min_mu, beta_tol, min_beta,
+                    max_beta, maxiter, d_beta, d_mu, d_hat, d_converged, d_iters, nullptr);
+}
+
+namespace {
+dsq::CellDesign to_cells(const dsq_cells* c) {
+    dsq::CellDesign d{};
+    if (c != nullptr && c->n_cells > 0) { d.cell_of = c->d_cell_of; d.Xc = c->d_Xc; d.XX = c->d_XX; d.C = c->n_cells; }
+    return d;
+}
+}  // namespace
+
+int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
+    DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr), "either mu or (coef, sf) is needed");
+    DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
+    dsq::AlphaExtras ex{};
+    ex.cells = to_cells(cells);
+    if (d_mu == nullptr) { ex.coef = d_coef; ex.sf = d_sf; ex.min_mu = min_mu; }
+    return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var, cr_reg,
+                     prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, &ex);
+}
+
+int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
+                        const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int N, int G,
+                        double* d_robust_disp) {
+    DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
+    DSQ_HIP(dsq::launch_robust_disp(ctx->stream, d_y, ldn, d_sf, d_cell_offsets, d_cell_index, n_cells, whole, max_cell,
+                                    N, G, d_robust_disp));
+    return DSQ_OK;
+}
+
+int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt, int ldx,
+                        int N, int G, int P, const double* d_disp, const double* d_beta, double min_mu, double* d_mu,
+                        double* d_hat) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_HIP(dsq::launch_irls_layers(ctx->stream, d_y, ldn, d_sf, d_Xt, ldx, N, G, P, d_disp, d_beta, min_mu, d_mu,
+                                    d_hat));
+    return DSQ_OK;
+}
+
+int dsq_side_begin(dsq_ctx* ctx) {
+    DSQ_CHECK_ARG(ctx->stream == ctx->main_stream || ctx->main_stream == nullptr, "already on the side stream");
+    if (ctx->main_stream == nullptr) ctx->main_stream = ctx->stream;
+    if (ctx->side_stream == nullptr) {
+        DSQ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    DSQ_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
+    DSQ_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    ctx->stream = ctx->side_stream;
+    return DSQ_OK;
+}
+
+int dsq_side_end(dsq_ctx* ctx) {
+    DSQ_CHECK_ARG(ctx->side_stream != nullptr && ctx->stream == ctx->side_stream, "not on the side stream");
+    DSQ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+    ctx->stream = ctx->main_stream;
+    return DSQ_OK;
+}
+
+int dsq_side_wait(dsq_ctx* ctx) {
+    if (ctx->side_stream == nullptr) return DSQ_OK;
+    DSQ_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->ev_join, 0));
+    return DSQ_OK;
+}
+
+int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                    const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                    double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
+                    double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
+                    const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
+                    uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
+                    const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
+                    double* d_stats, double* d_se) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
+    DSQ_CHECK_ARG(d_flags == nullptr || (d_robust_disp && d_any_all && d_any_use && d_any_use_nr && d_few_above),
+                  "the fused Cook's bookkeeping needs the robust dispersions and the four flag vectors");
+    DSQ_CHECK_ARG(h_ridge == nullptr || (h_contrast && d_pvals && d_stats && d_se && alt >= 0 && alt <= 4),
+                  "the fused Wald test needs contrast, outputs and a valid alternative");
+    if (G <= 0) return DSQ_OK;
+    dsq::IrlsExtras ex{};
+    ex.cells = to_cells(cells);
+    if (d_flags != nullptr) {
+        ex.robust_disp = d_robust_disp; ex.flags = d_flags; ex.cutoff = cutoff; ex.cooks = d_cooks;
+        ex.any_all = d_any_all; ex.any_use = d_any_use; ex.any_use_nr = d_any_use_nr; ex.few_above = d_few_above;
+    }
+    if (h_ridge != nullptr) {
+        double* d_ridge = ctx->d_scratch + 16;
+        double* d_contrast = d_ridge + DSQ_MAX_P * DSQ_MAX_P;
+        DSQ_HIP(hipMemcpyAsync(d_ridge, h_ridge, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DSQ_HIP(hipMemcpyAsync(d_contrast, h_contrast, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host arrays may be temporaries of the caller
+        ex.ridge = d_ridge; ex.contrast = d_contrast; ex.lfc_null = lfc_null; ex.alt = alt;
+        ex.pvals = d_pvals; ex.stats = d_stats; ex.se = d_se;
+    }
+    return run_irls(ctx, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp, min_mu, beta_tol, min_beta,
+                    max_beta, maxiter, d_beta, d_mu, d_hat, d_converged, d_iters, &ex);
 }
 
 int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_mu,

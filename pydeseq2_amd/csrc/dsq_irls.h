@@ -16,9 +16,28 @@
 #include "dsq_alpha.h"
 #include "dsq_lbfgsb.h"
 #include "dsq_linalg.h"
+#include "dsq_stats.h"
 #include "dsq_wave.h"
 
 namespace dsq {
+
+// Optional fused tail of the LFC fit: the per-sample part of the Cook's distances (dds.py:986-1040 and the
+// outlier bookkeeping of dds.py:1066-1110, 1325-1326; the robust dispersion comes from its own kernel, it does
+// not depend on the fit) and the Wald statistics (ds.py:303-360) are computed while mu and the hat diagonal are
+// still in registers, so the N x G layers need not be written and re-read (16 N bytes per gene each way).
+struct LfcEpilogue {
+    // Cook's (robust_disp < 0 or NaN handling as in cooks_gene): enabled when flags != nullptr
+    const uint8_t* flags = nullptr;  // [N]
+    double robust_disp = 0.0, cutoff = 0.0;
+    double* cooks_row = nullptr;     // this gene's row of the cooks layer (nullable)
+    CooksOut cooks;
+    // Wald: enabled when ridge != nullptr
+    const double* ridge = nullptr;     // [P*P]
+    const double* contrast = nullptr;  // [P]
+    double lfc_null = 0.0;
+    int alt = 0;
+    WaldOut wald;
+};
 
 struct IrlsArgs {
     const int32_t* y;     // [N]
@@ -30,6 +49,8 @@ struct IrlsArgs {
     double disp, min_mu, beta_tol, min_beta, max_beta;
     int maxiter;
     bool full_rank;
+    const CellDesign* cells = nullptr;  // CELL instantiations (designs with <= 64 distinct rows)
+    void* cell_ws = nullptr;            // this wave's CellWork<P>
 };
 
 // sweep: mu(beta) clamped, S = sum (y+a) log(a+mu) - y log mu, M = X^T W X, r = X^T W z
@@ -73,6 +94,66 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
     S = Wv::sum(s);
     Wv::template sum_n<T>(M);
     Wv::template sum_n<P>(r);
+}
+
+// The same sweep for a design with few distinct rows (dsq_linalg.h, CellDesign): the linear predictor and its
+// exponential are computed once per CELL, a sample fetches them by its cell index, adds its weight w and w z
+// into the cell's accumulators, and X^T W X, X^T W z are rebuilt from the <= 64 cell sums entry-parallel.  The
+// per-sample work no longer depends on P.
+template <class Wv, int P>
+DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a, double& S,
+                            double (&M)[Tri<P>::N], double (&r)[P]) {
+    constexpr int T = Tri<P>::N;
+    const CellDesign& D = *A.cells;
+    CellWork<P>& Wk = *(CellWork<P>*)A.cell_ws;
+    for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) {
+        double eta = 0.0;
+        if (c < D.C) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) eta += D.Xc[c * P + j] * beta[j];
+        }
+        Wk.tab[0][c] = eta;
+        Wk.tab[1][c] = exp(eta);
+        Wk.acc[0][c] = 0.0;
+        Wk.acc[1][c] = 0.0;
+    }
+    Wv::sync();
+    double s = 0.0;
+    const double lmin = log(A.min_mu);
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const double yv = (double)A.y[n];
+        const double sfn = A.sf[n];
+        const int cell = D.cell_of[n];
+        const double eta = Wk.tab[0][cell];
+        const double mu_raw = sfn * Wk.tab[1][cell];
+        const bool clamped = !(mu_raw > A.min_mu);
+        const double mu = clamped ? A.min_mu : mu_raw;
+        const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
+        const double lmu = clamped ? lmin : eta + lsfn;
+        const double rmu = frcp(mu);
+        s += (yv + a) * flog(a + mu) - yv * lmu;
+        const double w = mu * frcp(1.0 + mu * A.disp);
+        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
+        Wv::cell_add(&Wk.acc[0][cell], w);
+        Wv::cell_add(&Wk.acc[1][cell], w * z);
+    }
+    Wv::sync();
+    for (int e = Wv::lane(); e < T + P; e += Wv::W) {
+        double v = 0.0;
+        if (e < T) {
+            for (int c = 0; c < D.C; ++c) v += D.XX[c * T + e] * Wk.acc[0][c];
+        } else {
+            for (int c = 0; c < D.C; ++c) v += D.Xc[c * P + (e - T)] * Wk.acc[1][c];
+        }
+        Wk.ent[e] = v;
+    }
+    Wv::sync();
+#pragma unroll
+    for (int k = 0; k < T; ++k) M[k] = Wk.ent[k];
+#pragma unroll
+    for (int j = 0; j < P; ++j) r[j] = Wk.ent[T + j];
+    Wv::sync();  // ent is rewritten by the next sweep
+    S = Wv::sum(s);
 }
 
 struct IrlsOut {
@@ -157,37 +238,152 @@ DSQ_HD void irls_init_exact(const IrlsArgs& A, double a, double (&b0)[P], double
     if (!A.full_rank) b0[0] = b0[0] / (double)A.N;
 }
 
-// hat diagonal (:427-433) from M = X^T W X at the final clamped mu, and unclamped mu (:435-437)
+// hat diagonal (:427-433) from M = X^T W X at the final clamped mu, and unclamped mu (:435-437); with an
+// epilogue also the Cook's bookkeeping and the Wald statistics of the gene (LfcEpilogue)
 template <class Wv, int P>
 DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[Tri<P>::N],
-                        double* mu_out, double* H_out) {
+                        double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
     constexpr int T = Tri<P>::N;
-    if (mu_out == nullptr && H_out == nullptr) return;
+    const bool want_cooks = E != nullptr && E->flags != nullptr;
+    const bool want_wald = E != nullptr && E->ridge != nullptr;
+    if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
+    // few design columns: the Wald matrix (X^T W X at the UNclamped mu, ds.py:320-324) is accumulated in the
+    // same pass; wider designs take a second pass so that inv[] and the accumulators are not live together
+    constexpr bool kWaldInLoop = P <= 4;
     double inv[T];
+    if (H_out != nullptr || want_cooks) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
-    chol<P>(M);
-    chol_inverse<P>(M, inv);
+        for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
+        chol<P>(M);
+        chol_inverse<P>(M, inv);
+    }
+    CooksAcc<Wv> acc(want_cooks ? E->robust_disp : 0.0, want_cooks ? E->cutoff : 0.0, P);
+    double Mw[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) Mw[k] = 0.0;
+    if (mu_out != nullptr || H_out != nullptr || want_cooks || (want_wald && kWaldInLoop)) {
+        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            double x[P];
+            double eta = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
+            const double mu_raw = A.sf[n] * exp(eta);
+            if (mu_out != nullptr) mu_out[n] = mu_raw;
+            if (H_out != nullptr || want_cooks) {
+                const double mu = dmax(mu_raw, A.min_mu);
+                const double w = mu / (1.0 + mu * A.disp);
+                const double sw = sqrt(w);
+                const double h = sw * sym_quad<P>(inv, x) * sw;
+                if (H_out != nullptr) H_out[n] = h;
+                if (want_cooks) {
+                    const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
+                    if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
+                }
+            }
+            if (want_wald && kWaldInLoop) {
+                const double wu = mu_raw / (1.0 + mu_raw * A.disp);
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const double xw = x[i] * wu;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Mw[tri(i, j)] += xw * x[j];
+                }
+            }
+        }
+    }
+    if (want_cooks) E->cooks = acc.finish(A.y, A.N);
+    if (want_wald) {
+        if (!kWaldInLoop) {
+            for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+                double x[P];
+                double eta = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
+                const double m = A.sf[n] * exp(eta);
+                const double wu = m / (1.0 + m * A.disp);
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const double xw = x[i] * wu;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Mw[tri(i, j)] += xw * x[j];
+                }
+            }
+        }
+        Wv::template sum_n<T>(Mw);
+        E->wald = wald_from_M<P>(Mw, beta, E->ridge, E->contrast, E->lfc_null, E->alt);
+    }
+}
+
+// The same for a cell design: the table of exp(x_c . beta) left by the last sweep (it ran at the final beta)
+// gives mu, q_c = x_c^T (X^T W X + ridge)^-1 x_c per cell gives the hat diagonal h_n = w_n q_c, and the Wald
+// matrix is rebuilt from the cells' sums of the unclamped weights.
+template <class Wv, int P>
+DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double (&M)[Tri<P>::N],
+                             double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
+    constexpr int T = Tri<P>::N;
+    const bool want_cooks = E != nullptr && E->flags != nullptr;
+    const bool want_wald = E != nullptr && E->ridge != nullptr;
+    if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
+    const CellDesign& D = *A.cells;
+    CellWork<P>& Wk = *(CellWork<P>*)A.cell_ws;
+    {
+        double inv[T];
+#pragma unroll
+        for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
+        chol<P>(M);
+        chol_inverse<P>(M, inv);
+        for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) {
+            double q = 0.0;
+            if (c < D.C) {
+                double x[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) x[j] = D.Xc[c * P + j];
+                q = sym_quad<P>(inv, x);
+            }
+            Wk.acc[0][c] = q;     // read-only from here on
+            Wk.acc[1][c] = 0.0;   // sums of the unclamped weights (Wald)
+        }
+    }
+    Wv::sync();
+    CooksAcc<Wv> acc(want_cooks ? E->robust_disp : 0.0, want_cooks ? E->cutoff : 0.0, P);
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        double x[P];
-        double eta = 0.0;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
-        const double mu_raw = A.sf[n] * exp(eta);
+        const int cell = D.cell_of[n];
+        const double mu_raw = A.sf[n] * Wk.tab[1][cell];
         if (mu_out != nullptr) mu_out[n] = mu_raw;
-        if (H_out != nullptr) {
+        if (H_out != nullptr || want_cooks) {
             const double mu = dmax(mu_raw, A.min_mu);
             const double w = mu / (1.0 + mu * A.disp);
             const double sw = sqrt(w);
-            H_out[n] = sw * sym_quad<P>(inv, x) * sw;
+            const double h = sw * Wk.acc[0][cell] * sw;
+            if (H_out != nullptr) H_out[n] = h;
+            if (want_cooks) {
+                const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
+                if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
+            }
         }
+        if (want_wald) Wv::cell_add(&Wk.acc[1][cell], mu_raw / (1.0 + mu_raw * A.disp));
+    }
+    if (want_cooks) E->cooks = acc.finish(A.y, A.N);
+    if (want_wald) {
+        Wv::sync();
+        for (int e = Wv::lane(); e < T; e += Wv::W) {
+            double v = 0.0;
+            for (int c = 0; c < D.C; ++c) v += D.XX[c * T + e] * Wk.acc[1][c];
+            Wk.ent[e] = v;
+        }
+        Wv::sync();
+        double Mw[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) Mw[k] = Wk.ent[k];
+        E->wald = wald_from_M<P>(Mw, beta, E->ridge, E->contrast, E->lfc_null, E->alt);
     }
 }
 
 // beta (out), mu_out[N] = UNclamped sf*exp(X beta), H_out[N] hat diagonal (either may be null).
 // When IRLS diverges nothing is written and out.fallback = 1.
-template <class Wv, int P>
-DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, double* H_out) {
+template <class Wv, int P, bool CELL = false>
+DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, double* H_out,
+                         LfcEpilogue* E = nullptr) {
     constexpr int T = Tri<P>::N;
     IrlsOut out;
     out.converged = 1; out.iters = 0; out.fallback = 0;
@@ -196,7 +392,11 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     irls_init<Wv, P>(A, a, beta, cst);
     const double nlogterm = A.N * a * log(A.disp);
     double M[T], r[P], S;
-    irls_sweep<Wv, P>(A, beta, a, S, M, r);
+    auto sweep = [&]() {
+        if constexpr (CELL) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
+        else irls_sweep<Wv, P>(A, beta, a, S, M, r);
+    };
+    sweep();
     double dev = 1000.0, ratio = 1.0;
     int i = 0;
     while (ratio > A.beta_tol) {
@@ -220,13 +420,14 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
         }
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[j] = bh[j];
-        irls_sweep<Wv, P>(A, beta, a, S, M, r);
+        sweep();
         const double old = dev;
         dev = -2.0 * (nlogterm - cst + S);
         ratio = fabs(dev - old) / (fabs(dev) + 0.1);
     }
     out.iters = i;
-    irls_finish<Wv, P>(A, beta, M, mu_out, H_out);
+    if constexpr (CELL) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
+    else irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);
     return out;
 }
 
@@ -282,7 +483,7 @@ DSQ_HD void grid_fit_beta2(const IrlsArgs& A, double a, double cst, double (&bet
 // is scipy's res.success.
 template <class Wv, int P>
 DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double (&beta)[P],
-                                double* mu_out, double* H_out) {
+                                double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
     constexpr int T = Tri<P>::N;
     IrlsOut out;
     out.converged = 0; out.iters = 0; out.fallback = 1;
@@ -328,7 +529,7 @@ DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double
     }
     double M[T], r[P], S2;
     irls_sweep<Wv, P>(A, beta, a, S2, M, r);  // M = X^T W X at the final (clamped) mu
-    irls_finish<Wv, P>(A, beta, M, mu_out, H_out);
+    irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);
     return out;
 }
 

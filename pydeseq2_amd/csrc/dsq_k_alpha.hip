@@ -2,6 +2,8 @@
 // Algorithmic HBM traffic per gene and launch: 4N (counts) + 8N (mu) bytes read once
 // (re-reads during the ~5 L-BFGS-B evaluations hit L1/L2: 12 KB per gene at N = 1000),
 // 8 + 1 (+4) bytes written.  Compute: ~5 evaluations x N x (lgamma + digamma + 3 log).
+#include <type_traits>
+
 #include "dsq_alpha.h"
 #include "dsq_dispatch.h"
 #include "dsq_launch.h"
@@ -28,8 +30,13 @@ __device__ unsigned long long g_phase_total[16];
 // LDS segment and runs all ~5 evaluations from there.  Without it every evaluation re-reads the
 // row through L2 (16 resident genes x 12 KB per CU overflow L1 and the CU's share of L2), which the
 // PMC counters showed as ~10x the algorithmic HBM traffic and ~40 % of wave time in s_waitcnt.
-template <int P, bool STAGE>
-__global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int32_t* __restrict__ y,
+// CELL: the design has few distinct rows (AlphaExtras::cells): per-cell weight sums instead of p(p+1) register
+// accumulators per lane (dsq_alpha.h), so the register budget no longer depends on P.
+// ex.coef != nullptr (linear-mu designs, dds.py:747-756): mu_hat = max(sf * (x . coef_g), min_mu) is computed while
+// staging - the same expression, in the same order, as mom_lin_mu_gene - instead of being read from an N x G matrix
+// that k_mom_lin_mu would have had to write (8 N bytes per gene written once and read by both dispersion fits).
+template <int P, bool STAGE, bool CELL = false>
+__global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(P)) void k_alpha(const int32_t* __restrict__ y,
                                                   const double* __restrict__ mu, int ldn,
                                                   const double* __restrict__ Xt, int ldx, int N, int G,
                                                   const double* __restrict__ alpha_hat,
@@ -38,9 +45,11 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
                                                   uint8_t* __restrict__ conv, int32_t* __restrict__ nfev,
                                                   int32_t* __restrict__ grid_count,
                                                   int32_t* __restrict__ grid_list,
-                                                  double* __restrict__ nll_const, int const_mode) {
+                                                  double* __restrict__ nll_const, int const_mode,
+                                                  AlphaExtras ex) {
     // the (wave-uniform) optimiser state lives in LDS, not in every lane's registers
     __shared__ Lbfgsb1d machine[kWavesPerBlock];
+    __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
     extern __shared__ __attribute__((aligned(16))) double stage[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
@@ -68,11 +77,29 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
         const int full_d = N / 128, full_i = N / 256;  // pieces of 128 doubles / 256 ints
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
-        for (int c = 0; c < full_d; ++c)
-            __builtin_amdgcn_global_load_lds((glb_void*)(mg + c * 128 + lane * 2), (lds_void*)(ms + c * 128), 16, 0, 0);
+        if (ex.coef == nullptr) {
+            for (int c = 0; c < full_d; ++c)
+                __builtin_amdgcn_global_load_lds((glb_void*)(mg + c * 128 + lane * 2), (lds_void*)(ms + c * 128), 16, 0, 0);
+        }
         for (int c = 0; c < full_i; ++c)
             __builtin_amdgcn_global_load_lds((glb_void*)(yg + c * 256 + lane * 4), (lds_void*)(ys + c * 256), 16, 0, 0);
-        for (int n = full_d * 128 + lane; n < npad; n += 64) ms[n] = n < N ? mg[n] : 0.0;
+        if (ex.coef != nullptr) {
+            double b[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) b[j] = ex.coef[(size_t)g * P + j];
+            for (int n = lane; n < npad; n += 64) {
+                double v = 0.0;
+                if (n < N) {
+                    double yh = 0.0;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
+                    v = dmax(ex.sf[n] * yh, ex.min_mu);
+                }
+                ms[n] = v;
+            }
+        } else {
+            for (int n = full_d * 128 + lane; n < npad; n += 64) ms[n] = n < N ? mg[n] : 0.0;
+        }
         for (int n = full_i * 256 + lane; n < npad; n += 64) ys[n] = n < N ? yg[n] : 0;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed
         for (int n = lane; n < npad; n += 64) maxc = ys[n] > maxc ? ys[n] : maxc;
@@ -83,10 +110,11 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha(const int3
     }
     maxc = DeviceWave::maxi(maxc);
     const int memo_blocks = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (maxc >> 6) + 1));
-    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false, STAGE>(
+    const AlphaOut o = fit_alpha_gene<DeviceWave, P, false, STAGE, CELL>(
         yg, mg, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var, cr_reg != 0, prior_reg != 0, machine[w],
         const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
-        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks);
+        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks, CELL ? &ex.cells : nullptr,
+        CELL ? (void*)&cellw[w] : nullptr);
     if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
@@ -121,8 +149,16 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
     A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = 0.0; A.prior_var = 1.0; A.cr_reg = true; A.prior_reg = false;
     A.cst = alpha_const<DeviceWave>(A.y, A.mu, N);
+    // the count memo of alpha_eval covers 64 * NB counts and relies on its caller to pick NB from the gene's
+    // largest count (as k_alpha does); NB = 1 for a gene with counts >= 64 reads other counts' memo entries
+    int maxc = 0;
+    for (int n = threadIdx.x & 63; n < N; n += 64) maxc = A.y[n] > maxc ? A.y[n] : maxc;
+    const int mb = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (DeviceWave::maxi(maxc) >> 6) + 1));
+    const double la = linspace_at(lohi[2 * k], lohi[2 * k + 1], kGridLen, i);
     double f, gu;
-    alpha_eval<DeviceWave, P, false>(A, linspace_at(lohi[2 * k], lohi[2 * k + 1], kGridLen, i), true, false, f, gu);
+    if (mb <= 1) alpha_eval<DeviceWave, P, false, false, 1>(A, la, true, false, f, gu);
+    else if (mb == 2) alpha_eval<DeviceWave, P, false, false, 2>(A, la, true, false, f, gu);
+    else alpha_eval<DeviceWave, P, false, false, 4>(A, la, true, false, f, gu);
     if ((threadIdx.x & 63) == 0) ll[(size_t)k * kGridLen + i] = f;
 }
 
@@ -160,28 +196,37 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         int ldx, int N, int G, int P_, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
-                        double* nll_const, int const_mode) {
+                        double* nll_const, int const_mode, const AlphaExtras* extras) {
     if (G <= 0) return hipSuccess;
     if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
+    AlphaExtras ex{};
+    if (extras != nullptr) ex = *extras;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     const int npad = (N + 63) & ~63;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
-    if (smem <= 80 * 1024) {  // >= 2 workgroups per CU keep their rows in LDS
+    const bool stage = smem <= 80 * 1024;  // >= 2 workgroups per CU keep their rows in LDS
+    if (!stage && ex.coef != nullptr) return hipErrorInvalidValue;  // mu_hat on the fly needs the staged variant
+    const bool cell = stage && ex.cells.C > 0 && P_ >= 3 && cr_reg != 0;
+#define DSQ_ALPHA_LAUNCH(KERNEL, SMEM)                                                                            \
+    do {                                                                                                          \
+        if ((SMEM) > 48 * 1024) {                                                                                 \
+            (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM)); \
+            (void)hipGetLastError();                                                                              \
+        }                                                                                                         \
+        hipLaunchKernelGGL(KERNEL, grid, block, (SMEM), st, y, mu, ldn, Xt, ldx, N, G, alpha_hat, min_disp,      \
+                           max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count, grid_list,     \
+                           nll_const, const_mode, ex);                                                           \
+    } while (0)
+    if (cell) {
         DSQ_DISPATCH_P(P_, {
-            if (smem > 48 * 1024) {
-                (void)hipFuncSetAttribute((const void*)k_alpha<P, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                (void)hipGetLastError();
-            }
-            hipLaunchKernelGGL((k_alpha<P, true>), grid, block, smem, st, y, mu, ldn, Xt, ldx, N, G, alpha_hat,
-                               min_disp, max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count,
-                               grid_list, nll_const, const_mode);
+            if constexpr (P >= 3) DSQ_ALPHA_LAUNCH((k_alpha<P, true, true>), smem);
         })
+    } else if (stage) {
+        DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, true, false>), smem))
     } else {
-        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_alpha<P, false>), grid, block, 0, st, y, mu, ldn, Xt, ldx, N, G,
-                                              alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
-                                              alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode))
+        DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, false, false>), (size_t)0))
     }
+#undef DSQ_ALPHA_LAUNCH
     return hipGetLastError();
 }
 

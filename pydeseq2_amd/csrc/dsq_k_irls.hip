@@ -1,6 +1,8 @@
 // dsq_k_irls.hip — NB-GLM IRLS kernel (gfx950): one gene per wavefront.
 // Algorithmic HBM traffic per gene and launch: 4N bytes of counts read (re-reads of the
 // ~4 IRLS sweeps are L1/L2 hits), 8N (mu) + 8N (hat diagonal) written, O(P) scalars.
+#include <type_traits>
+
 #include "dsq_dispatch.h"
 #include "dsq_irls.h"
 #include "dsq_launch.h"
@@ -14,8 +16,27 @@ namespace dsq {
 #endif
 constexpr int irls_min_waves(int p) { return p <= 2 ? DSQ_IRLS_WAVES_P2 : (p <= 5 ? 1 : 2); }
 
+// fused outputs of one gene (lane 0 writes)
 template <int P>
-__global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
+__device__ __forceinline__ void epilogue_begin(LfcEpilogue& E, const IrlsExtras& ex, int g, int ldn) {
+    if (ex.flags != nullptr) {
+        E.flags = ex.flags; E.robust_disp = ex.robust_disp[g]; E.cutoff = ex.cutoff;
+        E.cooks_row = ex.cooks ? ex.cooks + (size_t)g * ldn : nullptr;
+    }
+    if (ex.ridge != nullptr) { E.ridge = ex.ridge; E.contrast = ex.contrast; E.lfc_null = ex.lfc_null; E.alt = ex.alt; }
+}
+__device__ __forceinline__ void epilogue_store(const LfcEpilogue& E, const IrlsExtras& ex, int g) {
+    if (ex.flags != nullptr) {
+        ex.any_all[g] = (uint8_t)E.cooks.any_gt_all;
+        ex.any_use[g] = (uint8_t)E.cooks.any_gt_use;
+        ex.any_use_nr[g] = (uint8_t)E.cooks.any_gt_use_nr;
+        ex.few_above[g] = (uint8_t)E.cooks.few_above;
+    }
+    if (ex.ridge != nullptr) { ex.pvals[g] = E.wald.p; ex.stats[g] = E.wald.stat; ex.se[g] = E.wald.se; }
+}
+
+template <int P, bool CELL>
+__global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
                                                  const double* __restrict__ sf, const double* __restrict__ lsf,
                                                  const double* __restrict__ Xt,
                                                  const double* __restrict__ pinvXt, int ldx, int N,
@@ -25,22 +46,27 @@ __global__ __launch_bounds__(kBlock, irls_min_waves(P)) void k_irls(const int32_
                                                  double* __restrict__ mu, double* __restrict__ hat,
                                                  uint8_t* __restrict__ conv, int32_t* __restrict__ iters,
                                                  int32_t* __restrict__ fb_count,
-                                                 int32_t* __restrict__ fb_list) {
+                                                 int32_t* __restrict__ fb_list, IrlsExtras ex) {
+    __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (g >= G) return;
     IrlsArgs A;
     A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
+    if (CELL) { A.cells = &ex.cells; A.cell_ws = (void*)&cellw[threadIdx.x >> 6]; }
+    LfcEpilogue E;
+    epilogue_begin<P>(E, ex, g, ldn);
     double b[P];
-    const IrlsOut o = irls_gene<DeviceWave, P>(A, b, mu ? mu + (size_t)g * ldn : nullptr,
-                                               hat ? hat + (size_t)g * ldn : nullptr);
+    const IrlsOut o = irls_gene<DeviceWave, P, CELL>(A, b, mu ? mu + (size_t)g * ldn : nullptr,
+                                                     hat ? hat + (size_t)g * ldn : nullptr, &E);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
         conv[g] = (uint8_t)o.converged;
         if (iters != nullptr) iters[g] = o.iters;
         if (o.fallback) fb_list[atomicAdd(fb_count, 1)] = g;
+        else epilogue_store(E, ex, g);
     }
 }
 
@@ -56,7 +82,8 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
                                                         double* __restrict__ mu, double* __restrict__ hat,
                                                         uint8_t* __restrict__ conv,
                                                         int32_t* __restrict__ iters,
-                                                        const int32_t* __restrict__ fb_list, int n_fb) {
+                                                        const int32_t* __restrict__ fb_list, int n_fb,
+                                                        IrlsExtras ex) {
     int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = k < n_fb;
     if (!live) return;
@@ -66,15 +93,18 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
     __shared__ IrlsRescueWork<P> work[kWavesPerBlock];
+    LfcEpilogue E;
+    epilogue_begin<P>(E, ex, g, ldn);
     double b[P];
     const IrlsOut o = irls_rescue_gene<DeviceWave, P>(A, work[threadIdx.x >> 6], b,
                                                       mu ? mu + (size_t)g * ldn : nullptr,
-                                                      hat ? hat + (size_t)g * ldn : nullptr);
+                                                      hat ? hat + (size_t)g * ldn : nullptr, &E);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
         conv[g] = (uint8_t)o.converged;
         if (iters != nullptr) iters[g] = o.iters;
+        epilogue_store(E, ex, g);
     }
 }
 
@@ -112,17 +142,59 @@ hipError_t launch_grid_beta(hipStream_t st, const int32_t* y, int ldn, const dou
     return hipGetLastError();
 }
 
+// N x G layers of a finished fit on demand (dds.layers["_mu_LFC"], ["_hat_diagonals"]): mu = sf exp(X beta)
+// (unclamped, utils.py:435-437) and the hat diagonal at the clamped mu (utils.py:427-433) from the stored beta
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_irls_layers(const int32_t* __restrict__ y, int ldn,
+                                                        const double* __restrict__ sf, const double* __restrict__ Xt,
+                                                        int ldx, int N, int G, const double* __restrict__ disp,
+                                                        const double* __restrict__ beta, double min_mu,
+                                                        double* __restrict__ mu, double* __restrict__ hat) {
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    IrlsArgs A;
+    A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = nullptr; A.ldx = ldx; A.N = N;
+    A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = 0.0; A.min_beta = 0.0; A.max_beta = 0.0; A.maxiter = 0;
+    A.full_rank = false;
+    double b[P], M[Tri<P>::N], r[P], S;
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = beta[(size_t)g * P + j];
+    irls_sweep<DeviceWave, P>(A, b, 1.0 / A.disp, S, M, r);
+    irls_finish<DeviceWave, P>(A, b, M, mu ? mu + (size_t)g * ldn : nullptr, hat ? hat + (size_t)g * ldn : nullptr);
+}
+
+hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt, int ldx,
+                              int N, int G, int P_, const double* disp, const double* beta, double min_mu, double* mu,
+                              double* hat) {
+    if (G <= 0) return hipSuccess;
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_layers<P>, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, sf,
+                                          Xt, ldx, N, G, disp, beta, min_mu, mu, hat))
+    return hipGetLastError();
+}
+
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P_, int full_rank,
                        const double* disp, double min_mu, double beta_tol, double min_beta,
                        double max_beta, int maxiter, double* beta, double* mu, double* hat,
-                       uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list) {
+                       uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list,
+                       const IrlsExtras* extras) {
     if (G <= 0) return hipSuccess;
+    IrlsExtras ex{};
+    if (extras != nullptr) ex = *extras;
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N,
-                                          G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                          maxiter, beta, mu, hat, conv, iters, fb_count, fb_list))
+    if (ex.cells.C > 0 && P_ >= 3) {
+        DSQ_DISPATCH_P(P_, {
+            if constexpr (P >= 3)
+                hipLaunchKernelGGL((k_irls<P, true>), grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G,
+                                   full_rank, disp, min_mu, beta_tol, min_beta, max_beta, maxiter, beta, mu, hat,
+                                   conv, iters, fb_count, fb_list, ex);
+        })
+    } else {
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_irls<P, false>), grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx,
+                                              N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
+                                              maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex))
+    }
     return hipGetLastError();
 }
 
@@ -131,12 +203,14 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
-                              int n_fb) {
+                              int n_fb, const IrlsExtras* extras) {
     if (n_fb <= 0) return hipSuccess;
+    IrlsExtras ex{};
+    if (extras != nullptr) ex = *extras;
     const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
                                           ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                          maxiter, beta, mu, hat, conv, iters, fb_list, n_fb))
+                                          maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, ex))
     return hipGetLastError();
 }
 

@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void k_transpose(const SrcT* __restrict__ src,
 template <class SrcT, class DstT, bool CHECK>
 __global__ __launch_bounds__(256) void k_repitch(const SrcT* __restrict__ src, int N, int G,
                                                  DstT* __restrict__ dst, int ldn, int* bad) {
-    const int g = blockIdx.y;
+    const int g = blockIdx.x;  // genes on grid.x: grid.y is limited to 65535
     int isbad = 0;
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    for (int n = blockIdx.y * 256 + threadIdx.x; n < N; n += gridDim.y * 256) {
         const SrcT v = src[(size_t)g * N + n];
         if (CHECK) {
             if ((double)v < 0.0 || (double)v > 2147483647.0) isbad = 1;
@@ -123,7 +123,7 @@ hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_ty
             hipLaunchKernelGGL((k_transpose<int32_t, int32_t, true>), grid, block, 0, st,
                                (const int32_t*)src, N, G, dst, ldn, bad_flag);
     } else {
-        const dim3 grid((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, G), block(256);
+        const dim3 grid(G, (N + 255) / 256 > 64 ? 64 : (N + 255) / 256), block(256);
         if (count_type == 1)
             hipLaunchKernelGGL((k_repitch<int64_t, int32_t, true>), grid, block, 0, st,
                                (const int64_t*)src, N, G, dst, ldn, bad_flag);
@@ -142,7 +142,7 @@ hipError_t launch_transpose_f64(hipStream_t st, const double* src, int layout, i
         hipLaunchKernelGGL((k_transpose<double, double, false>), grid, block, 0, st, src, N, G, dst, ldn,
                            (int*)nullptr);
     } else {
-        const dim3 grid((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, G), block(256);
+        const dim3 grid(G, (N + 255) / 256 > 64 ? 64 : (N + 255) / 256), block(256);
         hipLaunchKernelGGL((k_repitch<double, double, false>), grid, block, 0, st, src, N, G, dst, ldn,
                            (int*)nullptr);
     }
@@ -670,12 +670,17 @@ template <class SrcT>
 __global__ __launch_bounds__(256) void k_ratio_keys_c(const SrcT* __restrict__ counts, int N, int G,
                                                       const double* __restrict__ logmeans,
                                                       const int* __restrict__ idx, const int* __restrict__ count,
-                                                      unsigned long long* __restrict__ keys) {
+                                                      unsigned long long* __restrict__ keys, int zeros_low) {
     const int n = blockIdx.y, Gu = *count;
+    // a zero count: never among the usable genes of the training data in "ratio" mode; left out of the sample's
+    // median in "poscounts" mode (dds.py:668-671); for NEW samples transformed with the training log means
+    // (zeros_low) it is log(0) - logmean = -inf and counts at the low end of the median, as numpy does
+    // (preprocessing.py:59-102)
+    const unsigned long long kz = zeros_low ? f64_key(-INFINITY) : ~0ull;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < Gu; j += gridDim.x * 256) {
         const int g = idx[j];
         const double c = (double)counts[(size_t)n * G + g];
-        keys[(size_t)n * Gu + j] = (c > 0.0) ? f64_key((c < 256.0 ? kLogInt[(int)c] : flog(c)) - logmeans[g]) : ~0ull;
+        keys[(size_t)n * Gu + j] = (c > 0.0) ? f64_key((c < 256.0 ? kLogInt[(int)c] : flog(c)) - logmeans[g]) : kz;
     }
 }
 
@@ -695,7 +700,7 @@ size_t size_factors_work_doubles(int N, int G) { return (size_t)N * G + (size_t)
 
 hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
                                const double* logmeans, const uint8_t* gene_mask, double* work,
-                               double* sf) {
+                               double* sf, int zeros_low) {
     if (N <= 0 || G <= 0) return hipSuccess;
     unsigned long long* keys = (unsigned long long*)work;
     int* idx = (int*)(work + (size_t)N * G);
@@ -706,10 +711,10 @@ hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_
     const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
     if (count_type == 1)
         hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
-                           logmeans, (const int*)idx, (const int*)count, keys);
+                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low);
     else
         hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
-                           logmeans, (const int*)idx, (const int*)count, keys);
+                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low);
     hipLaunchKernelGGL(k_row_median_c, dim3(N), dim3(1024), 0, st, (const unsigned long long*)keys, N,
                        (const int*)count, sf);
     return hipGetLastError();
@@ -774,11 +779,12 @@ __global__ __launch_bounds__(kBlock) void k_mom_lin_mu(const int32_t* __restrict
                                                        const double* __restrict__ s_mean_inv, double min_disp,
                                                        double max_disp, double min_mu,
                                                        double* __restrict__ normed_mean, double* __restrict__ mom,
-                                                       double* __restrict__ mu) {
+                                                       double* __restrict__ mu, double* __restrict__ coef) {
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (g >= G) return;
     const MomOut o = mom_lin_mu_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
-                                                    min_disp, max_disp, min_mu, mu + (size_t)g * ldn);
+                                                    min_disp, max_disp, min_mu, mu ? mu + (size_t)g * ldn : nullptr,
+                                                    coef ? coef + (size_t)g * P : nullptr);
     if ((threadIdx.x & 63) == 0) {
         normed_mean[g] = o.normed_mean;
         mom[g] = o.mom;
@@ -787,12 +793,14 @@ __global__ __launch_bounds__(kBlock) void k_mom_lin_mu(const int32_t* __restrict
 
 hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
                              const double* pinvXt, int ldx, int N, int G, int P_, double min_disp, double max_disp,
-                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar) {
+                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar,
+                             double* coef) {
     if (G <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf, N, d_scalar);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
-                                          (const double*)d_scalar, min_disp, max_disp, min_mu, normed_mean, mom, mu))
+                                          (const double*)d_scalar, min_disp, max_disp, min_mu, normed_mean, mom, mu,
+                                          coef))
     return hipGetLastError();
 }
 
@@ -814,6 +822,37 @@ hipError_t launch_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N,
                                           G, min_mu, mu))
+    return hipGetLastError();
+}
+
+// mu_hat rows of a few listed genes from their OLS coefficients (the grid-search fallback of the dispersion fit
+// when no N x G mu_hat was materialised): dst[k][:] = max(sf * (X coef[list[k]]), min_mu), idx_out[k] = k
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_mu_from_coef(const double* __restrict__ coef, const double* __restrict__ sf,
+                                                         const double* __restrict__ Xt, int ldx, int N, double min_mu,
+                                                         const int32_t* __restrict__ list, int n_list,
+                                                         double* __restrict__ dst, int ldn, int32_t* __restrict__ idx_out) {
+    const int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (k >= n_list) return;
+    const int g = list[k];
+    double b[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) b[j] = coef[(size_t)g * P + j];
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+        double yh = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
+        dst[(size_t)k * ldn + n] = dmax(sf[n] * yh, min_mu);
+    }
+    if ((threadIdx.x & 63) == 0) idx_out[k] = k;
+}
+
+hipError_t launch_mu_from_coef(hipStream_t st, const double* coef, const double* sf, const double* Xt, int ldx, int N,
+                               int P_, double min_mu, const int32_t* list, int n_list, double* dst, int ldn,
+                               int32_t* idx_out) {
+    if (n_list <= 0) return hipSuccess;
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mu_from_coef<P>, dim3(genes_to_blocks(n_list)), dim3(kBlock), 0, st, coef,
+                                          sf, Xt, ldx, N, min_mu, list, n_list, dst, ldn, idx_out))
     return hipGetLastError();
 }
 
@@ -994,6 +1033,53 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
     return hipGetLastError();
 }
 
+// The design-only half of the Cook's stage on its own (robust_disp_gene): what the fused LFC epilogue
+// (dsq_irls.h, LfcEpilogue) needs beforehand.  Independent of every fit, so the pipeline runs it on a side
+// stream underneath the latency-bound dispersion-trend / prior kernels.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restrict__ y, int ldn,
+                                                          const double* __restrict__ sf,
+                                                          const int32_t* __restrict__ cell_offsets,
+                                                          const int32_t* __restrict__ cell_index, int n_cells,
+                                                          int whole, int cap, int stride, int N, int G,
+                                                          double* __restrict__ robust_disp) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= G) return;
+    double* scratch = lds + (size_t)w * stride;
+    unsigned int* hist = (unsigned int*)(scratch + cap);
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    const double ar = robust_disp_gene<DeviceWave>(y + (size_t)g * ldn, sf, C, N, scratch, hist, LdsSorter());
+    if ((threadIdx.x & 63) == 0) robust_disp[g] = ar;
+}
+
+hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const double* sf,
+                              const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
+                              int max_cell, int N, int G, double* robust_disp) {
+    if (G <= 0) return hipSuccess;
+    const int biggest = whole ? N : max_cell;
+    const int cap = biggest <= kTrimSortMax ? next_pow2(biggest) : ((biggest + 15) & ~15);
+    const int stride = cap + (biggest <= kTrimSortMax ? 0 : kTrimBins);
+    const size_t per_wave = (size_t)stride * sizeof(double);
+    if (per_wave > 160 * 1024) return hipErrorInvalidValue;
+#define DSQ_RD_LAUNCH(WPB)                                                                                   \
+    do {                                                                                                     \
+        if (per_wave * WPB > 48 * 1024) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)k_robust_disp<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(per_wave * WPB));                                                \
+            (void)hipGetLastError();                                                                         \
+        }                                                                                                    \
+        hipLaunchKernelGGL(k_robust_disp<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, y, \
+                           ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, N, G, robust_disp); \
+    } while (0)
+    if (per_wave * 4 <= 64 * 1024) DSQ_RD_LAUNCH(4);
+    else if (per_wave * 2 <= 160 * 1024) DSQ_RD_LAUNCH(2);
+    else DSQ_RD_LAUNCH(1);
+#undef DSQ_RD_LAUNCH
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ outlier replacement
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict__ y,
@@ -1054,9 +1140,9 @@ template <class T>
 __global__ __launch_bounds__(256) void k_gather_rows(const T* __restrict__ src, int ld,
                                                      const int32_t* __restrict__ idx, int n_idx,
                                                      int ncols, T* __restrict__ dst) {
-    const int k = blockIdx.y;
+    const int k = blockIdx.x;  // rows (genes) on grid.x: grid.y is limited to 65535
     const int g = idx[k];
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < ncols; c += gridDim.x * 256)
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < ncols; c += gridDim.y * 256)
         dst[(size_t)k * ld + c] = src[(size_t)g * ld + c];
 }
 
@@ -1064,7 +1150,7 @@ hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, con
                                   int n_idx, int ncols, double* dst) {
     if (n_idx <= 0) return hipSuccess;
     const int gx = (ncols + 255) / 256 > 64 ? 64 : (ncols + 255) / 256;
-    hipLaunchKernelGGL(k_gather_rows<double>, dim3(gx, n_idx), dim3(256), 0, st, src, ld, idx, n_idx, ncols,
+    hipLaunchKernelGGL(k_gather_rows<double>, dim3(n_idx, gx), dim3(256), 0, st, src, ld, idx, n_idx, ncols,
                        dst);
     return hipGetLastError();
 }
@@ -1073,7 +1159,7 @@ hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, co
                                   int n_idx, int ncols, int32_t* dst) {
     if (n_idx <= 0) return hipSuccess;
     const int gx = (ncols + 255) / 256 > 64 ? 64 : (ncols + 255) / 256;
-    hipLaunchKernelGGL(k_gather_rows<int32_t>, dim3(gx, n_idx), dim3(256), 0, st, src, ld, idx, n_idx,
+    hipLaunchKernelGGL(k_gather_rows<int32_t>, dim3(n_idx, gx), dim3(256), 0, st, src, ld, idx, n_idx,
                        ncols, dst);
     return hipGetLastError();
 }
@@ -1619,10 +1705,10 @@ hipError_t launch_sf_keys_compact(hipStream_t st, const void* counts_sm, int cou
     const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
     if (count_type == 1)
         hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
-                           logmeans, idx_work, idx_work + G, keys);
+                           logmeans, idx_work, idx_work + G, keys, 0);
     else
         hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
-                           logmeans, idx_work, idx_work + G, keys);
+                           logmeans, idx_work, idx_work + G, keys, 0);
     return hipGetLastError();
 }
 hipError_t launch_sf_count(hipStream_t st, const unsigned long long* keys, int N, int G, unsigned int* counts) {

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/deseq_hip.h"
+#include "dsq_linalg.h"
 
 namespace dsq {
 
@@ -14,29 +15,60 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 
 inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerBlock; }
 
+// waves per SIMD requested for the cell-path kernels: their sample loops need few registers at any P, but the
+// p x p algebra between the loops (Cholesky, inverse, Wald) holds 2-3 packed matrices
+#ifndef DSQ_CELL_WAVES_WIDE
+#define DSQ_CELL_WAVES_WIDE 2
+#endif
+constexpr int cell_min_waves(int p) { return p <= 6 ? 3 : DSQ_CELL_WAVES_WIDE; }
+
 // ---- dsq_k_alpha.hip
+// optional inputs of the dispersion kernel (zero-initialised = none)
+struct AlphaExtras {
+    CellDesign cells;    // cells.C > 0: the design's distinct rows (<= 64) -> per-cell weight sums (P >= 3)
+    const double* coef;  // [G][P] OLS coefficients of the normalised counts (k_mom_lin_mu): mu_hat is computed
+    const double* sf;    // while staging instead of being read from `mu` (which may then be null)
+    double min_mu;
+};
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
-                        double* nll_const, int const_mode);
+                        double* nll_const, int const_mode, const AlphaExtras* extras = nullptr);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
                              const int32_t* grid_list, int n_grid, double* work);
 
 // ---- dsq_k_irls.hip
+// optional inputs / fused outputs of the IRLS kernel (zero-initialised = none)
+struct IrlsExtras {
+    CellDesign cells;            // cells.C > 0: per-cell path (dsq_irls.h, irls_sweep_cell)
+    // fused Cook's bookkeeping (LfcEpilogue): on when flags != nullptr
+    const double* robust_disp;   // [G] from launch_robust_disp
+    const uint8_t* flags;        // [N]
+    double cutoff;
+    double* cooks;               // [G][ldn] or null
+    uint8_t *any_all, *any_use, *any_use_nr, *few_above;  // [G]
+    // fused Wald statistics: on when ridge != nullptr (device pointers)
+    const double* ridge;         // [P*P]
+    const double* contrast;      // [P]
+    double lfc_null;
+    int alt;
+    double *pvals, *stats, *se;  // [G]
+};
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P, int full_rank,
                        const double* disp, double min_mu, double beta_tol, double min_beta,
                        double max_beta, int maxiter, double* beta, double* mu, double* hat,
-                       uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list);
+                       uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list,
+                       const IrlsExtras* extras = nullptr);
 hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf,
                               const double* lsf, const double* Xt, const double* pinvXt, int ldx, int N, int P,
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
-                              int n_fb);
+                              int n_fb, const IrlsExtras* extras = nullptr);
 
 // ---- dsq_k_stats.hip
 hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
@@ -47,14 +79,21 @@ hipError_t launch_logmeans(hipStream_t st, const int32_t* y, int ldn, int N, int
                            uint8_t* nonzero);
 hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_type, int N, int G,
                                const double* logmeans, const uint8_t* gene_mask, double* work,
-                               double* sf);
+                               double* sf, int zeros_low = 0);
 hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
                       const double* pinvXt, int ldx, int N, int G, int P, double min_disp,
                       double max_disp, double* normed_mean, double* rough, double* moments,
                       double* mom, double* d_scalar, const double* sf_moments = nullptr);
 hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
                              const double* pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
-                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar);
+                             double min_mu, double* normed_mean, double* mom, double* mu, double* d_scalar,
+                             double* coef = nullptr);
+hipError_t launch_mu_from_coef(hipStream_t st, const double* coef, const double* sf, const double* Xt, int ldx, int N,
+                               int P, double min_mu, const int32_t* list, int n_list, double* dst, int ldn,
+                               int32_t* idx_out);
+hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt, int ldx,
+                              int N, int G, int P, const double* disp, const double* beta, double min_mu, double* mu,
+                              double* hat);
 hipError_t launch_nll_const(hipStream_t st, const int32_t* y, int ldn, int N, int G, const double* disp, double* cst);
 hipError_t launch_nll_scaled(hipStream_t st, const int32_t* y, const double* mu, int ldn, int N, int G,
                              const double* disp, const double* scale, const double* cst, double* nll);
@@ -70,6 +109,10 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
                         int n_cells, int whole, int max_cell, const uint8_t* flags, int N, int G,
                         int P, double cutoff, double* cooks, double* robust_disp, uint8_t* any_all,
                         uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above);
+// robust dispersion of utils.robust_method_of_moments_disp (the design-only half of launch_cooks)
+hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const double* sf,
+                              const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
+                              int max_cell, int N, int G, double* robust_disp);
 hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
                           const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero);

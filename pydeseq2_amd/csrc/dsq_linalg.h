@@ -7,6 +7,8 @@
 // Replaces numpy.linalg.slogdet / inv and scipy.linalg.solve(assume_a="pos")
 // at pydeseq2/utils.py:370-371, 428-430, 515, 532, 772-776.
 #pragma once
+#include <cstdint>
+
 #include "dsq_math.h"
 
 namespace dsq {
@@ -18,6 +20,25 @@ struct Tri {
 
 DSQ_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }          // i >= j
 DSQ_HD constexpr int tris(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }  // any order
+
+// Designs whose rows take few distinct values ("design cells": every purely categorical design): X^T W X is
+// sum_c (sum_{n in cell c} w_n) x_c x_c^T, so the per-sample work of the fits does not depend on P at all.
+// The per-gene routines then add w_n into per-cell accumulators (wave-private LDS) and rebuild the matrix
+// entry-parallel: lane e owns entry e and walks the <= 64 cells.
+constexpr int kMaxCells = 64;
+struct CellDesign {
+    const int32_t* cell_of;  // [ldx] design cell of every sample (0 beyond N)
+    const double* Xc;        // [C][P] the cells' design rows
+    const double* XX;        // [C][T] x_i x_j of the cells' rows, packed lower triangle
+    int C;
+};
+// wave-private workspace of the cell path (LDS on the device)
+template <int P>
+struct CellWork {
+    double acc[2][kMaxCells];        // per-cell sums of the current sweep
+    double tab[2][kMaxCells];        // per-cell table fetched by the samples (linear predictor, its exponential, ...)
+    double ent[2 * (P * (P + 1) / 2)];  // matrix entries on their way from the lane that computed them to all lanes
+};
 
 // in-place Cholesky A = L L^T (lower, packed).  Non-SPD input yields NaNs (sqrt of <0).
 template <int P>

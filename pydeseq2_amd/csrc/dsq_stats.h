@@ -93,7 +93,7 @@ DSQ_HD MomOut mom_gene(const int32_t* y, const double* sf, const double* Xt, con
 template <class Wv, int P>
 DSQ_HD MomOut mom_lin_mu_gene(const int32_t* y, const double* sf, const double* Xt, const double* pinvXt,
                               int ldx, int N, double s_mean_inv, double min_disp, double max_disp,
-                              double min_mu, double* mu_out) {
+                              double min_mu, double* mu_out, double* coef_out = nullptr) {
     double s = 0.0, b[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) b[j] = 0.0;
@@ -116,12 +116,16 @@ DSQ_HD MomOut mom_lin_mu_gene(const int32_t* y, const double* sf, const double* 
         double yh = 0.0;
 #pragma unroll
         for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
-        mu_out[n] = dmax(sfn * yh, min_mu);
+        if (mu_out != nullptr) mu_out[n] = dmax(sfn * yh, min_mu);
         yh = dmax(yh, 1.0);
         rr += ((v - yh) * (v - yh) - yh) / (dof * yh * yh);
     }
     ss = Wv::sum(ss);
     rr = Wv::sum(rr);
+    if (coef_out != nullptr && Wv::lane() == 0) {  // the dispersion kernel rebuilds mu_hat from these (k_alpha, ex.coef)
+#pragma unroll
+        for (int j = 0; j < P; ++j) coef_out[j] = b[j];
+    }
     MomOut o;
     o.normed_mean = mean;
     o.rough = dmax(rr, 0.0);
@@ -163,31 +167,11 @@ struct WaldOut {
     double p, stat, se;
 };
 
-// mu == nullptr: mu_n = sf_n exp(x_n . beta) is recomputed (what ds.py:320-324 builds on the
-// host); otherwise the caller's mu row is used (Inference.wald_test contract).
-template <class Wv, int P>
-DSQ_HD WaldOut wald_gene(const double* mu, const double* sf, const double* Xt, int ldx, int N,
-                         double disp, const double (&beta)[P], const double* ridge /*[P*P]*/,
-                         const double* contrast /*[P]*/, double lfc_null, int alt) {
+// Wald statistic from M = X^T W X (packed, WITHOUT ridge; W = mu/(1 + mu disp) at the UNclamped mu, ds.py:320-324)
+template <int P>
+DSQ_HD WaldOut wald_from_M(const double (&M)[Tri<P>::N], const double (&beta)[P], const double* ridge /*[P*P]*/,
+                           const double* contrast /*[P]*/, double lfc_null, int alt) {
     constexpr int T = Tri<P>::N;
-    double M[T];
-#pragma unroll
-    for (int k = 0; k < T; ++k) M[k] = 0.0;
-    for (int n = Wv::lane(); n < N; n += Wv::W) {
-        double x[P];
-        double eta = 0.0;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { x[j] = Xt[j * ldx + n]; eta += x[j] * beta[j]; }
-        const double m = (mu != nullptr) ? mu[n] : sf[n] * exp(eta);
-        const double w = m / (1.0 + m * disp);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const double xw = x[i] * w;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) M[tri(i, j)] += xw * x[j];
-        }
-    }
-    Wv::template sum_n<T>(M);
     double Hm[T], c[P], Hc[P], MHc[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -240,6 +224,34 @@ DSQ_HD WaldOut wald_gene(const double* mu, const double* sf, const double* Xt, i
     o.stat = stat;
     o.p = pval;
     return o;
+}
+
+// mu == nullptr: mu_n = sf_n exp(x_n . beta) is recomputed (what ds.py:320-324 builds on the
+// host); otherwise the caller's mu row is used (Inference.wald_test contract).
+template <class Wv, int P>
+DSQ_HD WaldOut wald_gene(const double* mu, const double* sf, const double* Xt, int ldx, int N,
+                         double disp, const double (&beta)[P], const double* ridge /*[P*P]*/,
+                         const double* contrast /*[P]*/, double lfc_null, int alt) {
+    constexpr int T = Tri<P>::N;
+    double M[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) M[k] = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        double x[P];
+        double eta = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { x[j] = Xt[j * ldx + n]; eta += x[j] * beta[j]; }
+        const double m = (mu != nullptr) ? mu[n] : sf[n] * exp(eta);
+        const double w = m / (1.0 + m * disp);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const double xw = x[i] * w;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[tri(i, j)] += xw * x[j];
+        }
+    }
+    Wv::template sum_n<T>(M);
+    return wald_from_M<P>(M, beta, ridge, contrast, lfc_null, alt);
 }
 
 // ---------------------------------------------------------------- Cook's distances
@@ -380,10 +392,12 @@ constexpr int kTrimSortMax = 2048;
 // scratch: >= max cell doubles (next power of two when the cell is sorted), hist: 2 * kTrimBins
 // counters (both wave-private LDS on the device).
 // flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
+// Robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960): per design cell the trimmed
+// variance of the normalised counts around their trimmed mean, the largest cell variance vs the overall mean.
+// Depends on the counts, the size factors and the design cells only - not on any fit.
 template <class Wv, class Sorter>
-DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu, const double* H,
-                           const CellPlan& C, const uint8_t* flags, int N, int P, double cutoff,
-                           double* scratch, unsigned int* hist, Sorter&& sorter, double* cooks_out) {
+DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPlan& C, int N, double* scratch,
+                               unsigned int* hist, Sorter&& sorter) {
     const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
     const double scales[3] = {2.04, 1.86, 1.51};
     double vmax = -INFINITY;
@@ -433,35 +447,42 @@ DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu,
     double ar = (vmax - m) / (m * m);
     ar = (ar > 0.04) ? ar : 0.04;  // np.maximum(alpha, 0.04) (NaN -> stays NaN in numpy; see below)
     if (vmax != vmax) ar = vmax;
-    CooksOut o;
-    o.robust_disp = ar;
-    // cooks + outlier bookkeeping
+    return ar;
+}
+
+// Per-sample accumulator of the Cook's bookkeeping (dds.py:1034-1040, 1066-1110, 1325-1326): feed every
+// sample's (y, mu, hat) once, finish() reduces over the wave.  Used by cooks_gene (mu / hat rows from memory)
+// and by the epilogue of the LFC fit (mu / hat straight from the IRLS registers).
+template <class Wv>
+struct CooksAcc {
+    double ar, cutoff, invP;
     int g_all = 0, g_use = 0, g_use_nr = 0;
     double best = -INFINITY;
     int best_idx = 0x7fffffff;
     bool best_nan = false;
-    for (int n = Wv::lane(); n < N; n += Wv::W) {
-        const double yv = (double)y[n], mv = mu[n], h = H[n];
+    DSQ_HD CooksAcc(double robust_disp, double cutoff_, int P) : ar(robust_disp), cutoff(cutoff_), invP((double)P) {}
+    DSQ_HD double add(int n, double yv, double mv, double h, int fl) {
         const double V = (mv * mv) * ar + mv;
         const double r = yv - mv;
-        const double ck = (r * r) / V / (double)P * (h / ((1.0 - h) * (1.0 - h)));
-        if (cooks_out != nullptr) cooks_out[n] = ck;
+        const double ck = (r * r) / V / invP * (h / ((1.0 - h) * (1.0 - h)));
         const bool gt = ck > cutoff;
-        const int fl = flags[n];
         g_all |= gt ? 1 : 0;
         if (gt && (fl & 1)) { g_use = 1; if (!(fl & 2)) g_use_nr = 1; }
-        // np.argmax: first NaN wins, else first maximum
+        // np.argmax: first NaN wins, else first maximum (samples arrive in ascending order per lane)
         const bool isn = (ck != ck);
         if (!best_nan) {
             if (isn) { best_nan = true; best_idx = n; }
             else if (ck > best) { best = ck; best_idx = n; }
         }
+        return ck;
     }
-    o.any_gt_all = Wv::sumi(g_all) > 0;
-    o.any_gt_use = Wv::sumi(g_use) > 0;
-    o.any_gt_use_nr = Wv::sumi(g_use_nr) > 0;
-    // wave argmax: (nan first, then value desc, then index asc)
-    {
+    DSQ_HD CooksOut finish(const int32_t* y, int N) {
+        CooksOut o;
+        o.robust_disp = ar;
+        o.any_gt_all = Wv::sumi(g_all) > 0;
+        o.any_gt_use = Wv::sumi(g_use) > 0;
+        o.any_gt_use_nr = Wv::sumi(g_use_nr) > 0;
+        // wave argmax: (nan first, then value desc, then index asc)
         const int any_nan = Wv::sumi(best_nan ? 1 : 0);
         int cand;
         if (any_nan > 0) {
@@ -470,17 +491,32 @@ DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu,
             const double wmax = Wv::max(best);
             cand = (best == wmax) ? best_idx : 0x7fffffff;
         }
-        // min index over lanes
-        const double ci = -Wv::max(-(double)cand);
-        best_idx = (int)ci;
+        const double ci = -Wv::max(-(double)cand);  // min index over lanes
+        const int bi = (int)ci;
+        int above = 0;
+        if (bi >= 0 && bi < N) {
+            const int yref = y[bi];
+            for (int n = Wv::lane(); n < N; n += Wv::W) above += (y[n] > yref) ? 1 : 0;
+        }
+        o.few_above = Wv::sumi(above) < 3;
+        return o;
     }
-    int above = 0;
-    if (best_idx >= 0 && best_idx < N) {
-        const int yref = y[best_idx];
-        for (int n = Wv::lane(); n < N; n += Wv::W) above += (y[n] > yref) ? 1 : 0;
+};
+
+// scratch: >= max cell doubles (next power of two when the cell is sorted), hist: 2 * kTrimBins
+// counters (both wave-private LDS on the device).
+// flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
+template <class Wv, class Sorter>
+DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu, const double* H,
+                           const CellPlan& C, const uint8_t* flags, int N, int P, double cutoff,
+                           double* scratch, unsigned int* hist, Sorter&& sorter, double* cooks_out) {
+    const double ar = robust_disp_gene<Wv>(y, sf, C, N, scratch, hist, sorter);
+    CooksAcc<Wv> acc(ar, cutoff, P);
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double ck = acc.add(n, (double)y[n], mu[n], H[n], flags[n]);
+        if (cooks_out != nullptr) cooks_out[n] = ck;
     }
-    o.few_above = Wv::sumi(above) < 3;
-    return o;
+    return acc.finish(y, N);
 }
 
 // trimmed mean (trim 0.2) of the normalised counts over all samples (dds.py:1332-1340)

@@ -138,6 +138,12 @@ struct DeviceWave {
     }
     // wave-private LDS histogram cell += 1; the segment is touched by this wave only
     static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
+    // wave-private LDS accumulator cell += v (several lanes may name the same cell: ds_add_f64; the segment is
+    // touched by this wave only and the LDS serialises same-address lanes in a fixed order => deterministic)
+    static __device__ __forceinline__ void cell_add(double* cell, double v) {
+        typedef __attribute__((address_space(3))) double lds_double;  // always an LDS address: ds_add_f64, not flat
+        __hip_atomic_fetch_add((lds_double*)cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
     static __device__ __forceinline__ void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -189,6 +195,7 @@ struct HostWave {
     static inline int maxi(int v) { return v; }
     static inline int excl_scan_i(int) { return 0; }
     static inline void hist_add(unsigned int* cell) { *cell += 1u; }
+    static inline void cell_add(double* cell, double v) { *cell += v; }
     static inline void sync() {}
     static inline bool any(bool p) { return p; }
     static inline double from_lane(double v, int) { return v; }

@@ -338,6 +338,10 @@ class DistDeseqPipeline(DeseqPipeline):
         comm.allgather(d_g, d_all)
         self.Gpad = int(d_all.to_host().max())
 
+    def _pool_reset(self):
+        super()._pool_reset()
+        self._gathered = None  # the gathered trend inputs lived in the recycled buffers
+
     def _pooled_once(self, shape, dtype, value):
         arr = DeviceArray(self.ctx, shape, dtype)
         self.ctx.h2d(arr.ptr, np.full(shape, value, dtype=dtype))

@@ -15,6 +15,7 @@ refitted, pvalue / stat / lfcSE, ...
 """
 from __future__ import annotations
 
+import os
 import time
 import warnings
 from dataclasses import dataclass, field
@@ -24,7 +25,7 @@ from scipy.stats import f as f_dist
 
 from . import trend as _trend
 from ._design import DesignPack, pad16
-from ._lib import ALT, I32, I64, SAMPLE_MAJOR, Context, DeviceArray
+from ._lib import ALT, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells
 
 import ctypes as C
 
@@ -190,6 +191,14 @@ class DeseqPipeline:
         self.d_flags = DeviceArray.from_host(ctx_, D.flags)
         self.d_cell_off = DeviceArray.from_host(ctx_, D.cell_offsets)
         self.d_cell_idx = DeviceArray.from_host(ctx_, D.cell_index)
+        self._cells = None  # dsq_cells: designs with 5..64 distinct rows take the per-cell kernels (P >= 3)
+        if D.cell_path and not os.environ.get("DSQ_NO_CELL_PATH"):
+            self._d_cell_of = DeviceArray.from_host(ctx_, D.cell_of)
+            self._d_Xc = DeviceArray.from_host(ctx_, D.Xc)
+            self._d_XXc = DeviceArray.from_host(ctx_, D.XXc)
+            self._cells = DsqCells(self._d_cell_of.ptr, self._d_Xc.ptr, self._d_XXc.ptr, int(D.n_design_cells))
+        self.keep_layers = False   # True: the LFC fit also writes the N x G layers mu / hat diagonals (else on demand)
+        self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -221,6 +230,7 @@ class DeseqPipeline:
     def _pool_reset(self):
         self._pool_free.extend(self._pool_used)
         self._pool_used = []
+        self.layers = {}  # they point into the buffers that have just been recycled
 
     def _pooled(self, shape, dtype, ld=None):
         arr = DeviceArray.__new__(DeviceArray)
@@ -269,7 +279,7 @@ class DeseqPipeline:
             self.kernel_log.setdefault(name, []).append((ms, int(genes)))
         else:
             self.ctx.call(cname, *args)
-        if cname == "dsq_dev_alpha_mle":
+        if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2"):
             kms, ng = C.c_float(), C.c_int()
             self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
             self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
@@ -337,59 +347,82 @@ class DeseqPipeline:
         return out
 
     # ------------------------------------------------------------------ stages (device in, device out)
+    def _cells_arg(self):
+        return C.byref(self._cells) if self._cells is not None else None
+
     def _stage_genewise(self, d_y, Gs, d_sf, S):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
-        unclipped), gconv]; returns the device mu_hat matrix."""
+        unclipped), gconv]; returns the description of mu_hat the MAP fit needs: the device matrix, or - for
+        the designs with the linear-model mu_hat (dds.py:747-756) - only the per-gene OLS coefficients from
+        which the dispersion kernel rebuilds mu_hat = max(sf * X coef, min_mu) while staging."""
         D = self.design
-        d_mu = self._dmat(Gs)
+        mh = type("MuHat", (), {})()
+        mh.d_mu, mh.d_coef = None, None
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
-            self._k("mom_lin_mu", Gs, "dsq_dev_mom_lin_mu", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
-                    _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
-                    c_double(self.min_mu), _vp(S["nm"].ptr), _vp(S["mom"].ptr), _vp(d_mu.ptr))
+            mh.d_coef = self._dvec(Gs * self.P)
+            if 48 * ((self.N + 63) & ~63) > 80 * 1024:  # rows too long for the LDS staging (launch_alpha): materialise
+                mh.d_mu = self._dmat(Gs)
+            self._k("mom_lin_mu", Gs, "dsq_dev_mom_lin_coef", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr),
+                    _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp),
+                    c_double(self.max_disp), c_double(self.min_mu), _vp(S["nm"].ptr), _vp(S["mom"].ptr),
+                    _vp(mh.d_mu.ptr) if mh.d_mu else None, _vp(mh.d_coef.ptr))
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
+            mh.d_mu = self._dmat(Gs)
             self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
                     _vp(S["nm"].ptr), None, None, _vp(S["mom"].ptr))
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
-            self._k("irls_mu", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+            self._k("irls_mu", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
-                    _vp(d_b.ptr), _vp(d_mu.ptr), None, _vp(d_c.ptr), None)
-        d_mu.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
+                    _vp(d_b.ptr), _vp(mh.d_mu.ptr), None, _vp(d_c.ptr), None, self._cells_arg(),
+                    None, None, c_double(0.0), None, None, None, None, None,
+                    None, None, c_double(0.0), 0, None, None, None)
+        mh.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
+        self._alpha_fit("alpha_mle", d_y, mh, Gs, d_sf, S["mom"], 1.0, 0, S["gw"], S["gconv"], 1)
+        return mh
+
+    def _alpha_fit(self, name, d_y, mh, Gs, d_sf, d_start, prior_var, prior_reg, d_out, d_conv, const_mode):
         d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
-        self._k("alpha_mle", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
-                D.ldx, self.N, Gs, self.P, _vp(S["mom"].ptr), c_double(self.min_disp), c_double(self.max_disp),
-                c_double(1.0), 1, 0, _vp(S["gw"].ptr), _vp(S["gconv"].ptr),
-                _vp(d_nfev.ptr) if d_nfev else None, _vp(d_mu.nll_const.ptr), 1)
+        use_coef = mh.d_mu is None
+        self._k(name, Gs, "dsq_dev_alpha_mle2", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
+                _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
+                c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
+                _vp(d_nfev.ptr) if d_nfev else None, _vp(mh.nll_const.ptr), const_mode, self._cells_arg(),
+                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if use_coef else None, c_double(self.min_mu))
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
-        return d_mu
 
-    def _stage_map(self, d_y, d_mu, Gs, prior_var, squared_logres, S):
+    def _stage_map(self, d_y, mh, Gs, d_sf, prior_var, squared_logres, S):
         """MAP dispersions (dds.py:886-935) from S[fit] -> S[map (raw), mconv], then the final
         dispersions S[disp] and the dispersion-outlier flags S[outl]."""
-        d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
-        self._k("alpha_map", Gs, "dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), self.ldn, _vp(self.d_Xt.ptr),
-                self.design.ldx, self.N, Gs, self.P, _vp(S["fit"].ptr), c_double(self.min_disp),
-                c_double(self.max_disp), c_double(prior_var), 1, 1, _vp(S["map"].ptr), _vp(S["mconv"].ptr),
-                _vp(d_nfev.ptr) if d_nfev else None,
-                *((_vp(d_mu.nll_const.ptr), 2) if getattr(d_mu, "nll_const", None) is not None else (None, 0)))
-        if d_nfev:
-            self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
+        self._alpha_fit("alpha_map", d_y, mh, Gs, d_sf, S["fit"], prior_var, 1, S["map"], S["mconv"], 2)
         self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
                       c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
                       _vp(S["disp"].ptr), _vp(S["outl"].ptr))
 
-    def _stage_lfc(self, d_y, Gs, d_sf, S, want_layers=True):
-        """IRLS LFC fit (dds.py:937-984) with S[disp] -> S[beta, lconv]; returns device (mu, hat)."""
+    def _stage_lfc(self, d_y, Gs, d_sf, S, wald, cooks=None):
+        """IRLS LFC fit (dds.py:937-984) with S[disp] -> S[beta, lconv] and, fused into its epilogue, the Wald
+        statistics S[p, stat, se] (ds.py:303-360; wald = (ridge, contrast, lfc_null, alt)) and - cooks =
+        (robust dispersions, cutoff, cooks layer) - the per-sample half of the Cook's stage (dds.py:986-1040,
+        1066-1110): S[any_all, any_use, any_use_nr, few_above].  Returns device (mu, hat) when keep_layers."""
         D = self.design
-        d_mu = self._dmat(Gs) if want_layers else None
-        d_hat = self._dmat(Gs) if want_layers else None
-        self._k("irls_lfc", Gs, "dsq_dev_irls", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+        want = self.keep_layers and cooks is not None
+        d_mu = self._dmat(Gs) if want else None
+        d_hat = self._dmat(Gs) if want else None
+        ridge, contrast, lfc_null, alt = wald
+        ck = [None, None, c_double(0.0), None, None, None, None, None]
+        if cooks is not None:
+            d_rd, cutoff, d_cooks = cooks
+            ck = [_vp(d_rd.ptr), _vp(self.d_flags.ptr), c_double(cutoff), _vp(d_cooks.ptr)] + \
+                 [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
+        self._k("lfc_fit", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                 _vp(S["beta"].ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
-                _vp(S["lconv"].ptr), None)
+                _vp(S["lconv"].ptr), None, self._cells_arg(), *ck,
+                _vp(ridge.ctypes.data), _vp(contrast.ctypes.data), c_double(lfc_null), alt,
+                _vp(S["p"].ptr), _vp(S["stat"].ptr), _vp(S["se"].ptr))
         return d_mu, d_hat
 
     # ------------------------------------------------------------------ cross-gene steps (hooks)
@@ -539,6 +572,17 @@ class DeseqPipeline:
         # ---- genewise dispersions (dds.py:713-797)
         d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S)
         self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
+        # the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
+        # cells only: they run on a side stream underneath the latency-bound trend / prior kernels that follow
+        d_rd = S["rd"]
+        if not (stop_after_trend or stop_after_size_factors):
+            if self.overlap:
+                ctx.call("dsq_side_begin")
+            self._k("robust_disp", Gn, "dsq_dev_robust_disp", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
+                    _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell, N, Gn,
+                    _vp(d_rd.ptr))
+            if self.overlap:
+                ctx.call("dsq_side_end")
         t2 = tick(); T["genewise"] = t2 - t1
 
         # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
@@ -582,26 +626,29 @@ class DeseqPipeline:
         t3 = tick(); T["trend_prior"] = t3 - t2
 
         # ---- MAP dispersions + dispersion outliers (dds.py:886-935)
-        self._stage_map(d_ynz, d_mu_hat, Gn, r.prior_disp_var, r.squared_logres, S)
+        self._stage_map(d_ynz, d_mu_hat, Gn, d_sf, r.prior_disp_var, r.squared_logres, S)
         t4 = tick(); T["MAP"] = t4 - t3
 
-        # ---- LFC (dds.py:937-984)
-        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S)
-        t5 = tick(); T["LFC"] = t5 - t4
-
-        # ---- Cook's (dds.py:986-1040)
+        # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics
+        # (ds.py:303-360) in its epilogue: mu and the hat diagonal are consumed from registers
         cutoff = self._cooks_cutoff
+        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
+        wald_args = (ridge, contrast, float(np.log(2) * lfc_null), ALT[alt_hypothesis])
         d_cooks = self._dmat(Gn)
-        flag_names = ["any_all", "any_use", "any_use_nr", "few_above"]
-        self._k("cooks", Gn, "dsq_dev_cooks", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr), _vp(d_mu.ptr), _vp(d_hat.ptr),
-                _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
-                _vp(self.d_flags.ptr), N, Gn, P, c_double(cutoff), _vp(d_cooks.ptr), _vp(S["rd"].ptr),
-                *[_vp(S[x].ptr) for x in flag_names])
+        if self.overlap:
+            ctx.call("dsq_side_wait")
+        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks))
         want_refit = self.refit_cooks and D.replaceable.sum() > 0
         flags = self._fetch(S, ["any_all"]) if want_refit else None
+        # the layers of THIS fit (before the refit patches beta / dispersions): cooks is always materialised, mu and
+        # the hat diagonals only with keep_layers, otherwise layer() rebuilds them from these copies on demand
+        d_b0, d_d0 = self._dvec(Gn * P), self._dvec(Gn)
+        ctx.call("dsq_d2d", _vp(d_b0.ptr), _vp(S["beta"].ptr), C.c_size_t(8 * Gn * P))
+        ctx.call("dsq_d2d", _vp(d_d0.ptr), _vp(S["disp"].ptr), C.c_size_t(8 * Gn))
         self.layers = {"nz_idx": np.arange(G) if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
-                       "cooks": d_cooks}
-        t6 = tick(); T["cooks"] = t6 - t5
+                       "cooks": d_cooks, "_fit": (d_ynz, d_sf, d_b0, d_d0, Gn)}
+        t5 = tick(); T["LFC_cooks_wald"] = t5 - t4
+        t6 = t5
 
         # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem, patched into the device vectors
         replaced_nz = np.zeros(Gn, dtype=bool)
@@ -641,20 +688,15 @@ class DeseqPipeline:
                     s_mu = self._stage_genewise(d_yf, Gf, d_sf, S2)
                     ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gf, c_double(a0), c_double(a1),
                              _vp(S2["fit"].ptr))
-                    self._stage_map(d_yf, s_mu, Gf, r.prior_disp_var, r.squared_logres, S2)
-                    self._stage_lfc(d_yf, Gf, d_sf, S2, want_layers=False)
+                    self._stage_map(d_yf, s_mu, Gf, d_sf, r.prior_disp_var, r.squared_logres, S2)
+                    self._stage_lfc(d_yf, Gf, d_sf, S2, wald_args)
                     d_rf = self._up(rf.astype(np.int32), np.int32)
-                    for k, wdt in (("disp", 1), ("beta", P)):
+                    for k, wdt in (("disp", 1), ("beta", P), ("p", 1), ("stat", 1), ("se", 1)):
                         ctx.call("dsq_dev_scatter_rows_f64", _vp(S2[k].ptr), _vp(d_rf.ptr), Gf, wdt, _vp(S[k].ptr))
                     patch = (rf, self._fetch(S2, ["nm", "gw", "fit"]))
         t7 = tick(); T["refit"] = t7 - t6
 
-        # ---- Wald (ds.py:303-360) on the device vectors; mu = sf * exp(X beta) is recomputed there
-        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
-        self._k("wald", Gn, "dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, Gn, P,
-                _vp(S["disp"].ptr), _vp(S["beta"].ptr), _vp(ridge.ctypes.data), _vp(contrast.ctypes.data),
-                c_double(np.log(2) * lfc_null), ALT[alt_hypothesis], _vp(S["p"].ptr), _vp(S["stat"].ptr),
-                _vp(S["se"].ptr))
+        # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues (refitted genes: patched above)
         H = self._fetch(S)
         t8 = tick(); T["wald"] = t8 - t7
 
@@ -735,7 +777,7 @@ class DeseqPipeline:
         d_lm = DeviceArray.from_host(ctx, np.ascontiguousarray(lm))
         d_work = DeviceArray(ctx, (ctx.lib.dsq_size_factors_work_doubles(M, G),), np.float64)
         d_sf = DeviceArray(ctx, (M,), np.float64)
-        ctx.call("dsq_dev_size_factors", _vp(d_c.ptr), ct, M, G, _vp(d_lm.ptr), None, _vp(d_work.ptr), _vp(d_sf.ptr))
+        ctx.call("dsq_dev_size_factors_new", _vp(d_c.ptr), ct, M, G, _vp(d_lm.ptr), None, _vp(d_work.ptr), _vp(d_sf.ptr))
         d_out = DeviceArray(ctx, (M, G), np.float64)
         if trend_coeffs is not None:
             mode, a0, a1 = 0, float(trend_coeffs[0]), float(trend_coeffs[1])
@@ -744,9 +786,10 @@ class DeseqPipeline:
         ctx.call("dsq_dev_vst", _vp(d_c.ptr), ct, M, G, _vp(d_sf.ptr), mode, c_double(a0), c_double(a1), _vp(d_out.ptr))
         return d_out.to_host()
 
-    def wald(self, res: DeseqResult, contrast, lfc_null=0.0, alt_hypothesis=None):
+    def wald(self, res: DeseqResult, contrast, lfc_null=0.0, alt_hypothesis=None, lfc=None, ridge=None):
         """Wald test only (ds.py:303-360) on the dispersions / LFCs of ``res`` (e.g. another contrast or
-        alternative hypothesis after ``deseq2()``).  Returns (pvalue, stat, lfcSE), NaN for all-zero genes."""
+        alternative hypothesis after ``deseq2()``; ``lfc``: other coefficients, e.g. shrunk ones; ``ridge``: other
+        ridge matrix, ds.py:326-334).  Returns (pvalue, stat, lfcSE), NaN for all-zero genes."""
         if alt_hypothesis not in ALT:
             raise KeyError(alt_hypothesis)
         if lfc_null < 0 and alt_hypothesis in {"greaterAbs", "lessAbs"}:
@@ -754,10 +797,10 @@ class DeseqPipeline:
                              f"positive lfc_null value (got {lfc_null}).")
         G, N, P, D = self.G, self.N, self.P, self.design
         contrast = np.ascontiguousarray(contrast, dtype=np.float64)
-        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
+        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)) if ridge is None else ridge, dtype=np.float64)
         ctx = self.ctx
         d_sf = DeviceArray.from_host(ctx, np.ascontiguousarray(res.size_factors, dtype=np.float64))
-        d_beta = DeviceArray.from_host(ctx, np.ascontiguousarray(res.LFC, dtype=np.float64))
+        d_beta = DeviceArray.from_host(ctx, np.ascontiguousarray(res.LFC if lfc is None else lfc, dtype=np.float64))
         d_disp = DeviceArray.from_host(ctx, np.ascontiguousarray(res.dispersions, dtype=np.float64))
         d_out = DeviceArray(ctx, (3 * G,), np.float64)
         ctx.call("dsq_dev_wald", None, self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx, N, G, P, _vp(d_disp.ptr),
@@ -787,6 +830,14 @@ class DeseqPipeline:
     def layer(self, name):
         """Fetch an N x G layer ("mu_LFC", "hat_diagonals", "cooks") to the host (NaN for zero genes)."""
         d = self.layers[name]
+        if d is None:  # mu / hat diagonals of the LFC fit were consumed in its epilogue: rebuild from beta
+            d_y, d_sf, d_b, d_d, Gn = self.layers["_fit"]
+            D = self.design
+            self.layers["mu_LFC"], self.layers["hat_diagonals"] = self._dmat(Gn), self._dmat(Gn)
+            self.ctx.call("dsq_dev_irls_layers", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr), D.ldx,
+                          self.N, Gn, self.P, _vp(d_d.ptr), _vp(d_b.ptr), c_double(self.min_mu),
+                          _vp(self.layers["mu_LFC"].ptr), _vp(self.layers["hat_diagonals"].ptr))
+            d = self.layers[name]
         nzi = self.layers["nz_idx"]
         rows = self.ctx.d2h_rows(d.ptr, len(nzi), self.N, self.ldn)
         out = np.full((self.N, self.G), np.nan)

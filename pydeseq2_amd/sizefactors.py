@@ -33,6 +33,7 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
 
     p1.design = DesignPack(np.ones((N, 1)), pipe.min_replicates)
     p1.P = 1
+    p1._cells = None
     p1.d_Xt = DeviceArray.from_host(ctx, p1.design.Xt)
     p1.d_pinv = DeviceArray.from_host(ctx, p1.design.pinvXt)
     p1._pool_free, p1._pool_used = [], []
@@ -58,10 +59,11 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
             d_mu = p1._dmat(Gn)
             ctx.call("dsq_dev_lin_mu", _vp(d_y.ptr), p1.ldn, _vp(d_sf.ptr), _vp(p1.d_Xt.ptr), _vp(p1.d_pinv.ptr),
                      p1.design.ldx, N, Gn, 1, c_double(p1.min_mu), _vp(d_mu.ptr))
-            d_mu.nll_const = p1._dvec(Gn)
+            mh = type("MuHat", (), {})()
+            mh.d_mu, mh.d_coef, mh.nll_const = d_mu, None, p1._dvec(Gn)
             ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), p1.ldn, _vp(p1.d_Xt.ptr), p1.design.ldx, N, Gn, 1,
                      _vp(S["mom"].ptr), c_double(p1.min_disp), c_double(p1.max_disp), c_double(1.0), 1, 0,
-                     _vp(S["gw"].ptr), _vp(S["gconv"].ptr), None, _vp(d_mu.nll_const.ptr), 1)
+                     _vp(S["gw"].ptr), _vp(S["gconv"].ptr), None, _vp(mh.nll_const.ptr), 1)
             gw = np.clip(p1._down(S["gw"], Gn), p1.min_disp, p1.max_disp)
             use = gw > 10 * p1.min_disp
             if not use.any():
@@ -73,7 +75,7 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
             r = DeseqResult()
             r.disp_function_type, r.mean_disp = "mean", mean_disp
             sq, prior_var = p1._prior(Gn, S["fit"], r)
-            p1._stage_map(d_y, d_mu, Gn, prior_var, sq, S)
+            p1._stage_map(d_y, mh, Gn, d_sf, prior_var, sq, S)
             # objective of the Powell search
             d_cst, d_nll, d_scale = p1._dvec(Gn), p1._dvec(Gn), p1._dvec(N)
             ctx.call("dsq_dev_nll_const", _vp(d_y.ptr), p1.ldn, N, Gn, _vp(S["disp"].ptr), _vp(d_cst.ptr))

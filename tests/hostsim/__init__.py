@@ -314,3 +314,73 @@ def shrink(counts, X, size, offset, prior_no_shrink_scale, prior_scale, shrink_i
                          _p(invh, C.c_double), _p(conv, C.c_uint8))
     assert rc == 0
     return beta, invh, conv.astype(bool)
+
+
+def cell_design(X):
+    """(cell_of int32 [N], Xc [C][P], XX [C][T], C): the design's distinct rows (pydeseq2_amd/_design.py)."""
+    X = np.asarray(X, dtype=np.float64)
+    rows, inv = np.unique(X, axis=0, return_inverse=True)
+    ii, jj = np.tril_indices(X.shape[1])
+    Xc = np.ascontiguousarray(rows)
+    return (np.ascontiguousarray(np.asarray(inv).reshape(-1).astype(np.int32)), Xc,
+            np.ascontiguousarray(Xc[:, ii] * Xc[:, jj]), len(rows))
+
+
+def alpha_mle_cell(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False):
+    y = gene_major(counts)
+    G, N = y.shape
+    m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
+    Xt, _, _ = design_pack(X)
+    cof, Xc, XX, Cn = cell_design(X)
+    ah = np.ascontiguousarray(alpha_hat, dtype=np.float64)
+    out, conv = np.empty(G), np.empty(G, np.uint8)
+    rc = lib().hs_alpha_mle_cell(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
+                                 C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), _p(ah, C.c_double),
+                                 C.c_double(min_disp), C.c_double(max_disp),
+                                 C.c_double(prior_var if prior_var is not None else 1.0), C.c_int(cr_reg),
+                                 C.c_int(prior_reg), _p(cof, C.c_int32), _p(Xc, C.c_double), _p(XX, C.c_double),
+                                 C.c_int(Cn), _p(out, C.c_double), _p(conv, C.c_uint8))
+    assert rc == 0
+    return out, conv.astype(bool)
+
+
+def lfc_fit(counts, sf, X, disp, cells=False, robust_disp=None, cutoff=0.0, contrast=None, lfc_null=0.0, alt=0,
+            min_replicates=7, want_layers=True):
+    """IRLS + fused epilogue (Cook's bookkeeping if robust_disp is given, Wald if contrast is given)."""
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, fr = design_pack(X)
+    P = Xt.shape[0]
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    d = np.ascontiguousarray(disp, dtype=np.float64)
+    cof, Xc, XX, Cn = cell_design(X)
+    if not cells:
+        Cn = 0
+    _, _, _, _, flags = cell_plan(X, min_replicates)
+    beta, conv = np.empty((G, P)), np.empty(G, np.uint8)
+    mu = np.empty((G, N)) if want_layers else None
+    H = np.empty((G, N)) if want_layers else None
+    ck = np.empty((G, N)) if robust_disp is not None else None
+    fl = [np.empty(G, np.uint8) for _ in range(4)]
+    pv, st, se = np.empty(G), np.empty(G), np.empty(G)
+    rd = np.ascontiguousarray(robust_disp, dtype=np.float64) if robust_disp is not None else None
+    ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P))) if contrast is not None else None
+    cvec = np.ascontiguousarray(contrast, dtype=np.float64) if contrast is not None else None
+    rc = lib().hs_lfc_fit(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
+                          C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(P), _p(d, C.c_double), C.c_double(0.5),
+                          C.c_double(1e-8), C.c_int(fr), _p(cof, C.c_int32), _p(Xc, C.c_double), _p(XX, C.c_double),
+                          C.c_int(Cn), _p(rd, C.c_double) if rd is not None else None,
+                          _p(flags, C.c_uint8) if rd is not None else None, C.c_double(cutoff),
+                          _p(ck, C.c_double) if ck is not None else None, *[_p(a, C.c_uint8) for a in fl],
+                          _p(ridge, C.c_double) if ridge is not None else None,
+                          _p(cvec, C.c_double) if cvec is not None else None, C.c_double(lfc_null), C.c_int(alt),
+                          _p(beta, C.c_double), _p(mu, C.c_double) if mu is not None else None,
+                          _p(H, C.c_double) if H is not None else None, _p(conv, C.c_uint8), _p(pv, C.c_double),
+                          _p(st, C.c_double), _p(se, C.c_double))
+    assert rc == 0
+    out = dict(beta=beta, conv=conv.astype(bool), p=pv, stat=st, se=se, flags=[a.astype(bool) for a in fl])
+    if want_layers:
+        out["mu"], out["H"] = mu.T, H.T
+    if ck is not None:
+        out["cooks"] = ck.T
+    return out

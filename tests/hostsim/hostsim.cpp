@@ -112,6 +112,71 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
     return 0;
 }
 
+// dispersion fit through the cell path (designs with few distinct rows)
+int hs_alpha_mle_cell(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N, int G, int P_,
+                      const double* alpha_hat, double min_disp, double max_disp, double prior_var, int cr_reg,
+                      int prior_reg, const int32_t* cell_of, const double* Xc, const double* XX, int C,
+                      double* alpha, uint8_t* conv) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    Lbfgsb1d mach;
+    CellDesign D{cell_of, Xc, XX, C};
+    DSQ_DISPATCH_P(P_, {
+        static CellWork<P> Wk;
+        for (int g = 0; g < G; ++g) {
+            AlphaOut o = fit_alpha_gene<HostWave, P, false, false, true>(
+                y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var,
+                cr_reg != 0, prior_reg != 0, mach, nullptr, nullptr, 1, &D, (void*)&Wk);
+            alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
+        }
+    })
+    return 0;
+}
+
+// LFC fit with the fused epilogue (Cook's bookkeeping + Wald), general (C == 0) or cell path
+int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt, int ldx, int N,
+               int G, int P_, const double* disp, double min_mu, double beta_tol, int full_rank,
+               const int32_t* cell_of, const double* Xc, const double* XX, int C,
+               const double* robust_disp, const uint8_t* flags, double cutoff, double* cooks,
+               uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above,
+               const double* ridge, const double* contrast, double lfc_null, int alt,
+               double* beta, double* mu, double* H, uint8_t* conv, double* pv, double* st, double* se) {
+    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    CellDesign D{cell_of, Xc, XX, C};
+    DSQ_DISPATCH_P(P_, {
+        static CellWork<P> Wk;
+        for (int g = 0; g < G; ++g) {
+            IrlsArgs A;
+            A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+            A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = -30.0; A.max_beta = 30.0;
+            A.maxiter = 250; A.full_rank = full_rank != 0;
+            if (C > 0) { A.cells = &D; A.cell_ws = (void*)&Wk; }
+            LfcEpilogue E;
+            if (flags != nullptr) {
+                E.flags = flags; E.robust_disp = robust_disp[g]; E.cutoff = cutoff;
+                E.cooks_row = cooks ? cooks + (size_t)g * ldn : nullptr;
+            }
+            if (ridge != nullptr) { E.ridge = ridge; E.contrast = contrast; E.lfc_null = lfc_null; E.alt = alt; }
+            double b[P];
+            double* mo = mu ? mu + (size_t)g * ldn : nullptr;
+            double* ho = H ? H + (size_t)g * ldn : nullptr;
+            IrlsOut o = (C > 0) ? irls_gene<HostWave, P, true>(A, b, mo, ho, &E) : irls_gene<HostWave, P, false>(A, b, mo, ho, &E);
+            if (o.fallback) {
+                static IrlsRescueWork<P> Rk;
+                std::memset(&Rk, 0, sizeof(Rk));
+                o = irls_rescue_gene<HostWave, P>(A, Rk, b, mo, ho, &E);
+            }
+            for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
+            conv[g] = (uint8_t)o.converged;
+            if (flags != nullptr) {
+                any_all[g] = E.cooks.any_gt_all; any_use[g] = E.cooks.any_gt_use; any_use_nr[g] = E.cooks.any_gt_use_nr;
+                few_above[g] = E.cooks.few_above;
+            }
+            if (ridge != nullptr) { pv[g] = E.wald.p; st[g] = E.wald.stat; se[g] = E.wald.se; }
+        }
+    })
+    return 0;
+}
+
 int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx, int N, int G, int P_,
               const double* size, double sigma0, double sigma, int shrink_index, double* beta /*[G][P]*/,
               double* invh /*[G][P][P]*/, uint8_t* conv) {

@@ -200,3 +200,48 @@ def test_vst_train_test_split():
     np.testing.assert_allclose(out, ref, rtol=1e-6)
     # the dataset's own samples: same as vst()
     np.testing.assert_allclose(dds.vst_transform(), dds.vst(), rtol=1e-12)
+
+
+def test_vst_new_samples_with_zero_counts():
+    """New samples may hold zeros in genes that were usable in training: log(0) - logmean = -inf takes part in the
+    sample's median (preprocessing.py:59-102); a sample with more than half zeros gets size factor 0 as in numpy."""
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    train = counts[25:75]
+    test = counts[0:25].to_numpy().copy()
+    test[0, :3] = 0          # a few zeros: the median moves down among the finite ratios
+    test[1, :6] = 0          # more than half of the 10 genes: the median is -inf -> size factor 0
+    dds = DeseqDataSet(counts=train, metadata=meta[25:75], design="~condition")
+    dds.vst_fit()
+    out = dds.vst_transform(test)
+    _, info = orc.vst(train.to_numpy(), dds.obsm["design_matrix"].to_numpy())
+    with np.errstate(all="ignore"):
+        ref = orc.vst_transform_new(test, train.to_numpy(), info)
+    ok = np.isfinite(ref)
+    assert (np.isfinite(out) == ok).all()
+    np.testing.assert_allclose(out[ok], ref[ok], rtol=1e-6)
+
+
+def test_more_than_65535_genes():
+    """Genes sit on grid.x of every launch (grid.y is limited to 65535): a dataset with 70 000 genes, some of them
+    all-zero so that the row gather of the non-zero genes runs, against per-gene results of a 2 000-gene slice."""
+    import pydeseq2_amd
+    from oracle import nbglm_oracle as orc
+
+    counts, X = orc.synth_counts(70000, 24, "2level", 9)
+    counts[:, ::1000] = 0
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    assert (~res.non_zero).sum() >= 70 and np.isnan(res.dispersions[::1000]).all()
+    nz = res.non_zero
+    assert np.isfinite(res.dispersions[nz]).all() and np.isfinite(res.LFC[nz]).all()
+    # the genewise fits depend on the gene and the size factors only: compare the last 2000 genes with the oracle
+    sl = slice(68000, 70000)
+    sub = counts[:, sl]
+    keep = ~(sub == 0).all(0)
+    mu = orc.lin_reg_mu(sub[:, keep], res.size_factors, X, 0.5)
+    a, cv = orc.alpha_mle(sub[:, keep], X, mu, res.mom_dispersions[sl][keep], 1e-8, 24.0, n_jobs=8)
+    same = cv & (res.genewise_converged[sl][keep] == 1)
+    assert same.mean() > 0.99
+    np.testing.assert_allclose(res.genewise_dispersions[sl][keep][same], np.clip(a, 1e-8, 24.0)[same], rtol=1e-5)

@@ -155,7 +155,12 @@ def _compare(res, ref, frac_noise=0.002):
     assert (res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()
     assert_close(res.dispersions[ok], ref.dispersions[ok], RTOL, 0, "dispersions")
     assert_close(res.LFC[ok], ref.LFC[ok], RTOL, 1e-8, "LFC")
-    assert_close(res.pvalue[ok], ref.pvalue[ok], 2e-5, 1e-300, "pvalue")
+    # p = 2 sf(|z|): a relative error eps of the statistic is a relative error ~ eps * z^2 of the p-value in the tail
+    assert_close(res.stat[ok], ref.stat[ok], RTOL, 1e-8, "stat")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        perr = np.abs(res.pvalue[ok] - ref.pvalue[ok]) / np.maximum(ref.pvalue[ok], 1e-300)
+        perr = np.nan_to_num(perr / np.maximum(1.0, ref.stat[ok] ** 2))
+    assert (np.isnan(res.pvalue[ok]) == np.isnan(ref.pvalue[ok])).all() and perr.max() <= RTOL, perr.max()
     assert_close(res.lfcSE[ok], ref.lfcSE[ok], RTOL, 0, "lfcSE")
     # the trend is fitted on all genes, so it carries the noise genes' influence
     assert_close(res.trend_coeffs, ref.trend_coeffs, 1e-4, 0, "trend coeffs")

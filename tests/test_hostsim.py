@@ -286,3 +286,58 @@ def test_apeglm_shrinkage_templates_match_reference(case):
         np.testing.assert_allclose(b, k[f"{case}{tag}_beta"], rtol=1e-6, atol=1e-9)
         scale = np.abs(k[f"{case}{tag}_invh"]).max(axis=(1, 2), keepdims=True)
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["p8", "p4cat"])
+def test_cell_path_matches_the_general_path_and_the_reference(case):
+    """Designs with few distinct rows: per-cell weight sums + entry-parallel X^T W X (dsq_linalg.h, CellDesign)
+    against the per-sample accumulation and against the reference KATs (p8: 30 cells)."""
+    if case == "p8":
+        k = load_kat("p8")
+        counts, X, sf = k["counts"], k["X"], k["sf"]
+        mu_hat, mom, fitted = k["mu_hat"], k["mom"], k["fitted"]
+    else:  # 2 x 3 factorial with an interaction-free design: p = 4, 6 cells
+        rng = np.random.default_rng(8)
+        N = 90
+        a, b = np.arange(N) % 2, (np.arange(N) // 2) % 3
+        X = np.column_stack([np.ones(N), a == 1, b == 1, b == 2]).astype(float)
+        counts, _ = orc.synth_counts(80, N, "2level", 8)
+        sf = orc.size_factors_ratio(counts)[0]
+        mom = orc.mom_dispersions(counts / sf[:, None], X, sf, 1e-8, float(N))
+        _, mu_hat, _, _ = orc.irls(counts, sf, X, mom, 0.5, 1e-8)
+        fitted = mom * 1.1
+    N, P = X.shape
+    maxd = float(max(10, N))
+    for kw in (dict(), dict(prior_var=0.7, prior_reg=True)):
+        start = mom if not kw else fitted
+        ac, cc = hs.alpha_mle_cell(counts, X, mu_hat, start, 1e-8, maxd, **kw)
+        ag, cg, _ = hs.alpha_mle(counts, X, mu_hat, start, 1e-8, maxd, **kw)
+        assert (cc == cg).all()
+        assert_close(ac, ag, 1e-7, 0, "cell vs general dispersion")
+    if case == "p8":
+        assert_close(ac, k["map_alpha"], 1e-6, 0, "cell MAP alpha vs reference")
+    disp = np.clip(ag, 1e-8, maxd)
+    cutoff = f_dist.ppf(0.99, P, N - P)
+    contrast = np.zeros(P)
+    contrast[1] = 1.0
+    rd = orc.robust_mom_disp(counts / sf[:, None], X)
+    g = hs.lfc_fit(counts, sf, X, disp, cells=False, robust_disp=rd, cutoff=cutoff, contrast=contrast)
+    c = hs.lfc_fit(counts, sf, X, disp, cells=True, robust_disp=rd, cutoff=cutoff, contrast=contrast)
+    assert (g["conv"] == c["conv"]).all()
+    for key, tol in (("beta", 1e-9), ("mu", 1e-9), ("H", 1e-9), ("cooks", 1e-8), ("se", 1e-10), ("stat", 1e-8), ("p", 1e-7)):
+        assert_close(c[key], g[key], tol, 1e-12 if key != "p" else 1e-300, f"cell vs general {key}")
+    for fc, fg in zip(c["flags"], g["flags"]):
+        assert (fc == fg).all()
+    # the fused epilogue = the separate stages: Cook's from the (mu, H) layers, Wald from beta
+    ck, rd2, fl = hs.cooks(counts, sf, X, g["mu"], g["H"], cutoff)
+    assert_close(g["cooks"], ck, 1e-13, 1e-300, "fused cooks")
+    assert_close(rd2, rd, 1e-11, 0, "robust disp")
+    for fa, fb in zip(g["flags"], fl):
+        assert (fa == fb).all()
+    pw, sw, sew = hs.wald(X, disp, g["beta"], sf, np.diag(np.repeat(1e-6, P)), contrast, 0.0, None)
+    assert_close(g["se"], sew, 1e-13, 0, "fused wald se")
+    assert_close(g["p"], pw, 1e-11, 1e-300, "fused wald p")
+    if case == "p8":
+        assert_close(c["beta"], k["lfc_beta"], 1e-8, 1e-10, "cell beta vs reference")
+        assert_close(c["H"], k["lfc_H"], 1e-8, 1e-12, "cell H vs reference")
+        assert_close(c["se"], k["wald_se_none"], 1e-9, 0, "cell wald se vs reference")

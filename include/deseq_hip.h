@@ -20,7 +20,7 @@
  *     pitch `ldn` (elements), a multiple of 16.
  *   - counts are non-negative integers < 2^31 (int32 or int64 storage); everything else
  *     is IEEE double.  Natural-log fold changes, dispersion alpha with var = mu + alpha mu^2.
- *   - N = samples, G = genes, P = design columns (1..DSQ_MAX_P).
+ *   - N = samples, G = genes, P = design columns (1..DSQ_MAX_P = 32).
  *   - statistical non-convergence is NOT an error: it is reported in the `converged`
  *     arrays exactly like the reference does.
  */
@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define DSQ_MAX_P 12
+#define DSQ_MAX_P 32        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path */
+#define DSQ_SHRINK_MAX_P 12 /* apeGLM shrinkage (dsq_*_lfc_shrink*) */
 
 typedef struct dsq_ctx dsq_ctx;
 

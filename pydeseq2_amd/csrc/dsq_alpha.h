@@ -308,7 +308,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
             // entry-parallel: lane e owns entry e of X^T W X (and of X^T dW X) and walks the cells
             Wv::sync();
             const CellDesign& D = *A.cells;
-            const auto XXg = DSQ_AS_GLOBAL(double, D.XX);
+            const double* XXg = D.XX;  // the kernel stages the cells' tables in LDS (flat pointer)
             for (int e = Wv::lane(); e < T; e += Wv::W) {
                 double me = 0.0, de = 0.0;
                 for (int c = 0; c < D.C; ++c) {

@@ -695,7 +695,8 @@ int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                        uint8_t* d_converged) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
+    //DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
                                prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged));
@@ -1081,7 +1082,8 @@ int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_ty
                                   const double* design, const double* size, const double* offset, int N, int G,
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
                                   double* beta_out, double* inv_hessian_out, uint8_t* converged) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
+    //DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);

@@ -3,7 +3,7 @@
 // template parameter; the runtime value is dispatched here.
 #pragma once
 
-#define DSQ_MAX_P 12
+#define DSQ_REG_MAX_P 12  // widest design of the register / cell kernels; wider ones: dsq_wide.h
 
 #define DSQ_P_CASE(N_, ...) \
     case N_: {              \

@@ -53,6 +53,19 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     extern __shared__ __attribute__((aligned(16))) double stage[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
+    if (CELL) {
+        // the cells' tables (outer products and rows, <= 64 x (T + P) doubles) are read by every entry-parallel
+        // rebuild of X^T W X: once per workgroup into LDS, behind the rows' staging area
+        constexpr int T = Tri<P>::N;
+        const int npad = (N + 63) & ~63;
+        double* sXX = stage + (size_t)kWavesPerBlock * (npad + npad / 2);
+        double* sXc = sXX + ex.cells.C * T;
+        for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
+        for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
+        __syncthreads();
+        ex.cells.XX = sXX;
+        ex.cells.Xc = sXc;
+    }
     if (g >= G) return;
 #if defined(DSQ_PHASE_TIMING)
     if ((threadIdx.x & 63) == 0) {
@@ -201,6 +214,14 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
     AlphaExtras ex{};
     if (extras != nullptr) ex = *extras;
+    // designs beyond the register path's width - or, on request, any design without cell structure from
+    // DSQ_WIDE_MIN_P columns on - run the LDS / matrix-core kernels (dsq_k_wide.hip)
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0)) {
+        if (mu == nullptr) return hipErrorInvalidValue;  // that path reads a materialised mu_hat
+        return launch_wide_alpha(st, y, mu, ldn, Xt, ldx, N, G, P_, alpha_hat, min_disp, max_disp, prior_var, cr_reg,
+                                 prior_reg, alpha, conv, nfev, nll_const, const_mode,
+                                 ex.cells.C > 0 ? &ex.cells : nullptr);
+    }
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     const int npad = (N + 63) & ~63;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
@@ -218,8 +239,9 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                            nll_const, const_mode, ex);                                                           \
     } while (0)
     if (cell) {
+        const size_t smem_c = smem + (size_t)ex.cells.C * (P_ * (P_ + 1) / 2 + P_) * sizeof(double);
         DSQ_DISPATCH_P(P_, {
-            if constexpr (P >= 3) DSQ_ALPHA_LAUNCH((k_alpha<P, true, true>), smem);
+            if constexpr (P >= 3) DSQ_ALPHA_LAUNCH((k_alpha<P, true, true>), smem_c);
         })
     } else if (stage) {
         DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, true, false>), smem))
@@ -235,6 +257,8 @@ hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu,
                              int ldx, int N, int P_, double min_disp, double max_disp, double* alpha,
                              const int32_t* grid_list, int n_grid, double* work) {
     if (n_grid <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P)
+        return launch_wide_alpha_grid(st, y, mu, ldn, Xt, ldx, N, P_, min_disp, max_disp, alpha, grid_list, n_grid);
     double* lohi = work;
     double* ll = work + 2 * (size_t)n_grid;
     const dim3 ge(genes_to_blocks(n_grid * kGridLen)), block(kBlock), gp((n_grid + 63) / 64), bp(64);

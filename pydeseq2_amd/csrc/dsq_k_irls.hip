@@ -48,7 +48,18 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P
                                                  int32_t* __restrict__ fb_count,
                                                  int32_t* __restrict__ fb_list, IrlsExtras ex) {
     __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
+    extern __shared__ __attribute__((aligned(16))) double cell_tables[];
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (CELL) {  // the cells' tables once per workgroup into LDS (read by every entry-parallel rebuild)
+        constexpr int T = Tri<P>::N;
+        double* sXX = cell_tables;
+        double* sXc = sXX + ex.cells.C * T;
+        for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
+        for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
+        __syncthreads();
+        ex.cells.XX = sXX;
+        ex.cells.Xc = sXc;
+    }
     if (g >= G) return;
     IrlsArgs A;
     A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
@@ -167,6 +178,8 @@ hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const d
                               int N, int G, int P_, const double* disp, const double* beta, double min_mu, double* mu,
                               double* hat) {
     if (G <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P)
+        return launch_wide_irls_layers(st, y, ldn, sf, Xt, ldx, N, G, P_, disp, beta, min_mu, mu, hat);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_layers<P>, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, ldn, sf,
                                           Xt, ldx, N, G, disp, beta, min_mu, mu, hat))
     return hipGetLastError();
@@ -182,11 +195,16 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     if (G <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0))
+        return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,
+                                min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, &ex);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     if (ex.cells.C > 0 && P_ >= 3) {
         DSQ_DISPATCH_P(P_, {
             if constexpr (P >= 3)
-                hipLaunchKernelGGL((k_irls<P, true>), grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G,
+                hipLaunchKernelGGL((k_irls<P, true>), grid, block,
+                                   (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double), st, y, ldn, sf, lsf, Xt,
+                                   pinvXt, ldx, N, G,
                                    full_rank, disp, min_mu, beta_tol, min_beta, max_beta, maxiter, beta, mu, hat,
                                    conv, iters, fb_count, fb_list, ex);
         })
@@ -207,6 +225,9 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
     if (n_fb <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0))
+        return launch_wide_irls_rescue(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, P_, full_rank, disp, min_mu, beta_tol,
+                                       min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, &ex);
     const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
                                           ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,

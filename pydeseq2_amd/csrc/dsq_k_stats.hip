@@ -764,6 +764,9 @@ hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* s
     // sf_moments: the size factors whose mean reciprocal enters the moments estimate when they differ
     // from the ones the counts are normalised with (iterative size factors, dds.py:1149-1156 there)
     hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf_moments ? sf_moments : sf, N, d_scalar);
+    if (P_ > DSQ_REG_MAX_P)
+        return launch_wide_mom(st, y, ldn, sf, Xt, pinvXt, ldx, N, G, P_, min_disp, max_disp, 0.5, normed_mean, rough,
+                               moments, mom, nullptr, nullptr, d_scalar);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
                                           (const double*)d_scalar, min_disp, max_disp, normed_mean, rough,
@@ -797,6 +800,9 @@ hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const do
                              double* coef) {
     if (G <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_mean_inv, dim3(1), dim3(256), 0, st, sf, N, d_scalar);
+    if (P_ > DSQ_REG_MAX_P)
+        return launch_wide_mom(st, y, ldn, sf, Xt, pinvXt, ldx, N, G, P_, min_disp, max_disp, min_mu, normed_mean,
+                               nullptr, nullptr, mom, mu, coef, d_scalar);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
                                           (const double*)d_scalar, min_disp, max_disp, min_mu, normed_mean, mom, mu,
@@ -819,6 +825,10 @@ hipError_t launch_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double
                          const double* pinvXt, int ldx, int N, int G, int P_, double min_mu,
                          double* mu) {
     if (G <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P) {  // s_mean_inv is not used for mu_hat: any finite scalar (sf[0]) serves
+        return launch_wide_mom(st, y, ldn, sf, Xt, pinvXt, ldx, N, G, P_, 1e-8, 1.0, min_mu, nullptr, nullptr, nullptr,
+                               nullptr, mu, nullptr, sf);
+    }
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N,
                                           G, min_mu, mu))
@@ -889,6 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_rough_normed(const double* __restric
 hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
                                     const double* pinvXt, int ldx, int N, int G, int P_, double* out) {
     if (G <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P) return launch_wide_rough_normed(st, normed, ldn, Xt, pinvXt, ldx, N, G, P_, out);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_rough_normed<P>, grid, block, 0, st, normed, ldn, Xt, pinvXt,
                                           ldx, N, G, out))
@@ -952,6 +963,9 @@ hipError_t launch_wald(hipStream_t st, const double* mu, int ldn, const double* 
                        const double* d_ridge, const double* d_contrast, double lfc_null, int alt,
                        double* pvals, double* stats, double* se) {
     if (G <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P)
+        return launch_wide_wald(st, mu, ldn, sf, Xt, ldx, N, G, P_, disp, beta, d_ridge, d_contrast, lfc_null, alt,
+                                pvals, stats, se);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_wald<P>, grid, block, 0, st, mu, ldn, sf, Xt, ldx, N, G, disp,
                                           beta, d_ridge, d_contrast, lfc_null, alt, pvals, stats, se))

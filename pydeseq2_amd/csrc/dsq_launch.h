@@ -22,6 +22,40 @@ inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerB
 #endif
 constexpr int cell_min_waves(int p) { return p <= 6 ? 3 : DSQ_CELL_WAVES_WIDE; }
 
+// ---- dsq_k_wide.hip: run-time-P kernels (LDS matrices, matrix-core Gram accumulation), P <= 32
+int wide_min_p();  // designs at least this wide take them (default: DSQ_REG_MAX_P + 1)
+struct IrlsExtras;
+hipError_t launch_wide_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                           const double* pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,
+                           double min_mu, double* normed_mean, double* rough, double* moments, double* mom,
+                           double* mu, double* coef, const double* d_s_mean_inv);
+hipError_t launch_wide_rough_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
+                                    const double* pinvXt, int ldx, int N, int G, int P, double* out);
+hipError_t launch_wide_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
+                             int N, int G, int P, const double* alpha_hat, double min_disp, double max_disp,
+                             double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
+                             int32_t* nfev, double* nll_const, int const_mode, const CellDesign* cells);
+hipError_t launch_wide_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
+                                  int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
+                                  const int32_t* list, int n_list);
+hipError_t launch_wide_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
+                            const double* Xt, const double* pinvXt, int ldx, int N, int G, int P, int full_rank,
+                            const double* disp, double min_mu, double beta_tol, double min_beta, double max_beta,
+                            int maxiter, double* beta, double* mu, double* hat, uint8_t* conv, int32_t* iters,
+                            int32_t* fb_count, int32_t* fb_list, const IrlsExtras* extras);
+hipError_t launch_wide_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
+                                   const double* Xt, const double* pinvXt, int ldx, int N, int P, int full_rank,
+                                   const double* disp, double min_mu, double beta_tol, double min_beta,
+                                   double max_beta, int maxiter, double* beta, double* mu, double* hat, uint8_t* conv,
+                                   int32_t* iters, const int32_t* fb_list, int n_fb, const IrlsExtras* extras);
+hipError_t launch_wide_irls_layers(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
+                                   int ldx, int N, int G, int P, const double* disp, const double* beta, double min_mu,
+                                   double* mu, double* hat);
+hipError_t launch_wide_wald(hipStream_t st, const double* mu, int ldn, const double* sf, const double* Xt, int ldx,
+                            int N, int G, int P, const double* disp, const double* beta, const double* d_ridge,
+                            const double* d_contrast, double lfc_null, int alt, double* pvals, double* stats,
+                            double* se);
+
 // ---- dsq_k_alpha.hip
 // optional inputs of the dispersion kernel (zero-initialised = none)
 struct AlphaExtras {

@@ -360,7 +360,9 @@ class DeseqPipeline:
         mh.d_mu, mh.d_coef = None, None
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
-            if 48 * ((self.N + 63) & ~63) > 80 * 1024:  # rows too long for the LDS staging (launch_alpha): materialise
+            # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
+            # (the LDS / matrix-core path of dsq_k_wide.hip reads mu_hat): materialise it
+            if 48 * ((self.N + 63) & ~63) > 80 * 1024 or self.P > 12:
                 mh.d_mu = self._dmat(Gs)
             self._k("mom_lin_mu", Gs, "dsq_dev_mom_lin_coef", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr),
                     _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp),

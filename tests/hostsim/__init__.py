@@ -326,7 +326,8 @@ def cell_design(X):
             np.ascontiguousarray(Xc[:, ii] * Xc[:, jj]), len(rows))
 
 
-def alpha_mle_cell(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False):
+def alpha_mle_cell(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False,
+                   entry="hs_alpha_mle_cell", cells=True):
     y = gene_major(counts)
     G, N = y.shape
     m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
@@ -334,18 +335,38 @@ def alpha_mle_cell(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None,
     cof, Xc, XX, Cn = cell_design(X)
     ah = np.ascontiguousarray(alpha_hat, dtype=np.float64)
     out, conv = np.empty(G), np.empty(G, np.uint8)
-    rc = lib().hs_alpha_mle_cell(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
-                                 C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), _p(ah, C.c_double),
-                                 C.c_double(min_disp), C.c_double(max_disp),
-                                 C.c_double(prior_var if prior_var is not None else 1.0), C.c_int(cr_reg),
-                                 C.c_int(prior_reg), _p(cof, C.c_int32), _p(Xc, C.c_double), _p(XX, C.c_double),
-                                 C.c_int(Cn), _p(out, C.c_double), _p(conv, C.c_uint8))
+    rc = getattr(lib(), entry)(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
+                               C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), _p(ah, C.c_double),
+                               C.c_double(min_disp), C.c_double(max_disp),
+                               C.c_double(prior_var if prior_var is not None else 1.0), C.c_int(cr_reg),
+                               C.c_int(prior_reg), _p(cof, C.c_int32), _p(Xc, C.c_double), _p(XX, C.c_double),
+                               C.c_int(Cn if cells else 0), _p(out, C.c_double), _p(conv, C.c_uint8))
     assert rc == 0
     return out, conv.astype(bool)
 
 
+def alpha_mle_wide(counts, X, mu, alpha_hat, min_disp, max_disp, cells=False, **kw):
+    """Run-time-P path (dsq_wide.h): Gram matrices by the (host stand-in of the) matrix-core accumulation."""
+    return alpha_mle_cell(counts, X, mu, alpha_hat, min_disp, max_disp, entry="hs_alpha_mle_wide", cells=cells, **kw)
+
+
+def mom_wide(counts, sf, X, min_disp, max_disp, min_mu=0.5):
+    y = gene_major(counts)
+    G, N = y.shape
+    Xt, pinv, _ = design_pack(X)
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    out = [np.empty(G) for _ in range(4)]
+    mu = np.empty((G, N))
+    rc = lib().hs_mom_wide(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
+                           C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), C.c_double(min_disp),
+                           C.c_double(max_disp), C.c_double(min_mu), *[_p(a, C.c_double) for a in out],
+                           _p(mu, C.c_double))
+    assert rc == 0
+    return dict(normed_mean=out[0], rough=out[1], moments=out[2], mom=out[3], lin_mu=mu.T)
+
+
 def lfc_fit(counts, sf, X, disp, cells=False, robust_disp=None, cutoff=0.0, contrast=None, lfc_null=0.0, alt=0,
-            min_replicates=7, want_layers=True):
+            min_replicates=7, want_layers=True, entry="hs_lfc_fit"):
     """IRLS + fused epilogue (Cook's bookkeeping if robust_disp is given, Wald if contrast is given)."""
     y = gene_major(counts)
     G, N = y.shape
@@ -366,7 +387,7 @@ def lfc_fit(counts, sf, X, disp, cells=False, robust_disp=None, cutoff=0.0, cont
     rd = np.ascontiguousarray(robust_disp, dtype=np.float64) if robust_disp is not None else None
     ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P))) if contrast is not None else None
     cvec = np.ascontiguousarray(contrast, dtype=np.float64) if contrast is not None else None
-    rc = lib().hs_lfc_fit(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
+    rc = getattr(lib(), entry)(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double), _p(pinv, C.c_double),
                           C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(P), _p(d, C.c_double), C.c_double(0.5),
                           C.c_double(1e-8), C.c_int(fr), _p(cof, C.c_int32), _p(Xc, C.c_double), _p(XX, C.c_double),
                           C.c_int(Cn), _p(rd, C.c_double) if rd is not None else None,

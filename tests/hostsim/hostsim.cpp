@@ -19,6 +19,7 @@
 #include "dsq_stats.h"
 #include "dsq_shrink.h"
 #include "dsq_trend.h"
+#include "dsq_wide.h"
 
 using namespace dsq;
 
@@ -59,7 +60,7 @@ int hs_alpha_mle(const int32_t* y, const double* mu, int ldn, const double* Xt, 
                  int G, int P_, const double* alpha_hat, double min_disp, double max_disp,
                  double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
                  int32_t* nfev) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     Lbfgsb1d mach;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         AlphaOut o = fit_alpha_gene<HostWave, P, true>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx,
@@ -73,7 +74,7 @@ int hs_alpha_mle(const int32_t* y, const double* mu, int ldn, const double* Xt, 
 
 int hs_grid_alpha(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N,
                   int G, int P_, double min_disp, double max_disp, double* log_alpha) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         AlphaArgs A;
         A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
@@ -89,7 +90,7 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
             double min_beta, double max_beta, int maxiter, int full_rank, double* beta /*[G][P]*/,
             double* mu /*[G][ldn]*/, double* H /*[G][ldn]*/, uint8_t* conv, int32_t* iters,
             uint8_t* fallback) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         IrlsArgs A;
         A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
@@ -117,7 +118,7 @@ int hs_alpha_mle_cell(const int32_t* y, const double* mu, int ldn, const double*
                       const double* alpha_hat, double min_disp, double max_disp, double prior_var, int cr_reg,
                       int prior_reg, const int32_t* cell_of, const double* Xc, const double* XX, int C,
                       double* alpha, uint8_t* conv) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     Lbfgsb1d mach;
     CellDesign D{cell_of, Xc, XX, C};
     DSQ_DISPATCH_P(P_, {
@@ -140,7 +141,7 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
                uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above,
                const double* ridge, const double* contrast, double lfc_null, int alt,
                double* beta, double* mu, double* H, uint8_t* conv, double* pv, double* st, double* se) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     CellDesign D{cell_of, Xc, XX, C};
     DSQ_DISPATCH_P(P_, {
         static CellWork<P> Wk;
@@ -177,10 +178,92 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
     return 0;
 }
 
+// ---- run-time-P ("wide") path: any number of design columns up to kWideMaxP
+int hs_alpha_mle_wide(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N, int G, int P_,
+                      const double* alpha_hat, double min_disp, double max_disp, double prior_var, int cr_reg,
+                      int prior_reg, const int32_t* cell_of, const double* Xc, const double* XX, int C,
+                      double* alpha, uint8_t* conv) {
+    if (P_ < 1 || P_ > kWideMaxP) return -1;
+    std::vector<double> buf((size_t)wide_work_doubles(P_));
+    WideWork W;
+    W.bind(buf.data(), P_);
+    Lbfgsb1d mach;
+    CellDesign D{cell_of, Xc, XX, C};
+    for (int g = 0; g < G; ++g) {
+        AlphaOut o = fit_alpha_wide<HostWave>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx, N, W,
+                                              C > 0 ? &D : nullptr, alpha_hat[g], min_disp, max_disp, prior_var,
+                                              cr_reg != 0, prior_reg != 0, mach, nullptr, nullptr);
+        alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
+    }
+    return 0;
+}
+
+int hs_lfc_fit_wide(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt, int ldx, int N,
+                    int G, int P_, const double* disp, double min_mu, double beta_tol, int full_rank,
+                    const int32_t* cell_of, const double* Xc, const double* XX, int C,
+                    const double* robust_disp, const uint8_t* flags, double cutoff, double* cooks,
+                    uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above,
+                    const double* ridge, const double* contrast, double lfc_null, int alt,
+                    double* beta, double* mu, double* H, uint8_t* conv, double* pv, double* st, double* se) {
+    if (P_ < 1 || P_ > kWideMaxP) return -1;
+    std::vector<double> buf((size_t)wide_work_doubles(P_)), xlu(3 * kWideMaxP);
+    std::vector<int> nbd(kWideMaxP);
+    static LbfgsbWork<kWideMaxP> Lb;
+    WideWork W;
+    W.bind(buf.data(), P_);
+    CellDesign D{cell_of, Xc, XX, C};
+    for (int g = 0; g < G; ++g) {
+        IrlsArgs A;
+        A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+        A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = -30.0; A.max_beta = 30.0;
+        A.maxiter = 250; A.full_rank = full_rank != 0;
+        if (C > 0) A.cells = &D;
+        LfcEpilogue E;
+        if (flags != nullptr) {
+            E.flags = flags; E.robust_disp = robust_disp[g]; E.cutoff = cutoff;
+            E.cooks_row = cooks ? cooks + (size_t)g * ldn : nullptr;
+        }
+        if (ridge != nullptr) { E.ridge = ridge; E.contrast = contrast; E.lfc_null = lfc_null; E.alt = alt; }
+        double* mo = mu ? mu + (size_t)g * ldn : nullptr;
+        double* ho = H ? H + (size_t)g * ldn : nullptr;
+        IrlsOut o = irls_gene_wide<HostWave>(A, W, mo, ho, &E);
+        if (o.fallback) {
+            std::memset(&Lb, 0, sizeof(Lb));
+            o = irls_rescue_wide<HostWave>(A, W, Lb, xlu.data(), nbd.data(), mo, ho, &E);
+        }
+        for (int j = 0; j < P_; ++j) beta[(size_t)g * P_ + j] = W.v(0)[j];
+        conv[g] = (uint8_t)o.converged;
+        if (flags != nullptr) {
+            any_all[g] = E.cooks.any_gt_all; any_use[g] = E.cooks.any_gt_use; any_use_nr[g] = E.cooks.any_gt_use_nr;
+            few_above[g] = E.cooks.few_above;
+        }
+        if (ridge != nullptr) { pv[g] = E.wald.p; st[g] = E.wald.stat; se[g] = E.wald.se; }
+    }
+    return 0;
+}
+
+int hs_mom_wide(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt, int ldx, int N,
+                int G, int P_, double min_disp, double max_disp, double min_mu, double* normed_mean, double* rough,
+                double* moments, double* mom, double* mu) {
+    if (P_ < 1 || P_ > kWideMaxP) return -1;
+    std::vector<double> buf((size_t)wide_work_doubles(P_));
+    WideWork W;
+    W.bind(buf.data(), P_);
+    double smi = 0.0;
+    for (int n = 0; n < N; ++n) smi += 1.0 / sf[n];
+    smi /= N;
+    for (int g = 0; g < G; ++g) {
+        MomOut o = mom_wide<HostWave>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, W, smi, min_disp, max_disp, min_mu,
+                                      mu ? mu + (size_t)g * ldn : nullptr);
+        normed_mean[g] = o.normed_mean; rough[g] = o.rough; moments[g] = o.moments; mom[g] = o.mom;
+    }
+    return 0;
+}
+
 int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx, int N, int G, int P_,
               const double* size, double sigma0, double sigma, int shrink_index, double* beta /*[G][P]*/,
               double* invh /*[G][P][P]*/, uint8_t* conv) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         ShrinkArgs A;
         A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
@@ -206,7 +289,7 @@ int hs_logmeans(const int32_t* y, int ldn, int N, int G, double* logmeans, uint8
 int hs_mom(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
            int ldx, int N, int G, int P_, double min_disp, double max_disp, double* normed_mean,
            double* rough, double* moments, double* mom) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     double smi = 0;
     for (int n = 0; n < N; ++n) smi += 1.0 / sf[n];
     smi /= N;
@@ -220,7 +303,7 @@ int hs_mom(const int32_t* y, int ldn, const double* sf, const double* Xt, const 
 
 int hs_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
               int ldx, int N, int G, int P_, double min_mu, double* mu) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g)
         lin_mu_gene<HostWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, min_mu,
                                  mu + (size_t)g * ldn);)
@@ -230,7 +313,7 @@ int hs_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, con
 int hs_mom_lin_mu(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt, int ldx,
                   int N, int G, int P_, double min_disp, double max_disp, double min_mu, double* normed_mean,
                   double* mom, double* mu) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     double smi = 0;
     for (int n = 0; n < N; ++n) smi += 1.0 / sf[n];
     smi /= N;
@@ -246,7 +329,7 @@ int hs_wald(const double* mu, int ldn, const double* sf, const double* Xt, int l
             int P_, const double* disp, const double* beta, const double* ridge,
             const double* contrast, double lfc_null, int alt, double* pval, double* stat,
             double* se) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         double b[P];
         for (int j = 0; j < P; ++j) b[j] = beta[(size_t)g * P + j];
@@ -294,7 +377,7 @@ int hs_trimmed_base_mean(const int32_t* y, int ldn, const double* sf, int N, int
 int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx, int N, int P_,
                   double la, double la_hat, double prior_var, int cr_reg, int prior_reg, double* f,
                   double* g) {
-    if (P_ < 1 || P_ > DSQ_MAX_P) return -1;
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
     DSQ_DISPATCH_P(P_, {
         AlphaArgs A;
         A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N; A.la_hat = la_hat;

@@ -239,7 +239,7 @@ def test_more_than_65535_genes():
     # the genewise fits depend on the gene and the size factors only: compare the last 2000 genes with the oracle
     sl = slice(68000, 70000)
     sub = counts[:, sl]
-    keep = ~(sub == 0).all(0)
+    keep = ~(sub == 0).all(0) & ~res.replaced[sl]  # refitted genes carry the dispersions of the replaced counts
     mu = orc.lin_reg_mu(sub[:, keep], res.size_factors, X, 0.5)
     a, cv = orc.alpha_mle(sub[:, keep], X, mu, res.mom_dispersions[sl][keep], 1e-8, 24.0, n_jobs=8)
     same = cv & (res.genewise_converged[sl][keep] == 1)

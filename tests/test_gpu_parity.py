@@ -216,8 +216,75 @@ def test_pipeline_vs_oracle_at_benchmark_shapes(cfg, G, N, design, seed):
     counts, X = orc.synth_counts(G, N, design, seed)
     res = pydeseq2_amd.deseq2(counts, X, device=0)
     ref = orc.deseq2(counts, X, n_jobs=_jobs(), keep_layers=False)
-    n_noise, n_grid = _compare(res, ref)
+    # At N >= 500 about 0.1 % of the fits per launch end with |gradient| between 1e-5 and 1e-3 at a point where
+    # the expected decrease of the next step (g^2 / 2h ~ 1e-11) is below the fp64 resolution of the loss itself
+    # (ulp(5000) ~ 1e-12): whether scipy's - or this engine's - line search then reports success is decided by
+    # the last bit of the loss, in both implementations, on different genes (DESIGN.md par. 7).  Measured on these
+    # slices: 6-8 genes of 2000 over the genewise fit, the MAP fit and the refit together.
+    n_noise, n_grid = _compare(res, ref, frac_noise=0.005)
     print(f"{cfg}: {n_noise} noise-limited genes, {n_grid} grid-fallback fits compared at 1e-10")
+
+
+def _wide_case(kind, G, N, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "factor16":  # one factor with 16 levels: P = 16 = number of cells (linear-model mu_hat, cell path)
+        lv = np.arange(N) % 16
+        rng.shuffle(lv)
+        X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, 16)])
+    else:  # a 2-level and a 4-level factor + 9 continuous covariates: P = 14, no cell structure
+        a, b = np.arange(N) % 2, (np.arange(N) // 2) % 4
+        X = np.column_stack([np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)] + [rng.normal(0, 0.5, N) for _ in range(9)])
+        X = X.astype(float)
+    P = X.shape[1]
+    beta = np.zeros((P, G))
+    beta[0] = rng.normal(4, 2, G)
+    beta[1:] = rng.normal(0, 0.3, (P - 1, G))
+    disp = 4 / np.maximum(2.0 ** beta[0], 1e-3) + 0.1
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * 2.0 ** (X @ beta)
+    size = 1 / disp
+    counts = rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu)).astype(np.int64)
+    return counts, X
+
+
+@pytest.mark.parametrize("kind,G,N", [("factor16", 600, 160), ("mixed14", 500, 120)])
+def test_pipeline_with_designs_wider_than_12_columns(kind, G, N):
+    """The reference has no limit on the design width (utils.py:345-371): designs beyond the 12 columns of the
+    register kernels run the LDS / matrix-core path (dsq_wide.h), end to end against the oracle."""
+    import pydeseq2_amd
+
+    counts, X = _wide_case(kind, G, N, 31)
+    counts[:, 4] = 0
+    c = np.zeros(X.shape[1])
+    c[1] = 1.0
+    res = pydeseq2_amd.deseq2(counts, X, contrast=c, device=0)
+    ref = orc.deseq2(counts, X, contrast=c, n_jobs=_jobs())
+    _compare(res, ref, frac_noise=0.01)
+
+
+def test_matrix_core_path_equals_register_path_at_p8():
+    """DSQ_WIDE_MIN_P routes narrower designs without cell structure through the LDS / MFMA kernels: same results
+    as the register kernels on the c5-shaped design (two categorical + three continuous covariates, p = 8)."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, pydeseq2_amd; from oracle import nbglm_oracle as orc; "
+            "counts, X = orc.synth_counts(400, 300, 'mixed', 6); r = pydeseq2_amd.deseq2(counts, X, device=0); "
+            "np.savez(sys.argv[1], d=r.dispersions, l=r.LFC, p=r.pvalue, g=r.genewise_converged, m=r.MAP_converged)")
+    import tempfile
+
+    outs = []
+    for env in ({}, {"DSQ_WIDE_MIN_P": "5"}):
+        f = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", "import sys; " + code, f], check=True, env={**os.environ, **env},
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(dict(np.load(f)))
+    a, b = outs
+    same = (a["g"] == b["g"]) & (a["m"] == b["m"])
+    assert same.mean() > 0.99
+    assert_close(b["d"][same], a["d"][same], 1e-6, 0, "dispersions")
+    assert_close(b["l"][same], a["l"][same], 1e-6, 1e-9, "LFC")
 
 
 def test_hip_inference_under_the_reference_orchestration():

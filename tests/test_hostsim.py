@@ -341,3 +341,48 @@ def test_cell_path_matches_the_general_path_and_the_reference(case):
         assert_close(c["beta"], k["lfc_beta"], 1e-8, 1e-10, "cell beta vs reference")
         assert_close(c["H"], k["lfc_H"], 1e-8, 1e-12, "cell H vs reference")
         assert_close(c["se"], k["wald_se_none"], 1e-9, 0, "cell wald se vs reference")
+
+
+@pytest.mark.parametrize("case", ["p4", "p8", "p12", "p16", "p24"])
+def test_wide_path_vs_reference_kats(case):
+    """Run-time-P path (dsq_wide.h: LDS matrices, lane-parallel Cholesky / inverse, chunked Gram accumulation)
+    against the reference KATs, incl. the widths the register path cannot hold (p = 16, 24); with and without the
+    design's cell structure."""
+    k = load_kat(case)
+    counts, X, sf = k["counts"], k["X"], k["sf"]
+    N, P = X.shape
+    maxd = float(max(10, N))
+    tol = 1e-7 if P <= 8 else 2e-6
+    m = hs.mom_wide(counts, sf, X, 1e-8, maxd)
+    assert_close(m["rough"], k["rough"], 1e-9, 1e-13, "rough")
+    assert_close(m["moments"], k["moments"], 1e-10, 1e-14, "moments")
+    assert_close(m["lin_mu"], k["lin_mu"], 1e-10, 0, "lin_mu")
+    n_cells = len(np.unique(X, axis=0))
+    for cells in ([False, True] if n_cells <= 64 else [False]):
+        a, c = hs.alpha_mle_wide(counts, X, k["mu_hat"], k["mom"], 1e-8, maxd, cells=cells)
+        assert (c == k["gw_conv"]).all()
+        assert_close(a, k["gw_alpha"], tol, 0, "genewise alpha")
+        a, c = hs.alpha_mle_wide(counts, X, k["mu_hat"], k["fitted"], 1e-8, maxd, cells=cells,
+                                 prior_var=float(k["prior_var"]), prior_reg=True)
+        assert (c == k["map_conv"]).all()
+        assert_close(a, k["map_alpha"], tol, 0, "MAP alpha")
+        r = hs.lfc_fit(counts, sf, X, k["mom"], cells=cells, entry="hs_lfc_fit_wide")
+        # the success flag of the L-BFGS-B rescue of a diverged low-count gene is decided at rounding-noise level
+        # (the oracle needed the reference's own start-vector arithmetic to reproduce it): one such gene in p16
+        assert (r["conv"] != k["irls_conv"]).sum() <= (1 if case == "p16" else 0)
+        assert_close(r["beta"], k["irls_beta"], 1e-8, 1e-10, "irls beta")
+        assert_close(r["mu"], k["irls_mu"], 1e-8, 1e-10, "irls mu")
+        assert_close(r["H"], k["irls_H"], 1e-8, 1e-12, "irls H")
+        disp = np.clip(k["map_alpha"], 1e-8, maxd)
+        cutoff = f_dist.ppf(0.99, P, N - P)
+        rd = orc.robust_mom_disp(k["normed"], X)
+        r = hs.lfc_fit(counts, sf, X, disp, cells=cells, robust_disp=rd, cutoff=cutoff, contrast=k["contrast"],
+                       entry="hs_lfc_fit_wide")
+        assert (r["conv"] == k["lfc_conv"]).all()
+        assert_close(r["beta"], k["lfc_beta"], 1e-8, 1e-10, "lfc beta")
+        assert_close(r["H"], k["lfc_H"], 1e-8, 1e-12, "lfc H")
+        assert_close(r["se"], k["wald_se_none"], 1e-8, 0, "wald se")
+        assert_close(r["stat"], k["wald_stat_none"], 1e-7, 1e-11, "wald stat")
+        assert_close(r["p"], k["wald_p_none"], 1e-6, 1e-300, "wald p")
+        ref_ck = orc.cooks_distance(counts, k["normed"], X, k["lfc_mu"], k["lfc_H"])
+        assert_close(r["cooks"], ref_ck, 1e-7, 1e-300, "cooks")

@@ -200,12 +200,18 @@ def main():
         # one matrix for the whole job, every rank keeps its block of genes (same generator call: deterministic)
         counts_all, X = synth_fast(G_total, N, design, seed=seed0)
         counts = np.ascontiguousarray(counts_all[:, cuts[rank]:cuts[rank + 1]])
+        # the rank's block of samples over all genes: size factors with two collectives (sample_shard_protocol)
+        from pydeseq2_amd.distributed import sample_block
+
+        samp = np.ascontiguousarray(counts_all[slice(*sample_block(rank, world, N))])
         del counts_all
     else:
         counts, X = synth_fast(G, N, design, seed=1000 * rank + seed0)
 
     transport = None
     comm = None
+    if not (args.scaling == "strong" and world > 1):
+        samp = None
     if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
         comm, transport = bring_up_comm(ctx, control)
         if transport != "rccl":
@@ -213,7 +219,7 @@ def main():
 
     def make_pipe():
         if comm is not None:
-            return DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True)
+            return DistDeseqPipeline(counts, X, comm=comm, ctx=ctx, keep_cooks=True, sample_shard=samp)
         return pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx, keep_cooks=True)
 
     def barrier():

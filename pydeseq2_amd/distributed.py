@@ -41,6 +41,23 @@ def median_select_protocol(ops, allreduce_sum):
     return ops.finish(total)
 
 
+def sample_shard_protocol(ops, allgather):
+    """Size factors with TWO collectives ("scalable variant"): every rank also holds a block of
+    SAMPLES with the genes of all ranks.  (1) all-gather of the per-gene log means (each rank computes them for
+    the genes it owns, all samples) -> every rank has the log means of every gene; (2) the rank takes the medians
+    of its own samples over all genes - locally, with the single-GPU kernel - and an all-gather of those N / world
+    values gives every rank all size factors.  `ops`: local_logmeans() -> padded vector, medians(all_logmeans) ->
+    padded vector of this rank's samples, finish(all_medians) -> size factors [N]; `allgather(x)` concatenates the
+    ranks' equally sized vectors in rank order."""
+    return ops.finish(allgather(ops.medians(allgather(ops.local_logmeans()))))
+
+
+def sample_block(rank, world, N):
+    """[start, stop) of the samples whose medians `rank` computes in the two-collective protocol."""
+    cuts = np.linspace(0, N, world + 1).astype(int)
+    return int(cuts[rank]), int(cuts[rank + 1])
+
+
 def trend_inputs_padded(gw_nz, nm_nz, G):
     """Fixed-size per-rank trend inputs: the Gn non-zero genes, then NaN padding (a NaN mean gives
     a NaN covariate, which the fit drops exactly like the reference drops non-finite covariates,
@@ -322,10 +339,48 @@ class _DeviceSfOps:
         return d_sf
 
 
-class DistDeseqPipeline(DeseqPipeline):
-    """DeseqPipeline over a gene shard; `comm` provides allreduce_sum / allgather on device arrays."""
+class _DeviceSampleShardOps:
+    """Device side of sample_shard_protocol: the rank's sample block [n_r x (world * Gpad)] in the padded global
+    gene order (rank-major; padding columns hold zeros and get a log mean of -inf, which excludes them)."""
 
-    def __init__(self, counts, design_matrix, *, comm, **kw):
+    def __init__(self, pipe, d_lm):
+        self.p, self.d_lm = pipe, d_lm
+
+    def local_logmeans(self):
+        p = self.p
+        d_send = p._pooled((p.Gpad,), np.float64)
+        p.ctx.h2d(d_send.ptr, np.full(p.Gpad, -np.inf)) if p.G < p.Gpad else None
+        p.ctx.call("dsq_d2d", _vp(d_send.ptr), _vp(self.d_lm.ptr), C.c_size_t(8 * p.G))
+        return d_send
+
+    def medians(self, d_lm_all):
+        p = self.p
+        n_r, Gall = p._samp_rows, p.Gpad * p.comm.world
+        d_part = p._pooled((p._samp_pad,), np.float64)
+        p.ctx.memset(d_part.ptr, 0, 8 * p._samp_pad)
+        if n_r:
+            if p._samp_work is None:
+                p._samp_work = DeviceArray(p.ctx, (p.ctx.lib.dsq_size_factors_work_doubles(n_r, Gall),), np.float64)
+            p.ctx.call("dsq_dev_size_factors", _vp(p._d_samp.ptr), 0, n_r, Gall, _vp(d_lm_all.ptr), None,
+                       _vp(p._samp_work.ptr), _vp(d_part.ptr))
+        return d_part
+
+    def finish(self, d_all):
+        p = self.p
+        W = p.comm.world
+        allv = p._down(d_all, W * p._samp_pad).reshape(W, p._samp_pad)
+        sf = np.concatenate([allv[r, : sample_block(r, W, p.N)[1] - sample_block(r, W, p.N)[0]] for r in range(W)])
+        return p._up(sf)
+
+
+class DistDeseqPipeline(DeseqPipeline):
+    """DeseqPipeline over a gene shard; `comm` provides allreduce_sum / allgather on device arrays.
+
+    ``sample_shard``: optionally the counts of this rank's block of samples (``sample_block(rank, world, N)``) for
+    the genes of ALL ranks, [n_r x G_total] in rank order of the gene blocks: the size factors then take two
+    collectives (sample_shard_protocol) instead of the 1 + 8 all-reduces of the distributed radix select."""
+
+    def __init__(self, counts, design_matrix, *, comm, sample_shard=None, **kw):
         super().__init__(counts, design_matrix, **kw)
         if self.size_factors_fit_type == "iterative":
             raise NotImplementedError("the gene-sharded pipeline implements the median-of-ratios size factors "
@@ -336,7 +391,23 @@ class DistDeseqPipeline(DeseqPipeline):
         d_g = self._pooled_once((1,), np.float64, float(self.G))
         d_all = DeviceArray(self.ctx, (comm.world,), np.float64)
         comm.allgather(d_g, d_all)
-        self.Gpad = int(d_all.to_host().max())
+        sizes = d_all.to_host().astype(int)
+        self.Gpad = int(sizes.max())
+        self._d_samp = None
+        if sample_shard is not None and self.size_factors_fit_type == "ratio" and self._control_mask is None:
+            samp = np.asarray(sample_shard)
+            n0, n1 = sample_block(comm.rank, comm.world, self.N)
+            if samp.shape != (n1 - n0, int(sizes.sum())):
+                raise ValueError(f"sample_shard must be {(n1 - n0, int(sizes.sum()))}, got {samp.shape}")
+            padded = np.zeros((n1 - n0, comm.world * self.Gpad), dtype=np.int32)
+            o = 0
+            for r, gsz in enumerate(sizes):
+                padded[:, r * self.Gpad: r * self.Gpad + gsz] = samp[:, o:o + gsz]
+                o += gsz
+            self._d_samp = DeviceArray.from_host(self.ctx, padded)
+            self._samp_rows = n1 - n0
+            self._samp_pad = -(-self.N // comm.world)  # ceil: every rank sends the same number of medians
+            self._samp_work = None
 
     def _pool_reset(self):
         super()._pool_reset()
@@ -350,6 +421,12 @@ class DistDeseqPipeline(DeseqPipeline):
     def _size_factors(self, d_lm):
         # log means and masks are per gene (local; `control_genes` index this rank's genes); the medians over
         # the genes of all ranks come from the shared radix protocol; every rank ends with the same factors
+        if self._d_samp is not None:  # two collectives: log means all-gathered, medians of the rank's own samples
+            def gather(d_send):
+                d_recv = self._pooled((d_send.nbytes // 8 * self.comm.world,), np.float64)
+                return self.comm.allgather(d_send, d_recv)
+
+            return sample_shard_protocol(_DeviceSampleShardOps(self, d_lm), gather)
         d_lm, d_mask = self._sf_inputs(d_lm)
         ops = _DeviceSfOps(self, d_lm, d_mask)
         if self.time_kernels:

@@ -59,7 +59,33 @@ def _worker(rank, world, port, q):
     out = [torch.zeros(2 * G, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(out, torch.from_numpy(np.concatenate([gw, nm])))
     allv = torch.stack(out).numpy().reshape(world, 2, G)
-    q.put((rank, sf, allv))
+    # the two-collective protocol: all-gather of log means, medians of the rank's own samples, all-gather of medians
+    class NumpySampleOps:
+        def local_logmeans(self):
+            return lm
+
+        def medians(self, lm_all):
+            n0, n1 = D.sample_block(rank, world, counts.shape[0])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ratios = np.log(counts[n0:n1].astype(float)) - lm_all[None, :]
+            med = np.median(ratios[:, np.isfinite(lm_all)], axis=1)
+            out = np.zeros(-(-counts.shape[0] // world))
+            out[: n1 - n0] = np.exp(med)
+            return out
+
+        def finish(self, allm):
+            pad = -(-counts.shape[0] // world)
+            allm = allm.reshape(world, pad)
+            return np.concatenate([allm[r, : D.sample_block(r, world, counts.shape[0])[1]
+                                             - D.sample_block(r, world, counts.shape[0])[0]] for r in range(world)])
+
+    def allgather(x):
+        out = [torch.zeros(len(x), dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)))
+        return torch.cat(out).numpy()
+
+    sf2 = D.sample_shard_protocol(NumpySampleOps(), allgather)
+    q.put((rank, sf, allv, sf2))
     dist.destroy_process_group()
 
 
@@ -77,8 +103,9 @@ def test_world2_gloo_protocol_matches_single_process():
         p.join(timeout=60)
     counts, X = orc.synth_counts(400, 20, "2level", 11)
     sf_ref = orc.size_factors_ratio(counts)[0]
-    for rank, sf, allv in res:
+    for rank, sf, allv, sf2 in res:
         np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
+        np.testing.assert_allclose(sf2, sf_ref, rtol=1e-14)  # two-collective protocol
         assert np.isnan(allv[:, :, -3:]).all() and not np.isnan(allv[:, :, :-3]).any()
         assert np.allclose(allv[1, 0, :-3], 0.2)
 

@@ -40,6 +40,11 @@ struct CellWork {
     double ent[2 * (P * (P + 1) / 2)];  // matrix entries on their way from the lane that computed them to all lanes
 };
 
+// The p x p algebra runs redundantly in every lane between the sample loops; at p = 8 and N = 500 it used to cost
+// three times the sample loop itself, almost all of it in IEEE divisions (~30 instructions each on gfx950) and
+// library logarithms (~120).  Reciprocals therefore go through frcp (v_rcp_f64 + two Newton steps, <= 1 ulp), the
+// log-determinant takes ONE log of the product of the pivots, and a pivot's reciprocal is computed once.
+//
 // in-place Cholesky A = L L^T (lower, packed).  Non-SPD input yields NaNs (sqrt of <0).
 template <int P>
 DSQ_HD void chol(double (&a)[Tri<P>::N]) {
@@ -50,7 +55,7 @@ DSQ_HD void chol(double (&a)[Tri<P>::N]) {
         for (int k = 0; k < j; ++k) d -= a[tri(j, k)] * a[tri(j, k)];
         d = sqrt(d);
         a[tri(j, j)] = d;
-        const double r = 1.0 / d;
+        const double r = frcp(d);
 #pragma unroll
         for (int i = j + 1; i < P; ++i) {
             double s = a[tri(i, j)];
@@ -61,8 +66,15 @@ DSQ_HD void chol(double (&a)[Tri<P>::N]) {
     }
 }
 
+// log det(L L^T) = 2 log prod_j L_jj.  The pivots are square roots of weighted sums of squares of design entries
+// (1e-4 .. 1e5 for any realistic fit), so the product of up to 12 of them stays far inside the double range; a
+// non-finite or non-positive product (NaN pivot) falls back to the sum of logs, which propagates the NaN.
 template <int P>
 DSQ_HD double chol_logdet(const double (&l)[Tri<P>::N]) {
+    double prod = 1.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) prod *= l[tri(j, j)];
+    if (prod > 1e-280 && prod < 1e280) return 2.0 * flog(prod);
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < P; ++j) s += log(l[tri(j, j)]);
@@ -72,19 +84,22 @@ DSQ_HD double chol_logdet(const double (&l)[Tri<P>::N]) {
 // solve (L L^T) x = b in place
 template <int P>
 DSQ_HD void chol_solve(const double (&l)[Tri<P>::N], double (&b)[P]) {
+    double rinv[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rinv[i] = frcp(l[tri(i, i)]);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= l[tri(i, k)] * b[k];
-        b[i] = s / l[tri(i, i)];
+        b[i] = s * rinv[i];
     }
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) {
         double s = b[i];
 #pragma unroll
         for (int k = i + 1; k < P; ++k) s -= l[tri(k, i)] * b[k];
-        b[i] = s / l[tri(i, i)];
+        b[i] = s * rinv[i];
     }
 }
 
@@ -94,14 +109,15 @@ DSQ_HD void chol_inverse(const double (&l)[Tri<P>::N], double (&inv)[Tri<P>::N])
     // Linv (lower) first
     double li[Tri<P>::N];
 #pragma unroll
+    for (int j = 0; j < P; ++j) li[tri(j, j)] = frcp(l[tri(j, j)]);
+#pragma unroll
     for (int j = 0; j < P; ++j) {
-        li[tri(j, j)] = 1.0 / l[tri(j, j)];
 #pragma unroll
         for (int i = j + 1; i < P; ++i) {
             double s = 0.0;
 #pragma unroll
             for (int k = j; k < i; ++k) s -= l[tri(i, k)] * li[tri(k, j)];
-            li[tri(i, j)] = s / l[tri(i, i)];
+            li[tri(i, j)] = s * li[tri(i, i)];
         }
     }
     // inv = Linv^T Linv

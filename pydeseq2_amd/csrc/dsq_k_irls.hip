@@ -46,26 +46,51 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P
                                                  double* __restrict__ mu, double* __restrict__ hat,
                                                  uint8_t* __restrict__ conv, int32_t* __restrict__ iters,
                                                  int32_t* __restrict__ fb_count,
-                                                 int32_t* __restrict__ fb_list, IrlsExtras ex) {
+                                                 int32_t* __restrict__ fb_list, IrlsExtras ex, int stage) {
     __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
-    extern __shared__ __attribute__((aligned(16))) double cell_tables[];
-    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) double irls_lds[];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * kWavesPerBlock + w;
+    double* lds_next = irls_lds;
     if (CELL) {  // the cells' tables once per workgroup into LDS (read by every entry-parallel rebuild)
         constexpr int T = Tri<P>::N;
-        double* sXX = cell_tables;
+        double* sXX = lds_next;
         double* sXc = sXX + ex.cells.C * T;
+        lds_next = sXc + ex.cells.C * P;
         for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
         for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
-        __syncthreads();
         ex.cells.XX = sXX;
         ex.cells.Xc = sXc;
     }
+    // The ~5 sweeps of a fit re-read the gene's counts and the per-sample vectors shared by all genes (size factors,
+    // their logs, cell indices); from L2 every such read parks the wave (SQ counters: 35 % - 63 % of the wave cycles
+    // of this kernel were s_waitcnt).  stage: they are copied into LDS once - the shared vectors per workgroup, the
+    // counts per wave - and the sweeps run from there.
+    const int32_t* yrow = y + (size_t)(g < G ? g : G - 1) * ldn;
+    if (stage) {
+        const int npad = (N + 15) & ~15;
+        double* s_sf = lds_next;
+        double* s_lsf = s_sf + npad;
+        int32_t* s_cell = (int32_t*)(s_lsf + npad);
+        int32_t* s_y = s_cell + npad + (size_t)w * npad;
+        for (int n = threadIdx.x; n < N; n += kBlock) {
+            s_sf[n] = sf[n];
+            s_lsf[n] = lsf != nullptr ? lsf[n] : 0.0;
+            if (CELL) s_cell[n] = ex.cells.cell_of[n];
+        }
+        for (int n = threadIdx.x & 63; n < N; n += 64) s_y[n] = yrow[n];
+        sf = s_sf;
+        if (lsf != nullptr) lsf = s_lsf;
+        if (CELL) ex.cells.cell_of = s_cell;
+        yrow = s_y;
+    }
+    if (CELL || stage) __syncthreads();
     if (g >= G) return;
     IrlsArgs A;
-    A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+    A.y = yrow; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
-    if (CELL) { A.cells = &ex.cells; A.cell_ws = (void*)&cellw[threadIdx.x >> 6]; }
+    if (CELL) { A.cells = &ex.cells; A.cell_ws = (void*)&cellw[w]; }
     LfcEpilogue E;
     epilogue_begin<P>(E, ex, g, ldn);
     double b[P];
@@ -199,19 +224,26 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
         return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,
                                 min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, &ex);
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    // LDS staging of the per-sample vectors (sf, log sf: 16 B; cell index: 4 B) and the waves' count rows (4 B each)
+    const int npad = (N + 15) & ~15;
+    const size_t stage_bytes = (size_t)npad * (16 + 4 + 4 * kWavesPerBlock);
+    static const bool allow_stage = getenv("DSQ_IRLS_NO_STAGE") == nullptr;
     if (ex.cells.C > 0 && P_ >= 3) {
         DSQ_DISPATCH_P(P_, {
-            if constexpr (P >= 3)
-                hipLaunchKernelGGL((k_irls<P, true>), grid, block,
-                                   (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double), st, y, ldn, sf, lsf, Xt,
-                                   pinvXt, ldx, N, G,
-                                   full_rank, disp, min_mu, beta_tol, min_beta, max_beta, maxiter, beta, mu, hat,
-                                   conv, iters, fb_count, fb_list, ex);
+            if constexpr (P >= 3) {
+                const size_t tables = (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double);
+                const int stage = allow_stage && tables + stage_bytes <= 48 * 1024;
+                hipLaunchKernelGGL((k_irls<P, true>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn, sf,
+                                   lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
+                                   maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
+            }
         })
     } else {
-        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_irls<P, false>), grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt, ldx,
-                                              N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                              maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex))
+        const int stage = allow_stage && stage_bytes <= 48 * 1024;
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_irls<P, false>), grid, block, stage ? stage_bytes : 0, st, y, ldn, sf,
+                                              lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta,
+                                              max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex,
+                                              stage))
     }
     return hipGetLastError();
 }

@@ -42,7 +42,9 @@ class DesignPack:
         self.n_design_cells = len(cnt)
         # cell path of the dispersion / IRLS kernels (include/deseq_hip.h, dsq_cells): per-sample cell index, the
         # cells' design rows and their packed outer products, for designs with at most 64 distinct rows
-        self.cell_path = 4 < self.n_design_cells <= 64 and self.P >= 3
+        # (the launchers pick per kernel: 5..64 cells with P >= 3 -> LDS sums; <= 4 cells with P <= 4 -> register sums)
+        self.cell_path = self.n_design_cells <= 64 and ((self.n_design_cells > 4 and self.P >= 3)
+                                                        or (self.n_design_cells <= 4 and self.P <= 4))
         if self.cell_path:
             self.cell_of = np.zeros(self.ldx, dtype=np.int32)
             self.cell_of[: self.N] = inv

@@ -156,6 +156,147 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
     S = Wv::sum(s);
 }
 
+// Designs with at most kSmallCells distinct rows (the two-group comparison of most experiments): the per-cell
+// linear predictors and their exponentials are wave-uniform registers, a sample selects its cell's pair (no exp,
+// no design loads, no outer product per sample) and adds its weight into per-cell register accumulators.
+template <int CS>
+DSQ_HD double cell_select(int cell, const double (&v)[CS]) {
+    double r = v[0];
+#pragma unroll
+    for (int c = 1; c < CS; ++c) r = (cell == c) ? v[c] : r;
+    return r;
+}
+
+template <class Wv, int P>
+DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, double& S,
+                          double (&M)[Tri<P>::N], double (&r)[P], double (&e_c)[kSmallCells]) {
+    constexpr int T = Tri<P>::N;
+    constexpr int CS = kSmallCells;
+    const CellDesign& D = *A.cells;
+    double eta_c[CS], sw[CS], swz[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        double eta = 0.0;
+        if (c < D.C) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) eta += D.Xc[c * P + j] * beta[j];
+        }
+        eta_c[c] = Wv::uniform(eta);
+        e_c[c] = Wv::uniform(exp(eta));
+        sw[c] = 0.0;
+        swz[c] = 0.0;
+    }
+    double s = 0.0;
+    const double lmin = log(A.min_mu);
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const double yv = (double)A.y[n];
+        const double sfn = A.sf[n];
+        const int cell = D.cell_of[n];
+        const double eta = cell_select<CS>(cell, eta_c);
+        const double mu_raw = sfn * cell_select<CS>(cell, e_c);
+        const bool clamped = !(mu_raw > A.min_mu);
+        const double mu = clamped ? A.min_mu : mu_raw;
+        const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
+        const double lmu = clamped ? lmin : eta + lsfn;
+        const double rmu = frcp(mu);
+        s += (yv + a) * flog(a + mu) - yv * lmu;
+        const double w = mu * frcp(1.0 + mu * A.disp);
+        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
+        const double wz = w * z;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            sw[c] += (cell == c) ? w : 0.0;
+            swz[c] += (cell == c) ? wz : 0.0;
+        }
+    }
+    S = Wv::sum(s);
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        if (c < D.C) { sw[c] = Wv::sum(sw[c]); swz[c] = Wv::sum(swz[c]); }  // D.C is wave-uniform
+    }
+#pragma unroll
+    for (int k = 0; k < T; ++k) M[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) r[j] = 0.0;
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        if (c < D.C) {
+#pragma unroll
+            for (int k = 0; k < T; ++k) M[k] += D.XX[c * T + k] * sw[c];
+#pragma unroll
+            for (int j = 0; j < P; ++j) r[j] += D.Xc[c * P + j] * swz[c];
+        }
+    }
+}
+
+template <class Wv, int P>
+DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&M)[Tri<P>::N],
+                           const double (&e_c)[kSmallCells], double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
+    constexpr int T = Tri<P>::N;
+    constexpr int CS = kSmallCells;
+    const bool want_cooks = E != nullptr && E->flags != nullptr;
+    const bool want_wald = E != nullptr && E->ridge != nullptr;
+    if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
+    const CellDesign& D = *A.cells;
+    double q_c[CS], swu[CS];
+    {
+        double inv[T];
+#pragma unroll
+        for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
+        chol<P>(M);
+        chol_inverse<P>(M, inv);
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            double q = 0.0;
+            if (c < D.C) {
+                double x[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) x[j] = D.Xc[c * P + j];
+                q = sym_quad<P>(inv, x);
+            }
+            q_c[c] = Wv::uniform(q);
+            swu[c] = 0.0;
+        }
+    }
+    CooksAcc<Wv> acc(want_cooks ? E->robust_disp : 0.0, want_cooks ? E->cutoff : 0.0, P);
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const int cell = D.cell_of[n];
+        const double mu_raw = A.sf[n] * cell_select<CS>(cell, e_c);
+        if (mu_out != nullptr) mu_out[n] = mu_raw;
+        if (H_out != nullptr || want_cooks) {
+            const double mu = dmax(mu_raw, A.min_mu);
+            const double w = mu / (1.0 + mu * A.disp);
+            const double sw = sqrt(w);
+            const double h = sw * cell_select<CS>(cell, q_c) * sw;
+            if (H_out != nullptr) H_out[n] = h;
+            if (want_cooks) {
+                const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
+                if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
+            }
+        }
+        if (want_wald) {
+            const double wu = mu_raw / (1.0 + mu_raw * A.disp);
+#pragma unroll
+            for (int c = 0; c < CS; ++c) swu[c] += (cell == c) ? wu : 0.0;
+        }
+    }
+    if (want_cooks) E->cooks = acc.finish(A.y, A.N);
+    if (want_wald) {
+        double Mw[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) Mw[k] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            if (c < D.C) {
+                const double sc = Wv::sum(swu[c]);
+#pragma unroll
+                for (int k = 0; k < T; ++k) Mw[k] += D.XX[c * T + k] * sc;
+            }
+        }
+        E->wald = wald_from_M<P>(Mw, beta, E->ridge, E->contrast, E->lfc_null, E->alt);
+    }
+}
+
 struct IrlsOut {
     int converged;
     int iters;
@@ -381,7 +522,8 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
 
 // beta (out), mu_out[N] = UNclamped sf*exp(X beta), H_out[N] hat diagonal (either may be null).
 // When IRLS diverges nothing is written and out.fallback = 1.
-template <class Wv, int P, bool CELL = false>
+// CELL: 0 general design, 1 per-cell sums in LDS (5 .. 64 cells), 2 per-cell sums in registers (<= kSmallCells)
+template <class Wv, int P, int CELL = 0>
 DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, double* H_out,
                          LfcEpilogue* E = nullptr) {
     constexpr int T = Tri<P>::N;
@@ -392,8 +534,10 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     irls_init<Wv, P>(A, a, beta, cst);
     const double nlogterm = A.N * a * log(A.disp);
     double M[T], r[P], S;
+    double e_c[kSmallCells];  // CELL == 2: exp(x_c . beta) of the last sweep
     auto sweep = [&]() {
-        if constexpr (CELL) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
+        if constexpr (CELL == 1) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
+        else if constexpr (CELL == 2) irls_sweep_cs<Wv, P>(A, beta, a, S, M, r, e_c);
         else irls_sweep<Wv, P>(A, beta, a, S, M, r);
     };
     sweep();
@@ -426,7 +570,8 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
         ratio = fabs(dev - old) / (fabs(dev) + 0.1);
     }
     out.iters = i;
-    if constexpr (CELL) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
+    if constexpr (CELL == 1) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
+    else if constexpr (CELL == 2) irls_finish_cs<Wv, P>(A, beta, M, e_c, mu_out, H_out, E);
     else irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);
     return out;
 }

@@ -216,6 +216,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     if (extras != nullptr) ex = *extras;
     // designs beyond the register path's width - or, on request, any design without cell structure from
     // DSQ_WIDE_MIN_P columns on - run the LDS / matrix-core kernels (dsq_k_wide.hip)
+    if (ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // the dispersion kernels use cells from 5 upwards
     if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0)) {
         if (mu == nullptr) return hipErrorInvalidValue;  // that path reads a materialised mu_hat
         return launch_wide_alpha(st, y, mu, ldn, Xt, ldx, N, G, P_, alpha_hat, min_disp, max_disp, prior_var, cr_reg,
@@ -227,7 +228,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
     const bool stage = smem <= 80 * 1024;  // >= 2 workgroups per CU keep their rows in LDS
     if (!stage && ex.coef != nullptr) return hipErrorInvalidValue;  // mu_hat on the fly needs the staged variant
-    const bool cell = stage && ex.cells.C > 0 && P_ >= 3 && cr_reg != 0;
+    const bool cell = stage && ex.cells.C > kSmallCells && P_ >= 3 && cr_reg != 0;
 #define DSQ_ALPHA_LAUNCH(KERNEL, SMEM)                                                                            \
     do {                                                                                                          \
         if ((SMEM) > 48 * 1024) {                                                                                 \

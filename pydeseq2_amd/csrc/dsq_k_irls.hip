@@ -35,8 +35,8 @@ __device__ __forceinline__ void epilogue_store(const LfcEpilogue& E, const IrlsE
     if (ex.ridge != nullptr) { ex.pvals[g] = E.wald.p; ex.stats[g] = E.wald.stat; ex.se[g] = E.wald.se; }
 }
 
-template <int P, bool CELL>
-__global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
+template <int P, int CELL>
+__global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_waves(P)) void k_irls(const int32_t* __restrict__ y, int ldn,
                                                  const double* __restrict__ sf, const double* __restrict__ lsf,
                                                  const double* __restrict__ Xt,
                                                  const double* __restrict__ pinvXt, int ldx, int N,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P
                                                  uint8_t* __restrict__ conv, int32_t* __restrict__ iters,
                                                  int32_t* __restrict__ fb_count,
                                                  int32_t* __restrict__ fb_list, IrlsExtras ex, int stage) {
-    __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
+    __shared__ typename std::conditional<CELL == 1, CellWork<P>, char>::type cellw[kWavesPerBlock];
     extern __shared__ __attribute__((aligned(16))) double irls_lds[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : irls_min_waves(P
     A.y = yrow; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
-    if (CELL) { A.cells = &ex.cells; A.cell_ws = (void*)&cellw[w]; }
+    if (CELL) { A.cells = &ex.cells; A.cell_ws = CELL == 1 ? (void*)&cellw[w] : nullptr; }
     LfcEpilogue E;
     epilogue_begin<P>(E, ex, g, ldn);
     double b[P];
@@ -220,27 +220,40 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     if (G <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
-    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0))
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0)) {
+        if (ex.cells.C > 0 && ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // (the wide kernels take 5..64 cells)
         return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,
                                 min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, &ex);
+    }
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     // LDS staging of the per-sample vectors (sf, log sf: 16 B; cell index: 4 B) and the waves' count rows (4 B each)
     const int npad = (N + 15) & ~15;
     const size_t stage_bytes = (size_t)npad * (16 + 4 + 4 * kWavesPerBlock);
     static const bool allow_stage = getenv("DSQ_IRLS_NO_STAGE") == nullptr;
-    if (ex.cells.C > 0 && P_ >= 3) {
+    if (ex.cells.C > 0 && ex.cells.C <= kSmallCells && P_ <= 4) {
+        // <= 4 distinct design rows (two-group designs): per-cell exponentials and weight sums in registers
+        DSQ_DISPATCH_P(P_, {
+            if constexpr (P <= 4) {
+                const size_t tables = (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double);
+                const int stage = allow_stage && tables + stage_bytes <= 48 * 1024;
+                hipLaunchKernelGGL((k_irls<P, 2>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn, sf,
+                                   lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
+                                   maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
+            }
+        })
+    } else if (ex.cells.C > kSmallCells && P_ >= 3) {
         DSQ_DISPATCH_P(P_, {
             if constexpr (P >= 3) {
                 const size_t tables = (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double);
                 const int stage = allow_stage && tables + stage_bytes <= 48 * 1024;
-                hipLaunchKernelGGL((k_irls<P, true>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn, sf,
+                hipLaunchKernelGGL((k_irls<P, 1>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn, sf,
                                    lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
                                    maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
             }
         })
     } else {
         const int stage = allow_stage && stage_bytes <= 48 * 1024;
-        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_irls<P, false>), grid, block, stage ? stage_bytes : 0, st, y, ldn, sf,
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_irls<P, 0>), grid, block, stage ? stage_bytes : 0, st, y, ldn, sf,
                                               lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta,
                                               max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex,
                                               stage))

@@ -26,6 +26,7 @@ DSQ_HD constexpr int tris(int i, int j) { return i >= j ? tri(i, j) : tri(j, i);
 // The per-gene routines then add w_n into per-cell accumulators (wave-private LDS) and rebuild the matrix
 // entry-parallel: lane e owns entry e and walks the <= 64 cells.
 constexpr int kMaxCells = 64;
+constexpr int kSmallCells = 4;  // up to this many cells: per-cell sums in registers (IRLS, dsq_irls.h irls_sweep_cs)
 struct CellDesign {
     const int32_t* cell_of;  // [ldx] design cell of every sample (0 beyond N)
     const double* Xc;        // [C][P] the cells' design rows

@@ -160,7 +160,12 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
             double b[P];
             double* mo = mu ? mu + (size_t)g * ldn : nullptr;
             double* ho = H ? H + (size_t)g * ldn : nullptr;
-            IrlsOut o = (C > 0) ? irls_gene<HostWave, P, true>(A, b, mo, ho, &E) : irls_gene<HostWave, P, false>(A, b, mo, ho, &E);
+            IrlsOut o;
+            if (C > kSmallCells) o = irls_gene<HostWave, P, 1>(A, b, mo, ho, &E);
+            else if (C > 0) {
+                if constexpr (P <= 4) o = irls_gene<HostWave, P, 2>(A, b, mo, ho, &E);
+                else return -2;
+            } else o = irls_gene<HostWave, P, 0>(A, b, mo, ho, &E);
             if (o.fallback) {
                 static IrlsRescueWork<P> Rk;
                 std::memset(&Rk, 0, sizeof(Rk));

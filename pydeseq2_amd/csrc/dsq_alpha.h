@@ -142,7 +142,8 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
 #pragma unroll
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
     // CELL: per-cell sums of w and dw instead of p(p+1) accumulators per lane (dsq_linalg.h, CellDesign)
-    CellWork<P>* const Wk = CELL ? (CellWork<P>*)A.cell_ws : nullptr;
+    typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;  // ds_read / ds_write instead of flat accesses
+    LdsWork* const Wk = CELL ? (LdsWork*)A.cell_ws : nullptr;
     const int32_t* const cell_of = CELL ? A.cells->cell_of : nullptr;
     if (CELL && cr_reg) {
         for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) { Wk->acc[0][c] = 0.0; Wk->acc[1][c] = 0.0; }
@@ -308,7 +309,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
             // entry-parallel: lane e owns entry e of X^T W X (and of X^T dW X) and walks the cells
             Wv::sync();
             const CellDesign& D = *A.cells;
-            const double* XXg = D.XX;  // the kernel stages the cells' tables in LDS (flat pointer)
+            const auto XXg = DSQ_AS_LDS(double, D.XX);  // the kernel stages the cells' tables in LDS
             for (int e = Wv::lane(); e < T; e += Wv::W) {
                 double me = 0.0, de = 0.0;
                 for (int c = 0; c < D.C; ++c) {

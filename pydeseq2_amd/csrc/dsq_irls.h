@@ -105,12 +105,15 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
                             double (&M)[Tri<P>::N], double (&r)[P]) {
     constexpr int T = Tri<P>::N;
     const CellDesign& D = *A.cells;
-    CellWork<P>& Wk = *(CellWork<P>*)A.cell_ws;
+    typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;  // ds_read / ds_write instead of flat accesses
+    LdsWork& Wk = *(LdsWork*)A.cell_ws;
+    const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
+    const auto XX_ = DSQ_AS_LDS(double, D.XX);
     for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) {
         double eta = 0.0;
         if (c < D.C) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) eta += D.Xc[c * P + j] * beta[j];
+            for (int j = 0; j < P; ++j) eta += Xc_[c * P + j] * beta[j];
         }
         Wk.tab[0][c] = eta;
         Wk.tab[1][c] = exp(eta);
@@ -120,6 +123,7 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
     Wv::sync();
     double s = 0.0;
     const double lmin = log(A.min_mu);
+    DSQ_PHASE(3);
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
         const double yv = (double)A.y[n];
         const double sfn = A.sf[n];
@@ -137,13 +141,14 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
         Wv::cell_add(&Wk.acc[0][cell], w);
         Wv::cell_add(&Wk.acc[1][cell], w * z);
     }
+    DSQ_PHASE(4);
     Wv::sync();
     for (int e = Wv::lane(); e < T + P; e += Wv::W) {
         double v = 0.0;
         if (e < T) {
-            for (int c = 0; c < D.C; ++c) v += D.XX[c * T + e] * Wk.acc[0][c];
+            for (int c = 0; c < D.C; ++c) v += XX_[c * T + e] * Wk.acc[0][c];
         } else {
-            for (int c = 0; c < D.C; ++c) v += D.Xc[c * P + (e - T)] * Wk.acc[1][c];
+            for (int c = 0; c < D.C; ++c) v += Xc_[c * P + (e - T)] * Wk.acc[1][c];
         }
         Wk.ent[e] = v;
     }
@@ -173,13 +178,15 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
     constexpr int T = Tri<P>::N;
     constexpr int CS = kSmallCells;
     const CellDesign& D = *A.cells;
+    const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
+    const auto XX_ = DSQ_AS_LDS(double, D.XX);
     double eta_c[CS], sw[CS], swz[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) {
         double eta = 0.0;
         if (c < D.C) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) eta += D.Xc[c * P + j] * beta[j];
+            for (int j = 0; j < P; ++j) eta += Xc_[c * P + j] * beta[j];
         }
         eta_c[c] = Wv::uniform(eta);
         e_c[c] = Wv::uniform(exp(eta));
@@ -188,6 +195,7 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
     }
     double s = 0.0;
     const double lmin = log(A.min_mu);
+    DSQ_PHASE(3);
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
         const double yv = (double)A.y[n];
         const double sfn = A.sf[n];
@@ -209,6 +217,7 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
             swz[c] += (cell == c) ? wz : 0.0;
         }
     }
+    DSQ_PHASE(4);
     S = Wv::sum(s);
 #pragma unroll
     for (int c = 0; c < CS; ++c) {
@@ -222,9 +231,9 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
     for (int c = 0; c < CS; ++c) {
         if (c < D.C) {
 #pragma unroll
-            for (int k = 0; k < T; ++k) M[k] += D.XX[c * T + k] * sw[c];
+            for (int k = 0; k < T; ++k) M[k] += XX_[c * T + k] * sw[c];
 #pragma unroll
-            for (int j = 0; j < P; ++j) r[j] += D.Xc[c * P + j] * swz[c];
+            for (int j = 0; j < P; ++j) r[j] += Xc_[c * P + j] * swz[c];
         }
     }
 }
@@ -238,6 +247,8 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
     const bool want_wald = E != nullptr && E->ridge != nullptr;
     if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
     const CellDesign& D = *A.cells;
+    const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
+    const auto XX_ = DSQ_AS_LDS(double, D.XX);
     double q_c[CS], swu[CS];
     {
         double inv[T];
@@ -251,7 +262,7 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
             if (c < D.C) {
                 double x[P];
 #pragma unroll
-                for (int j = 0; j < P; ++j) x[j] = D.Xc[c * P + j];
+                for (int j = 0; j < P; ++j) x[j] = Xc_[c * P + j];
                 q = sym_quad<P>(inv, x);
             }
             q_c[c] = Wv::uniform(q);
@@ -265,7 +276,7 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
         if (mu_out != nullptr) mu_out[n] = mu_raw;
         if (H_out != nullptr || want_cooks) {
             const double mu = dmax(mu_raw, A.min_mu);
-            const double w = mu / (1.0 + mu * A.disp);
+            const double w = mu * frcp_g(1.0 + mu * A.disp);
             const double sw = sqrt(w);
             const double h = sw * cell_select<CS>(cell, q_c) * sw;
             if (H_out != nullptr) H_out[n] = h;
@@ -275,7 +286,7 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
             }
         }
         if (want_wald) {
-            const double wu = mu_raw / (1.0 + mu_raw * A.disp);
+            const double wu = mu_raw * frcp_g(1.0 + mu_raw * A.disp);
 #pragma unroll
             for (int c = 0; c < CS; ++c) swu[c] += (cell == c) ? wu : 0.0;
         }
@@ -290,7 +301,7 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
             if (c < D.C) {
                 const double sc = Wv::sum(swu[c]);
 #pragma unroll
-                for (int k = 0; k < T; ++k) Mw[k] += D.XX[c * T + k] * sc;
+                for (int k = 0; k < T; ++k) Mw[k] += XX_[c * T + k] * sc;
             }
         }
         E->wald = wald_from_M<P>(Mw, beta, E->ridge, E->contrast, E->lfc_null, E->alt);
@@ -339,9 +350,10 @@ DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst)
         c -= valid ? dl + lf : 0.0;
         if (valid) {
             if (A.full_rank) {
-                // library log and true division: beta_init decides, on ill-conditioned genes, whether
-                // IRLS diverges (and the gene goes to the rescue) exactly as it does in the reference
-                const double ly = log(yv / A.sf[n] + 0.1);
+                // log(y / sf + 0.1) (utils.py:351) with the lean log and a reciprocal (<= 1 ulp each; the sum over
+                // the samples runs in another order than numpy's anyway): the library log + IEEE division here
+                // were a sixth of the kernel
+                const double ly = flog(yv * frcp(A.sf[n]) + 0.1);
 #pragma unroll
                 for (int j = 0; j < P; ++j) b0[j] += A.pinvXt[j * A.ldx + n] * ly;
             } else {
@@ -412,7 +424,7 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
             if (mu_out != nullptr) mu_out[n] = mu_raw;
             if (H_out != nullptr || want_cooks) {
                 const double mu = dmax(mu_raw, A.min_mu);
-                const double w = mu / (1.0 + mu * A.disp);
+                const double w = mu * frcp_g(1.0 + mu * A.disp);
                 const double sw = sqrt(w);
                 const double h = sw * sym_quad<P>(inv, x) * sw;
                 if (H_out != nullptr) H_out[n] = h;
@@ -422,7 +434,7 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
                 }
             }
             if (want_wald && kWaldInLoop) {
-                const double wu = mu_raw / (1.0 + mu_raw * A.disp);
+                const double wu = mu_raw * frcp_g(1.0 + mu_raw * A.disp);
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     const double xw = x[i] * wu;
@@ -441,7 +453,7 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
 #pragma unroll
                 for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * beta[j]; }
                 const double m = A.sf[n] * exp(eta);
-                const double wu = m / (1.0 + m * A.disp);
+                const double wu = m * frcp_g(1.0 + m * A.disp);
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     const double xw = x[i] * wu;
@@ -466,7 +478,10 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
     const bool want_wald = E != nullptr && E->ridge != nullptr;
     if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
     const CellDesign& D = *A.cells;
-    CellWork<P>& Wk = *(CellWork<P>*)A.cell_ws;
+    typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;  // ds_read / ds_write instead of flat accesses
+    LdsWork& Wk = *(LdsWork*)A.cell_ws;
+    const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
+    const auto XX_ = DSQ_AS_LDS(double, D.XX);
     {
         double inv[T];
 #pragma unroll
@@ -478,7 +493,7 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
             if (c < D.C) {
                 double x[P];
 #pragma unroll
-                for (int j = 0; j < P; ++j) x[j] = D.Xc[c * P + j];
+                for (int j = 0; j < P; ++j) x[j] = Xc_[c * P + j];
                 q = sym_quad<P>(inv, x);
             }
             Wk.acc[0][c] = q;     // read-only from here on
@@ -493,7 +508,7 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
         if (mu_out != nullptr) mu_out[n] = mu_raw;
         if (H_out != nullptr || want_cooks) {
             const double mu = dmax(mu_raw, A.min_mu);
-            const double w = mu / (1.0 + mu * A.disp);
+            const double w = mu * frcp_g(1.0 + mu * A.disp);
             const double sw = sqrt(w);
             const double h = sw * Wk.acc[0][cell] * sw;
             if (H_out != nullptr) H_out[n] = h;
@@ -502,14 +517,14 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
                 if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
             }
         }
-        if (want_wald) Wv::cell_add(&Wk.acc[1][cell], mu_raw / (1.0 + mu_raw * A.disp));
+        if (want_wald) Wv::cell_add(&Wk.acc[1][cell], mu_raw * frcp_g(1.0 + mu_raw * A.disp));
     }
     if (want_cooks) E->cooks = acc.finish(A.y, A.N);
     if (want_wald) {
         Wv::sync();
         for (int e = Wv::lane(); e < T; e += Wv::W) {
             double v = 0.0;
-            for (int c = 0; c < D.C; ++c) v += D.XX[c * T + e] * Wk.acc[1][c];
+            for (int c = 0; c < D.C; ++c) v += XX_[c * T + e] * Wk.acc[1][c];
             Wk.ent[e] = v;
         }
         Wv::sync();
@@ -531,14 +546,17 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     out.converged = 1; out.iters = 0; out.fallback = 0;
     const double a = 1.0 / A.disp;
     double cst;
+    DSQ_PHASE(1);
     irls_init<Wv, P>(A, a, beta, cst);
     const double nlogterm = A.N * a * log(A.disp);
     double M[T], r[P], S;
     double e_c[kSmallCells];  // CELL == 2: exp(x_c . beta) of the last sweep
     auto sweep = [&]() {
+        DSQ_PHASE(2);
         if constexpr (CELL == 1) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
         else if constexpr (CELL == 2) irls_sweep_cs<Wv, P>(A, beta, a, S, M, r, e_c);
         else irls_sweep<Wv, P>(A, beta, a, S, M, r);
+        DSQ_PHASE(5);
     };
     sweep();
     double dev = 1000.0, ratio = 1.0;
@@ -570,6 +588,7 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
         ratio = fabs(dev - old) / (fabs(dev) + 0.1);
     }
     out.iters = i;
+    DSQ_PHASE(6);
     if constexpr (CELL == 1) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
     else if constexpr (CELL == 2) irls_finish_cs<Wv, P>(A, beta, M, e_c, mu_out, H_out, E);
     else irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);

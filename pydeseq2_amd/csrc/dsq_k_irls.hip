@@ -9,6 +9,10 @@
 
 namespace dsq {
 
+#if defined(DSQ_PHASE_TIMING)
+__device__ unsigned long long g_phase_total_irls[16];
+#endif
+
 // wide designs: ask for 2 waves/SIMD (a few spilled accumulators cost less than running one
 // wave per SIMD with nothing to overlap its fp64 dependency chains)
 #ifndef DSQ_IRLS_WAVES_P2
@@ -86,6 +90,13 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
     }
     if (CELL || stage) __syncthreads();
     if (g >= G) return;
+#if defined(DSQ_PHASE_TIMING)
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < kPhases; ++k) g_ph_acc[w][k] = 0;
+        g_ph_last[w] = clock64();
+        g_ph_cur[w] = 0;
+    }
+#endif
     IrlsArgs A;
     A.y = yrow; A.sf = sf; A.lsf = lsf; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
     A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
@@ -104,6 +115,11 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
         if (o.fallback) fb_list[atomicAdd(fb_count, 1)] = g;
         else epilogue_store(E, ex, g);
     }
+#if defined(DSQ_PHASE_TIMING)
+    DSQ_PHASE(0);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < kPhases; ++k) atomicAdd(&g_phase_total_irls[k], (unsigned long long)g_ph_acc[w][k]);
+#endif
 }
 
 template <int P>
@@ -281,3 +297,15 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
 }
 
 }  // namespace dsq
+
+#if defined(DSQ_PHASE_TIMING)
+// developer build only (tools/phase_probe.py): per-phase cycle totals of k_irls
+extern "C" int dsq_debug_phase_read_irls(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dsq::g_phase_total_irls), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dsq::g_phase_total_irls), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

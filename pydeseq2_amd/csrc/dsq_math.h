@@ -49,6 +49,7 @@ namespace dsq {
 DSQ_HD double flog(double x);
 DSQ_HD double flog1p(double u);
 DSQ_HD double frcp(double x);
+DSQ_HD double frcp_g(double x);
 
 constexpr double kHalfLog2Pi = 0.91893853320467274178032973640562;
 constexpr double kEps = 2.220446049250313e-16;
@@ -152,6 +153,19 @@ DSQ_HD double frcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
+// 1/x for the per-sample epilogues: as frcp, but 1/0 = inf and 1/inf = 0 survive the Newton steps (which would
+// turn them into NaN), as an IEEE division gives them
+DSQ_HD double frcp_g(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double r = fma(fma(-x, r0, 1.0), r0, r0);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return (r != r) ? r0 : r;
 #else
     return 1.0 / x;
 #endif

@@ -460,11 +460,14 @@ struct CooksAcc {
     double best = -INFINITY;
     int best_idx = 0x7fffffff;
     bool best_nan = false;
-    DSQ_HD CooksAcc(double robust_disp, double cutoff_, int P) : ar(robust_disp), cutoff(cutoff_), invP((double)P) {}
+    DSQ_HD CooksAcc(double robust_disp, double cutoff_, int P) : ar(robust_disp), cutoff(cutoff_), invP(1.0 / (double)P) {}
     DSQ_HD double add(int n, double yv, double mv, double h, int fl) {
+        // (y - mu)^2 / V / p * h / (1 - h)^2 (dds.py:1034-1040) with reciprocals instead of three IEEE divisions
+        // (~30 instructions each; the per-sample epilogue of the LFC fit was a third of that kernel)
         const double V = (mv * mv) * ar + mv;
         const double r = yv - mv;
-        const double ck = (r * r) / V / invP * (h / ((1.0 - h) * (1.0 - h)));
+        const double omh = 1.0 - h;
+        const double ck = (r * r) * frcp_g(V) * invP * (h * frcp_g(omh * omh));
         const bool gt = ck > cutoff;
         g_all |= gt ? 1 : 0;
         if (gt && (fl & 1)) { g_use = 1; if (!(fl & 2)) g_use_nr = 1; }

@@ -39,9 +39,11 @@ struct KSum {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DSQ_AS_LDS(T, p) ((const __attribute__((address_space(3))) T*)(p))
 #define DSQ_AS_GLOBAL(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#define DSQ_LDS_STRUCT(T) __attribute__((address_space(3))) T  // a struct that lives in LDS (writable)
 #else
 #define DSQ_AS_LDS(T, p) (p)
 #define DSQ_AS_GLOBAL(T, p) (p)
+#define DSQ_LDS_STRUCT(T) T
 #endif
 
 #if defined(__HIPCC__)

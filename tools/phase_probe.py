@@ -38,6 +38,17 @@ def main():
     print(f"{cfg}: {G} x {N}; cycles summed over waves and both launches (MLE + MAP)")
     for k, n in enumerate(NAMES):
         print(f"  {k} {n:16s} {buf[k] / 1e6:12.1f} Mcycles  {100.0 * buf[k] / tot:6.2f} %")
+    if hasattr(lib, "dsq_debug_phase_read_irls"):
+        lib.dsq_debug_phase_read_irls(buf, 1)
+        pipe.deseq2()
+        ctx.sync()
+        lib.dsq_debug_phase_read_irls(buf, 1)
+        tot = float(sum(buf[:8]))
+        names = ["stage/epilogue", "init", "sweep pre (cell tables)", "sweep sample loop", "sweep reduce/rebuild",
+                 "solve + deviance", "finish (hat, cooks, wald)", "-"]
+        print("k_irls (all launches of one step):")
+        for k, n in enumerate(names):
+            print(f"  {k} {n:26s} {buf[k] / 1e6:12.1f} Mcycles  {100.0 * buf[k] / tot:6.2f} %")
 
 
 if __name__ == "__main__":

@@ -19,6 +19,18 @@
 #include "dsq_stats.h"
 #include "dsq_wave.h"
 
+// The per-sample loops of this file are long dependent fp64 chains behind a handful of loads; two samples per
+// trip give the scheduler two independent chains to interleave (the SQ counters showed these kernels stalled on
+// instruction dependencies and waitcnt for two thirds of their cycles, not on issue bandwidth).  Measured (A/B
+// builds, c5-shaped p = 8 design without cells): -12 % on the general loops; the cell-path loops (LDS atomics,
+// per-cell selects) got slower with it and stay rolled.
+#ifndef DSQ_IRLS_UNROLL
+#define DSQ_IRLS_UNROLL 2
+#endif
+#define DSQ_PRAGMA_(x) _Pragma(#x)
+#define DSQ_PRAGMA(x) DSQ_PRAGMA_(x)
+#define DSQ_UNROLL2 DSQ_PRAGMA(unroll DSQ_IRLS_UNROLL)
+
 namespace dsq {
 
 // Optional fused tail of the LFC fit: the per-sample part of the Cook's distances (dds.py:986-1040 and the
@@ -64,6 +76,7 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
     for (int k = 0; k < T; ++k) M[k] = 0.0;
 #pragma unroll
     for (int j = 0; j < P; ++j) r[j] = 0.0;
+    DSQ_UNROLL2
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
         const double yv = (double)A.y[n];
         const double sfn = A.sf[n];
@@ -375,6 +388,7 @@ DSQ_HD void irls_init_exact(const IrlsArgs& A, double a, double (&b0)[P], double
 #pragma unroll
     for (int j = 0; j < P; ++j) b0[j] = 0.0;
     double c = 0.0;
+    DSQ_UNROLL2
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
         const double yv = (double)A.y[n];
         c += lgamma_pos(yv + a) - lgamma_pos(yv + 1.0);
@@ -415,7 +429,8 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
 #pragma unroll
     for (int k = 0; k < T; ++k) Mw[k] = 0.0;
     if (mu_out != nullptr || H_out != nullptr || want_cooks || (want_wald && kWaldInLoop)) {
-        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        DSQ_UNROLL2
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
             double x[P];
             double eta = 0.0;
 #pragma unroll
@@ -447,7 +462,8 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
     if (want_cooks) E->cooks = acc.finish(A.y, A.N);
     if (want_wald) {
         if (!kWaldInLoop) {
-            for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            DSQ_UNROLL2
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
                 double x[P];
                 double eta = 0.0;
 #pragma unroll
@@ -609,7 +625,8 @@ DSQ_HD void grid_fit_beta2(const IrlsArgs& A, double a, double cst, double (&bet
                            int grid_length = 60) {
     auto loss = [&](double bx, double by) {
         double s = 0.0;
-        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        DSQ_UNROLL2
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
             const double yv = (double)A.y[n];
             const double eta = A.Xt[n] * bx + A.Xt[A.ldx + n] * by;
             const double mu = dmax(A.sf[n] * exp(eta), A.min_mu);
@@ -664,7 +681,8 @@ DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double
         double s = 0.0, gr[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) gr[j] = 0.0;
-        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        DSQ_UNROLL2
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
             const double yv = (double)A.y[n];
             double x[P];
             double eta = 0.0;

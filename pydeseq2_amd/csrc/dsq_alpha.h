@@ -18,9 +18,12 @@
 
 // The sample loop is software-pipelined by hand (the reads of the next iteration are issued before this one's
 // arithmetic); rolled, the rotation of the prefetched values costs ~35 register moves per trip (22 % of the loop's
-// instructions): two trips per loop iteration let the compiler rename instead of move.
+// instructions).  Two trips per loop iteration (DSQ_ALPHA_UNROLL 2) let the compiler rename instead of move:
+// measured -13 % instructions in the loop but only -1.4 % time (the loop is bound by its dependent fp64 chains, not
+// by issue slots), and the larger live set spills: 680 MB of scratch writes per full-size launch instead of 48 MB.
+// Kept rolled.
 #ifndef DSQ_ALPHA_UNROLL
-#define DSQ_ALPHA_UNROLL 2
+#define DSQ_ALPHA_UNROLL 1
 #endif
 
 namespace dsq {

@@ -28,6 +28,11 @@
 
 namespace dsq {
 
+struct CellCtx {
+    CellDesign D;
+    void* ws;
+};
+
 struct AlphaArgs {
     const int32_t* y;   // [N]
     const double* mu;   // [N]
@@ -37,9 +42,10 @@ struct AlphaArgs {
     double cst;         // sum lgamma(y+1) - sum y log(mu)   (alpha independent)
     double la_hat;      // log(alpha_hat)
     double prior_var;
-    bool cr_reg, prior_reg;
-    const CellDesign* cells = nullptr;  // CELL instantiations: the design's cells ...
-    void* cell_ws = nullptr;            // ... and this wave's CellWork<P>
+    // CELL instantiations: the design's cells and this wave's CellWork<P>.  (16 dwords in all: the evaluation is an
+    // out-of-line call and an argument struct of up to 16 registers travels in VGPRs; one more field and the whole
+    // struct goes through scratch memory on every call - measured 0.64 GB of scratch writes per launch.)
+    const CellCtx* cell = nullptr;
 };
 
 // lgamma(a) - lgamma(y + a) and digamma(a) - digamma(y + a) for a count y >= 0.
@@ -153,8 +159,8 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
     for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
     // CELL: per-cell sums of w and dw instead of p(p+1) accumulators per lane (dsq_linalg.h, CellDesign)
     typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;  // ds_read / ds_write instead of flat accesses
-    LdsWork* const Wk = CELL ? (LdsWork*)A.cell_ws : nullptr;
-    const int32_t* const cell_of = CELL ? A.cells->cell_of : nullptr;
+    LdsWork* const Wk = CELL ? (LdsWork*)A.cell->ws : nullptr;
+    const int32_t* const cell_of = CELL ? A.cell->D.cell_of : nullptr;
     if (CELL && cr_reg) {
         for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) { Wk->acc[0][c] = 0.0; Wk->acc[1][c] = 0.0; }
         Wv::sync();
@@ -326,7 +332,7 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         if constexpr (CELL) {
             // entry-parallel: lane e owns entry e of X^T W X (and of X^T dW X) and walks the cells
             Wv::sync();
-            const CellDesign& D = *A.cells;
+            const CellDesign& D = A.cell->D;
             const auto XXg = DSQ_AS_LDS(double, D.XX);  // the kernel stages the cells' tables in LDS
             for (int e = Wv::lane(); e < T; e += Wv::W) {
                 double me = 0.0, de = 0.0;
@@ -449,15 +455,14 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
                                double alpha_hat, double min_disp, double max_disp,
                                double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
                                const double* cst_in = nullptr, double* cst_out = nullptr,
-                               int memo_blocks = 1, const CellDesign* cells = nullptr, void* cell_ws = nullptr) {
+                               int memo_blocks = 1, const CellCtx* cell = nullptr) {
     // PAD rows are LDS-staged; the in-place grid search evaluates with PAD = false (global rows)
     static_assert(!(RUN_GRID && PAD), "the in-place grid search expects un-staged rows");
     AlphaArgs A;
     A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = log(alpha_hat);
     A.prior_var = prior_var;
-    A.cr_reg = cr_reg; A.prior_reg = prior_reg;
-    A.cells = cells; A.cell_ws = cell_ws;
+    A.cell = cell;
     // the constant depends on (y, mu) only: the MAP fit re-uses the one the MLE fit stored
     DSQ_PHASE(1);
     A.cst = cst_in != nullptr ? *cst_in : alpha_const<Wv>(y, mu, N);
@@ -478,7 +483,7 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     o.nfev = m.nfev; o.nit = m.it; o.status = m.status;
     o.alpha = exp(m.x);
     if (RUN_GRID && !m.success) {
-        A.cells = nullptr;  // the (rare) grid search runs the general evaluation
+        A.cell = nullptr;  // the (rare) grid search runs the general evaluation
         o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
     }
     return o;
@@ -490,7 +495,7 @@ DSQ_HD double grid_alpha_gene(const int32_t* y, const double* mu, const double* 
                               double min_disp, double max_disp) {
     AlphaArgs A;
     A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
-    A.la_hat = 0.0; A.prior_var = 1.0; A.cr_reg = true; A.prior_reg = false;
+    A.la_hat = 0.0; A.prior_var = 1.0;
     A.cst = alpha_const<Wv>(y, mu, N);
     return exp(grid_fit_alpha<Wv, P>(A, log(min_disp), log(max_disp)));
 }

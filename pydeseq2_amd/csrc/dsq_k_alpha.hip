@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     // the (wave-uniform) optimiser state lives in LDS, not in every lane's registers
     __shared__ Lbfgsb1d machine[kWavesPerBlock];
     __shared__ typename std::conditional<CELL, CellWork<P>, char>::type cellw[kWavesPerBlock];
+    __shared__ CellCtx cellctx[kWavesPerBlock];
     extern __shared__ __attribute__((aligned(16))) double stage[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
         g_ph_cur[w] = 0;
     }
 #endif
+    if (CELL && (threadIdx.x & 63) == 0) {
+        cellctx[w].D = ex.cells;
+        cellctx[w].ws = (void*)&cellw[w];
+    }
     const int32_t* yg = y + (size_t)g * ldn;
     const double* mg = mu + (size_t)g * ldn;
     int maxc = 0;
@@ -126,8 +131,7 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     const AlphaOut o = fit_alpha_gene<DeviceWave, P, false, STAGE, CELL>(
         yg, mg, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var, cr_reg != 0, prior_reg != 0, machine[w],
         const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
-        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks, CELL ? &ex.cells : nullptr,
-        CELL ? (void*)&cellw[w] : nullptr);
+        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks, CELL ? &cellctx[w] : nullptr);
     if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
     const int g = grid_list[k];
     AlphaArgs A;
     A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
-    A.la_hat = 0.0; A.prior_var = 1.0; A.cr_reg = true; A.prior_reg = false;
+    A.la_hat = 0.0; A.prior_var = 1.0;
     A.cst = alpha_const<DeviceWave>(A.y, A.mu, N);
     // the count memo of alpha_eval covers 64 * NB counts and relies on its caller to pick NB from the gene's
     // largest count (as k_alpha does); NB = 1 for a gene with counts >= 64 reads other counts' memo entries

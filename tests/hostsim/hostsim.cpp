@@ -78,7 +78,7 @@ int hs_grid_alpha(const int32_t* y, const double* mu, int ldn, const double* Xt,
     DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
         AlphaArgs A;
         A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
-        A.la_hat = 0; A.prior_var = 1; A.cr_reg = true; A.prior_reg = false;
+        A.la_hat = 0; A.prior_var = 1;
         A.cst = alpha_const<HostWave>(A.y, A.mu, N);
         log_alpha[g] = grid_fit_alpha<HostWave, P>(A, log(min_disp), log(max_disp));
     })
@@ -123,10 +123,11 @@ int hs_alpha_mle_cell(const int32_t* y, const double* mu, int ldn, const double*
     CellDesign D{cell_of, Xc, XX, C};
     DSQ_DISPATCH_P(P_, {
         static CellWork<P> Wk;
+        CellCtx cctx{D, (void*)&Wk};
         for (int g = 0; g < G; ++g) {
             AlphaOut o = fit_alpha_gene<HostWave, P, false, false, true>(
                 y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var,
-                cr_reg != 0, prior_reg != 0, mach, nullptr, nullptr, 1, &D, (void*)&Wk);
+                cr_reg != 0, prior_reg != 0, mach, nullptr, nullptr, 1, &cctx);
             alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
         }
     })
@@ -386,7 +387,7 @@ int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx,
     DSQ_DISPATCH_P(P_, {
         AlphaArgs A;
         A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N; A.la_hat = la_hat;
-        A.prior_var = prior_var; A.cr_reg = cr_reg; A.prior_reg = prior_reg;
+        A.prior_var = prior_var;
         A.cst = alpha_const<HostWave>(y, mu, N);
         alpha_eval<HostWave, P, true>(A, la, cr_reg != 0, prior_reg != 0, *f, *g);
     })

@@ -520,7 +520,13 @@ def fit_parametric_trend(genewise_nz: np.ndarray, normed_means_nz: np.ndarray, g
     n_it = 0
     while (coeffs > 1e-10).all() and (np.log(np.abs(coeffs / old)) ** 2).sum() >= 1e-6:
         old = coeffs
-        coeffs, pred, conv = (glm or trend_gamma_glm)(cov_all[sel], genewise_nz[sel])
+        if glm is not None:  # a plugged-in Inference gets pandas Series, as dds.py:1212-1245 passes them
+            import pandas as pd
+
+            coeffs, pred, conv = glm(pd.Series(cov_all[sel]), pd.Series(genewise_nz[sel]))
+            pred = np.asarray(pred)
+        else:
+            coeffs, pred, conv = trend_gamma_glm(cov_all[sel], genewise_nz[sel])
         coeffs = np.asarray(coeffs)
         n_it += 1
         if not conv or (coeffs <= 1e-10).any():

@@ -109,22 +109,22 @@ DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double
 #else
 #define DSQ_EVAL_FN inline
 #endif
-// -DDSQ_EVAL_BYVAL (an experiment prepared for an A/B run on the GPU, off by default): the argument struct
-// and the two results travel in registers instead of through the caller's stack frame, which removes the
-// 12 flat scratch loads and 6 stores at the function's entry and exit.  The default build preprocesses to
-// exactly the code that was validated.
-#if defined(DSQ_EVAL_BYVAL)
+// The evaluation is an out-of-line function per (P, memo size, cell mode) for narrow designs - one inlined kernel
+// spilled at the 168-register budget of 3 waves/SIMD - whose argument struct (16 dwords) and two results travel in
+// registers.  The cell-path evaluation of P >= DSQ_EVAL_INLINE_MIN_P is inlined: at those widths the callee touches
+// most of the callee-saved VGPRs (v40-47, v56-63, ...) and its prologue / epilogue saved and restored 61 of them
+// through scratch on EVERY call (rocprofv3: 4.9 GB of WRITE_SIZE per k_alpha<8, cells> launch against 0.5 MB
+// algorithmic; same run time either way - the scratch stays in L2/MALL).  The general wide evaluation stays out of
+// line: inlined it is 16 % slower at N = 5000 (register allocation of the p(p+1) accumulators).
+#ifndef DSQ_EVAL_INLINE_MIN_P
+#define DSQ_EVAL_INLINE_MIN_P 7
+#endif
 struct EvalOut {
     double f, g;
 };
 template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
-DSQ_EVAL_FN EvalOut alpha_eval_v(const AlphaArgs A, double la, bool cr_reg, bool prior_reg) {
+DSQ_HD EvalOut alpha_eval_body(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg) {
     double f, g;
-#else
-template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
-DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f,
-                       double& g) {
-#endif
     constexpr int T = Tri<P>::N;
     constexpr bool kSplitDM = P >= 9 && !CELL;
     DSQ_PHASE(2);
@@ -368,19 +368,22 @@ DSQ_EVAL_FN void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool pri
         f += dl * dl / (2.0 * A.prior_var);
         if (GRAD) g += dl / A.prior_var;
     }
-#if defined(DSQ_EVAL_BYVAL)
     return EvalOut{f, g};
-#endif
 }
 
-#if defined(DSQ_EVAL_BYVAL)
+template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
+DSQ_EVAL_FN EvalOut alpha_eval_v(const AlphaArgs A, double la, bool cr_reg, bool prior_reg) {
+    return alpha_eval_body<Wv, P, GRAD, PAD, NB, CELL>(A, la, cr_reg, prior_reg);
+}
+
 template <class Wv, int P, bool GRAD, bool PAD = false, int NB = 1, bool CELL = false>
 DSQ_HD void alpha_eval(const AlphaArgs& A, double la, bool cr_reg, bool prior_reg, double& f, double& g) {
-    const EvalOut o = alpha_eval_v<Wv, P, GRAD, PAD, NB, CELL>(A, la, cr_reg, prior_reg);
+    EvalOut o;
+    if constexpr (P >= DSQ_EVAL_INLINE_MIN_P && CELL) o = alpha_eval_body<Wv, P, GRAD, PAD, NB, CELL>(A, la, cr_reg, prior_reg);
+    else o = alpha_eval_v<Wv, P, GRAD, PAD, NB, CELL>(A, la, cr_reg, prior_reg);
     f = o.f;
     g = o.g;
 }
-#endif
 
 // numpy.linspace(lo, hi, num)[i]
 DSQ_HD double linspace_at(double lo, double hi, int num, int i) {

@@ -382,10 +382,8 @@ class DistDeseqPipeline(DeseqPipeline):
 
     def __init__(self, counts, design_matrix, *, comm, sample_shard=None, **kw):
         super().__init__(counts, design_matrix, **kw)
-        if self.size_factors_fit_type == "iterative":
-            raise NotImplementedError("the gene-sharded pipeline implements the median-of-ratios size factors "
-                                      "('ratio', 'poscounts', control genes); the iterative mode is single-GPU")
         self.comm = comm
+        self._gene_counts = {}
         self._gathered = None
         # ranks may own different numbers of genes: the gathered vectors are padded to the largest shard
         d_g = self._pooled_once((1,), np.float64, float(self.G))
@@ -412,6 +410,25 @@ class DistDeseqPipeline(DeseqPipeline):
     def _pool_reset(self):
         super()._pool_reset()
         self._gathered = None  # the gathered trend inputs lived in the recycled buffers
+
+    def _all_genes_host(self, d_vec, n):
+        """The ranks' per-gene vectors concatenated in rank order (iterative size factors: the trimmed mean of the
+        dispersions and the objective's quantile / sum run over the genes of all ranks, dds.py:1460-1548).  One
+        all-gather of Gpad doubles per call; the ranks' lengths are exchanged once per distinct local length."""
+        W, G = self.comm.world, self.Gpad
+        if n not in self._gene_counts:
+            d_n = self._pooled_once((1,), np.float64, float(n))
+            d_all_n = DeviceArray(self.ctx, (W,), np.float64)
+            self.comm.allgather(d_n, d_all_n)
+            self._gene_counts[n] = d_all_n.to_host().astype(int)
+        sizes = self._gene_counts[n]
+        if getattr(self, "_agh", None) is None:  # called once per objective evaluation: two persistent buffers
+            self._agh = (DeviceArray(self.ctx, (G,), np.float64), DeviceArray(self.ctx, (G * W,), np.float64))
+        d_send, d_all = self._agh
+        self.ctx.call("dsq_d2d", _vp(d_send.ptr), _vp(d_vec.ptr), C.c_size_t(8 * n))
+        self.comm.allgather(d_send, d_all)
+        allv = self._down(d_all, G * W).reshape(W, G)
+        return np.concatenate([allv[r, : sizes[r]] for r in range(W)])
 
     def _pooled_once(self, shape, dtype, value):
         arr = DeviceArray(self.ctx, shape, dtype)

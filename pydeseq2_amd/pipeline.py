@@ -261,6 +261,11 @@ class DeseqPipeline:
         """Mask of genes with at least one count (cached by deseq2() before the iterative size factors)."""
         return self._nz_cache
 
+    def _all_genes_host(self, d_vec, n):
+        """Host copy of a per-gene device vector over ALL genes of the data set (the gene-sharded pipeline
+        concatenates the ranks' vectors; here: this pipeline's n genes)."""
+        return self._down(d_vec, n)
+
     def _down(self, darr, n, dtype=np.float64):
         out = np.empty(int(n), dtype=dtype)
         if n:
@@ -539,9 +544,6 @@ class DeseqPipeline:
         if size_factors is not None:
             if isinstance(size_factors, str):
                 from .sizefactors import iterative_size_factors
-
-                if type(self) is not DeseqPipeline:
-                    raise NotImplementedError("iterative size factors are not built for the gene-sharded pipeline")
 
                 self._nz_cache = self._down(d_nz, G, np.uint8).astype(bool)
                 size_factors = iterative_size_factors(self)

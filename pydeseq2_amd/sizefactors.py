@@ -27,7 +27,10 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
     from .pipeline import DeseqPipeline, DeseqResult
 
     ctx, N, G = pipe.ctx, pipe.N, pipe.G
-    p1 = DeseqPipeline.__new__(DeseqPipeline)  # intercept-only twin sharing the device-resident counts
+    # intercept-only twin sharing the device-resident counts; of the pipeline's own class: on a gene shard the
+    # cross-gene steps (trimmed mean of the dispersions, prior, the objective's quantile and sum) then run over the
+    # genes of ALL ranks (`_all_genes_host`, `_prior`), and every rank walks the same Powell search
+    p1 = type(pipe).__new__(type(pipe))
     p1.__dict__.update(pipe.__dict__)
     from ._design import DesignPack
 
@@ -64,7 +67,7 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
             ctx.call("dsq_dev_alpha_mle", _vp(d_y.ptr), _vp(d_mu.ptr), p1.ldn, _vp(p1.d_Xt.ptr), p1.design.ldx, N, Gn, 1,
                      _vp(S["mom"].ptr), c_double(p1.min_disp), c_double(p1.max_disp), c_double(1.0), 1, 0,
                      _vp(S["gw"].ptr), _vp(S["gconv"].ptr), None, _vp(mh.nll_const.ptr), 1)
-            gw = np.clip(p1._down(S["gw"], Gn), p1.min_disp, p1.max_disp)
+            gw = np.clip(p1._all_genes_host(S["gw"], Gn), p1.min_disp, p1.max_disp)
             use = gw > 10 * p1.min_disp
             if not use.any():
                 print("No genes have a dispersion above 10 * min_disp in iterative size factors.", file=sys.stderr)
@@ -80,14 +83,13 @@ def iterative_size_factors(pipe, niter: int = 10, quant: float = 0.95) -> np.nda
             d_cst, d_nll, d_scale = p1._dvec(Gn), p1._dvec(Gn), p1._dvec(N)
             ctx.call("dsq_dev_nll_const", _vp(d_y.ptr), p1.ldn, N, Gn, _vp(S["disp"].ptr), _vp(d_cst.ptr))
             old_sf = sf.copy()
-            nll = np.empty(Gn)
 
             def objective(p):
                 s = np.exp(p - np.mean(p))
                 ctx.h2d(d_scale.ptr, np.ascontiguousarray(s / old_sf))
                 ctx.call("dsq_dev_nll_scaled", _vp(d_y.ptr), _vp(d_mu.ptr), p1.ldn, N, Gn, _vp(S["disp"].ptr),
                          _vp(d_scale.ptr), _vp(d_cst.ptr), _vp(d_nll.ptr))
-                ctx.d2h(nll, d_nll.ptr)
+                nll = p1._all_genes_host(d_nll, Gn)
                 return np.sum(nll[nll < np.quantile(nll, quant)])
 
             res = minimize(objective, np.log(old_sf), method="Powell")

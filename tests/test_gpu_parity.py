@@ -422,7 +422,7 @@ def test_distributed_pipeline_world1_equals_single():
     comm.close()
 
 
-@pytest.mark.parametrize("sf_mode", ["ratio", "poscounts+control", "ratio-sample-shard"])
+@pytest.mark.parametrize("sf_mode", ["ratio", "poscounts+control", "ratio-sample-shard", "iterative"])
 def test_distributed_pipeline_two_ranks_threads(sf_mode):
     """Two gene shards run as two ranks (threads, one context each on the same GPU) through
     DistDeseqPipeline with a host-staged communicator: every rank must reproduce its slice of the
@@ -435,12 +435,18 @@ def test_distributed_pipeline_two_ranks_threads(sf_mode):
     from pydeseq2_amd.distributed import DistDeseqPipeline
 
     G, N, W = 1400, 40, 2
+    if sf_mode == "iterative":  # the Powell search over N log size factors: keep it small
+        G, N = 420, 10
     counts, X = orc.synth_counts(G, N, "2level", 11)
     counts[:, 3] = 0  # a gene without counts in rank 0's shard: its vectors are NaN padded
-    cuts = [0, 600, G]  # unequal shards: the gathered vectors are padded to the larger one
+    cuts = [0, 600 if G > 1000 else 180, G]  # unequal shards: the gathered vectors are padded to the larger one
     kw_full, kw_rank = {}, [{}, {}]
     n_collectives = [0] * W
-    if sf_mode == "ratio-sample-shard":  # the two-collective size-factor protocol (sample blocks of all genes)
+    if sf_mode == "iterative":
+        # every gene gets a zero: the median-of-ratios factors are NaN on every rank and both the single-GPU and
+        # the sharded pipeline switch to the iterative mode by themselves (dds.py:682-690)
+        counts[np.arange(G) % N, np.arange(G)] = 0
+    elif sf_mode == "ratio-sample-shard":  # the two-collective size-factor protocol (sample blocks of all genes)
         from pydeseq2_amd.distributed import sample_block
 
         kw_rank = [dict(sample_shard=counts[slice(*sample_block(r, W, N))]) for r in range(W)]
@@ -497,11 +503,12 @@ def test_distributed_pipeline_two_ranks_threads(sf_mode):
 
     ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
     [t.start() for t in ts]
-    [t.join(120) for t in ts]
+    [t.join(600) for t in ts]
     assert not errs, errs
     # collectives per step + 1 at construction: radix protocol 1 + 8 all-reduces, sample-shard protocol 2 all-gathers;
     # trend inputs 2 all-gathers in both
-    assert n_collectives[0] == (1 + 2 + 2 if sf_mode == "ratio-sample-shard" else 1 + 9 + 2), n_collectives
+    if sf_mode != "iterative":
+        assert n_collectives[0] == (1 + 2 + 2 if sf_mode == "ratio-sample-shard" else 1 + 9 + 2), n_collectives
     for rank in range(W):
         sl = slice(cuts[rank], cuts[rank + 1])
         r = out[rank]

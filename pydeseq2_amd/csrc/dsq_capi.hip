@@ -35,6 +35,9 @@ struct dsq_ctx {
     size_t lsf_cap = 0;
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
+    void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
+    size_t ws_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -70,6 +73,19 @@ hipError_t ensure_list(dsq_ctx* c, size_t n) {
     c->list_cap = 0;
     hipError_t e = hipMalloc((void**)&c->d_list, n * sizeof(int32_t));
     if (e == hipSuccess) c->list_cap = n;
+    return e;
+}
+
+// grow-only device workspace (a hipMalloc / hipFree pair per call costs tens of microseconds and the free
+// synchronises the device: the grid-search pass runs in EVERY full-size dispersion launch)
+hipError_t ensure_ws(dsq_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_cap) return hipSuccess;
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    c->d_ws = nullptr;
+    c->ws_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    hipError_t e = hipMalloc(&c->d_ws, cap);
+    if (e == hipSuccess) c->ws_cap = cap;
     return e;
 }
 
@@ -216,33 +232,40 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
                               prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
                               d_nll_const, const_mode, extras));
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
-    int32_t n_grid = 0;
-    DSQ_HIP(hipMemcpyAsync(&n_grid, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t* h_cnt = ctx->h_pin + 1;
+    DSQ_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     DSQ_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->evk0, ctx->evk1));
+    const int32_t n_grid = *h_cnt;
     ctx->last_n_grid = n_grid;
     if (n_grid > 0) {
-        DevBuf work, ysub, musub, idx;
-        DSQ_HIP(work.alloc((size_t)n_grid * 102 * sizeof(double)));
-        if (extras != nullptr && extras->coef != nullptr) {
+        // everything below is stream-ordered behind the launch above and ahead of whatever the caller enqueues
+        // next: no host synchronisation, no allocation (workspace carved from ctx->d_ws)
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const bool rebuild = extras != nullptr && extras->coef != nullptr;
+        const size_t b_work = up((size_t)n_grid * 102 * sizeof(double));
+        const size_t b_y = rebuild ? up((size_t)n_grid * ldn * sizeof(int32_t)) : 0;
+        const size_t b_mu = rebuild ? up((size_t)n_grid * ldn * sizeof(double)) : 0;
+        const size_t b_idx = rebuild ? up((size_t)n_grid * sizeof(int32_t)) : 0;
+        const size_t b_a = rebuild ? up((size_t)n_grid * sizeof(double)) : 0;
+        DSQ_HIP(ensure_ws(ctx, b_work + b_y + b_mu + b_idx + b_a));
+        char* w = (char*)ctx->d_ws;
+        double* work = (double*)w;
+        if (rebuild) {
             // no N x G mu_hat exists: rebuild the rows of the (few) fallback genes, compacted, and run the grid on them
-            DSQ_HIP(ysub.alloc((size_t)n_grid * ldn * sizeof(int32_t)));
-            DSQ_HIP(musub.alloc((size_t)n_grid * ldn * sizeof(double)));
-            DSQ_HIP(idx.alloc((size_t)n_grid * sizeof(int32_t)));
-            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub.as<int32_t>()));
+            int32_t* ysub = (int32_t*)(w + b_work);
+            double* musub = (double*)(w + b_work + b_y);
+            int32_t* idx = (int32_t*)(w + b_work + b_y + b_mu);
+            double* asub = (double*)(w + b_work + b_y + b_mu + b_idx);
+            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub));
             DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
-                                             ctx->d_list, n_grid, musub.as<double>(), ldn, idx.as<int32_t>()));
-            DevBuf asub;
-            DSQ_HIP(asub.alloc((size_t)n_grid * sizeof(double)));
-            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub.as<int32_t>(), musub.as<double>(), ldn, d_Xt, ldx, N, P,
-                                           min_disp, max_disp, asub.as<double>(), idx.as<int32_t>(), n_grid,
-                                           work.as<double>()));
-            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub.as<double>(), ctx->d_list, n_grid, 1, d_alpha));
-            DSQ_HIP(hipStreamSynchronize(ctx->stream));
+                                             ctx->d_list, n_grid, musub, ldn, idx));
+            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub, musub, ldn, d_Xt, ldx, N, P, min_disp, max_disp, asub,
+                                           idx, n_grid, work));
+            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub, ctx->d_list, n_grid, 1, d_alpha));
         } else {
             DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
-                                           ctx->d_list, n_grid, work.as<double>()));
-            DSQ_HIP(hipStreamSynchronize(ctx->stream));
+                                           ctx->d_list, n_grid, work));
         }
     }
     return DSQ_OK;
@@ -266,6 +289,7 @@ int dsq_create(int device_id, dsq_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->evk1);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch, kScratchBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pin, 16384, hipHostMallocDefault);
     if (e != hipSuccess) {
         fprintf(stderr, "dsq_create: %s\n", hipGetErrorString(e));
         delete ctx;
@@ -281,6 +305,8 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_list) (void)hipFree(ctx->d_list);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
     if (ctx->d_sum) (void)hipFree(ctx->d_sum);
@@ -523,14 +549,14 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
                              d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
-    int32_t n_fb = 0;
-    DSQ_HIP(hipMemcpyAsync(&n_fb, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t* h_cnt = ctx->h_pin;
+    DSQ_HIP(hipMemcpyAsync(h_cnt, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (n_fb > 0) {
+    const int32_t n_fb = *h_cnt;
+    if (n_fb > 0) {  // stream-ordered ahead of the caller's next work: no second synchronisation
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
                                         d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras));
-        DSQ_HIP(hipStreamSynchronize(ctx->stream));
     }
     return DSQ_OK;
 }
@@ -638,9 +664,16 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
     if (h_ridge != nullptr) {
         double* d_ridge = ctx->d_scratch + 16;
         double* d_contrast = d_ridge + DSQ_MAX_P * DSQ_MAX_P;
-        DSQ_HIP(hipMemcpyAsync(d_ridge, h_ridge, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        DSQ_HIP(hipMemcpyAsync(d_contrast, h_contrast, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        DSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host arrays may be temporaries of the caller
+        // via page-locked memory: the caller's arrays may be temporaries, and a pageable source would make the
+        // copy (and the launch behind it) wait for the host
+        // (stream-ordered: a rescue kernel of the previous call may still be reading them; the slot itself is free
+        // again because every call ends behind a synchronisation that follows its copies)
+        double* h_stage = (double*)(ctx->h_pin + 16);
+        std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
+        std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
+        DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DSQ_HIP(hipMemcpyAsync(d_contrast, h_stage + P * P, (size_t)P * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
         ex.ridge = d_ridge; ex.contrast = d_contrast; ex.lfc_null = lfc_null; ex.alt = alt;
         ex.pvals = d_pvals; ex.stats = d_stats; ex.se = d_se;
     }

@@ -185,11 +185,10 @@ DSQ_HD double cell_select(int cell, const double (&v)[CS]) {
     return r;
 }
 
-template <class Wv, int P>
+template <class Wv, int P, int CS>
 DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, double& S,
-                          double (&M)[Tri<P>::N], double (&r)[P], double (&e_c)[kSmallCells]) {
+                          double (&M)[Tri<P>::N], double (&r)[P], double (&e_c)[CS]) {
     constexpr int T = Tri<P>::N;
-    constexpr int CS = kSmallCells;
     const CellDesign& D = *A.cells;
     const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
     const auto XX_ = DSQ_AS_LDS(double, D.XX);
@@ -251,11 +250,10 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
     }
 }
 
-template <class Wv, int P>
+template <class Wv, int P, int CS>
 DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&M)[Tri<P>::N],
-                           const double (&e_c)[kSmallCells], double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
+                           const double (&e_c)[CS], double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
     constexpr int T = Tri<P>::N;
-    constexpr int CS = kSmallCells;
     const bool want_cooks = E != nullptr && E->flags != nullptr;
     const bool want_wald = E != nullptr && E->ridge != nullptr;
     if (mu_out == nullptr && H_out == nullptr && !want_cooks && !want_wald) return;
@@ -553,7 +551,8 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
 
 // beta (out), mu_out[N] = UNclamped sf*exp(X beta), H_out[N] hat diagonal (either may be null).
 // When IRLS diverges nothing is written and out.fallback = 1.
-// CELL: 0 general design, 1 per-cell sums in LDS (5 .. 64 cells), 2 per-cell sums in registers (<= kSmallCells)
+// CELL: 0 general design, 1 per-cell sums in LDS (5 .. 64 cells), 2 per-cell sums in registers (<= kSmallCells),
+// 3 the same for at most two cells (the two-group comparison: half the selects and accumulators per sample)
 template <class Wv, int P, int CELL = 0>
 DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, double* H_out,
                          LfcEpilogue* E = nullptr) {
@@ -566,11 +565,12 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     irls_init<Wv, P>(A, a, beta, cst);
     const double nlogterm = A.N * a * log(A.disp);
     double M[T], r[P], S;
-    double e_c[kSmallCells];  // CELL == 2: exp(x_c . beta) of the last sweep
+    constexpr int CS = CELL == 3 ? 2 : kSmallCells;
+    double e_c[CS];  // CELL == 2, 3: exp(x_c . beta) of the last sweep
     auto sweep = [&]() {
         DSQ_PHASE(2);
         if constexpr (CELL == 1) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
-        else if constexpr (CELL == 2) irls_sweep_cs<Wv, P>(A, beta, a, S, M, r, e_c);
+        else if constexpr (CELL >= 2) irls_sweep_cs<Wv, P, CS>(A, beta, a, S, M, r, e_c);
         else irls_sweep<Wv, P>(A, beta, a, S, M, r);
         DSQ_PHASE(5);
     };
@@ -606,7 +606,7 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     out.iters = i;
     DSQ_PHASE(6);
     if constexpr (CELL == 1) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
-    else if constexpr (CELL == 2) irls_finish_cs<Wv, P>(A, beta, M, e_c, mu_out, H_out, E);
+    else if constexpr (CELL >= 2) irls_finish_cs<Wv, P, CS>(A, beta, M, e_c, mu_out, H_out, E);
     else irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);
     return out;
 }

@@ -252,9 +252,15 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
             if constexpr (P <= 4) {
                 const size_t tables = (size_t)ex.cells.C * (Tri<P>::N + P) * sizeof(double);
                 const int stage = allow_stage && tables + stage_bytes <= 48 * 1024;
-                hipLaunchKernelGGL((k_irls<P, 2>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn, sf,
-                                   lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                   maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
+                if (ex.cells.C <= 2 && P <= 2)
+                    hipLaunchKernelGGL((k_irls<(P <= 2 ? P : 1), 3>), grid, block, tables + (stage ? stage_bytes : 0),
+                                       st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol,
+                                       min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex,
+                                       stage);
+                else
+                    hipLaunchKernelGGL((k_irls<P, 2>), grid, block, tables + (stage ? stage_bytes : 0), st, y, ldn,
+                                       sf, lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta,
+                                       max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
             }
         })
     } else if (ex.cells.C > kSmallCells && P_ >= 3) {

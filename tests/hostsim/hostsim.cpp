@@ -164,7 +164,10 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
             IrlsOut o;
             if (C > kSmallCells) o = irls_gene<HostWave, P, 1>(A, b, mo, ho, &E);
             else if (C > 0) {
-                if constexpr (P <= 4) o = irls_gene<HostWave, P, 2>(A, b, mo, ho, &E);
+                if constexpr (P <= 2) {
+                    if (C <= 2) o = irls_gene<HostWave, P, 3>(A, b, mo, ho, &E);
+                    else o = irls_gene<HostWave, P, 2>(A, b, mo, ho, &E);
+                } else if constexpr (P <= 4) o = irls_gene<HostWave, P, 2>(A, b, mo, ho, &E);
                 else return -2;
             } else o = irls_gene<HostWave, P, 0>(A, b, mo, ho, &E);
             if (o.fallback) {

@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel-trace of a few bench steps + idle-gap table (usage through gpurun: bash tools/gpu_gaps.sh <tag> [config])
+set -u
+TAG=${1:-r02_gaps}; CFG=${2:-c3}
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o run -- \
+    python "$REPO/bench.py" --config "$CFG" --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench.log" 2> "$OUT/bench.err"
+cd "$REPO"
+DB=$(find "$OUT/trace" -name "*_results.db" | head -1)
+python tools/rocprof_gaps.py "$DB" 3 > "$OUT/gaps_$CFG.txt" 2>&1
+find "$OUT" -name "*_results.db" -delete
+head -60 "$OUT/gaps_$CFG.txt"

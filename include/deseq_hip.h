@@ -317,7 +317,9 @@ int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, 
  * refitted genes (dds.py:1410-1458). */
 int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1,
                        double* d_fitted);
-int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const double* d_map_raw,
+/* dispersion-outlier rule and final dispersions (dds.py:909-935); the genewise and MAP dispersions are clipped to
+ * [min_disp, max_disp] IN PLACE, as the reference stores them (dds.py:792-794, 905-907). */
+int dsq_dev_select_dispersions(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw,
                                const double* d_fitted, int n, double min_disp, double max_disp,
                                double squared_logres, double* d_disp, uint8_t* d_outlier);
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,

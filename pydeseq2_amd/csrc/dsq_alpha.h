@@ -268,7 +268,7 @@ DSQ_HD EvalOut alpha_eval_body(const AlphaArgs& A, double la, bool cr_reg, bool 
         }
         const double ma = m * alpha;
         const double r1 = frcp(1.0 + ma);
-        const double L1 = flog1p(ma);
+        const double L1 = flog1p_t(ma, r1);
         accf.add(dl + yv * (L1 - lal) + a * L1);
         if (GRAD) accg += dd + L1 + (yv - m) * alpha * r1;
         if (cr_reg) {

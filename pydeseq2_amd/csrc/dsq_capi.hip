@@ -748,7 +748,7 @@ int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double
     return DSQ_OK;
 }
 
-int dsq_dev_select_dispersions(dsq_ctx* ctx, const double* d_genewise_raw, const double* d_map_raw,
+int dsq_dev_select_dispersions(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw,
                                const double* d_fitted, int n, double min_disp, double max_disp,
                                double squared_logres, double* d_disp, uint8_t* d_outlier) {
     DSQ_HIP(dsq::launch_select_disp(ctx->stream, d_genewise_raw, d_map_raw, d_fitted, n, min_disp, max_disp,

@@ -92,7 +92,7 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
         const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
         const double rmu = frcp(mu);
-        s += (yv + a) * flog(a + mu) - yv * lmu;
+        s += (yv + a) * flog_t(a + mu) - yv * lmu;
         const double w = mu * frcp(1.0 + mu * A.disp);
         const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
         const double wz = w * z;
@@ -148,7 +148,7 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
         const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
         const double rmu = frcp(mu);
-        s += (yv + a) * flog(a + mu) - yv * lmu;
+        s += (yv + a) * flog_t(a + mu) - yv * lmu;
         const double w = mu * frcp(1.0 + mu * A.disp);
         const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
         Wv::cell_add(&Wk.acc[0][cell], w);
@@ -219,7 +219,7 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
         const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
         const double rmu = frcp(mu);
-        s += (yv + a) * flog(a + mu) - yv * lmu;
+        s += (yv + a) * flog_t(a + mu) - yv * lmu;
         const double w = mu * frcp(1.0 + mu * A.disp);
         const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
         const double wz = w * z;
@@ -364,7 +364,7 @@ DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst)
                 // log(y / sf + 0.1) (utils.py:351) with the lean log and a reciprocal (<= 1 ulp each; the sum over
                 // the samples runs in another order than numpy's anyway): the library log + IEEE division here
                 // were a sixth of the kernel
-                const double ly = flog(yv * frcp(A.sf[n]) + 0.1);
+                const double ly = flog_t(yv * frcp(A.sf[n]) + 0.1);
 #pragma unroll
                 for (int j = 0; j < P; ++j) b0[j] += A.pinvXt[j * A.ldx + n] * ly;
             } else {

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     extern __shared__ __attribute__((aligned(16))) double stage[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
+    log_tab_fill();  // the table of flog1p_t (dsq_math.h)
+    if (!CELL) __syncthreads();
     if (CELL) {
         // the cells' tables (outer products and rows, <= 64 x (T + P) doubles) are read by every entry-parallel
         // rebuild of X^T W X: once per workgroup into LDS, behind the rows' staging area
@@ -158,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
                                                             const int32_t* __restrict__ grid_list, int n_grid,
                                                             const double* __restrict__ lohi,
                                                             double* __restrict__ ll) {
+    log_tab_fill();  // the table of flog1p_t (dsq_math.h)
+    __syncthreads();
     const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (w >= n_grid * kGridLen) return;
     const int k = w / kGridLen, i = w % kGridLen;

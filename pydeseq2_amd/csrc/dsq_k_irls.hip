@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
     extern __shared__ __attribute__((aligned(16))) double irls_lds[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
+    log_tab_fill();  // the table of flog_t (dsq_math.h); the barrier below covers it
     double* lds_next = irls_lds;
     if (CELL) {  // the cells' tables once per workgroup into LDS (read by every entry-parallel rebuild)
         constexpr int T = Tri<P>::N;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
         if (CELL) ex.cells.cell_of = s_cell;
         yrow = s_y;
     }
-    if (CELL || stage) __syncthreads();
+    __syncthreads();
     if (g >= G) return;
 #if defined(DSQ_PHASE_TIMING)
     if ((threadIdx.x & 63) == 0) {
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
                                                         int32_t* __restrict__ iters,
                                                         const int32_t* __restrict__ fb_list, int n_fb,
                                                         IrlsExtras ex) {
+    log_tab_fill();  // the table of flog_t (dsq_math.h)
+    __syncthreads();
     int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = k < n_fb;
     if (!live) return;
@@ -202,6 +205,8 @@ __global__ __launch_bounds__(kBlock) void k_irls_layers(const int32_t* __restric
                                                         int ldx, int N, int G, const double* __restrict__ disp,
                                                         const double* __restrict__ beta, double min_mu,
                                                         double* __restrict__ mu, double* __restrict__ hat) {
+    log_tab_fill();  // the table of flog_t (dsq_math.h)
+    __syncthreads();
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (g >= G) return;
     IrlsArgs A;

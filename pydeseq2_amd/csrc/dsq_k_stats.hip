@@ -1188,7 +1188,9 @@ __global__ void k_trend_eval(const double* __restrict__ nm, int n, double a0, do
 
 // final dispersions (dds.py:912-935): MAP value, except for dispersion outliers
 // log(genewise) > log(fitted) + 2 sqrt(squared_logres), which keep the (clipped) genewise value
-__global__ void k_select_disp(const double* __restrict__ gw_raw, const double* __restrict__ map_raw,
+// the genewise and MAP dispersions are clipped IN PLACE (dds.py:792-794, 905-907: the reference stores them clipped):
+// the host then takes the vectors as they come
+__global__ void k_select_disp(double* __restrict__ gw_raw, double* __restrict__ map_raw,
                               const double* __restrict__ fitted, int n, double min_disp, double max_disp,
                               double two_sd, double* __restrict__ disp, uint8_t* __restrict__ outlier) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1198,6 +1200,8 @@ __global__ void k_select_disp(const double* __restrict__ gw_raw, const double* _
     const bool out = log(gw) > log(fitted[i]) + two_sd;
     disp[i] = out ? gw : mp;
     outlier[i] = out ? 1 : 0;
+    if (gw_raw[i] == gw_raw[i]) gw_raw[i] = gw;  // a NaN stays a NaN (numpy.clip), fmax / fmin would replace it
+    if (map_raw[i] == map_raw[i]) map_raw[i] = mp;
 }
 
 // dst[idx[k]][0..width) = src[k][0..width)   (results of the outlier refit back into the full vectors)
@@ -1290,7 +1294,7 @@ hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0,
     hipLaunchKernelGGL(k_trend_eval, dim3((n + 255) / 256), dim3(256), 0, st, nm, n, a0, a1, fitted);
     return hipGetLastError();
 }
-hipError_t launch_select_disp(hipStream_t st, const double* gw_raw, const double* map_raw, const double* fitted,
+hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted,
                               int n, double min_disp, double max_disp, double two_sd, double* disp,
                               uint8_t* outlier) {
     if (n <= 0) return hipSuccess;

@@ -28,6 +28,7 @@ from ._design import DesignPack, pad16
 from ._lib import ALT, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells
 
 import ctypes as C
+import functools
 
 _vp, c_double = C.c_void_p, C.c_double
 
@@ -67,6 +68,14 @@ def _scatter(G, idx, v, fill=np.nan):
     out = np.full(G, fill)
     out[idx] = v
     return out
+
+
+@functools.lru_cache(maxsize=64)
+def _trigamma(x):
+    """polygamma(1, x) (dds.py:882): a constant of the data set's shape, 40 us of scipy per call."""
+    from scipy.special import polygamma
+
+    return float(polygamma(1, x))
 
 
 class _View:
@@ -490,15 +499,13 @@ class DeseqPipeline:
 
     def _prior(self, Gn, d_fit, r):
         """(squared_logres, prior_disp_var) (dds.py:866-884); the two medians run on the device."""
-        from scipy.special import polygamma
-
         d_gw, _ = self._last_gw_dev
         sq = C.c_double()
         d_work = self._dvec(self.ctx.lib.dsq_prior_mad_work_doubles(int(Gn)))
         self._k("prior_mad", Gn, "dsq_dev_prior_mad", _vp(d_gw.ptr), _vp(d_fit.ptr), Gn,
                 c_double(self.min_disp), c_double(self.max_disp), _vp(d_work.ptr), C.byref(sq))
         sq = float(sq.value)
-        return sq, float(np.maximum(sq - polygamma(1, (self.N - self.P) / 2), 0.25))
+        return sq, float(max(sq - _trigamma((self.N - self.P) / 2), 0.25))
 
     # ------------------------------------------------------------------ the pipeline
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False,
@@ -532,10 +539,23 @@ class DeseqPipeline:
         # ---- size factors (dds.py:692-708)
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
         self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
+        spec = None
         if size_factors is None and self.size_factors_fit_type != "iterative":
             d_sf = self._size_factors(d_lm)
-            sf = self._down(d_sf, N)
-            if np.isnan(sf).any():  # dds.py:682-690
+            pred = getattr(self, "_nz_pred", None)
+            if pred is not None and not (profile or stop_after_size_factors or self.time_kernels):
+                # The host needs the size factors only for the result and for the NaN test below, and the non-zero
+                # mask only for the number of genes it compacts to.  Neither changes between two passes over the
+                # same counts: read both back asynchronously, enqueue the genewise stage on the previous pass's mask
+                # and compare once that stage has synchronised anyway (a mismatch re-runs the pass in order).
+                hs = self._host_slab(8 * N + G)
+                ctx.call("dsq_d2h_async", _vp(hs.ptr), _vp(d_sf.ptr), C.c_size_t(8 * N))
+                ctx.call("dsq_d2h_async", _vp(hs.ptr + 8 * N), _vp(d_nz.ptr), C.c_size_t(G))
+                spec = (hs.view(0, N, np.float64), hs.view(8 * N, G, np.uint8))
+                sf = None
+            else:
+                sf = self._down(d_sf, N)
+            if spec is None and np.isnan(sf).any():  # dds.py:682-690
                 warnings.warn("Every gene contains at least one zero, cannot compute log geometric means. "
                               "Switching to iterative mode.", UserWarning, stacklevel=2)
                 size_factors = "iterative"
@@ -553,7 +573,7 @@ class DeseqPipeline:
                         _vp(d_nz.ptr))
             sf = np.ascontiguousarray(size_factors, dtype=np.float64)
             d_sf = self._up(sf)
-        non_zero = self._down(d_nz, G, np.uint8).astype(bool)
+        non_zero = pred.copy() if spec is not None else self._down(d_nz, G, np.uint8).astype(bool)
         r.size_factors, r.non_zero = sf, non_zero
         self.d_sf = d_sf
         if stop_after_size_factors:
@@ -575,6 +595,15 @@ class DeseqPipeline:
 
         # ---- genewise dispersions (dds.py:713-797)
         d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S)
+        if spec is not None:  # the genewise stage has synchronised behind the two read-backs
+            if Gn == 0:
+                ctx.sync()
+            sf = np.array(spec[0])
+            if np.isnan(sf).any() or not np.array_equal(spec[1].view(np.bool_), non_zero):
+                self._nz_pred = None
+                return self.deseq2(contrast, lfc_null, alt_hypothesis, profile, stop_after_trend,
+                                   stop_after_size_factors, size_factors)
+            r.size_factors = sf
         self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
         # the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
         # cells only: they run on a side stream underneath the latency-bound trend / prior kernels that follow
@@ -649,7 +678,9 @@ class DeseqPipeline:
         d_b0, d_d0 = self._dvec(Gn * P), self._dvec(Gn)
         ctx.call("dsq_d2d", _vp(d_b0.ptr), _vp(S["beta"].ptr), C.c_size_t(8 * Gn * P))
         ctx.call("dsq_d2d", _vp(d_d0.ptr), _vp(S["disp"].ptr), C.c_size_t(8 * Gn))
-        self.layers = {"nz_idx": np.arange(G) if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
+        if all_nz and getattr(self, "_arange_G", None) is None:
+            self._arange_G = np.arange(G)
+        self.layers = {"nz_idx": self._arange_G if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
                        "cooks": d_cooks, "_fit": (d_ynz, d_sf, d_b0, d_d0, Gn)}
         t5 = tick(); T["LFC_cooks_wald"] = t5 - t4
         t6 = t5
@@ -712,7 +743,7 @@ class DeseqPipeline:
             out[nzi] = v
             return out
 
-        gw = np.clip(H["gw"], self.min_disp, self.max_disp)  # dds.py:792-794
+        gw = H["gw"]  # clipped to [min_disp, max_disp] on the device (dds.py:792-794; k_select_disp)
         nm, fit, disp, beta = H["nm"], H["fit"], H["disp"], H["beta"]
         if patch is not None or new_zero_nz.any():
             nm, fit = nm.copy(), fit.copy()
@@ -727,9 +758,9 @@ class DeseqPipeline:
         r.genewise_dispersions = full(gw)
         r.genewise_converged = full(H["gconv"].astype(float))
         r.fitted_dispersions = full(fit) if coeffs is not None else np.full(G, r.mean_disp)
-        r.MAP_dispersions = full(np.clip(H["map"], self.min_disp, self.max_disp))
+        r.MAP_dispersions = full(H["map"])  # clipped on the device as well (dds.py:905-907)
         r.MAP_converged = full(H["mconv"].astype(float))
-        r.outlier_genes = full(H["outl"].astype(bool), fill=False)
+        r.outlier_genes = full(H["outl"].view(np.bool_), fill=False)
         r.dispersions = full(disp)
         r.LFC = full(beta)
         r.LFC_converged = full(H["lconv"].astype(float))
@@ -737,9 +768,9 @@ class DeseqPipeline:
         r.refitted = full(refitted_nz, fill=False)
         r.new_all_zeroes = full(new_zero_nz, fill=False)
         # ---- cooks_outlier (dds.py:1066-1110)
-        any_use, any_use_nr = H["any_use"].astype(bool), H["any_use_nr"].astype(bool)
+        any_use, any_use_nr = H["any_use"].view(np.bool_), H["any_use_nr"].view(np.bool_)
         co_nz = np.where(refitted_nz, any_use_nr, any_use) if (self.refit_cooks and refitted_nz.any()) else any_use
-        r.cooks_outlier = full(co_nz & H["few_above"].astype(bool), fill=False)
+        r.cooks_outlier = full(co_nz & H["few_above"].view(np.bool_), fill=False)
         pv, st, se = H["p"], H["stat"], H["se"]
         if new_zero_nz.any():  # ds.py:357-360
             pv, st, se = pv.copy(), st.copy(), se.copy()
@@ -749,6 +780,7 @@ class DeseqPipeline:
         T["total"] = t9 - t0
         if not self.keep_cooks:
             self.layers = {}
+        self._nz_pred = non_zero
         return r
 
     def vst_transform(self, size_factors, trend_coeffs=None, mean_disp=None):

@@ -225,7 +225,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     // designs beyond the register path's width - or, on request, any design without cell structure from
     // DSQ_WIDE_MIN_P columns on - run the LDS / matrix-core kernels (dsq_k_wide.hip)
     if (ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // the dispersion kernels use cells from 5 upwards
-    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0)) {
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()))) {
         if (mu == nullptr) return hipErrorInvalidValue;  // that path reads a materialised mu_hat
         return launch_wide_alpha(st, y, mu, ldn, Xt, ldx, N, G, P_, alpha_hat, min_disp, max_disp, prior_var, cr_reg,
                                  prior_reg, alpha, conv, nfev, nll_const, const_mode,

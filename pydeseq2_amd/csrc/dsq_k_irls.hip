@@ -241,7 +241,7 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     if (G <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
-    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0)) {
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()))) {
         if (ex.cells.C > 0 && ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // (the wide kernels take 5..64 cells)
         return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,
                                 min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, &ex);
@@ -297,7 +297,7 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
     if (n_fb <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
-    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && ex.cells.C == 0))
+    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells())))
         return launch_wide_irls_rescue(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, P_, full_rank, disp, min_mu, beta_tol,
                                        min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, &ex);
     const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);

@@ -407,4 +407,9 @@ int wide_min_p() {
     return v;
 }
 
+bool wide_with_cells() {
+    static const bool v = getenv("DSQ_WIDE_CELLS") != nullptr;
+    return v;
+}
+
 }  // namespace dsq

@@ -23,7 +23,9 @@ inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerB
 constexpr int cell_min_waves(int p) { return p <= 6 ? 3 : DSQ_CELL_WAVES_WIDE; }
 
 // ---- dsq_k_wide.hip: run-time-P kernels (LDS matrices, matrix-core Gram accumulation), P <= 32
-int wide_min_p();  // designs at least this wide take them (default: DSQ_REG_MAX_P + 1)
+int wide_min_p();
+bool wide_with_cells();  // DSQ_WIDE_CELLS=1 (measurements): designs with cells may take the LDS path as well
+  // designs at least this wide take them (default: DSQ_REG_MAX_P + 1)
 struct IrlsExtras;
 hipError_t launch_wide_mom(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt,
                            const double* pinvXt, int ldx, int N, int G, int P, double min_disp, double max_disp,

@@ -61,7 +61,7 @@ template <class Wv, bool GRAD, bool BIG = false>
 DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double& dl, double& dd) {
     if (BIG) {  // caller guarantees yi >= 256: Stirling only, truncated tails
         const double z = (double)yi + a;
-        const double lg = flog(z);
+        const double lg = flog_t(z);
         const double rc = frcp(z);
         dl = lga - ((z - 0.5) * lg - z + kHalfLog2Pi + stirling_tail_big(rc));
         dd = GRAD ? dga - (lg + digamma_tail_big(rc)) : 0.0;
@@ -83,7 +83,7 @@ DSQ_HD void lgamma_digamma_diff(int yi, double a, double lga, double dga, double
     // ONE log and ONE reciprocal serve both branches (each lane needs only its own)
     const double z = (double)yi + a;
     const double arg = small ? prod : z;
-    const double lg = flog(arg);
+    const double lg = flog_t(arg);  // (every kernel that builds the memo has filled the table, dsq_math.h)
     const double rc = frcp(arg);
     if (small) {
         dl = -lg;
@@ -133,9 +133,9 @@ DSQ_HD EvalOut alpha_eval_body(const AlphaArgs& A, double la, bool cr_reg, bool 
     const double a = Wv::uniform(frcp(alpha));
     // log of the ROUNDED alpha: keeps every term a function of the same alpha (using `la` itself
     // would leave an inconsistency of ulp(1) * sum(y) in the loss, i.e. line-search noise)
-    const double lal = Wv::uniform(flog(alpha));
+    const double lal = Wv::uniform(flog_t(alpha));
     double lga, dga;
-    lgamma_digamma<GRAD>(a, lga, dga);
+    lgamma_digamma<GRAD, true>(a, lga, dga);
     lga = Wv::uniform(lga);
     dga = Wv::uniform(dga);
     // Wave-level memo: lane k evaluates the two gamma-function differences for the COUNTS k, k+64,

@@ -336,7 +336,7 @@ DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst)
 #pragma unroll
     for (int j = 0; j < P; ++j) b0[j] = 0.0;
     double lga, dga_unused, tab_dl, tab_dd;
-    lgamma_digamma<false>(a, lga, dga_unused);
+    lgamma_digamma<false, true>(a, lga, dga_unused);
     lgamma_digamma_diff<Wv, false>(Wv::lane(), a, lga, 0.0, tab_dl, tab_dd);
     double c = 0.0;
     for (int base = 0; base < A.N; base += Wv::W) {  // wave-uniform trip count (cross-lane memo reads)

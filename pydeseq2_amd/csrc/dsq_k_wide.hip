@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void k_alpha_wide(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ list) {
     __shared__ Lbfgsb1d machine[kWideMaxWaves];
     extern __shared__ __attribute__((aligned(16))) double wide_lds[];
+    log_tab_fill();  // the count memo takes its logarithms through the LDS table (flog_t, dsq_math.h)
+    __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int k = blockIdx.x * (blockDim.x >> 6) + wv;
     if (k >= G) return;
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(256) void k_alpha_grid_wide(const int32_t* __restri
                                                          double* __restrict__ alpha, const int32_t* __restrict__ list,
                                                          int n_list) {
     extern __shared__ __attribute__((aligned(16))) double wide_lds[];
+    log_tab_fill();  // the count memo takes its logarithms through the LDS table (flog_t, dsq_math.h)
+    __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int k = blockIdx.x * (blockDim.x >> 6) + wv;
     if (k >= n_list) return;

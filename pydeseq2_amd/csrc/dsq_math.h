@@ -50,6 +50,7 @@ __device__ __forceinline__ void phase_mark(int k) {
 namespace dsq {
 
 DSQ_HD double flog(double x);
+DSQ_HD double flog_t(double x);
 DSQ_HD double flog1p(double u);
 DSQ_HD double frcp(double x);
 DSQ_HD double frcp_g(double x);
@@ -95,7 +96,8 @@ DSQ_HD double digamma_tail_big(double rz) {
 
 // lgamma(x) and digamma(x) for x > 0, sharing the upward shift to z >= 10.
 // want_dg == false skips the digamma arithmetic.
-template <bool WANT_DG>
+// TAB: the two logarithms through the LDS table (flog_t: only in kernels that filled it)
+template <bool WANT_DG, bool TAB = false>
 DSQ_HD void lgamma_digamma(double x, double& lg, double& dg) {
     double z = x, prod = 1.0, num = 0.0;
     bool shifted = false;
@@ -106,9 +108,9 @@ DSQ_HD void lgamma_digamma(double x, double& lg, double& dg) {
         shifted = true;
     }
     const double rz = frcp(z);
-    const double lz = flog(z);
+    const double lz = TAB ? flog_t(z) : flog(z);
     lg = (z - 0.5) * lz - z + kHalfLog2Pi + stirling_tail(rz);
-    if (shifted) lg -= flog(prod);
+    if (shifted) lg -= TAB ? flog_t(prod) : flog(prod);
     if (WANT_DG) {
         dg = lz + digamma_tail(rz);
         if (shifted) dg -= num * frcp(prod);

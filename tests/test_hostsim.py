@@ -75,9 +75,11 @@ def test_alpha_mle(case):
     N = k["counts"].shape[0]
     a, c, nfev = hs.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, max(10, N))
     assert (c == k["gw_conv"]).all()
-    # wide designs: the p x p log-det / trace terms carry more rounding, the stopping point moves within
-    # scipy's own loose tolerance (still an order of magnitude inside the 1e-5 parity bar)
-    tol = 1e-7 if k["X"].shape[1] <= 8 else 2e-6
+    # L-BFGS-B stops on scipy's loose defaults (ftol 2.2e-9): the last bits of the loss (logarithms, summation
+    # order) move the stopping point by up to a few 1e-7 relative on individual genes (wide designs, whose
+    # p x p log-det / trace terms carry more rounding: 2e-6) - an order of magnitude inside the 1e-5 parity bar;
+    # the same 1e-6 as the GPU run of these vectors
+    tol = 1e-6 if k["X"].shape[1] <= 8 else 2e-6
     assert_close(a, k["gw_alpha"], tol, 0, "genewise alpha")
     a, c, _ = hs.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["fitted"], 1e-8, max(10, N),
                            prior_var=float(k["prior_var"]), cr_reg=True, prior_reg=True)
@@ -315,7 +317,7 @@ def test_cell_path_matches_the_general_path_and_the_reference(case):
             continue  # the dispersion kernel uses cells from 5 upwards
         ac, cc = hs.alpha_mle_cell(counts, X, mu_hat, start, 1e-8, maxd, **kw)
         assert (cc == cg).all()
-        assert_close(ac, ag, 1e-7, 0, "cell vs general dispersion")
+        assert_close(ac, ag, 1e-6, 0, "cell vs general dispersion")
     if case == "p8":
         assert_close(ac, k["map_alpha"], 1e-6, 0, "cell MAP alpha vs reference")
     disp = np.clip(ag, 1e-8, maxd)

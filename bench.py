@@ -193,7 +193,9 @@ def main():
     # the data-path collectives are RCCL calls the product makes through its C ABI
     control = TcpControl(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                          int(os.environ.get("MASTER_PORT", "29500")))
-    ctx = Context(local_rank)
+    # (DSQ_BENCH_SHARE_GPU=1: every rank on device 0 - exercises the multi-process path on a one-GPU box; RCCL refuses
+    # two ranks on one device, so the job then runs on the host-staged fallback transport)
+    ctx = Context(0 if os.environ.get("DSQ_BENCH_SHARE_GPU") else local_rank)
     info = ctx.device_info()
     seed0 = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config]
     if args.scaling == "strong" and world > 1:

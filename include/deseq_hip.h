@@ -59,6 +59,11 @@ enum dsq_alt { DSQ_ALT_NONE = 0, DSQ_ALT_GREATER_ABS = 1, DSQ_ALT_LESS_ABS = 2,
 
 /* ------------------------------------------------------------------ context */
 int dsq_create(int device_id, dsq_ctx** out);
+/* optimizer of the two per-gene fits that take one in the reference (utils.py:343 irls_solver's rescue,
+ * utils.py:546-554 fit_alpha_mle): 0 = "L-BFGS-B" (the default and the only one dds.py / ds.py use), 1 = "BFGS"
+ * (scipy's unbounded BFGS restated, csrc/dsq_bfgs.h; designs of at most 12 columns, mu_hat given as a matrix).
+ * Sticky per context until set again. */
+int dsq_set_optimizer(dsq_ctx* ctx, int optimizer);
 void dsq_destroy(dsq_ctx* ctx);
 const char* dsq_last_error(const dsq_ctx* ctx);
 /* name (<= name_len bytes), compute units, total device memory, gcnArchName */

@@ -278,8 +278,9 @@ def grid_fit_alpha(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=
 
 
 def alpha_mle_gene(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
-                   cr_reg=True, prior_reg=False, return_info=False):
-    """One gene's dispersion fit by L-BFGS-B in log(alpha) (utils.py:441-564).
+                   cr_reg=True, prior_reg=False, return_info=False, optimizer="L-BFGS-B"):
+    """One gene's dispersion fit by L-BFGS-B (or, optimizer="BFGS", unbounded BFGS) in log(alpha)
+    (utils.py:441-564).
 
     On ``success == False`` the grid search is called with the reference's six
     positional arguments only, i.e. *without* the prior (utils.py:556-564).
@@ -311,8 +312,8 @@ def alpha_mle_gene(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=
         lambda x: loss(x[0]),
         x0=np.asarray([la_hat]),
         jac=lambda x: np.asarray([dloss(x[0])]),
-        method="L-BFGS-B",
-        bounds=[(np.log(min_disp), np.log(max_disp))],
+        method=optimizer,
+        bounds=[(np.log(min_disp), np.log(max_disp))] if optimizer == "L-BFGS-B" else None,
     )
     if res.success:
         out = np.exp(res.x[0])
@@ -324,10 +325,14 @@ def alpha_mle_gene(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=
 
 
 def _alpha_chunk(args):
-    counts, X, mu, ah, min_disp, max_disp, pv, cr, pr = args
-    with np.errstate(all="ignore"):
+    counts, X, mu, ah, min_disp, max_disp, pv, cr, pr = args[:9]
+    opt = args[9] if len(args) > 9 else "L-BFGS-B"
+    import warnings
+
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
         out = [
-            alpha_mle_gene(counts[:, j], X, mu[:, j], ah[j], min_disp, max_disp, pv, cr, pr)
+            alpha_mle_gene(counts[:, j], X, mu[:, j], ah[j], min_disp, max_disp, pv, cr, pr, optimizer=opt)
             for j in range(counts.shape[1])
         ]
     return np.array([o[0] for o in out]), np.array([o[1] for o in out], dtype=bool)
@@ -342,12 +347,12 @@ def _run_chunks(fn, chunks, n_jobs):
 
 
 def alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
-              cr_reg=True, prior_reg=False, n_jobs=1, chunk=256):
+              cr_reg=True, prior_reg=False, n_jobs=1, chunk=256, optimizer="L-BFGS-B"):
     """All genes (default_inference.py:126-161).  Returns (alpha[G], converged[G])."""
     G = counts.shape[1]
     chunks = [
         (counts[:, s:s + chunk], X, mu[:, s:s + chunk], alpha_hat[s:s + chunk], min_disp,
-         max_disp, prior_disp_var, cr_reg, prior_reg)
+         max_disp, prior_disp_var, cr_reg, prior_reg, optimizer)
         for s in range(0, G, chunk)
     ]
     res = _run_chunks(_alpha_chunk, chunks, n_jobs)
@@ -383,8 +388,8 @@ def grid_fit_beta(counts, sf, X, disp, min_mu=0.5, grid_length=60, min_beta=-30,
     return np.array([fx[k[0]], fy[k[1]]])
 
 
-def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta):
-    """L-BFGS-B (+ grid for p<=2) rescue when IRLS diverges (utils.py:374-413)."""
+def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta, optimizer="L-BFGS-B"):
+    """L-BFGS-B (or unbounded BFGS) (+ grid for p<=2) rescue when IRLS diverges (utils.py:374-413)."""
     p = X.shape[1]
     ridge = np.diag(np.repeat(1e-6, p))
 
@@ -396,7 +401,12 @@ def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta):
         mu_ = np.maximum(sf * np.exp(X @ beta), min_mu)
         return -X.T @ counts + ((1 / disp + counts) * mu_ / (1 / disp + mu_)) @ X + ridge @ beta
 
-    res = minimize(f, beta_init, jac=df, method="L-BFGS-B", bounds=[(min_beta, max_beta)] * p)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize(f, beta_init, jac=df, method=optimizer,
+                       bounds=[(min_beta, max_beta)] * p if optimizer == "L-BFGS-B" else None)
     beta = res.x
     if not res.success and p <= 2:
         beta = grid_fit_beta(counts, sf, X, disp)
@@ -404,7 +414,7 @@ def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta):
 
 
 def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=30, maxiter=250,
-         return_iters=False):
+         return_iters=False, optimizer="L-BFGS-B"):
     """NB log-link GLM by IRLS for all genes at once (utils.py:273-438).
 
     Vectorised over genes with a per-gene ``active`` mask so every gene runs
@@ -450,7 +460,7 @@ def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=
             if full_rank:
                 with np.errstate(divide="ignore"):
                     b0 = sp_solve(R, Q.T @ np.log(counts[:, g] / sf + 0.1))
-            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], b0, min_mu, min_beta, max_beta)
+            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], b0, min_mu, min_beta, max_beta, optimizer)
             beta[:, g] = b
             mu[:, g] = np.maximum(sf * np.exp(X @ b), min_mu)
             converged[g] = ok

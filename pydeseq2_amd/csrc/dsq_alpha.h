@@ -11,6 +11,7 @@
 // inverse runs redundantly in every lane (wave-uniform, no LDS round trip needed at
 // these sizes).
 #pragma once
+#include "dsq_bfgs.h"
 #include "dsq_lbfgsb1d.h"
 #include "dsq_lgamma_int.h"
 #include "dsq_linalg.h"
@@ -489,6 +490,34 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
         A.cell = nullptr;  // the (rare) grid search runs the general evaluation
         o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
     }
+    return o;
+}
+
+// optimizer="BFGS" (utils.py:546-554): scipy's unbounded BFGS in log(alpha) from log(alpha_hat); on success = False
+// the same grid search as above.  General evaluation on un-staged rows (not a hot path: no caller in dds.py selects it).
+template <class Wv, int P, bool RUN_GRID>
+DSQ_HD AlphaOut fit_alpha_gene_bfgs(const int32_t* y, const double* mu, const double* Xt, int ldx, int N,
+                                    double alpha_hat, double min_disp, double max_disp, double prior_var,
+                                    bool cr_reg, bool prior_reg, int memo_blocks) {
+    AlphaArgs A;
+    A.y = y; A.mu = mu; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.la_hat = log(alpha_hat);
+    A.prior_var = prior_var;
+    A.cell = nullptr;
+    A.cst = alpha_const<Wv>(y, mu, N);
+    auto fg = [&](const double* x, double& f, double* g) {
+        if (memo_blocks <= 1) alpha_eval<Wv, P, true, false, 1>(A, x[0], cr_reg, prior_reg, f, g[0]);
+        else if (memo_blocks == 2) alpha_eval<Wv, P, true, false, 2>(A, x[0], cr_reg, prior_reg, f, g[0]);
+        else alpha_eval<Wv, P, true, false, 4>(A, x[0], cr_reg, prior_reg, f, g[0]);
+    };
+    BfgsWork<1> W;
+    double x = A.la_hat;
+    const BfgsResult r = bfgs_min<1>(fg, 1, &x, W);
+    AlphaOut o;
+    o.converged = r.success ? 1 : 0;
+    o.nfev = r.nfev; o.nit = r.nit; o.status = r.status;
+    o.alpha = exp(x);
+    if (RUN_GRID && !r.success) o.alpha = exp(grid_fit_alpha<Wv, P>(A, log(min_disp), log(max_disp)));
     return o;
 }
 

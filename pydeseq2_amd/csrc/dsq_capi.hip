@@ -35,6 +35,7 @@ struct dsq_ctx {
     size_t lsf_cap = 0;
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int optimizer = 0;            // dsq_set_optimizer: 0 L-BFGS-B (the reference's default), 1 BFGS
     int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
     size_t ws_cap = 0;
@@ -228,9 +229,18 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     int32_t* d_cnt = ctx->d_counter + 4;
     DSQ_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
-    DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
-                              prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
-                              d_nll_const, const_mode, extras));
+    if (ctx->optimizer == 1) {
+        DSQ_CHECK_ARG(d_mu != nullptr && P <= DSQ_SHRINK_MAX_P,
+                      "optimizer=\"BFGS\" takes mu_hat as a matrix and designs of at most 12 columns");
+        DSQ_HIP(dsq::launch_alpha_bfgs(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp,
+                                       max_disp, prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt,
+                                       ctx->d_list));
+        extras = nullptr;  // (the grid pass below then reads the mu_hat matrix)
+    } else {
+        DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
+                                  prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
+                                  d_nll_const, const_mode, extras));
+    }
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t* h_cnt = ctx->h_pin + 1;
     DSQ_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -296,6 +306,12 @@ int dsq_create(int device_id, dsq_ctx** out) {
         return DSQ_ERR_HIP;
     }
     *out = ctx;
+    return DSQ_OK;
+}
+
+int dsq_set_optimizer(dsq_ctx* ctx, int optimizer) {
+    DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
+    ctx->optimizer = optimizer;
     return DSQ_OK;
 }
 
@@ -537,6 +553,11 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
              double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters,
              const dsq::IrlsExtras* extras) {
     if (G <= 0) return DSQ_OK;
+    dsq::IrlsExtras ex_local{};
+    if (extras != nullptr) ex_local = *extras;
+    ex_local.optimizer = ctx->optimizer;
+    DSQ_CHECK_ARG(ctx->optimizer == 0 || P <= DSQ_SHRINK_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
+    extras = &ex_local;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     if ((size_t)N > ctx->lsf_cap) {
         if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);

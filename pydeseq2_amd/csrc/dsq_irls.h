@@ -14,6 +14,7 @@
 // mu and are computed once per gene.
 #pragma once
 #include "dsq_alpha.h"
+#include "dsq_bfgs.h"
 #include "dsq_lbfgsb.h"
 #include "dsq_linalg.h"
 #include "dsq_stats.h"
@@ -614,7 +615,10 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
 // Workspace of the rescue (wave-private LDS on the device).
 template <int P>
 struct IrlsRescueWork {
-    LbfgsbWork<P> lb;
+    union {
+        LbfgsbWork<P> lb;
+        BfgsWork<P> bf;  // optimizer="BFGS"
+    };
     double x[P], l[P], u[P];
     int nbd[P];
 };
@@ -664,7 +668,7 @@ DSQ_HD void grid_fit_beta2(const IrlsArgs& A, double a, double cst, double (&bet
 // is scipy's res.success.
 template <class Wv, int P>
 DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double (&beta)[P],
-                                double* mu_out, double* H_out, LfcEpilogue* E = nullptr) {
+                                double* mu_out, double* H_out, LfcEpilogue* E = nullptr, int optimizer = 0) {
     constexpr int T = Tri<P>::N;
     IrlsOut out;
     out.converged = 0; out.iters = 0; out.fallback = 1;
@@ -701,12 +705,20 @@ DSQ_HD IrlsOut irls_rescue_gene(const IrlsArgs& A, IrlsRescueWork<P>& Wk, double
         for (int j = 0; j < P; ++j) { pen += 1e-6 * (b[j] * b[j]); g[j] = gr[j] + 1e-6 * b[j]; }
         f = (nlogterm - cst + s) + 0.5 * pen;
     };
-    const LbfgsbResult res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb);
+    bool ok;
+    if (optimizer == 1) {  // scipy's unbounded BFGS (utils.py:389-399 with optimizer="BFGS")
+        const BfgsResult rb = bfgs_min<P>(fg, P, Wk.x, Wk.bf);
+        ok = rb.success;
+        out.iters = rb.nit;
+    } else {
+        const LbfgsbResult res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb);
+        ok = res.success;
+        out.iters = res.nit;
+    }
 #pragma unroll
     for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
-    out.converged = res.success ? 1 : 0;
-    out.iters = res.nit;
-    if (!res.success && P <= 2) {
+    out.converged = ok ? 1 : 0;
+    if (!ok && P <= 2) {
         if constexpr (P == 2) grid_fit_beta2<Wv>(A, a, cst, beta);
     }
     double M[T], r[P], S2;

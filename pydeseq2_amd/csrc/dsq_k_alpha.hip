@@ -213,6 +213,48 @@ __global__ void k_fill_lohi(double* lohi, int n, double lo, double hi) {
     if (k < n) { lohi[2 * k] = lo; lohi[2 * k + 1] = hi; }
 }
 
+// optimizer="BFGS" (utils.py:546-554): one gene per wavefront, rows read from global memory (a plug-in option of
+// fit_alpha_mle that dds.py never selects - kept simple, not tuned)
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_alpha_bfgs(const int32_t* __restrict__ y, const double* __restrict__ mu,
+                                                       int ldn, const double* __restrict__ Xt, int ldx, int N, int G,
+                                                       const double* __restrict__ alpha_hat, double min_disp,
+                                                       double max_disp, double prior_var, int cr_reg, int prior_reg,
+                                                       double* __restrict__ alpha, uint8_t* __restrict__ conv,
+                                                       int32_t* __restrict__ nfev, int32_t* __restrict__ grid_count,
+                                                       int32_t* __restrict__ grid_list) {
+    log_tab_fill();  // the table of flog_t / flog1p_t (dsq_math.h)
+    __syncthreads();
+    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int32_t* yg = y + (size_t)g * ldn;
+    int maxc = 0;
+    for (int n = threadIdx.x & 63; n < N; n += 64) maxc = yg[n] > maxc ? yg[n] : maxc;
+    maxc = DeviceWave::maxi(maxc);
+    const int memo_blocks = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (maxc >> 6) + 1));
+    const AlphaOut o = fit_alpha_gene_bfgs<DeviceWave, P, false>(yg, mu + (size_t)g * ldn, Xt, ldx, N, alpha_hat[g],
+                                                                 min_disp, max_disp, prior_var, cr_reg != 0,
+                                                                 prior_reg != 0, memo_blocks);
+    if ((threadIdx.x & 63) == 0) {
+        alpha[g] = o.alpha;
+        conv[g] = (uint8_t)o.converged;
+        if (nfev != nullptr) nfev[g] = o.nfev;
+        if (!o.converged) grid_list[atomicAdd(grid_count, 1)] = g;
+    }
+}
+
+hipError_t launch_alpha_bfgs(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
+                             int N, int G, int P_, const double* alpha_hat, double min_disp, double max_disp,
+                             double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
+                             int32_t* nfev, int32_t* grid_count, int32_t* grid_list) {
+    if (G <= 0) return hipSuccess;
+    if (P_ > DSQ_REG_MAX_P || mu == nullptr) return hipErrorInvalidValue;
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha_bfgs<P>, dim3(genes_to_blocks(G)), dim3(kBlock), 0, st, y, mu, ldn,
+                                          Xt, ldx, N, G, alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
+                                          alpha, conv, nfev, grid_count, grid_list))
+    return hipGetLastError();
+}
+
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P_, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,

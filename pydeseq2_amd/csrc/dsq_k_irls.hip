@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     double b[P];
     const IrlsOut o = irls_rescue_gene<DeviceWave, P>(A, work[threadIdx.x >> 6], b,
                                                       mu ? mu + (size_t)g * ldn : nullptr,
-                                                      hat ? hat + (size_t)g * ldn : nullptr, &E);
+                                                      hat ? hat + (size_t)g * ldn : nullptr, &E, ex.optimizer);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];

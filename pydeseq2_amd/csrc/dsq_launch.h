@@ -66,6 +66,11 @@ struct AlphaExtras {
     const double* sf;    // while staging instead of being read from `mu` (which may then be null)
     double min_mu;
 };
+// optimizer="BFGS" variant of the dispersion fit (P <= DSQ_REG_MAX_P, mu_hat as a matrix)
+hipError_t launch_alpha_bfgs(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
+                             int N, int G, int P, const double* alpha_hat, double min_disp, double max_disp,
+                             double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
+                             int32_t* nfev, int32_t* grid_count, int32_t* grid_list);
 hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                         int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
@@ -91,6 +96,7 @@ struct IrlsExtras {
     double lfc_null;
     int alt;
     double *pvals, *stats, *se;  // [G]
+    int optimizer;               // rescue of diverged genes: 0 L-BFGS-B (bounded, default), 1 BFGS (utils.py:389-399)
 };
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,

@@ -97,8 +97,6 @@ class HipInference:
         Returns (beta G x p, mu N x G, hat diagonals N x G, converged G).
         """
         assert optimizer in ["BFGS", "L-BFGS-B"]
-        if optimizer != "L-BFGS-B":
-            raise NotImplementedError("HipInference implements the bounded (L-BFGS-B) rescue only")
         y, ct, lay = _counts_arg(counts)
         N, G = y.shape
         X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
@@ -106,19 +104,34 @@ class HipInference:
         sf, d = _vec(size_factors), _vec(disp)
         beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
         conv = np.empty(G, dtype=np.uint8)
-        self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
-                      _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
-                      c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
-                      _vp(H.ctypes.data), _vp(conv.ctypes.data))
+        with self._optimizer(optimizer):  # the rescue of diverged genes: bounded L-BFGS-B or scipy's BFGS restated
+            self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
+                          _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
+                          c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
+                          _vp(H.ctypes.data), _vp(conv.ctypes.data))
         return beta, mu.T, H.T, conv.astype(bool)
+
+    def _optimizer(self, name):
+        """Context manager: optimizer="BFGS" for the C calls inside (utils.py:343, 546-554), back to the default after."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if name == "BFGS":
+                self.ctx.call("dsq_set_optimizer", 1)
+            try:
+                yield
+            finally:
+                if name == "BFGS":
+                    self.ctx.call("dsq_set_optimizer", 0)
+
+        return cm()
 
     # ------------------------------------------------------------------ alpha_mle
     def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
                   cr_reg=True, prior_reg=False, optimizer: Literal["BFGS", "L-BFGS-B"] = "L-BFGS-B"):
         """See ``Inference.alpha_mle`` (inference.py:121-178). Returns (alpha G, converged G)."""
         assert optimizer in ["BFGS", "L-BFGS-B"]
-        if optimizer != "L-BFGS-B":
-            raise NotImplementedError("HipInference implements the L-BFGS-B dispersion fit only")
         if prior_reg and prior_disp_var is None:
             raise ValueError("Sigma_prior is required for prior regularization")
         y, ct, lay = _counts_arg(counts)
@@ -127,10 +140,11 @@ class HipInference:
         m, mlay = _matrix_arg(mu)
         ah = _vec(alpha_hat)
         out, conv = np.empty(G), np.empty(G, dtype=np.uint8)
-        self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
-                      mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
-                      c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
-                      int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data))
+        with self._optimizer(optimizer):
+            self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
+                          mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
+                          c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
+                          int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data))
         return out, conv.astype(bool)
 
     # ------------------------------------------------------------------ wald_test

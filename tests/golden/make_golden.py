@@ -251,11 +251,102 @@ def hard_cases(ut, gs):
           "| LFC genes with a failed rescue", len(found))
 
 
+def bfgs_cases(ut):
+    """optimizer="BFGS" of the reference's per-gene kernels (utils.py:343, 389-399, 546-554): kat_bfgs.npz.
+
+    * dispersion: fit_alpha_mle(..., optimizer="BFGS") on the inputs of kat_p2 / kat_p8 (genewise and MAP fits) and on
+      the huge-count genes of kat_hard (unbounded search: several end in "precision loss" -> grid value);
+    * LFC: irls_solver(..., optimizer="BFGS") on genes whose IRLS diverges (a group without counts, a huge outlier,
+      low counts on the 30-cell design): the unbounded BFGS rescue, grid_fit_beta when it fails at p = 2."""
+    import warnings
+
+    out = {}
+    for case in ("p2", "p8"):
+        k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
+        Y, X, mu, mom, fit = k["counts"], k["X"], k["mu_hat"], k["mom"], k["fitted"]
+        N = Y.shape[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r1 = [ut.fit_alpha_mle(Y[:, g], X, mu[:, g], mom[g], 1e-8, max(10, N), optimizer="BFGS")
+                  for g in range(Y.shape[1])]
+            r2 = [ut.fit_alpha_mle(Y[:, g], X, mu[:, g], fit[g], 1e-8, max(10, N), float(k["prior_var"]), True, True,
+                                   optimizer="BFGS") for g in range(Y.shape[1])]
+        out[f"{case}_gw_alpha"] = np.array([r[0] for r in r1])
+        out[f"{case}_gw_conv"] = np.array([r[1] for r in r1], dtype=bool)
+        out[f"{case}_map_alpha"] = np.array([r[0] for r in r2])
+        out[f"{case}_map_conv"] = np.array([r[1] for r in r2], dtype=bool)
+    h = np.load(os.path.join(HERE, "kat_hard.npz"))
+    Y, X, mu, mom = h["a_counts"], h["X"], h["a_mu_hat"], h["a_mom"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = [ut.fit_alpha_mle(Y[:, g], X, mu[:, g], mom[g], 1e-8, 40.0, optimizer="BFGS") for g in range(Y.shape[1])]
+    out["hard_alpha"] = np.array([x[0] for x in r])
+    out["hard_conv"] = np.array([x[1] for x in r], dtype=bool)
+    # ---- LFC rescue with BFGS: p = 2 (the failed-rescue genes of kat_hard + fresh divergent genes) and p = 8
+    sf = h["sf"]
+    Yb, db = h["b_counts"], h["b_disp"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rb = [ut.irls_solver(Yb[:, g], sf, X, db[g], 0.5, 1e-8, optimizer="BFGS") for g in range(Yb.shape[1])]
+    out["b2_beta"] = np.stack([x[0] for x in rb])
+    out["b2_mu"] = np.stack([x[1] for x in rb], axis=1)
+    out["b2_H"] = np.stack([x[2] for x in rb], axis=1)
+    out["b2_conv"] = np.array([x[3] for x in rb], dtype=bool)
+    k8 = np.load(os.path.join(HERE, "kat_p8.npz"))
+    X8 = k8["X"]
+    N8 = X8.shape[0]
+    rng = np.random.default_rng(91)
+    sf8 = np.exp(rng.normal(0, 0.2, N8))
+    found = []
+    state = {}
+    orig = ut.minimize
+
+    def spy(*a, **kw):
+        state["res"] = orig(*a, **kw)
+        return state["res"]
+
+    ut.minimize = spy
+    try:
+        for trial in range(4000):
+            base = 2.0 ** rng.uniform(-4, 1)
+            y = rng.negative_binomial(2.0, 2.0 / (2.0 + sf8 * base)).astype(np.int64)
+            if trial % 3 == 0:
+                y[rng.integers(0, N8)] = int(10 ** rng.uniform(2, 5))
+            if y.sum() == 0:
+                continue
+            d = 10 ** rng.uniform(-3, 1)
+            state.pop("res", None)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                b, mu_, H, cv = ut.irls_solver(y, sf8, X8, d, 0.5, 1e-8, optimizer="BFGS")
+            if "res" in state:
+                found.append((y, d, b, mu_, H, cv))
+            if len(found) >= 24:
+                break
+    finally:
+        ut.minimize = orig
+    out["b8_X"], out["b8_sf"] = X8, sf8
+    out["b8_counts"] = np.stack([f[0] for f in found], axis=1)
+    out["b8_disp"] = np.array([f[1] for f in found])
+    out["b8_beta"] = np.stack([f[2] for f in found])
+    out["b8_mu"] = np.stack([f[3] for f in found], axis=1)
+    out["b8_H"] = np.stack([f[4] for f in found], axis=1)
+    out["b8_conv"] = np.array([f[5] for f in found], dtype=bool)
+    np.savez_compressed(os.path.join(HERE, "kat_bfgs.npz"), **out)
+    print("bfgs: dispersion non-converged p2/p8/hard", int((~out["p2_gw_conv"]).sum()), int((~out["p8_gw_conv"]).sum()),
+          int((~out["hard_conv"]).sum()), "| p=2 rescues converged", int(out["b2_conv"].sum()), "of", len(rb),
+          "| p=8 rescues", len(found), "converged", int(out["b8_conv"].sum()))
+
+
 def main():
     ut, gs, pp, di = _import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
         wide_cases(ut, gs, pp, di)
         hard_cases(ut, gs)
+        bfgs_cases(ut)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "bfgs":
+        bfgs_cases(ut)
         return
     # case A: 2-level factor (linear-mu route), p = 2
     N = 40
@@ -278,6 +369,7 @@ def main():
 
     wide_cases(ut, gs, pp, di)
     hard_cases(ut, gs)
+    bfgs_cases(ut)
     rest_of_main(ut)
 
 

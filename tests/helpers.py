@@ -113,3 +113,40 @@ def check_hard_lfc_genes(k, b, mu, H, conv, min_fallback=0.6):
     assert_close(H[:, nc], k["b_H"][:, nc], 1e-8, 1e-12, "H")
     assert_close(b[~nc], k["b_rescue_x"][~nc], 1e-3, 1e-6, "rescue iterate")
     return float(nc.mean())
+
+
+def check_bfgs_kats(load_kat, alpha_mle, irls, exact=False):
+    """optimizer="BFGS" (utils.py:343, 389-399, 546-554) against kat_bfgs.npz (the unmodified reference).
+
+    ``alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg) -> (alpha, conv)`` and
+    ``irls(counts, sf, X, disp) -> (beta, conv)`` with the BFGS optimiser selected.  exact: the oracle (scipy itself).
+    For the device templates the usual rule applies: genes on which both sides agree about scipy's ``success`` must
+    agree to 1e-6 (the stopping point under gtol = 1e-5 moves with the last bits of the loss); the flag itself is a
+    coin flip on the genes whose line search ends in the rounding noise of the loss ("precision loss" at
+    |g| ~ 1.2e-5, the huge-count genes of kat_hard), so only the number of such genes is bounded."""
+    k = load_kat("bfgs")
+    tol = 1e-12 if exact else 1e-6
+    for case in ("p2", "p8"):
+        kk = load_kat(case)
+        N = kk["counts"].shape[0]
+        a, c = alpha_mle(kk["counts"], kk["X"], kk["mu_hat"], kk["mom"], 1e-8, max(10, N), None, True, False)
+        assert (c == k[f"{case}_gw_conv"]).all()
+        assert_close(a, k[f"{case}_gw_alpha"], tol, 0, f"{case} genewise alpha (BFGS)")
+        a, c = alpha_mle(kk["counts"], kk["X"], kk["mu_hat"], kk["fitted"], 1e-8, max(10, N),
+                         float(kk["prior_var"]), True, True)
+        same = c == k[f"{case}_map_conv"]
+        assert (~same).sum() <= (0 if exact else 3)
+        assert_close(a[same], k[f"{case}_map_alpha"][same], tol, 0, f"{case} MAP alpha (BFGS)")
+    h = load_kat("hard")
+    a, c = alpha_mle(h["a_counts"], h["X"], h["a_mu_hat"], h["a_mom"], 1e-8, 40.0, None, True, False)
+    same = c == k["hard_conv"]
+    assert same.mean() >= (1.0 if exact else 0.5)
+    assert_close(a[same & c], k["hard_alpha"][same & c], 1e-12 if exact else 1e-5, 0, "huge-count genes, both converged")
+    assert_close(a[same & ~c], k["hard_alpha"][same & ~c], 1e-12, 0, "huge-count genes, both on the grid")
+    b, cv = irls(h["b_counts"], h["sf"], h["X"], h["b_disp"])
+    same = cv == k["b2_conv"]
+    assert (~same).sum() <= (0 if exact else 2)
+    assert_close(b[same], k["b2_beta"][same], 1e-12 if exact else 1e-6, 1e-9, "p = 2 rescue (BFGS / grid)")
+    b, cv = irls(k["b8_counts"], k["b8_sf"], k["b8_X"], k["b8_disp"])
+    assert (cv == k["b8_conv"]).all()
+    assert_close(b, k["b8_beta"], 1e-12 if exact else 1e-6, 1e-7, "p = 8 rescue (BFGS)")

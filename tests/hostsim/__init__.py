@@ -61,14 +61,16 @@ def lbfgsb1d(fg, x0, l, u):
     return x.value, f.value, bool(ok.value), nfev.value, nit.value, st.value
 
 
-def alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False):
+def alpha_mle(counts, X, mu, alpha_hat, min_disp, max_disp, prior_var=None, cr_reg=True, prior_reg=False,
+              optimizer="L-BFGS-B"):
     y = gene_major(counts)
     G, N = y.shape
     m = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).T)
     Xt, _, _ = design_pack(X)
     ah = np.ascontiguousarray(alpha_hat, dtype=np.float64)
     out, conv, nfev = np.empty(G), np.empty(G, np.uint8), np.empty(G, np.int32)
-    rc = lib().hs_alpha_mle(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
+    fn = lib().hs_alpha_mle if optimizer == "L-BFGS-B" else lib().hs_alpha_mle_bfgs
+    rc = fn(_p(y, C.c_int32), _p(m, C.c_double), C.c_int(N), _p(Xt, C.c_double), C.c_int(N),
                             C.c_int(N), C.c_int(G), C.c_int(Xt.shape[0]), _p(ah, C.c_double),
                             C.c_double(min_disp), C.c_double(max_disp),
                             C.c_double(prior_var if prior_var is not None else 1.0), C.c_int(cr_reg),
@@ -90,7 +92,8 @@ def grid_alpha(counts, X, mu, min_disp, max_disp):
     return out
 
 
-def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30.0, max_beta=30.0, maxiter=250):
+def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30.0, max_beta=30.0, maxiter=250,
+         optimizer="L-BFGS-B"):
     y = gene_major(counts)
     G, N = y.shape
     Xt, pinv, fr = design_pack(X)
@@ -99,7 +102,8 @@ def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30.0, max_bet
     d = np.ascontiguousarray(disp, dtype=np.float64)
     beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
     conv, it, fb = np.empty(G, np.uint8), np.empty(G, np.int32), np.empty(G, np.uint8)
-    rc = lib().hs_irls(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double),
+    fn = lib().hs_irls if optimizer == "L-BFGS-B" else lib().hs_irls_bfgs
+    rc = fn(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(Xt, C.c_double),
                        _p(pinv, C.c_double), C.c_int(N), C.c_int(N), C.c_int(G), C.c_int(P), _p(d, C.c_double),
                        C.c_double(min_mu), C.c_double(beta_tol), C.c_double(min_beta), C.c_double(max_beta),
                        C.c_int(maxiter), C.c_int(fr), _p(beta, C.c_double), _p(mu, C.c_double),
@@ -272,6 +276,25 @@ def lbfgsb_nd(fg, x0, bounds, entry="hs_lbfgsb_nd"):
                             _p(nbd, C.c_int32), C.byref(f), C.byref(ok), C.byref(nfev), C.byref(nit), C.byref(st))
     assert rc == 0
     return x, f.value, bool(ok.value), nfev.value, nit.value, st.value
+
+
+def bfgs(fg, x0):
+    """scipy.optimize.minimize(method="BFGS") restatement (dsq_bfgs.h) on a Python objective fg(x) -> (f, g)."""
+    n = len(x0)
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+
+    def cb(px, pf, pg):
+        xx = np.array([px[i] for i in range(n)])
+        f, g = fg(xx)
+        pf[0] = f
+        for i in range(n):
+            pg[i] = g[i]
+
+    ok, nfev, nit, st = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().hs_bfgs(FGN_CB(cb), C.c_int(n), _p(x, C.c_double), C.byref(ok), C.byref(nfev), C.byref(nit),
+                       C.byref(st))
+    assert rc == 0
+    return x, bool(ok.value), nfev.value, nit.value, st.value
 
 
 def trend_fit(disp, means, min_disp, max_disp):

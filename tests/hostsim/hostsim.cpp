@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dsq_alpha.h"
+#include "dsq_bfgs.h"
 #include "dsq_dispatch.h"
 #include "dsq_irls.h"
 #include "dsq_lbfgsb.h"
@@ -68,6 +69,48 @@ int hs_alpha_mle(const int32_t* y, const double* mu, int ldn, const double* Xt, 
                                                  cr_reg != 0, prior_reg != 0, mach);
         alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
         if (nfev) nfev[g] = o.nfev;
+    })
+    return 0;
+}
+
+// optimizer="BFGS" variants (utils.py:546-554, 389-399)
+int hs_alpha_mle_bfgs(const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx, int N,
+                      int G, int P_, const double* alpha_hat, double min_disp, double max_disp,
+                      double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev) {
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        AlphaOut o = fit_alpha_gene_bfgs<HostWave, P, true>(y + (size_t)g * ldn, mu + (size_t)g * ldn, Xt, ldx, N,
+                                                            alpha_hat[g], min_disp, max_disp, prior_var, cr_reg != 0,
+                                                            prior_reg != 0, 1);
+        alpha[g] = o.alpha; conv[g] = (uint8_t)o.converged;
+        if (nfev) nfev[g] = o.nfev;
+    })
+    return 0;
+}
+
+int hs_irls_bfgs(const int32_t* y, int ldn, const double* sf, const double* Xt, const double* pinvXt,
+                 int ldx, int N, int G, int P_, const double* disp, double min_mu, double beta_tol,
+                 double min_beta, double max_beta, int maxiter, int full_rank, double* beta, double* mu, double* H,
+                 uint8_t* conv, int32_t* iters, uint8_t* fallback) {
+    if (P_ < 1 || P_ > DSQ_REG_MAX_P) return -1;
+    DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
+        IrlsArgs A;
+        A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
+        A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
+        A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
+        double b[P];
+        double* mo = mu ? mu + (size_t)g * ldn : nullptr;
+        double* ho = H ? H + (size_t)g * ldn : nullptr;
+        IrlsOut o = irls_gene<HostWave, P>(A, b, mo, ho);
+        if (o.fallback) {
+            static IrlsRescueWork<P> Wk;
+            std::memset(&Wk, 0, sizeof(Wk));
+            o = irls_rescue_gene<HostWave, P>(A, Wk, b, mo, ho, nullptr, 1);
+        }
+        for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
+        conv[g] = (uint8_t)o.converged;
+        if (iters) iters[g] = o.iters;
+        if (fallback) fallback[g] = (uint8_t)o.fallback;
     })
     return 0;
 }
@@ -416,6 +459,15 @@ int hs_trend_fit(const double* disp, const double* means, int n, double min_disp
     std::memset(&W, 0, sizeof(W));
     TrendOut o = trend_fit<HostWave>(disp, means, n, min_disp, max_disp, keep.data(), W);
     coeffs[0] = o.a0; coeffs[1] = o.a1; *ok = o.ok; *n_outer = o.n_outer;
+    return 0;
+}
+
+int hs_bfgs(fgn_cb cb, int n, double* x, int* success, int* nfev, int* nit, int* status) {
+    if (n < 1 || n > 16) return -1;
+    static BfgsWork<16> W;
+    auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
+    const BfgsResult r = bfgs_min<16>(fg, n, x, W);
+    *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
     return 0;
 }
 

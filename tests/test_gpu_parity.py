@@ -126,6 +126,21 @@ def test_grid_fallbacks_on_genes_where_the_reference_takes_them(inf):
     check_hard_lfc_genes(k, b, mu, H, conv)
 
 
+def test_bfgs_option_of_alpha_mle_and_irls(inf):
+    """optimizer="BFGS" through the plug-in interface (Inference.alpha_mle / Inference.irls, inference.py:46-178):
+    scipy's BFGS restated on the device (csrc/dsq_bfgs.h) against the unmodified reference (kat_bfgs.npz)."""
+    from tests.helpers import check_bfgs_kats
+
+    check_bfgs_kats(
+        load_kat,
+        lambda y, X, mu, ah, lo, hi, pv, cr, pr: inf.alpha_mle(y, X, mu, ah, lo, hi, pv, cr, pr, optimizer="BFGS"),
+        lambda y, sf, X, d: (lambda r: (r[0], r[3]))(inf.irls(y, sf, X, d, 0.5, 1e-8, optimizer="BFGS")))
+    # the default optimiser is back afterwards
+    k = load_kat("p2")
+    a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, 40.0)
+    assert_close(a, k["gw_alpha"], 1e-6, 0, "genewise alpha (L-BFGS-B after a BFGS call)")
+
+
 def test_rough_dispersions_n_equals_p_raises(inf):
     X = np.eye(3)
     with pytest.raises(ValueError):

@@ -2,6 +2,8 @@
 (tests/hostsim), against the reference's own kernels (golden KATs) and against scipy."""
 import os
 
+import warnings
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -185,6 +187,52 @@ def test_lbfgsb_nd_matches_scipy():
         if ok != res.success or nit != res.nit or np.max(np.abs(x - res.x)) > 1e-8 * max(1, np.max(np.abs(res.x))):
             bad += 1
     assert bad <= 1
+
+
+def test_bfgs_matches_scipy():
+    """The restatement of scipy's BFGS (line_search_wolfe1 = MINPACK-2 dcsrch, line_search_wolfe2 / zoom as the
+    fall-back, dense inverse-Hessian update; dsq_bfgs.h) against scipy itself on random smooth and kinked problems,
+    incl. ones whose line search fails ("precision loss")."""
+    rng = np.random.default_rng(5)
+    bad, failures = 0, 0
+    for t in range(160):
+        n = int(rng.integers(1, 9))
+        A = rng.normal(size=(n + 3, n))
+        Q = A.T @ A * 10 ** rng.uniform(-1, 2) + np.eye(n) * 10 ** rng.uniform(-3, 0)
+        c, b, w = rng.normal(0, 3, n), rng.normal(0, 2, n), rng.uniform(0.2, 2, n)
+        kinked = t % 4 == 3
+
+        def fg(x):
+            d = x - c
+            e = np.exp(np.clip(w * d, -50, 50))
+            if kinked:
+                ge = np.where(e > 0.5, w * e, 0.0)
+                e = np.maximum(e, 0.5)
+                return 0.05 * d @ Q @ d + e.sum() - (b * d).sum(), 0.1 * Q @ d + ge - b
+            return 0.5 * d @ Q @ d + e.sum(), Q @ d + w * e
+
+        x0 = c + rng.normal(0, 3, n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = minimize(lambda x: fg(x)[0], x0, jac=lambda x: fg(x)[1], method="BFGS")
+        x, ok, nfev, nit, st = hs.bfgs(fg, x0)
+        failures += not res.success
+        if ok != res.success or nit != res.nit or st != res.status or \
+                np.max(np.abs(x - res.x)) > 1e-8 * max(1, np.max(np.abs(res.x))):
+            bad += 1
+    assert failures >= 3  # the fall-back search and the failure exit are exercised
+    assert bad <= 2
+
+
+def test_bfgs_option_matches_the_reference():
+    """optimizer="BFGS" of the dispersion fit and of the IRLS rescue (host instantiation of dsq_bfgs.h inside the
+    per-gene templates) against the unmodified reference (kat_bfgs.npz)."""
+    from tests.helpers import check_bfgs_kats
+
+    check_bfgs_kats(
+        load_kat,
+        lambda y, X, mu, ah, lo, hi, pv, cr, pr: hs.alpha_mle(y, X, mu, ah, lo, hi, pv, cr, pr, optimizer="BFGS")[:2],
+        lambda y, sf, X, d: (lambda r: (r[0], r[3]))(hs.irls(y, sf, X, d, optimizer="BFGS")))
 
 
 def test_irls_rescue_matches_reference_fallback():

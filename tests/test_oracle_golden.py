@@ -64,6 +64,17 @@ def test_grid_beta():
         assert np.abs(b - k["grid_beta"][g]).max() < 1e-12
 
 
+def test_bfgs_option_of_the_per_gene_kernels():
+    """optimizer="BFGS" of fit_alpha_mle / irls_solver: the oracle (scipy's BFGS itself) on the reference's outputs."""
+    from tests.helpers import check_bfgs_kats
+
+    check_bfgs_kats(
+        load_kat,
+        lambda y, X, mu, ah, lo, hi, pv, cr, pr: orc.alpha_mle(y, X, mu, ah, lo, hi, pv, cr, pr, optimizer="BFGS"),
+        lambda y, sf, X, d: (lambda r: (r[0], r[3]))(orc.irls(y, sf, X, d, optimizer="BFGS")),
+        exact=True)
+
+
 def test_hard_genes_grid_fallbacks():
     """kat_hard.npz: genes on which the unmodified reference leaves its optimiser for a grid search
     (fit_alpha_mle -> grid_fit_alpha, utils.py:556-564; irls_solver -> grid_fit_beta, utils.py:404-411)."""

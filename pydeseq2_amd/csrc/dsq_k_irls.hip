@@ -123,6 +123,71 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
 #endif
 }
 
+// The same fit with SIXTEEN lanes per gene (RowWave, dsq_wave.h): four genes per wavefront, sixteen per workgroup.
+// For designs with more than kSmallCells cells and p >= 5 the kernel above spends most of its cycles in the
+// wave-redundant p x p algebra and the per-cell tables between short sample loops (profiles/r02_phase_c4.txt: sample
+// loops 14 % of the cycles); here those instructions serve four genes at once, the sample loops take four times as
+// many (light) trips.  Rows diverge when their genes need different numbers of sweeps.  Shared per-sample vectors and
+// the cells' tables are staged in LDS; the count rows are read from global memory (L2: 16 rows per workgroup would not
+// leave LDS for two workgroups per CU).
+constexpr int kRowGenes = kBlock / 16;
+template <int P>
+__global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restrict__ y, int ldn,
+                                                        const double* __restrict__ sf, const double* __restrict__ lsf,
+                                                        const double* __restrict__ Xt,
+                                                        const double* __restrict__ pinvXt, int ldx, int N, int G,
+                                                        int full_rank, const double* __restrict__ disp, double min_mu,
+                                                        double beta_tol, double min_beta, double max_beta, int maxiter,
+                                                        double* __restrict__ beta, double* __restrict__ mu,
+                                                        double* __restrict__ hat, uint8_t* __restrict__ conv,
+                                                        int32_t* __restrict__ iters, int32_t* __restrict__ fb_count,
+                                                        int32_t* __restrict__ fb_list, IrlsExtras ex) {
+    __shared__ CellWork<P> cellw[kRowGenes];
+    extern __shared__ __attribute__((aligned(16))) double irls_lds[];
+    constexpr int T = Tri<P>::N;
+    const int row = threadIdx.x >> 4;
+    const int g = blockIdx.x * kRowGenes + row;
+    log_tab_fill();
+    double* sXX = irls_lds;
+    double* sXc = sXX + ex.cells.C * T;
+    const int npad = (N + 15) & ~15;
+    double* s_sf = sXc + ex.cells.C * P;
+    double* s_lsf = s_sf + npad;
+    int32_t* s_cell = (int32_t*)(s_lsf + npad);
+    for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
+    for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+        s_sf[n] = sf[n];
+        s_lsf[n] = lsf != nullptr ? lsf[n] : 0.0;
+        s_cell[n] = ex.cells.cell_of[n];
+    }
+    ex.cells.XX = sXX;
+    ex.cells.Xc = sXc;
+    ex.cells.cell_of = s_cell;
+    __syncthreads();
+    if (g >= G) return;
+    IrlsArgs A;
+    A.y = y + (size_t)g * ldn; A.sf = s_sf; A.lsf = lsf != nullptr ? s_lsf : nullptr; A.Xt = Xt; A.pinvXt = pinvXt;
+    A.ldx = ldx; A.N = N;
+    A.disp = disp[g]; A.min_mu = min_mu; A.beta_tol = beta_tol; A.min_beta = min_beta;
+    A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
+    A.cells = &ex.cells;
+    A.cell_ws = (void*)&cellw[row];
+    LfcEpilogue E;
+    epilogue_begin<P>(E, ex, g, ldn);
+    double b[P];
+    const IrlsOut o = irls_gene<RowWave, P, 1>(A, b, mu ? mu + (size_t)g * ldn : nullptr,
+                                               hat ? hat + (size_t)g * ldn : nullptr, &E);
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
+        conv[g] = (uint8_t)o.converged;
+        if (iters != nullptr) iters[g] = o.iters;
+        if (o.fallback) fb_list[atomicAdd(fb_count, 1)] = g;
+        else epilogue_store(E, ex, g);
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restrict__ y, int ldn,
                                                         const double* __restrict__ sf, const double* __restrict__ lsf,
@@ -231,6 +296,16 @@ hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const d
     return hipGetLastError();
 }
 
+constexpr int kRowMinP = 5;  // narrower designs: the sample loops dominate, one gene per wavefront stays ahead
+static bool row_wave_enabled() {
+    static const bool v = getenv("DSQ_NO_ROW_WAVE") == nullptr;  // A/B switch
+    return v;
+}
+static size_t row_lds_bytes(int C, int P, int N) {
+    const int npad = (N + 15) & ~15;
+    return (size_t)C * (P * (P + 1) / 2 + P) * sizeof(double) + (size_t)npad * 20;
+}
+
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P_, int full_rank,
@@ -267,6 +342,16 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
                                        sf, lsf, Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta,
                                        max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
             }
+        })
+    } else if (ex.cells.C > kSmallCells && P_ >= kRowMinP && row_wave_enabled() &&
+               row_lds_bytes(ex.cells.C, P_, N) <= 40 * 1024) {
+        // wide categorical designs: sixteen lanes per gene (k_irls_row)
+        const dim3 grid_r((G + kRowGenes - 1) / kRowGenes);
+        DSQ_DISPATCH_P(P_, {
+            if constexpr (P >= kRowMinP)
+                hipLaunchKernelGGL((k_irls_row<P>), grid_r, block, row_lds_bytes(ex.cells.C, P, N), st, y, ldn, sf, lsf,
+                                   Xt, pinvXt, ldx, N, G, full_rank, disp, min_mu, beta_tol, min_beta, max_beta, maxiter,
+                                   beta, mu, hat, conv, iters, fb_count, fb_list, ex);
         })
     } else if (ex.cells.C > kSmallCells && P_ >= 3) {
         DSQ_DISPATCH_P(P_, {

@@ -186,6 +186,74 @@ struct DeviceWave {
         for (int k = 0; k < K; ++k) v[k] = sum(v[k]);
     }
 };
+
+// Sixteen lanes per gene, four genes per wavefront.  For designs whose kernels spend their time in the p x p algebra
+// between short sample loops (p >= 5 with design cells: dsq_irls.h, irls_sweep_cell) the wave-redundant algebra of
+// DeviceWave repeats ONE gene's Cholesky / solve in 64 lanes; here the four 16-lane rows of a wavefront work on four
+// genes, so the same instructions serve four of them.  Reductions stay inside a row (DPP row_ror / quad permutations:
+// the last four stages of the butterfly above), "uniform" values are uniform per row only (no scalar registers), and
+// rows may diverge (different sweep counts): every cross-lane operation used by the per-gene templates is row-scoped,
+// and a row is always active or inactive as a whole.
+struct RowWave {
+    static constexpr int W = 16;
+    static __device__ __forceinline__ int lane() { return threadIdx.x & 15; }
+    static __device__ __forceinline__ double sum(double v) {
+        v += detail::dpp_d<detail::kRor8>(v);
+        v += detail::dpp_d<detail::kRor4>(v);
+        v += detail::dpp_d<detail::kXor2>(v);
+        v += detail::dpp_d<detail::kXor1>(v);
+        return v;
+    }
+    static __device__ __forceinline__ double max(double v) {
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(v, m, 16);
+            v = v > o ? v : o;
+        }
+        return v;
+    }
+    static __device__ __forceinline__ int sumi(int v) {
+        v += detail::dpp_i<detail::kRor8>(v);
+        v += detail::dpp_i<detail::kRor4>(v);
+        v += detail::dpp_i<detail::kXor2>(v);
+        v += detail::dpp_i<detail::kXor1>(v);
+        return v;
+    }
+    static __device__ __forceinline__ int maxi(int v) {
+        { const int o = detail::dpp_i<detail::kRor8>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kRor4>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kXor2>(v); v = v > o ? v : o; }
+        { const int o = detail::dpp_i<detail::kXor1>(v); v = v > o ? v : o; }
+        return v;
+    }
+    static __device__ __forceinline__ int excl_scan_i(int v) {
+        int s = v;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int o = __shfl_up(s, d, 16);
+            if ((int)(threadIdx.x & 15) >= d) s += o;
+        }
+        return s - v;
+    }
+    static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
+    static __device__ __forceinline__ void cell_add(double* cell, double v) { DeviceWave::cell_add(cell, v); }
+    static __device__ __forceinline__ void sync() { DeviceWave::sync(); }
+    static __device__ __forceinline__ bool any(bool p) { return __any(p); }  // over the active rows: conservative
+    static __device__ __forceinline__ double from_lane(double v, int src) { return __shfl(v, src, 16); }
+    static __device__ __forceinline__ double uniform(double v) { return v; }
+    static __device__ __forceinline__ double sum_comp(KSum k) {
+        k.merge(detail::dpp_d<detail::kRor8>(k.s), detail::dpp_d<detail::kRor8>(k.c));
+        k.merge(detail::dpp_d<detail::kRor4>(k.s), detail::dpp_d<detail::kRor4>(k.c));
+        k.merge(detail::dpp_d<detail::kXor2>(k.s), detail::dpp_d<detail::kXor2>(k.c));
+        k.merge(detail::dpp_d<detail::kXor1>(k.s), detail::dpp_d<detail::kXor1>(k.c));
+        return k.value();
+    }
+    template <int K>
+    static __device__ __forceinline__ void sum_n(double (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = sum(v[k]);
+    }
+};
 #endif
 
 struct HostWave {

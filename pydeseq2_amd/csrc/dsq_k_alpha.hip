@@ -215,8 +215,11 @@ __global__ void k_fill_lohi(double* lohi, int n, double lo, double hi) {
 
 // optimizer="BFGS" (utils.py:546-554): one gene per wavefront, rows read from global memory (a plug-in option of
 // fit_alpha_mle that dds.py never selects - kept simple, not tuned)
+// (same occupancy request as k_alpha: the out-of-line evaluation is shared with it, and the compiler gives a callee
+// the loosest register budget among its callers - without this the un-staged k_alpha of wide designs dropped to one
+// wave per SIMD: c5-shaped shard 5.1 -> 7.2 ms per launch)
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_alpha_bfgs(const int32_t* __restrict__ y, const double* __restrict__ mu,
+__global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha_bfgs(const int32_t* __restrict__ y, const double* __restrict__ mu,
                                                        int ldn, const double* __restrict__ Xt, int ldx, int N, int G,
                                                        const double* __restrict__ alpha_hat, double min_disp,
                                                        double max_disp, double prior_var, int cr_reg, int prior_reg,

@@ -45,6 +45,7 @@ CONFIGS = {
     "c2": (20000, 200, "2level"),
     "c3": (60000, 1000, "2level"),
     "c4": (60000, 500, "3factor"),
+    "c4b": (60000, 500, "2factor"),  # developer measurements: p = 4, 6 cells (not a BASELINE configuration)
     "c5": (60000, 5000, "mixed"),  # not a default bench line: host generation alone takes minutes
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -197,7 +198,7 @@ def main():
     # two ranks on one device, so the job then runs on the host-staged fallback transport)
     ctx = Context(0 if os.environ.get("DSQ_BENCH_SHARE_GPU") else local_rank)
     info = ctx.device_info()
-    seed0 = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}[args.config]
+    seed0 = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4b": 5}[args.config]
     if args.scaling == "strong" and world > 1:
         # one matrix for the whole job, every rank keeps its block of genes (same generator call: deterministic)
         counts_all, X = synth_fast(G_total, N, design, seed=seed0)

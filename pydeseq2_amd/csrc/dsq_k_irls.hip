@@ -296,9 +296,13 @@ hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const d
     return hipGetLastError();
 }
 
-constexpr int kRowMinP = 5;  // narrower designs: the sample loops dominate, one gene per wavefront stays ahead
+constexpr int kRowMinP = 3;  // instantiated from here on; taken from row_min_p() on
 static bool row_wave_enabled() {
     static const bool v = getenv("DSQ_NO_ROW_WAVE") == nullptr;  // A/B switch
+    return v;
+}
+static int row_min_p() {  // narrower designs: the sample loops dominate, one gene per wavefront stays ahead
+    static const int v = getenv("DSQ_ROW_MIN_P") ? atoi(getenv("DSQ_ROW_MIN_P")) : 5;
     return v;
 }
 static size_t row_lds_bytes(int C, int P, int N) {
@@ -343,7 +347,7 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
                                        max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
             }
         })
-    } else if (ex.cells.C > kSmallCells && P_ >= kRowMinP && row_wave_enabled() &&
+    } else if (ex.cells.C > kSmallCells && P_ >= kRowMinP && P_ >= row_min_p() && row_wave_enabled() &&
                row_lds_bytes(ex.cells.C, P_, N) <= 40 * 1024) {
         // wide categorical designs: sixteen lanes per gene (k_irls_row)
         const dim3 grid_r((G + kRowGenes - 1) / kRowGenes);

@@ -24,6 +24,9 @@ def make_design(kind: str, N: int, rng: np.random.Generator) -> np.ndarray:
     elif kind == "3factor":  # 2/3/5 levels -> p = 8
         for lv in (2, 3, 5):
             cols.append(dummies(bal(lv), lv))
+    elif kind == "2factor":  # 2/3 levels -> p = 4, 6 cells (developer measurements: condition + batch)
+        for lv in (2, 3):
+            cols.append(dummies(bal(lv), lv))
     elif kind == "mixed":  # 2 + 4 levels + 3 continuous -> p = 8
         for lv in (2, 4):
             cols.append(dummies(bal(lv), lv))

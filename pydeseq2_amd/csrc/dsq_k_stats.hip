@@ -153,11 +153,15 @@ hipError_t launch_transpose_f64(hipStream_t st, const double* src, int layout, i
 __global__ __launch_bounds__(kBlock) void k_logmeans(const int32_t* __restrict__ y, int ldn, int N,
                                                      int G, double* __restrict__ logmeans,
                                                      uint8_t* __restrict__ nonzero) {
+    __shared__ double s_logint[256];
+    static_assert(kBlock == 256, "one table entry per thread");
+    s_logint[threadIdx.x] = kLogInt[threadIdx.x];
+    __syncthreads();
     const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (g >= G) return;
     double lm;
     int nz;
-    gene_logmean<DeviceWave>(y + (size_t)g * ldn, N, lm, nz);
+    gene_logmean<DeviceWave>(y + (size_t)g * ldn, N, lm, nz, s_logint);
     if ((threadIdx.x & 63) == 0) {
         logmeans[g] = lm;
         nonzero[g] = (uint8_t)nz;

@@ -23,14 +23,22 @@ DSQ_HD double log_count(int c) { return c < 256 ? kLogInt[c] : flog((double)c); 
 
 // ---------------------------------------------------------------- size factors, pass A
 // logmean = mean_n log(y_n)  (-inf as soon as one count is zero); nonzero = any(y > 0)
+// log_tab: the kernel's LDS copy of kLogInt (null: the table itself).  The pass is two dependent reads per sample
+// (count, then its logarithm): unrolled so that four of each are in flight, the table read an LDS hit.
 template <class Wv>
-DSQ_HD void gene_logmean(const int32_t* y, int N, double& logmean, int& nonzero) {
+DSQ_HD void gene_logmean(const int32_t* y, int N, double& logmean, int& nonzero, const double* log_tab = nullptr) {
     double s = 0.0;
     int has_zero = 0, any_pos = 0;
+    const auto tab = DSQ_AS_LDS(double, log_tab);
+#pragma unroll 4
     for (int n = Wv::lane(); n < N; n += Wv::W) {
         const int v = y[n];
-        if (v > 0) { s += log_count(v); any_pos = 1; }
-        else has_zero = 1;
+        if (v > 0) {
+            s += (v < 256) ? (log_tab != nullptr ? tab[v] : kLogInt[v]) : flog((double)v);
+            any_pos = 1;
+        } else {
+            has_zero = 1;
+        }
     }
     s = Wv::sum(s);
     has_zero = Wv::sumi(has_zero);

@@ -445,7 +445,7 @@ DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
             const double big = (z - 0.5) * lz - z + kHalfLog2Pi + stirling_tail(frcp(z));
             if (!in_tab) lg = big;
         }
-        c.add(lg - yv * flog(m));
+        c.add(lg - yv * flog_t(m));  // (every kernel that gets here has filled the table: k_alpha*, the wide and BFGS ones)
     }
     return Wv::sum_comp(c);
 }

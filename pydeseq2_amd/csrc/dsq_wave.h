@@ -82,6 +82,33 @@ __device__ __forceinline__ void swap_d(double v, double& a, double& c) {
     a = __longlong_as_double(((long long)ahi << 32) | (unsigned int)alo);
     c = __longlong_as_double(((long long)chi << 32) | (unsigned int)clo);
 }
+// two different operands: a = [x.lower | y.lower], c = [x.upper | y.upper] (halves for HALF, else 16-lane rows: rows 0, 2
+// of the result take x, rows 1, 3 take y)
+template <bool HALF>
+__device__ __forceinline__ void swap_xy_i(int x, int y, int& a, int& c) {
+    if constexpr (HALF) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+        a = (int)r[0]; c = (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)y, false, false);
+        a = (int)r[0]; c = (int)r[1];
+    }
+}
+template <bool HALF>
+__device__ __forceinline__ void swap_xy_d(double x, double y, double& a, double& c) {
+    const long long bx = __double_as_longlong(x), by = __double_as_longlong(y);
+    int alo, clo, ahi, chi;
+    swap_xy_i<HALF>((int)(bx & 0xffffffffll), (int)(by & 0xffffffffll), alo, clo);
+    swap_xy_i<HALF>((int)(bx >> 32), (int)(by >> 32), ahi, chi);
+    a = __longlong_as_double(((long long)ahi << 32) | (unsigned int)alo);
+    c = __longlong_as_double(((long long)chi << 32) | (unsigned int)clo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 constexpr int kRor8 = 0x128, kRor4 = 0x124, kXor2 = 0x4E, kXor1 = 0xB1;
 }  // namespace detail
 
@@ -180,10 +207,42 @@ struct DeviceWave {
         k.merge(detail::dpp_d<detail::kXor1>(k.s), detail::dpp_d<detail::kXor1>(k.c));
         return k.value();
     }
+    // K sums at once.  The butterfly above, applied per value, moves every value through all six stages in all 64
+    // lanes (18 instructions each).  Here the two exchange stages pair the values up - after the half-wave swap a
+    // lane keeps one of two values, after the row swap one of four - so the four in-row stages run on K/4 registers,
+    // and the totals (one value per 16-lane row) are broadcast with v_readlane.  Same partners and the same order of
+    // additions for every value: bit-identical to sum(), at about 40 % of its instructions for K >= 8.
     template <int K>
     static __device__ __forceinline__ void sum_n(double (&v)[K]) {
+        if constexpr (K < 3) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = sum(v[k]);
+            for (int k = 0; k < K; ++k) v[k] = sum(v[k]);
+        } else {
+            constexpr int Q = (K + 3) / 4;
+            double u[2 * Q], w[Q];
+#pragma unroll
+            for (int i = 0; i < 2 * Q; ++i) {
+                const double x = i < K ? v[i] : 0.0;
+                const double y = i + 2 * Q < K ? v[i + 2 * Q] : 0.0;
+                double a, c;
+                detail::swap_xy_d<true>(x, y, a, c);
+                u[i] = a + c;
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                double a, c;
+                detail::swap_xy_d<false>(u[i], u[i + Q], a, c);
+                double t = a + c;
+                t += detail::dpp_d<detail::kRor8>(t);
+                t += detail::dpp_d<detail::kRor4>(t);
+                t += detail::dpp_d<detail::kXor2>(t);
+                t += detail::dpp_d<detail::kXor1>(t);
+                w[i] = t;
+            }
+            // row r of w[i] holds the total of value i + r * Q
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = detail::readlane_d(w[k % Q], 16 * (k / Q));
+        }
     }
 };
 

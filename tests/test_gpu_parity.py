@@ -304,6 +304,38 @@ def test_matrix_core_path_equals_register_path_at_p8():
     assert_close(b["l"][same], a["l"][same], 1e-6, 1e-9, "LFC")
 
 
+def test_sixteen_lane_irls_equals_the_wavefront_kernel():
+    """Designs with cells and p >= 5 fit their LFCs (and the IRLS mu_hat) with sixteen lanes per gene (k_irls_row,
+    RowWave); DSQ_NO_ROW_WAVE=1 keeps the one-gene-per-wavefront kernel: the same results to rounding on the 30-cell
+    design, incl. the rescue of diverged genes, the Cook's flags and the refit of an injected outlier (apart from the
+    odd gene whose dispersion fit flips its convergence flag on the last bits of mu_hat)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = ("import numpy as np, pydeseq2_amd; from oracle import nbglm_oracle as orc; "
+            "counts, X = orc.synth_counts(2400, 90, '3factor', 7); counts[5, :40] = 200000; "
+            "r = pydeseq2_amd.deseq2(counts, X, device=0); "
+            "np.savez(sys.argv[1], d=r.dispersions, l=r.LFC, p=r.pvalue, se=r.lfcSE, g=r.genewise_converged, "
+            "m=r.MAP_converged, c=r.cooks_outlier, f=r.refitted, lc=r.LFC_converged)")
+    outs = []
+    for env in ({}, {"DSQ_NO_ROW_WAVE": "1"}):
+        f = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", "import sys; " + code, f], check=True, env={**os.environ, **env},
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(dict(np.load(f)))
+    a, b = outs
+    assert (a["f"] == b["f"]).all() and (a["c"] == b["c"]).all() and (a["lc"] == b["lc"]).all()
+    with np.errstate(invalid="ignore"):
+        same = (a["g"] == b["g"]) & (a["m"] == b["m"]) & \
+            ~(np.abs(a["d"] - b["d"]) > 1e-6 * np.abs(b["d"]))  # (a flipped dispersion-outlier decision shows here)
+    assert (~same).sum() <= 3
+    assert_close(b["d"][same], a["d"][same], 1e-9, 0, "dispersions")
+    assert_close(b["l"][same], a["l"][same], 1e-8, 1e-10, "LFC")
+    assert_close(b["se"][same], a["se"][same], 1e-8, 0, "lfcSE")
+
+
 def test_hip_inference_under_the_reference_orchestration():
     """All Inference methods of the plug-in driven in DeseqDataSet.deseq2()'s call order with the reference's
     keyword arguments (dds.py:713-984, ds.py:303-360; the orchestration is the oracle's restatement of it, since

@@ -739,6 +739,9 @@ __global__ void k_mean_inv(const double* __restrict__ sf, int N, double* out) {
     if (threadIdx.x == 0) out[0] = part[0] / (double)N;
 }
 
+constexpr int kMomGenes = 4;  // genes per wavefront of the method-of-moments kernels
+static inline int mom_blocks(int G) { return (G + kWavesPerBlock * kMomGenes - 1) / (kWavesPerBlock * kMomGenes); }
+
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_mom(const int32_t* __restrict__ y, int ldn,
                                                 const double* __restrict__ sf,
@@ -748,15 +751,23 @@ __global__ __launch_bounds__(kBlock) void k_mom(const int32_t* __restrict__ y, i
                                                 double max_disp, double* __restrict__ normed_mean,
                                                 double* __restrict__ rough, double* __restrict__ moments,
                                                 double* __restrict__ mom) {
-    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const MomOut o = mom_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
-                                             min_disp, max_disp);
+    // four genes per wavefront: the shared vectors are read once for four count rows (dsq_stats.h, mom_lin_mu_block)
+    const int g0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * kMomGenes;
+    if (g0 >= G) return;
+    const int nv = G - g0 < kMomGenes ? G - g0 : kMomGenes;
+    MomOut o[kMomGenes];
+    mom_lin_mu_block<DeviceWave, P, kMomGenes>(y + (size_t)g0 * ldn, ldn, nv, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
+                                               min_disp, max_disp, 0.0, nullptr, nullptr, o);
     if ((threadIdx.x & 63) == 0) {
-        normed_mean[g] = o.normed_mean;
-        if (rough) rough[g] = o.rough;
-        if (moments) moments[g] = o.moments;
-        mom[g] = o.mom;
+#pragma unroll
+        for (int k = 0; k < kMomGenes; ++k) {
+            if (k < nv) {
+                normed_mean[g0 + k] = o[k].normed_mean;
+                if (rough) rough[g0 + k] = o[k].rough;
+                if (moments) moments[g0 + k] = o[k].moments;
+                mom[g0 + k] = o[k].mom;
+            }
+        }
     }
 }
 
@@ -771,7 +782,7 @@ hipError_t launch_mom(hipStream_t st, const int32_t* y, int ldn, const double* s
     if (P_ > DSQ_REG_MAX_P)
         return launch_wide_mom(st, y, ldn, sf, Xt, pinvXt, ldx, N, G, P_, min_disp, max_disp, 0.5, normed_mean, rough,
                                moments, mom, nullptr, nullptr, d_scalar);
-    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    const dim3 grid(mom_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
                                           (const double*)d_scalar, min_disp, max_disp, normed_mean, rough,
                                           moments, mom))
@@ -787,14 +798,21 @@ __global__ __launch_bounds__(kBlock) void k_mom_lin_mu(const int32_t* __restrict
                                                        double max_disp, double min_mu,
                                                        double* __restrict__ normed_mean, double* __restrict__ mom,
                                                        double* __restrict__ mu, double* __restrict__ coef) {
-    const int g = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const MomOut o = mom_lin_mu_gene<DeviceWave, P>(y + (size_t)g * ldn, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
-                                                    min_disp, max_disp, min_mu, mu ? mu + (size_t)g * ldn : nullptr,
-                                                    coef ? coef + (size_t)g * P : nullptr);
+    const int g0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * kMomGenes;
+    if (g0 >= G) return;
+    const int nv = G - g0 < kMomGenes ? G - g0 : kMomGenes;
+    MomOut o[kMomGenes];
+    mom_lin_mu_block<DeviceWave, P, kMomGenes>(y + (size_t)g0 * ldn, ldn, nv, sf, Xt, pinvXt, ldx, N, s_mean_inv[0],
+                                               min_disp, max_disp, min_mu, mu ? mu + (size_t)g0 * ldn : nullptr,
+                                               coef ? coef + (size_t)g0 * P : nullptr, o);
     if ((threadIdx.x & 63) == 0) {
-        normed_mean[g] = o.normed_mean;
-        mom[g] = o.mom;
+#pragma unroll
+        for (int k = 0; k < kMomGenes; ++k) {
+            if (k < nv) {
+                normed_mean[g0 + k] = o[k].normed_mean;
+                mom[g0 + k] = o[k].mom;
+            }
+        }
     }
 }
 
@@ -807,7 +825,7 @@ hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const do
     if (P_ > DSQ_REG_MAX_P)
         return launch_wide_mom(st, y, ldn, sf, Xt, pinvXt, ldx, N, G, P_, min_disp, max_disp, min_mu, normed_mean,
                                nullptr, nullptr, mom, mu, coef, d_scalar);
-    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    const dim3 grid(mom_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mom_lin_mu<P>, grid, block, 0, st, y, ldn, sf, Xt, pinvXt, ldx, N, G,
                                           (const double*)d_scalar, min_disp, max_disp, min_mu, normed_mean, mom, mu,
                                           coef))

@@ -147,6 +147,80 @@ DSQ_HD MomOut mom_lin_mu_gene(const int32_t* y, const double* sf, const double* 
     return o;
 }
 
+// NG genes per wavefront (device kernels k_mom4 / k_mom_lin_mu4): the size factors and the rows of pinvXt / Xt are
+// read once per sample and applied to NG count rows - the single-gene loops read 8 + 16 p bytes of shared vectors per
+// 4 bytes of counts and ran at 1 TB/s of HBM.  Per gene the same operations in the same per-lane order, and the
+// multi-value reduction is bit-identical to the single sums: same results as mom_lin_mu_gene.
+template <class Wv, int P, int NG>
+DSQ_HD void mom_lin_mu_block(const int32_t* y0, int ldn, int n_valid, const double* sf, const double* Xt,
+                             const double* pinvXt, int ldx, int N, double s_mean_inv, double min_disp,
+                             double max_disp, double min_mu, double* mu0, double* coef0, MomOut (&out)[NG]) {
+    const int32_t* yr[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) yr[k] = y0 + (size_t)(k < n_valid ? k : n_valid - 1) * ldn;
+    double s[NG], b[NG * P];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) s[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NG * P; ++i) b[i] = 0.0;
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double sfn = sf[n];
+        double pv[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) pv[j] = pinvXt[j * ldx + n];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const double v = (double)yr[k][n] / sfn;
+            s[k] += v;
+#pragma unroll
+            for (int j = 0; j < P; ++j) b[k * P + j] += pv[j] * v;
+        }
+    }
+    Wv::template sum_n<NG>(s);
+    Wv::template sum_n<NG * P>(b);
+    double mean[NG], acc[2 * NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) { mean[k] = s[k] / (double)N; acc[k] = 0.0; acc[NG + k] = 0.0; }
+    const double dof = (double)(N - P);
+    for (int n = Wv::lane(); n < N; n += Wv::W) {
+        const double sfn = sf[n];
+        double xv[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) xv[j] = Xt[j * ldx + n];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const double v = (double)yr[k][n] / sfn;
+            const double d = v - mean[k];
+            acc[k] += d * d;
+            double yh = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) yh += xv[j] * b[k * P + j];
+            if (mu0 != nullptr && k < n_valid) mu0[(size_t)k * ldn + n] = dmax(sfn * yh, min_mu);
+            yh = dmax(yh, 1.0);
+            acc[NG + k] += ((v - yh) * (v - yh) - yh) / (dof * yh * yh);
+        }
+    }
+    Wv::template sum_n<2 * NG>(acc);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        if (coef0 != nullptr && Wv::lane() == 0 && k < n_valid) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) coef0[(size_t)k * P + j] = b[k * P + j];
+        }
+        MomOut o;
+        o.normed_mean = mean[k];
+        o.rough = dmax(acc[NG + k], 0.0);
+        const double var = acc[k] / (double)(N - 1);
+        double m = (var - s_mean_inv * mean[k]) / (mean[k] * mean[k]);
+        if (m != m) m = 0.0;
+        else if (m == INFINITY) m = DBL_MAX;
+        else if (m == -INFINITY) m = -DBL_MAX;
+        o.moments = m;
+        o.mom = dmin(dmax(dmin(o.rough, o.moments), min_disp), max_disp);
+        out[k] = o;
+    }
+}
+
 // ---------------------------------------------------------------- linear-model mu_hat
 template <class Wv, int P>
 DSQ_HD void lin_mu_gene(const int32_t* y, const double* sf, const double* Xt, const double* pinvXt,

@@ -214,6 +214,7 @@ class DeseqPipeline:
         self.collect_nfev = False  # profiling aid: log the L-BFGS-B evaluation count of every dispersion launch
         self.kernel_log = {}
         self._pool_free, self._pool_used = [], []
+        self._inflight = []
         self._pinned = _PinnedPool(ctx_)
         # Cook's cutoff F.ppf(0.99, p, N - p) (dds.py:1073, 1324): a scipy call of ~0.1 ms, off the step's path
         self._cooks_cutoff = float(f_dist.ppf(0.99, self.P, self.N - self.P)) if self.N > self.P else float("nan")
@@ -239,6 +240,9 @@ class DeseqPipeline:
     def _pool_reset(self):
         self._pool_free.extend(self._pool_used)
         self._pool_used = []
+        if getattr(self, "_inflight", None):  # staging slabs of _up(): make sure their copies have run
+            self.ctx.sync()
+        self._inflight = []
         self.layers = {}  # they point into the buffers that have just been recycled
 
     def _pooled(self, shape, dtype, ld=None):
@@ -260,10 +264,19 @@ class DeseqPipeline:
         return self._pooled((max(int(rows), 1), self.N), dtype, ld=self.ldn)
 
     def _up(self, arr, dtype=np.float64):
+        """Host array -> pooled device buffer.  Small arrays (index lists of the refit, ...) go through a page-locked
+        staging slab and an asynchronous copy: a pageable source makes the copy - and the host - wait for everything
+        queued before it.  The slab stays referenced until the pool is reset (the copy is stream-ordered)."""
         arr = np.ascontiguousarray(arr, dtype=dtype)
         d = self._pooled(arr.shape if arr.ndim else (1,), arr.dtype)
         if arr.size:
-            self.ctx.h2d(d.ptr, arr)
+            if arr.nbytes <= 65536:
+                hs = self._host_slab(arr.nbytes)
+                hs.view(0, arr.size, arr.dtype)[:] = arr.reshape(-1)
+                self.ctx.call("dsq_h2d_async", _vp(d.ptr), _vp(hs.ptr), C.c_size_t(arr.nbytes))
+                self._inflight.append(hs)
+            else:
+                self.ctx.h2d(d.ptr, arr)
         return d
 
     def _down_nonzero(self):
@@ -334,6 +347,13 @@ class DeseqPipeline:
 
     def _fetch(self, slab, names=None):
         """Device slab -> numpy views over a pinned host slab (dict name -> array)."""
+        tok = self._fetch_begin(slab, names)
+        self.ctx.sync()
+        return self._fetch_end(tok)
+
+    def _fetch_begin(self, slab, names=None):
+        """Enqueue the copies of _fetch without waiting; _fetch_end(token) after any later synchronisation of the
+        stream gives the views (the refit's small vectors ride on the final fetch's synchronisation)."""
         Gs, off = slab["_Gs"], slab["_off"]
         width = lambda k: Gs * (8 * self.P if k == "beta" else (8 if k in self._F64 else 1))  # noqa: E731
         if names is None:
@@ -349,7 +369,10 @@ class DeseqPipeline:
             for k in names:
                 self.ctx.call("dsq_d2h_async", _vp(host.ptr + hoff[k]), _vp(slab["_base"] + off[k]),
                               C.c_size_t(width(k)))
-        self.ctx.sync()
+        return host, hoff, names, Gs
+
+    def _fetch_end(self, tok):
+        host, hoff, names, Gs = tok
         out = {}
         for k in names:
             if k == "beta":
@@ -728,7 +751,7 @@ class DeseqPipeline:
                     d_rf = self._up(rf.astype(np.int32), np.int32)
                     for k, wdt in (("disp", 1), ("beta", P), ("p", 1), ("stat", 1), ("se", 1)):
                         ctx.call("dsq_dev_scatter_rows_f64", _vp(S2[k].ptr), _vp(d_rf.ptr), Gf, wdt, _vp(S[k].ptr))
-                    patch = (rf, self._fetch(S2, ["nm", "gw", "fit"]))
+                    patch = (rf, self._fetch_begin(S2, ["nm", "gw", "fit"]))
         t7 = tick(); T["refit"] = t7 - t6
 
         # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues (refitted genes: patched above)
@@ -748,7 +771,7 @@ class DeseqPipeline:
         if patch is not None or new_zero_nz.any():
             nm, fit = nm.copy(), fit.copy()
             if patch is not None:  # dds.py:1410-1458: the refitted genes take their new values
-                rf, h2 = patch
+                rf, h2 = patch[0], self._fetch_end(patch[1])  # (copied before the final fetch's synchronisation)
                 nm[rf] = h2["nm"]
                 gw[rf] = np.clip(h2["gw"], self.min_disp, self.max_disp)
                 fit[rf] = h2["fit"]

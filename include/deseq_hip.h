@@ -320,6 +320,12 @@ int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, 
  * fitted trend a0 + a1/normed_mean (dds.py:826-833; a1 == 0: mean trend), final dispersions with the
  * dispersion-outlier rule (dds.py:912-935; inputs are the UNclipped fits), and the write-back of the
  * refitted genes (dds.py:1410-1458). */
+/* dsq_dev_trend_fit + the fitted values (dds.py:826-833) + dsq_dev_prior_mad with one host synchronisation: the
+ * coefficients stay on the device between the three kernels.  *h_ok = 0: the trend fit did not converge
+ * (dds.py:811-823); the caller then takes the mean trend through dsq_dev_trend_eval / dsq_dev_prior_mad. */
+int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n, double min_disp,
+                        double max_disp, uint8_t* d_keep, double* d_fitted, double* d_work, double* h_coeffs2,
+                        int* h_ok, int* h_n_outer, double* h_squared_logres);
 int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1,
                        double* d_fitted);
 /* dispersion-outlier rule and final dispersions (dds.py:909-935); the genewise and MAP dispersions are clipped to

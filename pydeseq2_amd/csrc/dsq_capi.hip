@@ -950,6 +950,34 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
     return DSQ_OK;
 }
 
+// Parametric trend, its fitted values and the MAD prior in one call with ONE host synchronisation: the fitted values
+// are evaluated from the coefficients the trend kernel left on the device, the prior kernel follows, and the five
+// scalars come back together through page-locked memory.  *h_ok = 0 (the fit did not converge, dds.py:811-823): the
+// caller falls back to the mean trend with dsq_dev_trend_eval + dsq_dev_prior_mad; d_fitted / *h_squared_logres are
+// then meaningless.
+int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n, double min_disp,
+                        double max_disp, uint8_t* d_keep, double* d_fitted, double* d_work, double* h_coeffs2,
+                        int* h_ok, int* h_n_outer, double* h_squared_logres) {
+    double* d_out = ctx->d_scratch + 1536;  // {c0, c1, ok, n_outer, -}  then {squared_logres, status} at + 64
+    double* d_out2 = ctx->d_scratch + 1600;
+    if (ctx->d_trend_grid == nullptr) DSQ_HIP(hipMalloc(&ctx->d_trend_grid, dsq::trend_grid_mem_bytes()));
+    static const int force_grid = getenv("DSQ_TREND_GRID") ? atoi(getenv("DSQ_TREND_GRID")) : 0;
+    DSQ_HIP(dsq::launch_trend_fit(ctx->stream, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out,
+                                  ctx->d_trend_grid, force_grid));
+    DSQ_HIP(dsq::launch_trend_eval_dev(ctx->stream, d_means, n, d_out, d_fitted));
+    DSQ_HIP(dsq::launch_prior_mad(ctx->stream, d_disp, d_fitted, n, min_disp, max_disp, d_work, d_out2));
+    double* h = (double*)(ctx->h_pin + 3072);  // 12 KiB into the page-locked block (behind the ridge / contrast staging)
+    DSQ_HIP(hipMemcpyAsync(h, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(h + 8, d_out2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    h_coeffs2[0] = h[0]; h_coeffs2[1] = h[1];
+    *h_ok = (int)h[2];
+    if (h_n_outer) *h_n_outer = (int)h[3];
+    if (*h_ok && h[9] < 0.0) return fail(ctx, DSQ_ERR_HIP, "prior MAD: grid barrier timed out");
+    *h_squared_logres = h[8];
+    return DSQ_OK;
+}
+
 size_t dsq_prior_mad_work_doubles(int n) { return dsq::prior_mad_work_doubles(n); }
 
 int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitted, int n, double min_disp,

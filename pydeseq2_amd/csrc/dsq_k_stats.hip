@@ -1208,6 +1208,15 @@ __global__ void k_trend_eval(const double* __restrict__ nm, int n, double a0, do
     if (i < n) fitted[i] = (a1 == 0.0) ? a0 : a0 + a1 / nm[i];
 }
 
+// the same with the coefficients where the trend-fit kernel left them on the device (coef[0], coef[1]): the fitted
+// values and the prior can then be enqueued without the host seeing the coefficients first
+__global__ void k_trend_eval_dev(const double* __restrict__ nm, int n, const double* __restrict__ coef,
+                                 double* __restrict__ fitted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a0 = coef[0], a1 = coef[1];
+    if (i < n) fitted[i] = (a1 == 0.0) ? a0 : a0 + a1 / nm[i];
+}
+
 // final dispersions (dds.py:912-935): MAP value, except for dispersion outliers
 // log(genewise) > log(fitted) + 2 sqrt(squared_logres), which keep the (clipped) genewise value
 // the genewise and MAP dispersions are clipped IN PLACE (dds.py:792-794, 905-907: the reference stores them clipped):
@@ -1314,6 +1323,11 @@ hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int
 hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_trend_eval, dim3((n + 255) / 256), dim3(256), 0, st, nm, n, a0, a1, fitted);
+    return hipGetLastError();
+}
+hipError_t launch_trend_eval_dev(hipStream_t st, const double* nm, int n, const double* coef, double* fitted) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trend_eval_dev, dim3((n + 255) / 256), dim3(256), 0, st, nm, n, coef, fitted);
     return hipGetLastError();
 }
 hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted,

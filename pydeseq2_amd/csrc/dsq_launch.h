@@ -183,6 +183,7 @@ size_t size_factors_work_doubles(int N, int G);
 hipError_t launch_vst(hipStream_t st, const void* counts_sm, int count_type, int N, int G, const double* sf, int mode,
                       double a0, double a1, double* out);
 hipError_t launch_trend_eval(hipStream_t st, const double* nm, int n, double a0, double a1, double* fitted);
+hipError_t launch_trend_eval_dev(hipStream_t st, const double* nm, int n, const double* coef, double* fitted);
 hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted,
                               int n, double min_disp, double max_disp, double two_sd, double* disp,
                               uint8_t* outlier);

@@ -514,6 +514,20 @@ class DeseqPipeline:
                 C.byref(n_outer))
         return np.array([c2[0], c2[1]]) if ok.value else None
 
+    def _trend_prior_fused(self, Gn, d_fit):
+        """(coeffs or None, squared_logres): dsq_dev_trend_prior - the parametric trend (dds.py:1199-1275), its fitted
+        values and the MAD prior (dds.py:866-884) enqueued back to back, one synchronisation."""
+        d_gw, d_nm = self._last_gw_dev
+        c2, ok, n_outer, sq = (C.c_double * 2)(), C.c_int(0), C.c_int(0), C.c_double()
+        d_keep = self._dvec(Gn, np.uint8)
+        d_work = self._dvec(self.ctx.lib.dsq_prior_mad_work_doubles(int(Gn)))
+        self.ctx.call("dsq_dev_trend_prior", _vp(d_gw.ptr), _vp(d_nm.ptr), int(Gn), c_double(self.min_disp),
+                      c_double(self.max_disp), _vp(d_keep.ptr), _vp(d_fit.ptr), _vp(d_work.ptr), c2, C.byref(ok),
+                      C.byref(n_outer), C.byref(sq))
+        if not ok.value:
+            return None, None
+        return np.array([c2[0], c2[1]]), float(sq.value)
+
     def _mean_trend(self, Gn):
         """Mean-based trend (dds.py:1277-1299) over this pipeline's (clipped) genewise dispersions."""
         d_gw, _ = self._last_gw_dev
@@ -643,8 +657,15 @@ class DeseqPipeline:
 
         # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
         coeffs = None
+        fused_sq = None
         if self.fit_type == "parametric":
-            coeffs = self._fit_trend(Gn)
+            cls = type(self)
+            if (cls._fit_trend is DeseqPipeline._fit_trend and cls._prior is DeseqPipeline._prior
+                    and not (stop_after_trend or self.time_kernels)):
+                # trend fit, fitted values and prior in one call (one synchronisation instead of two and a launch gap)
+                coeffs, fused_sq = self._trend_prior_fused(Gn, S["fit"])
+            else:
+                coeffs = self._fit_trend(Gn)
             if coeffs is None:
                 warnings.warn("The dispersion trend curve fitting did not converge. "
                               "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
@@ -673,12 +694,17 @@ class DeseqPipeline:
             r.genewise_dispersions = fullv(np.clip(Hh["gw"], self.min_disp, self.max_disp))
             r.genewise_converged = fullv(Hh["gconv"].astype(float))
             return r
-        ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(a0), c_double(a1), _vp(S["fit"].ptr))
+        if fused_sq is None or coeffs is None:
+            ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(a0), c_double(a1), _vp(S["fit"].ptr))
         if (N - P) <= 3:
             warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
                           "dispersions is especially asymmetric and likely to be poorly estimated by the MAD.",
                           UserWarning, stacklevel=2)
-        r.squared_logres, r.prior_disp_var = self._prior(Gn, S["fit"], r)
+        if fused_sq is not None and coeffs is not None:
+            r.squared_logres = fused_sq
+            r.prior_disp_var = float(max(fused_sq - _trigamma((N - P) / 2), 0.25))
+        else:
+            r.squared_logres, r.prior_disp_var = self._prior(Gn, S["fit"], r)
         t3 = tick(); T["trend_prior"] = t3 - t2
 
         # ---- MAP dispersions + dispersion outliers (dds.py:886-935)

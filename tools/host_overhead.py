@@ -52,6 +52,10 @@ class FakeContext(_lib.Context):
         elif name == "dsq_dev_trend_fit":
             args[-2]._obj.value = 1
             args[-3][0], args[-3][1] = 1.0, 0.05
+        elif name == "dsq_dev_trend_prior":
+            args[-4][0], args[-4][1] = 1.0, 0.05
+            args[-3]._obj.value = 1
+            args[-1]._obj.value = 0.5
         elif name == "dsq_dev_prior_mad":
             args[-1]._obj.value = 0.5
 

@@ -287,6 +287,9 @@ int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double*
 int dsq_side_begin(dsq_ctx* ctx);
 int dsq_side_end(dsq_ctx* ctx);
 int dsq_side_wait(dsq_ctx* ctx);
+/* Error paths of the caller: back to the main stream from whatever state, then both streams synchronised (buffers the
+ * side stream was writing may be recycled afterwards).  No-op on a context that never forked. */
+int dsq_side_abort(dsq_ctx* ctx);
 /* d_mu / d_hat may be null.  d_iters may be null. */
 int dsq_dev_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                  const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank,

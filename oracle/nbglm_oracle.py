@@ -15,7 +15,13 @@ Parity pinning
   ``tests/test_oracle_golden.py`` on every run;
 * the end-to-end orchestration is checked against the reference's own
   R-DESeq2 fixtures (``tests/data/{single_factor,multi_factor,continuous,wide}``,
-  copied to ``tests/golden/r_*``) at the reference's own tolerances.
+  copied to ``tests/golden/r_*``) at the reference's own tolerances;
+* end to end at the benchmark shapes (8000 x 1000 p=2, 4000 x 500 p=8, 1000 x 5000 p=8 with continuous
+  covariates) against the outputs of the unmodified ``DefaultInference`` (``tests/golden/kat_e2e_*.npz``): the
+  per-gene routines below repeat the reference's operation sequence call for call (per-gene ``scipy.linalg.lstsq`` as
+  sklearn's ``LinearRegression`` does, per-gene IRLS with ``scipy.linalg.solve(assume_a="pos")``, the gamma-GLM
+  regressors built through pandas, ``(X.T * W) @ X`` products), so every output is BIT-IDENTICAL to the reference's on
+  the machine that generated the files (``test_oracle_end_to_end_is_the_unmodified_reference_at_benchmark_shapes``).
 
 Third-party arithmetic the reference delegates to (and so does this oracle):
 scipy 1.15.3 ``optimize.minimize(method="L-BFGS-B")``, ``special.gammaln``,
@@ -197,8 +203,22 @@ def mom_dispersions(normed, X, sf, min_disp, max_disp):
 
 
 def lin_reg_mu(counts, sf, X, min_mu):
-    """mu_hat = max(sf * OLS-fit(counts/sf), min_mu) for all genes (utils.py:682-715)."""
-    return np.maximum(sf[:, None] * _ols_fit_predict(X, counts / sf[:, None]), min_mu)
+    """mu_hat = max(sf * OLS-fit(counts/sf), min_mu), gene by gene (utils.py:682-715).
+
+    The reference fits ``sklearn.linear_model.LinearRegression(fit_intercept=False)`` per gene; sklearn's dense path is
+    ``scipy.linalg.lstsq(X, y, cond=max(X.shape) * eps)`` on the gene's vector and ``X @ coef`` for the prediction.
+    The same two calls per gene give the bit-identical mu_hat (a batched lstsq over all genes differs in the last
+    bit on a quarter of the entries, which is enough to move the stopping point of ~0.06 % of the L-BFGS-B runs that
+    consume it - measured, DESIGN.md par. 7)."""
+    from scipy.linalg import lstsq
+
+    counts = np.asarray(counts)
+    cond = max(X.shape) * np.finfo(np.float64).eps
+    out = np.empty(counts.shape, dtype=np.float64)
+    for g in range(counts.shape[1]):
+        coef = lstsq(X, counts[:, g] / sf, cond=cond)[0]
+        out[:, g] = np.maximum(sf * (X @ coef.T), min_mu)
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -413,77 +433,80 @@ def _irls_fallback(counts, sf, X, disp, beta_init, min_mu, min_beta, max_beta, o
     return beta, bool(res.success)
 
 
-def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=30, maxiter=250,
-         return_iters=False, optimizer="L-BFGS-B"):
-    """NB log-link GLM by IRLS for all genes at once (utils.py:273-438).
+def irls_gene(y, sf, X, disp, start, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=30, maxiter=250,
+              optimizer="L-BFGS-B"):
+    """One gene's NB log-link GLM by IRLS, in the reference's own operation sequence (utils.py:340-438) so that the
+    result is bit-identical to ``utils.irls_solver``: ``start`` = (Q, R) of the design when it has full rank, else None
+    (utils.py:349-357; rank and QR depend on the design only and are hoisted out of the gene loop).
+    Returns (beta[p], mu[N] UNclamped, hat diagonal[N], converged, sweeps)."""
+    p = X.shape[1]
+    if start is not None:  # utils.py:349-353
+        Q, R = start
+        with np.errstate(divide="ignore"):
+            beta_init = sp_solve(R, Q.T @ np.log(y / sf + 0.1))
+    else:  # utils.py:354-357
+        beta_init = np.zeros(p)
+        with np.errstate(divide="ignore"):
+            beta_init[0] = np.log(y / sf).mean()
+    beta = beta_init
+    ridge = np.diag(np.repeat(1e-6, p))
+    mu = np.maximum(sf * np.exp(X @ beta), min_mu)
+    dev, ratio, sweeps, converged = 1000.0, 1.0, 0, True
+    while ratio > beta_tol:
+        W = mu / (1.0 + mu * disp)
+        z = np.log(mu / sf) + (y - mu) / mu
+        bh = sp_solve((X.T * W) @ X + ridge, X.T @ (W * z), assume_a="pos")
+        sweeps += 1
+        if sum(np.abs(bh) > max_beta) > 0 or sweeps >= maxiter:  # utils.py:374-413
+            beta, converged = _irls_fallback(y, sf, X, disp, beta_init, min_mu, min_beta, max_beta, optimizer)
+            mu = np.maximum(sf * np.exp(X @ beta), min_mu)
+            break
+        beta = bh
+        mu = np.maximum(sf * np.exp(X @ beta), min_mu)
+        old = dev
+        dev = -2 * nb_nll(y, mu, disp)
+        ratio = np.abs(dev - old) / (np.abs(dev) + 0.1)
+    # hat diagonal with the CLAMPED mu (utils.py:427-433); returned mu is UNclamped (utils.py:435-437)
+    W = mu / (1.0 + mu * disp)
+    h = np.einsum("ij,jk,ki->i", X, np.linalg.inv((X.T * W[None, :]) @ X + ridge), X.T)
+    sq = np.sqrt(W)
+    return beta, sf * np.exp(X @ beta), sq * h * sq, converged, sweeps
 
-    Vectorised over genes with a per-gene ``active`` mask so every gene runs
-    exactly the reference's scalar ``while dev_ratio > beta_tol`` loop.
-    Returns (beta[G,p], mu[N,G] (UNclamped), H[N,G], converged[G]).
-    """
-    counts = np.asarray(counts, dtype=float)
+
+def _irls_chunk(args):
+    counts, sf, X, disp, start, min_mu, beta_tol, min_beta, max_beta, maxiter, optimizer = args
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = [irls_gene(counts[:, g], sf, X, disp[g], start, min_mu, beta_tol, min_beta, max_beta, maxiter, optimizer)
+               for g in range(counts.shape[1])]
+    return (np.array([o[0] for o in out]).reshape(len(out), X.shape[1]),
+            np.array([o[1] for o in out]).reshape(len(out), X.shape[0]),
+            np.array([o[2] for o in out]).reshape(len(out), X.shape[0]),
+            np.array([o[3] for o in out], dtype=bool), np.array([o[4] for o in out], dtype=int))
+
+
+def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=30, maxiter=250,
+         return_iters=False, optimizer="L-BFGS-B", n_jobs=1, chunk=256):
+    """NB log-link GLM by IRLS for all genes (utils.py:273-438 per gene, default_inference.py:83-124 over genes).
+    Returns (beta[G,p], mu[N,G] (UNclamped), H[N,G], converged[G])."""
+    counts = np.asarray(counts)
     N, G = counts.shape
     p = X.shape[1]
-    disp = np.asarray(disp, dtype=float)
-    ridge = np.diag(np.repeat(1e-6, p))
-    with np.errstate(divide="ignore"):
-        full_rank = np.linalg.matrix_rank(X) == p
-        if full_rank:  # utils.py:349-353
-            Q, R = np.linalg.qr(X)
-            beta_init = np.linalg.solve(R, Q.T @ np.log(counts / sf[:, None] + 0.1))
-        else:  # utils.py:354-357
-            beta_init = np.zeros((p, G))
-            beta_init[0] = np.log(counts / sf[:, None]).mean(0)
-    beta = beta_init.copy()  # p x G
-    mu = np.maximum(sf[:, None] * np.exp(X @ beta), min_mu)
-    dev = np.full(G, 1000.0)
-    ratio = np.ones(G)
-    iters = np.zeros(G, dtype=int)
-    converged = np.ones(G, dtype=bool)
-    active = ratio > beta_tol
-    while active.any():
-        idx = np.nonzero(active)[0]
-        m = mu[:, idx]
-        W = m / (1.0 + m * disp[idx])
-        z = np.log(m / sf[:, None]) + (counts[:, idx] - m) / m
-        H = np.einsum("ni,ng,nj->gij", X, W, X) + ridge
-        rhs = np.einsum("ni,ng->gi", X, W * z)
-        bh = np.linalg.solve(H, rhs[:, :, None])[:, :, 0]  # len(idx) x p
-        iters[idx] += 1
-        bad = (np.abs(bh) > max_beta).any(1) | (iters[idx] >= maxiter)
-        for k in np.nonzero(bad)[0]:
-            g = idx[k]
-            # the rescue restarts from beta_init; its termination flag on these ill-conditioned genes reacts to
-            # the last bit of the start point, so it is recomputed per gene with the reference's own calls
-            # (utils.py:349-353: scipy.linalg.solve on the gene's vector, not the batched matrix product)
-            b0 = beta_init[:, g]
-            if full_rank:
-                with np.errstate(divide="ignore"):
-                    b0 = sp_solve(R, Q.T @ np.log(counts[:, g] / sf + 0.1))
-            b, ok = _irls_fallback(counts[:, g], sf, X, disp[g], b0, min_mu, min_beta, max_beta, optimizer)
-            beta[:, g] = b
-            mu[:, g] = np.maximum(sf * np.exp(X @ b), min_mu)
-            converged[g] = ok
-            active[g] = False
-        good = ~bad
-        gi = idx[good]
-        if gi.size:
-            beta[:, gi] = bh[good].T
-            mu[:, gi] = np.maximum(sf[:, None] * np.exp(X @ beta[:, gi]), min_mu)
-            old = dev[gi]
-            dev[gi] = np.array([-2 * nb_nll(counts[:, g], mu[:, g], disp[g]) for g in gi])
-            ratio[gi] = np.abs(dev[gi] - old) / (np.abs(dev[gi]) + 0.1)
-            active[gi] = ratio[gi] > beta_tol
-    # hat diagonals with the CLAMPED mu (utils.py:427-433)
-    W = mu / (1.0 + mu * disp)
-    Hm = np.einsum("ni,ng,nj->gij", X, W, X) + ridge
-    Hinv = np.linalg.inv(Hm)
-    h = np.einsum("ni,gij,nj->ng", X, Hinv, X)
-    Hd = np.sqrt(W) * h * np.sqrt(W)
-    mu_out = sf[:, None] * np.exp(X @ beta)  # UNclamped (utils.py:435-437)
+    disp = np.broadcast_to(np.asarray(disp, dtype=float), (G,))
+    start = np.linalg.qr(X) if np.linalg.matrix_rank(X) == p else None  # utils.py:349-350, hoisted
+    chunks = [(counts[:, s:s + chunk], sf, X, disp[s:s + chunk], start, min_mu, beta_tol, min_beta, max_beta, maxiter,
+               optimizer) for s in range(0, G, chunk)]
+    res = _run_chunks(_irls_chunk, chunks, n_jobs)
+    if not res:
+        z = np.zeros((N, 0))
+        return (np.zeros((0, p)), z, z.copy(), np.zeros(0, dtype=bool)) + ((np.zeros(0, dtype=int),) if return_iters else ())
+    beta = np.concatenate([r[0] for r in res])
+    mu = np.concatenate([r[1] for r in res]).T
+    Hd = np.concatenate([r[2] for r in res]).T
+    conv = np.concatenate([r[3] for r in res])
     if return_iters:
-        return beta.T.copy(), mu_out, Hd, converged, iters
-    return beta.T.copy(), mu_out, Hd, converged
+        return beta, mu, Hd, conv, np.concatenate([r[4] for r in res])
+    return beta, mu, Hd, conv
 
 
 # --------------------------------------------------------------------------
@@ -493,7 +516,15 @@ def irls(counts, sf, X, disp, min_mu=0.5, beta_tol=1e-8, min_beta=-30, max_beta=
 
 def trend_gamma_glm(cov: np.ndarray, targets: np.ndarray):
     """2-coefficient gamma GLM disp ~ a0 + a1*cov (default_inference.py:200-230)."""
-    A = np.column_stack([np.ones_like(cov), cov])
+    import pandas as pd
+
+    # the reference builds the regressors through pandas (Series.to_frame, insert of an integer intercept column,
+    # .values): the resulting array's memory layout decides which BLAS kernel ``A @ c`` runs, i.e. the last bit of mu -
+    # built the same way here so that the fit is bit-identical (default_inference.py:203-206)
+    frame = pd.Series(np.asarray(cov)).to_frame()
+    frame.insert(0, "intercept", 1)
+    A = frame.values
+    targets = np.asarray(targets)
 
     def loss(c):
         mu = A @ c
@@ -640,16 +671,16 @@ def wald_test(X, disp, lfc, mu, ridge, contrast, lfc_null=0.0, alt_hypothesis=No
     ``lfc`` is G x p, ``mu`` N x G.  Returns (pvalue[G], stat[G], se[G]).
     """
     G = lfc.shape[0]
-    W = mu / (1 + mu * disp[None, :])
-    M = np.einsum("ni,ng,nj->gij", X, W, X)
     pv = np.full(G, np.nan)
     st = np.full(G, np.nan)
     se = np.full(G, np.nan)
     for g in range(G):
-        if not np.isfinite(M[g]).all():
+        Wg = mu[:, g] / (1 + mu[:, g] * disp[g])
+        Mg = (X.T * Wg[None, :]) @ X  # the reference's own product (utils.py:771-772): bit-identical M
+        if not np.isfinite(Mg).all():
             continue
-        Hc = np.linalg.inv(M[g] + ridge) @ contrast
-        s = np.sqrt(Hc.T @ M[g] @ Hc)
+        Hc = np.linalg.inv(Mg + ridge) @ contrast
+        s = np.sqrt(Hc.T @ Mg @ Hc)
         b = lfc[g]
         with np.errstate(divide="ignore", invalid="ignore"):
             if alt_hypothesis is None:
@@ -738,7 +769,7 @@ class _OracleInference:
         return lin_reg_mu(counts, size_factors, design_matrix, min_mu)
 
     def irls(self, counts, size_factors, design_matrix, disp, min_mu, beta_tol, **kw):
-        return irls(counts, size_factors, design_matrix, disp, min_mu, beta_tol)
+        return irls(counts, size_factors, design_matrix, disp, min_mu, beta_tol, n_jobs=self.n_jobs)
 
     def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
                   cr_reg=True, prior_reg=False, **kw):

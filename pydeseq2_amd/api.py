@@ -216,23 +216,21 @@ class DeseqDataSet:
         X = self.obsm["design_matrix"].to_numpy() if use_design else np.ones((self.n_obs, 1))
         pipe = p0 if use_design else DeseqPipeline(self.X, X, ctx=p0.ctx, min_mu=p0.min_mu, min_disp=p0.min_disp,
                                                     max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type,
-                                                    size_factors_fit_type=p0.size_factors_fit_type,
-                                                    control_genes=self._control_genes)
-        # size factors are fitted only when there are none yet (dds.py:397-401): after deseq2() / fit_size_factors()
-        # the transformation uses the ones the model was fitted with (control genes included)
-        have_sf = "size_factors" in self.obs
+                                                    size_factors_fit_type=p0.size_factors_fit_type)
+        # The reference tests `"size_factors" not in self.obsm` (dds.py:404) - size factors live in .obs, so the test is
+        # always true: vst_fit() ALWAYS refits them with size_factors_fit_type and WITHOUT control genes
+        # (fit_size_factors' default) and overwrites obs["size_factors"].  Mirrored as is.
         old_ft, pipe.fit_type = pipe.fit_type, self.vst_fit_type
+        old_cm, pipe._control_mask = pipe._control_mask, None
         try:
-            r = pipe.deseq2(stop_after_trend=True,
-                            size_factors=np.asarray(self.obs["size_factors"], dtype=float) if have_sf else None)
+            r = pipe.deseq2(stop_after_trend=True)
         finally:
-            pipe.fit_type = old_ft
+            pipe.fit_type, pipe._control_mask = old_ft, old_cm
             if pipe is not p0:
                 pipe.close()
         if pipe is p0:
             self.layers.clear()  # the device layers of an earlier deseq2() were recycled by this run
-        if not have_sf:
-            self.obs["size_factors"] = r.size_factors
+        self.obs["size_factors"] = r.size_factors
         self.var["vst_genewise_dispersions"] = r.genewise_dispersions
         if r.disp_function_type == "parametric":
             self.uns["vst_trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])

@@ -650,8 +650,21 @@ int dsq_side_begin(dsq_ctx* ctx) {
 
 int dsq_side_end(dsq_ctx* ctx) {
     DSQ_CHECK_ARG(ctx->side_stream != nullptr && ctx->stream == ctx->side_stream, "not on the side stream");
+    ctx->stream = ctx->main_stream;  // first: a failing record must not leave the context on the side stream
     DSQ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
-    ctx->stream = ctx->main_stream;
+    return DSQ_OK;
+}
+
+// Leave the side stream whatever state the context is in (error paths of the caller: a stage failed between
+// dsq_side_begin and dsq_side_end) and wait until everything queued on either stream has run, so that buffers the
+// side stream was writing may be recycled.  A no-op on a context that never forked.
+int dsq_side_abort(dsq_ctx* ctx) {
+    if (ctx->main_stream != nullptr) ctx->stream = ctx->main_stream;
+    if (ctx->side_stream != nullptr) {
+        (void)hipEventRecord(ctx->ev_join, ctx->side_stream);
+        DSQ_HIP(hipStreamSynchronize(ctx->side_stream));
+    }
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
     return DSQ_OK;
 }
 
@@ -750,7 +763,6 @@ int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                        uint8_t* d_converged) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
-    //DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
                                prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged));
@@ -1011,6 +1023,20 @@ int dsq_dev_trend_loss_grad(dsq_ctx* ctx, const double* d_cov, const double* d_t
 
 
 // ------------------------------------------------------------------ grid searches + trend GLM as entry points
+// The table logarithm of the dispersion kernels (flog_t, dsq_math.h) is defined for positive, finite, normal
+// arguments.  The pipeline's mu_hat always is (>= min_mu, or exp of a finite predictor); a plug-in caller hands over
+// its own mu, and the reference's loss is inf / NaN for mu <= 0 anyway (y * log(mu), utils.py:227-234): refuse.
+static int check_mu_positive(dsq_ctx* ctx, const double* mu, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const double m = mu[i];
+        if (!(m >= 2.2250738585072014e-308) || m > 1.7976931348623157e308) {
+            ctx->err = "mu must be positive, finite and normal (the negative binomial log-likelihood takes log(mu))";
+            return DSQ_ERR_ARG;
+        }
+    }
+    return DSQ_OK;
+}
+
 int dsq_inf_grid_fit_alpha(dsq_ctx* ctx, const void* counts, int count_type, int count_layout, const double* design,
                            const double* mu, int mu_layout, int N, int G, int P, double min_disp, double max_disp,
                            double* log_alpha_out) {
@@ -1020,6 +1046,7 @@ int dsq_inf_grid_fit_alpha(dsq_ctx* ctx, const void* counts, int count_type, int
     DevBuf y, m, a, work;
     DesignDev D;
     int rc;
+    if ((rc = check_mu_positive(ctx, mu, (size_t)N * G))) return rc;
     if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
     if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
     if ((rc = upload_design(ctx, design, N, P, D))) return rc;
@@ -1144,6 +1171,7 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
     DevBuf y, m, ah, a, conv;
     DesignDev D;
     int rc;
+    if ((rc = check_mu_positive(ctx, mu, (size_t)N * G))) return rc;
     if ((rc = upload_counts(ctx, counts, count_type, count_layout, N, G, y, ldn))) return rc;
     if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
     if ((rc = upload_design(ctx, design, N, P, D))) return rc;
@@ -1165,7 +1193,6 @@ int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_ty
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
                                   double* beta_out, double* inv_hessian_out, uint8_t* converged) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
-    //DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);

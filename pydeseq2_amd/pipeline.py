@@ -215,6 +215,7 @@ class DeseqPipeline:
         self.kernel_log = {}
         self._pool_free, self._pool_used = [], []
         self._inflight = []
+        self._side_pending = False
         self._pinned = _PinnedPool(ctx_)
         # Cook's cutoff F.ppf(0.99, p, N - p) (dds.py:1073, 1324): a scipy call of ~0.1 ms, off the step's path
         self._cooks_cutoff = float(f_dist.ppf(0.99, self.P, self.N - self.P)) if self.N > self.P else float("nan")
@@ -238,6 +239,9 @@ class DeseqPipeline:
         return ptr
 
     def _pool_reset(self):
+        if getattr(self, "_side_pending", False):  # a previous step died between the fork and the join of the side
+            self.ctx.call("dsq_side_abort")        # stream: its kernel may still be writing pooled buffers
+            self._side_pending = False
         self._pool_free.extend(self._pool_used)
         self._pool_used = []
         if getattr(self, "_inflight", None):  # staging slabs of _up(): make sure their copies have run
@@ -648,9 +652,16 @@ class DeseqPipeline:
         if not (stop_after_trend or stop_after_size_factors):
             if self.overlap:
                 ctx.call("dsq_side_begin")
-            self._k("robust_disp", Gn, "dsq_dev_robust_disp", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
-                    _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell, N, Gn,
-                    _vp(d_rd.ptr))
+                self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
+            try:
+                self._k("robust_disp", Gn, "dsq_dev_robust_disp", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
+                        _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell, N, Gn,
+                        _vp(d_rd.ptr))
+            except BaseException:
+                if self.overlap:  # back on the main stream, both streams drained (a shared Context stays usable)
+                    ctx.call("dsq_side_abort")
+                    self._side_pending = False
+                raise
             if self.overlap:
                 ctx.call("dsq_side_end")
         t2 = tick(); T["genewise"] = t2 - t1
@@ -719,6 +730,7 @@ class DeseqPipeline:
         d_cooks = self._dmat(Gn)
         if self.overlap:
             ctx.call("dsq_side_wait")
+            self._side_pending = False
         d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks))
         want_refit = self.refit_cooks and D.replaceable.sum() > 0
         flags = self._fetch(S, ["any_all"]) if want_refit else None
@@ -900,6 +912,9 @@ class DeseqPipeline:
 
     def close(self):
         """Release the pooled device buffers."""
+        if getattr(self, "_side_pending", False):
+            self.ctx.call("dsq_side_abort")
+            self._side_pending = False
         for _cap, ptr in self._pool_free + self._pool_used:
             self.ctx.free(ptr)
         self._pool_free, self._pool_used = [], []

@@ -338,8 +338,58 @@ def bfgs_cases(ut):
           "| p=8 rescues", len(found), "converged", int(out["b8_conv"].sum()))
 
 
+# end-to-end cases at the benchmark SHAPES (BASELINE configs[2..4]: N = 1000 / 500 / 5000): gene count, samples, design
+# kind and seed of pydeseq2_amd.synth.synth_counts - the counts regenerate from these, only outputs are committed
+E2E_CASES = {"c3": (8000, 1000, "2level", 2), "c4": (4000, 500, "3factor", 3), "c5": (1000, 5000, "mixed", 4)}
+E2E_FIELDS = ("size_factors", "normed_means", "non_zero", "mom_dispersions", "genewise_dispersions",
+              "genewise_converged", "trend_coeffs", "fitted_dispersions", "squared_logres", "prior_disp_var",
+              "MAP_dispersions", "MAP_converged", "outlier_genes", "dispersions", "LFC", "LFC_converged", "replaced",
+              "refitted", "new_all_zeroes", "cooks_outlier", "pvalue", "stat", "lfcSE")
+
+
+def e2e_cases(di, which=None):
+    """kat_e2e_{c3,c4,c5}.npz: the UNMODIFIED reference kernels end to end at the benchmark shapes.
+
+    ``DefaultInference`` (default_inference.py:14-264: utils.fit_alpha_mle / irls_solver / wald_test / fit_lin_mu /
+    fit_rough_dispersions / fit_moments_dispersions / dispersion_trend_gamma_glm per gene through joblib) is driven in
+    dds.py / ds.py call order by the oracle's orchestrator (pydeseq2.dds itself needs anndata).  What the orchestrator
+    adds around the reference's kernels - size factors, trend iteration, prior, Cook's, refit bookkeeping - is the part
+    of the oracle that the R fixtures pin; every per-gene number in these files was produced by the reference's own
+    code.  The counts are not stored: tests regenerate them with pydeseq2_amd.synth.synth_counts(G, N, design, seed)."""
+    import time
+    import warnings
+
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.synth import synth_counts
+
+    inf = di.DefaultInference(n_cpus=os.cpu_count())
+    for name, (G, N, design, seed) in E2E_CASES.items():
+        if which and name not in which:
+            continue
+        counts, X = synth_counts(G, N, design, seed)
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = orc.deseq2(counts, X, inference=inf, keep_layers=False)
+        dt = time.perf_counter() - t0
+        out = {"G": np.array(G), "N": np.array(N), "seed": np.array(seed), "design": np.array(design),
+               "counts_sha256": np.array(__import__("hashlib").sha256(np.ascontiguousarray(counts)).hexdigest()),
+               "X": X}
+        for f in E2E_FIELDS:
+            out[f] = np.asarray(getattr(r, f))
+        np.savez_compressed(os.path.join(HERE, f"kat_e2e_{name}.npz"), **out)
+        print(f"e2e {name}: {G} genes x {N} samples p={X.shape[1]}: {dt:.1f} s, genewise non-converged "
+              f"{int(np.nansum(r.genewise_converged == 0))}, MAP non-converged {int(np.nansum(r.MAP_converged == 0))}, "
+              f"refitted {int(r.refitted.sum())}, cooks_outlier {int(r.cooks_outlier.sum())}", flush=True)
+
+
 def main():
     ut, gs, pp, di = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e":  # round 3: end-to-end outputs at the benchmark shapes
+        e2e_cases(di, sys.argv[2:])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
         wide_cases(ut, gs, pp, di)
         hard_cases(ut, gs)

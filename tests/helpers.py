@@ -11,6 +11,32 @@ def load_kat(name):
     return dict(np.load(os.path.join(GOLD, f"kat_{name}.npz"), allow_pickle=False))
 
 
+def load_e2e(name):
+    """kat_e2e_<name>.npz (tests/golden/make_golden.py e2e): the UNMODIFIED reference end to end at a benchmark shape.
+    Returns (counts, X, ref) with the counts regenerated from the stored seed (checked against the stored digest) and
+    ``ref`` an object carrying the reference's outputs under the oracle's / engine's result field names."""
+    import hashlib
+    from types import SimpleNamespace
+
+    from pydeseq2_amd.synth import synth_counts
+
+    k = load_kat(f"e2e_{name}")
+    counts, X = synth_counts(int(k["G"]), int(k["N"]), str(k["design"]), int(k["seed"]))
+    assert hashlib.sha256(np.ascontiguousarray(counts)).hexdigest() == str(k["counts_sha256"]), "generator drifted"
+    assert np.array_equal(X, k["X"])
+    ref = SimpleNamespace(**{f: (v if v.ndim else v.item()) for f, v in k.items()
+                             if f not in ("G", "N", "seed", "design", "counts_sha256", "X")})
+    return counts, X, ref
+
+
+def flag_flips(res, ref):
+    """Genes on which two runs disagree about an L-BFGS-B success flag (genewise, MAP) or about the refit."""
+    with np.errstate(invalid="ignore"):
+        gw = (res.genewise_converged != ref.genewise_converged) & ref.non_zero
+        mp = (res.MAP_converged != ref.MAP_converged) & ref.non_zero
+    return gw, mp, np.asarray(res.refitted) != np.asarray(ref.refitted)
+
+
 def load_dataset(which):
     """Return (counts DataFrame samples x genes, metadata DataFrame)."""
     d = {"synthetic": "synthetic", "continuous": "r_continuous", "wide": "r_wide"}[which]

@@ -62,19 +62,12 @@ def test_fails_loudly_without_gpu():
         assert "gfx" in ctx.device_info()["arch"]
 
 
-def test_host_trend_helpers_match_oracle():
+def test_host_mean_trend_matches_oracle():
     import numpy as np
 
     from oracle import nbglm_oracle as orc
     from pydeseq2_amd import trend
     from tests.helpers import load_kat
 
-    k = load_kat("p2")
-    gw = np.clip(k["gw_alpha"], 1e-8, 40)
-    nm = k["normed"].mean(0)
-    c1 = trend.fit_parametric_trend(gw, nm)
-    c2, _ = orc.fit_parametric_trend(gw, nm)
-    assert np.allclose(c1, c2, rtol=1e-12)
-    fitted = c1[0] + c1[1] / nm
-    assert np.allclose(trend.dispersion_prior(gw, fitted, 40, 2, 1e-8), orc.dispersion_prior(gw, fitted, 40, 2, 1e-8))
+    gw = np.clip(load_kat("p2")["gw_alpha"], 1e-8, 40)
     assert trend.mean_trend(gw, 1e-8) == orc.mean_trend(gw, 1e-8)

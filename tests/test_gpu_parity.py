@@ -242,6 +242,38 @@ def test_pipeline_vs_oracle_at_benchmark_shapes(cfg, G, N, design, seed):
     print(f"{cfg}: {n_noise} noise-limited genes, {n_grid} grid-fallback fits compared at 1e-10")
 
 
+@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+def test_pipeline_vs_unmodified_reference_at_benchmark_shapes(name):
+    """The engine against the outputs of the UNMODIFIED reference (tests/golden/kat_e2e_*.npz: DefaultInference end to end,
+    8000 x 1000 p=2 / 4000 x 500 p=8 / 1000 x 5000 p=8 continuous) - no oracle in between.  1e-5 on every gene whose
+    success flags agree; the flips are counted per stage and written next to the bench outputs.  The floor of that count
+    is what a one-ulp change of mu_hat does to the reference's own fits: 0.09-0.18 % of the genes per fit
+    (profiles/r03_flip_floor.json)."""
+    import json
+    import os
+
+    import pydeseq2_amd
+    from tests.helpers import flag_flips, load_e2e
+
+    counts, X, ref = load_e2e(name)
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    gw, mp, rf = flag_flips(res, ref)
+    n_noise, n_grid = _compare(res, ref, frac_noise=0.004)
+    rec = {"case": name, "genes": int(counts.shape[1]), "samples": int(counts.shape[0]), "p": int(X.shape[1]),
+           "flips_genewise": int(gw.sum()), "flips_MAP": int(mp.sum()), "flips_refit": int(rf.sum()),
+           "flip_genes": n_noise, "flip_rate": round(n_noise / counts.shape[1], 6), "both_on_grid": n_grid,
+           "reference_non_converged": int(np.nansum(ref.genewise_converged == 0) + np.nansum(ref.MAP_converged == 0))}
+    ok = ~(gw | mp | rf) & ref.non_zero
+    for f in ("dispersions", "lfcSE", "stat"):
+        a, b = np.asarray(getattr(res, f))[ok], np.asarray(getattr(ref, f))[ok]
+        rec[f"max_rel_{f}"] = float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 if f == "stat" else 1e-300)))
+    rec["max_rel_LFC"] = float(np.nanmax(np.abs(res.LFC[ok] - ref.LFC[ok]) / np.maximum(np.abs(ref.LFC[ok]), 1e-3)))
+    print(rec)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, f"parity_vs_reference_{name}.json"), "w"), indent=1)
+
+
 def _wide_case(kind, G, N, seed):
     rng = np.random.default_rng(seed)
     if kind == "factor16":  # one factor with 16 levels: P = 16 = number of cells (linear-model mu_hat, cell path)
@@ -615,6 +647,23 @@ def test_full_size_c3_properties():
     z = res.LFC[ok, 1] / res.lfcSE[ok]
     assert np.allclose(z, res.stat[ok], rtol=1e-9, atol=1e-12)
     assert np.allclose(res.pvalue[ok], 2 * norm.sf(np.abs(res.stat[ok])), rtol=1e-9, atol=1e-300)
+    # ---- the cross-gene steps at the benchmark size, against the oracle on the engine's own per-gene vectors:
+    # size factors over all 60 000 genes (preprocessing.py:31-102), the iterated parametric trend on the 60 000
+    # genewise dispersions (dds.py:1199-1275) and the MAD prior (dds.py:840-884)
+    sf_o = orc.size_factors_ratio(counts)[0]
+    assert_close(res.size_factors, sf_o, 1e-12, 0, "size factors, 60 000 genes")
+    # (the refit overwrites the refitted genes' genewise dispersions and means with those of the replaced counts, while
+    # trend and prior were fitted before it: a second pass without the refit exposes the vectors they were fitted on)
+    pipe_nr = pydeseq2_amd.DeseqPipeline(counts, X, device=0, refit_cooks=False)
+    r0 = pipe_nr.deseq2()
+    pipe_nr.close()
+    assert np.array_equal(r0.trend_coeffs, res.trend_coeffs) and r0.prior_disp_var == res.prior_disp_var
+    coeffs_o, _ = orc.fit_parametric_trend(r0.genewise_dispersions[nz], r0.normed_means[nz])
+    assert_close(res.trend_coeffs, coeffs_o, 1e-9, 0, "trend coefficients, 60 000 genes")
+    fitted_o = coeffs_o[0] + coeffs_o[1] / r0.normed_means[nz]
+    assert_close(r0.fitted_dispersions[nz], fitted_o, 1e-9, 0, "fitted dispersions")
+    sq_o, pv_o = orc.dispersion_prior(r0.genewise_dispersions[nz], r0.fitted_dispersions[nz], 1000, 2, 1e-8)
+    assert abs(res.squared_logres - sq_o) <= 1e-10 * sq_o and abs(res.prior_disp_var - pv_o) <= 1e-10 * pv_o
     sel = np.sort(np.random.default_rng(3).choice(np.nonzero(nz & ~res.replaced)[0], 2000, replace=False))
     c = counts[:, sel]
     mu = orc.lin_reg_mu(c, res.size_factors, X, 0.5)

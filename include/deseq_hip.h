@@ -64,6 +64,12 @@ int dsq_create(int device_id, dsq_ctx** out);
  * (scipy's unbounded BFGS restated, csrc/dsq_bfgs.h; designs of at most 12 columns, mu_hat given as a matrix).
  * Sticky per context until set again. */
 int dsq_set_optimizer(dsq_ctx* ctx, int optimizer);
+/* Deferred second passes (sticky until set again).  The dispersion fit's grid-search pass (utils.py:556-564) and the
+ * IRLS rescue (utils.py:374-413) normally wait for the host to read how many genes need them.  With on != 0, batches of
+ * at most 2048 genes on the register kernels (P <= 12) enqueue those passes for every gene of the batch as a capacity
+ * and the kernels read the count from device memory: no host synchronisation inside dsq_dev_alpha_mle* /
+ * dsq_dev_lfc_fit / dsq_dev_irls (dsq_last_alpha_kernel then reports -1 ms / -1 genes).  Results are identical. */
+int dsq_set_deferred(dsq_ctx* ctx, int on);
 void dsq_destroy(dsq_ctx* ctx);
 const char* dsq_last_error(const dsq_ctx* ctx);
 /* name (<= name_len bytes), compute units, total device memory, gcnArchName */

@@ -20,6 +20,8 @@ struct dsq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t main_stream = nullptr, side_stream = nullptr;  // `stream` is whichever of the two is current
+    hipStream_t small_stream = nullptr;  // CU-masked stream of the latency-bound cross-gene kernels (dsq_side_begin)
+    hipEvent_t ev_small0 = nullptr, ev_small1 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     float last_kernel_ms = 0.0f;  // k_alpha launch of the last dsq_*_alpha_mle call (HIP events)
@@ -36,6 +38,7 @@ struct dsq_ctx {
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int optimizer = 0;            // dsq_set_optimizer: 0 L-BFGS-B (the reference's default), 1 BFGS
+    int deferred = 0;             // dsq_set_deferred: second passes of small batches enqueued without a host round trip
     int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
     size_t ws_cap = 0;
@@ -47,6 +50,7 @@ struct dsq_ctx {
 namespace {
 
 constexpr size_t kScratchBytes = 16 * 1024;
+constexpr int kDeferredMaxGenes = 2048;  // deferred second passes are launched for every gene of the batch
 
 int fail(dsq_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -243,11 +247,24 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     }
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t* h_cnt = ctx->h_pin + 1;
-    DSQ_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    DSQ_HIP(hipStreamSynchronize(ctx->stream));
-    DSQ_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->evk0, ctx->evk1));
-    const int32_t n_grid = *h_cnt;
-    ctx->last_n_grid = n_grid;
+    // Deferred mode (dsq_set_deferred; small batches on the register kernels): the grid-search pass is enqueued for
+    // ALL G genes as a capacity and the kernels read the number of fallback genes from the device - no host round trip
+    // between the fit and its second pass (the refit of the outlier genes is a chain of ~15 tiny launches whose
+    // synchronisations cost more than its kernels).
+    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && ctx->optimizer == 0 &&
+                          !dsq::alpha_is_wide(P, extras != nullptr ? extras->cells.C : 0);
+    const int32_t* n_dev = deferred ? d_cnt : nullptr;
+    int32_t n_grid = G;
+    if (!deferred) {
+        DSQ_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        DSQ_HIP(hipEventElapsedTime(&ctx->last_kernel_ms, ctx->evk0, ctx->evk1));
+        n_grid = *h_cnt;
+        ctx->last_n_grid = n_grid;
+    } else {
+        ctx->last_kernel_ms = -1.0f;  // not measured: nobody waited for the launch
+        ctx->last_n_grid = -1;
+    }
     if (n_grid > 0) {
         // everything below is stream-ordered behind the launch above and ahead of whatever the caller enqueues
         // next: no host synchronisation, no allocation (workspace carved from ctx->d_ws)
@@ -267,15 +284,15 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             double* musub = (double*)(w + b_work + b_y);
             int32_t* idx = (int32_t*)(w + b_work + b_y + b_mu);
             double* asub = (double*)(w + b_work + b_y + b_mu + b_idx);
-            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub));
+            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub, n_dev));
             DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
-                                             ctx->d_list, n_grid, musub, ldn, idx));
+                                             ctx->d_list, n_grid, musub, ldn, idx, n_dev));
             DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub, musub, ldn, d_Xt, ldx, N, P, min_disp, max_disp, asub,
-                                           idx, n_grid, work));
-            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub, ctx->d_list, n_grid, 1, d_alpha));
+                                           idx, n_grid, work, n_dev));
+            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub, ctx->d_list, n_grid, 1, d_alpha, n_dev));
         } else {
             DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
-                                           ctx->d_list, n_grid, work));
+                                           ctx->d_list, n_grid, work, n_dev));
         }
     }
     return DSQ_OK;
@@ -309,6 +326,11 @@ int dsq_create(int device_id, dsq_ctx** out) {
     return DSQ_OK;
 }
 
+int dsq_set_deferred(dsq_ctx* ctx, int on) {
+    ctx->deferred = on ? 1 : 0;
+    return DSQ_OK;
+}
+
 int dsq_set_optimizer(dsq_ctx* ctx, int optimizer) {
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     ctx->optimizer = optimizer;
@@ -331,6 +353,9 @@ void dsq_destroy(dsq_ctx* ctx) {
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     }
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->small_stream) (void)hipStreamDestroy(ctx->small_stream);
+    if (ctx->ev_small0) (void)hipEventDestroy(ctx->ev_small0);
+    if (ctx->ev_small1) (void)hipEventDestroy(ctx->ev_small1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -571,13 +596,20 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
                              d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
     int32_t* h_cnt = ctx->h_pin;
-    DSQ_HIP(hipMemcpyAsync(h_cnt, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    DSQ_HIP(hipStreamSynchronize(ctx->stream));
-    const int32_t n_fb = *h_cnt;
+    // deferred mode (see run_alpha): the rescue pass is enqueued for all G genes as a capacity, count on the device
+    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && ctx->optimizer == 0 &&
+                          !dsq::irls_is_wide(P, extras->cells.C);
+    int32_t n_fb = G;
+    if (!deferred) {
+        DSQ_HIP(hipMemcpyAsync(h_cnt, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        n_fb = *h_cnt;
+    }
     if (n_fb > 0) {  // stream-ordered ahead of the caller's next work: no second synchronisation
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
-                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras));
+                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras,
+                                        deferred ? ctx->d_counter : nullptr));
     }
     return DSQ_OK;
 }
@@ -638,7 +670,25 @@ int dsq_side_begin(dsq_ctx* ctx) {
     DSQ_CHECK_ARG(ctx->stream == ctx->main_stream || ctx->main_stream == nullptr, "already on the side stream");
     if (ctx->main_stream == nullptr) ctx->main_stream = ctx->stream;
     if (ctx->side_stream == nullptr) {
-        DSQ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        // DSQ_CU_SPLIT=K: the side stream (robust dispersions: fills every CU it may use) is kept off K compute units
+        // and the trend / prior kernels - 32 workgroups that synchronise through grid barriers - get a stream that may
+        // use only those K: both then run at their stand-alone speed side by side, instead of the barrier kernel's
+        // workgroups time-slicing CUs with the other kernel's waves (measured: 0.51 ms alone, 1.32 ms co-scheduled).
+        // (c3: 9.10 -> 8.52 ms per step at K = 32, 8.58 at 64, no gain at 16 - two barrier workgroups per CU)
+        static const int split = getenv("DSQ_CU_SPLIT") ? atoi(getenv("DSQ_CU_SPLIT")) : 32;
+        hipDeviceProp_t prop;
+        DSQ_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        const int cus = prop.multiProcessorCount;
+        if (split > 0 && split < cus) {
+            std::vector<uint32_t> big((size_t)(cus + 31) / 32, 0u), small((size_t)(cus + 31) / 32, 0u);
+            for (int i = 0; i < cus; ++i) (i < split ? small : big)[(size_t)i / 32] |= 1u << (i % 32);
+            DSQ_HIP(hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)big.size(), big.data()));
+            DSQ_HIP(hipExtStreamCreateWithCUMask(&ctx->small_stream, (uint32_t)small.size(), small.data()));
+            DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_small0, hipEventDisableTiming));
+            DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_small1, hipEventDisableTiming));
+        } else {
+            DSQ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        }
         DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
@@ -974,14 +1024,25 @@ int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_mean
     double* d_out2 = ctx->d_scratch + 1600;
     if (ctx->d_trend_grid == nullptr) DSQ_HIP(hipMalloc(&ctx->d_trend_grid, dsq::trend_grid_mem_bytes()));
     static const int force_grid = getenv("DSQ_TREND_GRID") ? atoi(getenv("DSQ_TREND_GRID")) : 0;
-    DSQ_HIP(dsq::launch_trend_fit(ctx->stream, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out,
+    // with a CU split (dsq_side_begin) the three kernels run on the stream that owns the reserved compute units
+    hipStream_t st = ctx->stream;
+    if (ctx->small_stream != nullptr && ctx->stream == ctx->main_stream) {
+        DSQ_HIP(hipEventRecord(ctx->ev_small0, ctx->stream));
+        DSQ_HIP(hipStreamWaitEvent(ctx->small_stream, ctx->ev_small0, 0));
+        st = ctx->small_stream;
+    }
+    DSQ_HIP(dsq::launch_trend_fit(st, d_disp, d_means, n, min_disp, max_disp, d_keep, d_out,
                                   ctx->d_trend_grid, force_grid));
-    DSQ_HIP(dsq::launch_trend_eval_dev(ctx->stream, d_means, n, d_out, d_fitted));
-    DSQ_HIP(dsq::launch_prior_mad(ctx->stream, d_disp, d_fitted, n, min_disp, max_disp, d_work, d_out2));
+    DSQ_HIP(dsq::launch_trend_eval_dev(st, d_means, n, d_out, d_fitted));
+    DSQ_HIP(dsq::launch_prior_mad(st, d_disp, d_fitted, n, min_disp, max_disp, d_work, d_out2));
     double* h = (double*)(ctx->h_pin + 3072);  // 12 KiB into the page-locked block (behind the ridge / contrast staging)
-    DSQ_HIP(hipMemcpyAsync(h, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    DSQ_HIP(hipMemcpyAsync(h + 8, d_out2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    DSQ_HIP(hipMemcpyAsync(h, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    DSQ_HIP(hipMemcpyAsync(h + 8, d_out2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (st != ctx->stream) {
+        DSQ_HIP(hipEventRecord(ctx->ev_small1, st));
+        DSQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_small1, 0));
+    }
+    DSQ_HIP(hipStreamSynchronize(st));
     h_coeffs2[0] = h[0]; h_coeffs2[1] = h[1];
     *h_ok = (int)h[2];
     if (h_n_outer) *h_n_outer = (int)h[3];

@@ -159,7 +159,12 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
                                                             const double* __restrict__ Xt, int ldx, int N,
                                                             const int32_t* __restrict__ grid_list, int n_grid,
                                                             const double* __restrict__ lohi,
-                                                            double* __restrict__ ll) {
+                                                            double* __restrict__ ll,
+                                                            const int32_t* __restrict__ n_dev) {
+    if (n_dev != nullptr) {  // capacity launch: the number of genes lives on the device
+        n_grid = min(n_grid, *n_dev);
+        if ((int)(blockIdx.x * kWavesPerBlock) >= n_grid * kGridLen) return;
+    }
     log_tab_fill();  // the table of flog1p_t (dsq_math.h)
     __syncthreads();
     const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -186,8 +191,10 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
 // argmin over a gene's grid (numpy.argmin: first minimum, first NaN wins); stage 0 -> refine
 // interval [c - delta, c + delta] into lohi, stage 1 -> alpha = exp(best log alpha)
 __global__ void k_alpha_grid_pick(const double* __restrict__ ll, const int32_t* __restrict__ grid_list, int n_grid,
-                                  double* __restrict__ lohi, int stage, double* __restrict__ alpha) {
+                                  double* __restrict__ lohi, int stage, double* __restrict__ alpha,
+                                  const int32_t* __restrict__ n_dev) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev != nullptr) n_grid = min(n_grid, *n_dev);
     if (k >= n_grid) return;
     const double lo = lohi[2 * k], hi = lohi[2 * k + 1];
     double best = 0.0;
@@ -306,22 +313,30 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     return hipGetLastError();
 }
 
+// does the dispersion fit of such a design take the run-time-P (LDS) kernels?  (launch_alpha's routing rule)
+bool alpha_is_wide(int P_, int n_cells) {
+    if (n_cells <= kSmallCells) n_cells = 0;
+    return P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (n_cells == 0 || wide_with_cells()));
+}
+
 // work: n_grid * (2 + kGridLen) doubles of device scratch
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P_, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid, double* work) {
+                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev) {
     if (n_grid <= 0) return hipSuccess;
-    if (P_ > DSQ_REG_MAX_P)
+    if (P_ > DSQ_REG_MAX_P) {
+        if (n_dev != nullptr) return hipErrorInvalidValue;  // the LDS path takes its count from the host
         return launch_wide_alpha_grid(st, y, mu, ldn, Xt, ldx, N, P_, min_disp, max_disp, alpha, grid_list, n_grid);
+    }
     double* lohi = work;
     double* ll = work + 2 * (size_t)n_grid;
     const dim3 ge(genes_to_blocks(n_grid * kGridLen)), block(kBlock), gp((n_grid + 63) / 64), bp(64);
     hipLaunchKernelGGL(k_fill_lohi, gp, bp, 0, st, lohi, n_grid, log(min_disp), log(max_disp));
     for (int stage = 0; stage < 2; ++stage) {
         DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha_grid_eval<P>, ge, block, 0, st, y, mu, ldn, Xt, ldx, N,
-                                              grid_list, n_grid, (const double*)lohi, ll))
+                                              grid_list, n_grid, (const double*)lohi, ll, n_dev))
         hipLaunchKernelGGL(k_alpha_grid_pick, gp, bp, 0, st, (const double*)ll, grid_list, n_grid, lohi, stage,
-                           alpha);
+                           alpha, n_dev);
     }
     return hipGetLastError();
 }

@@ -201,7 +201,11 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
                                                         uint8_t* __restrict__ conv,
                                                         int32_t* __restrict__ iters,
                                                         const int32_t* __restrict__ fb_list, int n_fb,
-                                                        IrlsExtras ex) {
+                                                        IrlsExtras ex, const int32_t* __restrict__ n_dev) {
+    if (n_dev != nullptr) {  // capacity launch: the number of diverged genes lives on the device
+        n_fb = min(n_fb, *n_dev);
+        if ((int)(blockIdx.x * kWavesPerBlock) >= n_fb) return;
+    }
     log_tab_fill();  // the table of flog_t (dsq_math.h)
     __syncthreads();
     int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -382,18 +386,25 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
-                              int n_fb, const IrlsExtras* extras) {
+                              int n_fb, const IrlsExtras* extras, const int32_t* n_dev) {
     if (n_fb <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
-    if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells())))
+    const bool wide = P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()));
+    if (wide && n_dev != nullptr) return hipErrorInvalidValue;  // the LDS path takes its count from the host
+    if (wide)
         return launch_wide_irls_rescue(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, P_, full_rank, disp, min_mu, beta_tol,
                                        min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, &ex);
     const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
                                           ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                          maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, ex))
+                                          maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, ex, n_dev))
     return hipGetLastError();
+}
+
+// does a design of this shape take the run-time-P (LDS) kernels?  (they take their second-pass counts from the host)
+bool irls_is_wide(int P_, int n_cells) {
+    return P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (n_cells == 0 || wide_with_cells()));
 }
 
 }  // namespace dsq

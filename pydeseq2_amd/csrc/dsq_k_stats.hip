@@ -863,8 +863,10 @@ template <int P>
 __global__ __launch_bounds__(kBlock) void k_mu_from_coef(const double* __restrict__ coef, const double* __restrict__ sf,
                                                          const double* __restrict__ Xt, int ldx, int N, double min_mu,
                                                          const int32_t* __restrict__ list, int n_list,
-                                                         double* __restrict__ dst, int ldn, int32_t* __restrict__ idx_out) {
+                                                         double* __restrict__ dst, int ldn, int32_t* __restrict__ idx_out,
+                                                         const int32_t* __restrict__ n_dev) {
     const int k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (n_dev != nullptr) n_list = min(n_list, *n_dev);  // launched for a capacity, the count lives on the device
     if (k >= n_list) return;
     const int g = list[k];
     double b[P];
@@ -881,10 +883,10 @@ __global__ __launch_bounds__(kBlock) void k_mu_from_coef(const double* __restric
 
 hipError_t launch_mu_from_coef(hipStream_t st, const double* coef, const double* sf, const double* Xt, int ldx, int N,
                                int P_, double min_mu, const int32_t* list, int n_list, double* dst, int ldn,
-                               int32_t* idx_out) {
+                               int32_t* idx_out, const int32_t* n_dev) {
     if (n_list <= 0) return hipSuccess;
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mu_from_coef<P>, dim3(genes_to_blocks(n_list)), dim3(kBlock), 0, st, coef,
-                                          sf, Xt, ldx, N, min_mu, list, n_list, dst, ldn, idx_out))
+                                          sf, Xt, ldx, N, min_mu, list, n_list, dst, ldn, idx_out, n_dev))
     return hipGetLastError();
 }
 
@@ -1144,6 +1146,12 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
     }
     nonzero = DeviceWave::sumi(nonzero);
     if ((threadIdx.x & 63) == 0) all_zero[k] = (uint8_t)(nonzero == 0);
+    // A gene whose counts all became zero leaves the refit (dds.py:1368-1383: LFC = 0, its row is dropped from the
+    // sub-dataset).  The caller enqueues the refit stages for every row of the batch without waiting for these flags,
+    // so such a row keeps its ORIGINAL counts - an ordinary gene for the kernels downstream; its results are discarded
+    // by the flag.
+    if (nonzero == 0)
+        for (int n = DeviceWave::lane(); n < N; n += 64) y_out[(size_t)k * ldn + n] = yr[n];
 }
 
 hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
@@ -1175,8 +1183,10 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
 template <class T>
 __global__ __launch_bounds__(256) void k_gather_rows(const T* __restrict__ src, int ld,
                                                      const int32_t* __restrict__ idx, int n_idx,
-                                                     int ncols, T* __restrict__ dst) {
+                                                     int ncols, T* __restrict__ dst,
+                                                     const int32_t* __restrict__ n_dev = nullptr) {
     const int k = blockIdx.x;  // rows (genes) on grid.x: grid.y is limited to 65535
+    if (n_dev != nullptr && k >= *n_dev) return;
     const int g = idx[k];
     for (int c = blockIdx.y * 256 + threadIdx.x; c < ncols; c += gridDim.y * 256)
         dst[(size_t)k * ld + c] = src[(size_t)g * ld + c];
@@ -1192,11 +1202,11 @@ hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, con
 }
 
 hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, const int32_t* idx,
-                                  int n_idx, int ncols, int32_t* dst) {
+                                  int n_idx, int ncols, int32_t* dst, const int32_t* n_dev) {
     if (n_idx <= 0) return hipSuccess;
     const int gx = (ncols + 255) / 256 > 64 ? 64 : (ncols + 255) / 256;
     hipLaunchKernelGGL(k_gather_rows<int32_t>, dim3(n_idx, gx), dim3(256), 0, st, src, ld, idx, n_idx,
-                       ncols, dst);
+                       ncols, dst, n_dev);
     return hipGetLastError();
 }
 
@@ -1237,8 +1247,9 @@ __global__ void k_select_disp(double* __restrict__ gw_raw, double* __restrict__ 
 
 // dst[idx[k]][0..width) = src[k][0..width)   (results of the outlier refit back into the full vectors)
 __global__ void k_scatter_rows(const double* __restrict__ src, const int32_t* __restrict__ idx, int n_idx,
-                               int width, double* __restrict__ dst) {
+                               int width, double* __restrict__ dst, const int32_t* __restrict__ n_dev) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev != nullptr) n_idx = min(n_idx, *n_dev);
     if (t >= n_idx * width) return;
     const int k = t / width, c = t % width;
     dst[(size_t)idx[k] * width + c] = src[t];
@@ -1339,10 +1350,10 @@ hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, c
     return hipGetLastError();
 }
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,
-                               double* dst) {
+                               double* dst, const int32_t* n_dev) {
     if (n_idx <= 0 || width <= 0) return hipSuccess;
     const int total = n_idx * width;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((total + 255) / 256), dim3(256), 0, st, src, idx, n_idx, width, dst);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((total + 255) / 256), dim3(256), 0, st, src, idx, n_idx, width, dst, n_dev);
     return hipGetLastError();
 }
 

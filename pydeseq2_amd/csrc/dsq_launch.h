@@ -78,7 +78,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         double* nll_const, int const_mode, const AlphaExtras* extras = nullptr);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid, double* work);
+                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev = nullptr);
 
 // ---- dsq_k_irls.hip
 // optional inputs / fused outputs of the IRLS kernel (zero-initialised = none)
@@ -110,7 +110,10 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
                               int full_rank, const double* disp, double min_mu, double beta_tol,
                               double min_beta, double max_beta, int maxiter, double* beta, double* mu,
                               double* hat, uint8_t* conv, int32_t* iters, const int32_t* fb_list,
-                              int n_fb, const IrlsExtras* extras = nullptr);
+                              int n_fb, const IrlsExtras* extras = nullptr, const int32_t* n_dev = nullptr);
+
+bool irls_is_wide(int P, int n_cells);
+bool alpha_is_wide(int P, int n_cells);  // the design takes the run-time-P (LDS) kernels of dsq_k_wide.hip
 
 // ---- dsq_k_stats.hip
 hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
@@ -132,7 +135,7 @@ hipError_t launch_mom_lin_mu(hipStream_t st, const int32_t* y, int ldn, const do
                              double* coef = nullptr);
 hipError_t launch_mu_from_coef(hipStream_t st, const double* coef, const double* sf, const double* Xt, int ldx, int N,
                                int P, double min_mu, const int32_t* list, int n_list, double* dst, int ldn,
-                               int32_t* idx_out);
+                               int32_t* idx_out, const int32_t* n_dev = nullptr);
 hipError_t launch_irls_layers(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* Xt, int ldx,
                               int N, int G, int P, const double* disp, const double* beta, double min_mu, double* mu,
                               double* hat);
@@ -187,10 +190,12 @@ hipError_t launch_trend_eval_dev(hipStream_t st, const double* nm, int n, const 
 hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted,
                               int n, double min_disp, double max_disp, double two_sd, double* disp,
                               uint8_t* outlier);
+// n_dev (here and below): the kernel is launched for n_* rows as a CAPACITY and reads the actual count from device
+// memory - second passes can be enqueued without the host having seen how many genes need them
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,
-                               double* dst);
+                               double* dst, const int32_t* n_dev = nullptr);
 hipError_t launch_gather_rows_i32(hipStream_t st, const int32_t* src, int ld, const int32_t* idx,
-                                  int n_idx, int ncols, int32_t* dst);
+                                  int n_idx, int ncols, int32_t* dst, const int32_t* n_dev = nullptr);
 constexpr int kTrendPartials = 256;  // rows of 4 doubles
 hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const double* targets,
                                   const uint8_t* keep, int n, double a0, double a1, double* partials);

@@ -313,8 +313,9 @@ class DeseqPipeline:
         if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2"):
             kms, ng = C.c_float(), C.c_int()
             self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
-            self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
-            self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
+            if kms.value >= 0.0:  # (-1: a deferred launch, nobody waited for it)
+                self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
+                self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
 
     # ------------------------------------------------------------------ result slabs
     # All per-gene result vectors of a step live in ONE device buffer laid out like one page-locked
@@ -733,67 +734,73 @@ class DeseqPipeline:
             self._side_pending = False
         d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks))
         want_refit = self.refit_cooks and D.replaceable.sum() > 0
-        flags = self._fetch(S, ["any_all"]) if want_refit else None
-        # the layers of THIS fit (before the refit patches beta / dispersions): cooks is always materialised, mu and
-        # the hat diagonals only with keep_layers, otherwise layer() rebuilds them from these copies on demand
-        d_b0, d_d0 = self._dvec(Gn * P), self._dvec(Gn)
-        ctx.call("dsq_d2d", _vp(d_b0.ptr), _vp(S["beta"].ptr), C.c_size_t(8 * Gn * P))
-        ctx.call("dsq_d2d", _vp(d_d0.ptr), _vp(S["disp"].ptr), C.c_size_t(8 * Gn))
+        # Everything in S is final now except the rows the refit will replace: the block copy of the result vectors
+        # starts here, on the side stream, and runs underneath the refit's kernels; the host patches the (few)
+        # refitted rows afterwards from the refit's own small result block.  The main stream only carries the one
+        # flag vector that decides the refit, so waiting for it does not wait for the block copy.
+        flags_tok = self._fetch_begin(S, ["any_all"]) if want_refit else None
+        if self.overlap:
+            ctx.call("dsq_side_begin")
+            self._side_pending = True
+            try:
+                slab_tok = self._fetch_begin(S)
+            finally:
+                ctx.call("dsq_side_end")
+        else:
+            slab_tok = self._fetch_begin(S)
         if all_nz and getattr(self, "_arange_G", None) is None:
             self._arange_G = np.arange(G)
+        # the layers of THIS fit: cooks is always materialised, mu and the hat diagonals only with keep_layers,
+        # otherwise layer() rebuilds them on demand from the fit's coefficients / dispersions (S is not patched by the
+        # refit any more, so its vectors ARE those of this fit)
         self.layers = {"nz_idx": self._arange_G if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
-                       "cooks": d_cooks, "_fit": (d_ynz, d_sf, d_b0, d_d0, Gn)}
+                       "cooks": d_cooks, "_fit": (d_ynz, d_sf, S["beta"], S["disp"], Gn)}
         t5 = tick(); T["LFC_cooks_wald"] = t5 - t4
         t6 = t5
 
-        # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem, patched into the device vectors
+        # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem on the replaced counts.  One host round trip
+        # (which genes?), then the whole chain - replacement, MoM, mu_hat, genewise fit, trend value, MAP fit, LFC fit,
+        # Wald - is enqueued without another: second passes are launched for the whole batch as a capacity
+        # (dsq_set_deferred), and genes that became all-zero keep their original row on the device (their results are
+        # discarded by the flag that comes back with the results).
         replaced_nz = np.zeros(Gn, dtype=bool)
         refitted_nz = np.zeros(Gn, dtype=bool)
         new_zero_nz = np.zeros(Gn, dtype=bool)
         patch = None
         if want_refit:
-            replaced_nz = flags["any_all"].astype(bool)  # idx.any(axis=0), dds.py:1325-1326
+            ctx.sync()
+            replaced_nz = self._fetch_end(flags_tok)["any_all"].astype(bool)  # idx.any(axis=0), dds.py:1325-1326
             rp = np.nonzero(replaced_nz)[0]
             Gr = len(rp)
             if Gr > 0:
                 d_rp = self._up(rp.astype(np.int32), np.int32)
                 d_ysub = self._dmat(Gr, np.int32)
-                d_az = self._dvec(Gr, np.uint8)
+                S2 = self._dev_slab(Gr)
+                d_az = S2["any_all"]  # (a flag vector the sub-problem does not use)
                 ctx.call("dsq_dev_replace_outliers", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
                          _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(cutoff), _vp(d_ysub.ptr),
                          _vp(d_az.ptr))
-                naz = self._down(d_az, Gr, np.uint8).astype(bool)
-                new_zero_nz[rp[naz]] = True
-                refitted_nz[rp[~naz]] = True
-                if naz.any():  # dds.py:1380-1383: LFC = 0 for the genes that became all-zero
-                    zi = rp[naz].astype(np.int32)
-                    ctx.call("dsq_dev_scatter_rows_f64", _vp(self._up(np.zeros((len(zi), P))).ptr),
-                             _vp(self._up(zi, np.int32).ptr), len(zi), P, _vp(S["beta"].ptr))
-                if (~naz).any():
-                    keep = np.nonzero(~naz)[0]
-                    rf = rp[keep]
-                    Gf = len(rf)
-                    if Gf < Gr:
-                        d_keep = self._up(keep.astype(np.int32), np.int32)
-                        d_yf = self._dmat(Gf, np.int32)
-                        ctx.call("dsq_dev_gather_rows_i32", _vp(d_ysub.ptr), self.ldn, _vp(d_keep.ptr), Gf, N,
-                                 _vp(d_yf.ptr))
-                    else:
-                        d_yf = d_ysub
-                    S2 = self._dev_slab(Gf)
-                    s_mu = self._stage_genewise(d_yf, Gf, d_sf, S2)
-                    ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gf, c_double(a0), c_double(a1),
+                deferred = not (profile or self.time_kernels or self.collect_nfev)
+                if deferred:
+                    ctx.call("dsq_set_deferred", 1)
+                try:
+                    s_mu = self._stage_genewise(d_ysub, Gr, d_sf, S2)
+                    ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gr, c_double(a0), c_double(a1),
                              _vp(S2["fit"].ptr))
-                    self._stage_map(d_yf, s_mu, Gf, d_sf, r.prior_disp_var, r.squared_logres, S2)
-                    self._stage_lfc(d_yf, Gf, d_sf, S2, wald_args)
-                    d_rf = self._up(rf.astype(np.int32), np.int32)
-                    for k, wdt in (("disp", 1), ("beta", P), ("p", 1), ("stat", 1), ("se", 1)):
-                        ctx.call("dsq_dev_scatter_rows_f64", _vp(S2[k].ptr), _vp(d_rf.ptr), Gf, wdt, _vp(S[k].ptr))
-                    patch = (rf, self._fetch_begin(S2, ["nm", "gw", "fit"]))
+                    self._stage_map(d_ysub, s_mu, Gr, d_sf, r.prior_disp_var, r.squared_logres, S2)
+                    self._stage_lfc(d_ysub, Gr, d_sf, S2, wald_args)
+                finally:
+                    if deferred:
+                        ctx.call("dsq_set_deferred", 0)
+                patch = (rp, self._fetch_begin(S2, ["nm", "gw", "fit", "disp", "beta", "p", "stat", "se", "any_all"]))
         t7 = tick(); T["refit"] = t7 - t6
 
-        # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues (refitted genes: patched above)
-        H = self._fetch(S)
+        # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues
+        if self.overlap:
+            ctx.call("dsq_side_wait")
+            self._side_pending = False
+        ctx.sync()
+        H = self._fetch_end(slab_tok)
         t8 = tick(); T["wald"] = t8 - t7
 
         # ---- host view of the results (reference field names), scattered to all G genes
@@ -806,14 +813,20 @@ class DeseqPipeline:
 
         gw = H["gw"]  # clipped to [min_disp, max_disp] on the device (dds.py:792-794; k_select_disp)
         nm, fit, disp, beta = H["nm"], H["fit"], H["disp"], H["beta"]
-        if patch is not None or new_zero_nz.any():
-            nm, fit = nm.copy(), fit.copy()
-            if patch is not None:  # dds.py:1410-1458: the refitted genes take their new values
-                rf, h2 = patch[0], self._fetch_end(patch[1])  # (copied before the final fetch's synchronisation)
-                nm[rf] = h2["nm"]
-                gw[rf] = np.clip(h2["gw"], self.min_disp, self.max_disp)
-                fit[rf] = h2["fit"]
-            nm[new_zero_nz] = 0.0  # dds.py:1380-1383
+        pv, st, se = H["p"], H["stat"], H["se"]
+        if patch is not None:  # dds.py:1368-1458: the refitted genes take their new values
+            rp, h2 = patch[0], self._fetch_end(patch[1])
+            naz = h2["any_all"].astype(bool)  # all counts zero after the replacement (dds.py:1368-1383)
+            new_zero_nz[rp[naz]] = True
+            refitted_nz[rp[~naz]] = True
+            rf, k = rp[~naz], np.nonzero(~naz)[0]
+            nm[rf], fit[rf], disp[rf], beta[rf] = h2["nm"][k], h2["fit"][k], h2["disp"][k], h2["beta"][k]
+            gw[rf] = np.clip(h2["gw"][k], self.min_disp, self.max_disp)
+            pv[rf], st[rf], se[rf] = h2["p"][k], h2["stat"][k], h2["se"][k]
+            if naz.any():
+                zi = rp[naz]
+                nm[zi], beta[zi] = 0.0, 0.0            # dds.py:1380-1383
+                se[zi], st[zi], pv[zi] = 0.0, 0.0, 1.0  # ds.py:357-360
         r.normed_means = full(nm, fill=0.0)  # all-zero genes have normed mean 0 (dds.py:708)
         r.mom_dispersions = full(H["mom"])
         r.genewise_dispersions = full(gw)
@@ -832,10 +845,6 @@ class DeseqPipeline:
         any_use, any_use_nr = H["any_use"].view(np.bool_), H["any_use_nr"].view(np.bool_)
         co_nz = np.where(refitted_nz, any_use_nr, any_use) if (self.refit_cooks and refitted_nz.any()) else any_use
         r.cooks_outlier = full(co_nz & H["few_above"].view(np.bool_), fill=False)
-        pv, st, se = H["p"], H["stat"], H["se"]
-        if new_zero_nz.any():  # ds.py:357-360
-            pv, st, se = pv.copy(), st.copy(), se.copy()
-            se[new_zero_nz], st[new_zero_nz], pv[new_zero_nz] = 0.0, 0.0, 1.0
         r.pvalue, r.stat, r.lfcSE = full(pv), full(st), full(se)
         t9 = tick(); T["assemble"] = t9 - t8
         T["total"] = t9 - t0

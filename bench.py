@@ -9,9 +9,11 @@ one-off int64 -> int32 gene-major transposition happen in DeseqPipeline.__init__
 it; the per-gene result vectors ARE copied back to the host inside it).
 
 Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py
---gpus N ...`): genes shard across ranks.  `--scaling weak` (default): every rank owns `genes`
-genes x all samples; `--scaling strong`: the config's genes are split over the ranks (BASELINE
-configs[2]: "60k x 1k, 1 vs 8 MI355X gene-shard").  The two cross-gene steps are exchanged in
+--gpus N ...`; by hand `python bench.py --gpus N` starts the N ranks itself): genes shard across ranks.
+Default for N > 1 is `--scaling strong`: the NAMED configuration's genes are split over the ranks
+(BASELINE configs[2]: "60k x 1k, 1 vs 8 MI355X gene-shard"; configs[4]: c5 = 60k x 5k over 8 GPUs - every
+rank generates only its own gene shard and sample block, pydeseq2_amd.synth.synth_counts_block);
+`--scaling weak`: every rank owns the configuration's gene count.  The two cross-gene steps are exchanged in
 DistDeseqPipeline over RCCL (size-factor medians, trend/prior on all-gathered per-gene vectors).
 The harness itself is torch-free: the RCCL unique id travels over a TCP socket
 (pydeseq2_amd.distributed.exchange_unique_id), barriers and the max-over-ranks are RCCL all-gathers.
@@ -46,7 +48,7 @@ CONFIGS = {
     "c3": (60000, 1000, "2level"),
     "c4": (60000, 500, "3factor"),
     "c4b": (60000, 500, "2factor"),  # developer measurements: p = 4, 6 cells (not a BASELINE configuration)
-    "c5": (60000, 5000, "mixed"),  # not a default bench line: host generation alone takes minutes
+    "c5": (60000, 5000, "mixed"),  # BASELINE configs[4]; tiled generator (a rank builds only its shard; ~1 min at 1 GPU)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (256 CU x 128 flop/clk x 2.4 GHz)
@@ -57,6 +59,66 @@ def synth_fast(G, N, design, seed):
     from pydeseq2_amd.synth import synth_counts
 
     return synth_counts(G, N, design, seed)
+
+
+SEEDS = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4b": 5}
+
+
+def plan_rank_data(config, genes, scaling, rank, world):
+    """The matrix (block) one rank works on: (counts [N x G_rank] int64, X, sample block or None, G_rank, G_total,
+    generator name).  strong: the configuration's genes split into contiguous blocks, one per rank, plus the rank's block
+    of samples over all genes (size factors with two collectives); weak: every rank its own matrix of the
+    configuration's size.  c5 (60 000 x 5 000) always comes from the tiled generator: a rank generates its gene shard
+    and its sample block only, never the whole matrix."""
+    from pydeseq2_amd.distributed import sample_block
+    from pydeseq2_amd.synth import synth_counts_block
+
+    G_cfg, N, design = CONFIGS[config]
+    G_cfg = genes or G_cfg
+    seed0 = SEEDS[config]
+    tiled = config == "c5"
+    if scaling == "strong" and world > 1:
+        cuts = np.linspace(0, G_cfg, world + 1).astype(int)
+        g0, g1 = int(cuts[rank]), int(cuts[rank + 1])
+        n0, n1 = sample_block(rank, world, N)
+        if tiled:
+            counts, X = synth_counts_block(G_cfg, N, design, seed0, genes=(g0, g1))
+            samp, _ = synth_counts_block(G_cfg, N, design, seed0, samples=(n0, n1))
+        else:  # one matrix for the whole job (the single-GPU run's), every rank keeps its blocks
+            counts_all, X = synth_fast(G_cfg, N, design, seed=seed0)
+            counts = np.ascontiguousarray(counts_all[:, g0:g1])
+            samp = np.ascontiguousarray(counts_all[n0:n1])
+        return counts, X, samp, g1 - g0, G_cfg, "tiled" if tiled else "synth_counts"
+    if tiled:
+        counts, X = synth_counts_block(G_cfg, N, design, 1000 * rank + seed0)
+    else:
+        counts, X = synth_fast(G_cfg, N, design, seed=1000 * rank + seed0)
+    return counts, X, None, G_cfg, G_cfg * world, "tiled" if tiled else "synth_counts"
+
+
+def launch_local_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` started by hand: one child process per GPU with the environment a launcher would set
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); returns the worst exit code.  (The driver starts the
+    ranks itself through torch.distributed.run and never gets here.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+        if rc:  # a rank died: the others would wait for it in the control plane forever
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+    return rc
 
 
 def cpu_baseline(counts, X, n_sample, n_jobs):
@@ -155,39 +217,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--genes", type=int, default=0, help="override the config's gene count")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank owns the config's genes; strong: they are split over the ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default for --gpus > 1): the configuration's genes are split over the ranks; "
+                         "weak: every rank owns the configuration's gene count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the summary-tail / shrinkage / c4-parity extras")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
-        # started by hand without a launcher: re-run under torch.distributed.run, one rank per GPU
-        # (the driver launches the ranks itself and never takes this branch)
-        import socket
-        import subprocess
-
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(launch_local_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    G_cfg, N, design = CONFIGS[args.config]
-    if args.genes:
-        G_cfg = args.genes
-    # genes owned by this rank
-    if args.scaling == "strong" and world > 1:
-        cuts = np.linspace(0, G_cfg, world + 1).astype(int)
-        G = int(cuts[rank + 1] - cuts[rank])
-        G_total = G_cfg
-    else:
-        G, G_total = G_cfg, G_cfg * world
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
+    N, design = CONFIGS[args.config][1:]
+    counts, X, samp, G, G_total, generator = plan_rank_data(args.config, args.genes, args.scaling, rank, world)
 
     import pydeseq2_amd
     from pydeseq2_amd._lib import Context
@@ -201,23 +248,8 @@ def main():
     # two ranks on one device, so the job then runs on the host-staged fallback transport)
     ctx = Context(0 if os.environ.get("DSQ_BENCH_SHARE_GPU") else local_rank)
     info = ctx.device_info()
-    seed0 = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4b": 5}[args.config]
-    if args.scaling == "strong" and world > 1:
-        # one matrix for the whole job, every rank keeps its block of genes (same generator call: deterministic)
-        counts_all, X = synth_fast(G_total, N, design, seed=seed0)
-        counts = np.ascontiguousarray(counts_all[:, cuts[rank]:cuts[rank + 1]])
-        # the rank's block of samples over all genes: size factors with two collectives (sample_shard_protocol)
-        from pydeseq2_amd.distributed import sample_block
-
-        samp = np.ascontiguousarray(counts_all[slice(*sample_block(rank, world, N))])
-        del counts_all
-    else:
-        counts, X = synth_fast(G, N, design, seed=1000 * rank + seed0)
-
     transport = None
     comm = None
-    if not (args.scaling == "strong" and world > 1):
-        samp = None
     if world > 1 or os.environ.get("DSQ_FORCE_DIST"):
         comm, transport = bring_up_comm(ctx, control)
         if transport != "rccl":
@@ -241,7 +273,18 @@ def main():
     ctx.sync()
     h2d_s = control.max_float(time.perf_counter() - t_up)
 
-    for _ in range(args.warmup):
+    # the very first pass (kernel code objects, pool allocations) and a pass without the previous pass's non-zero mask
+    # (what a single deseq2() call on a fresh pipeline pays: the host waits for the mask before it can compact)
+    t_c = time.perf_counter()
+    res = pipe.deseq2()
+    ctx.sync()
+    cold_first_ms = (time.perf_counter() - t_c) * 1e3
+    pipe._nz_pred = None
+    t_c = time.perf_counter()
+    res = pipe.deseq2()
+    ctx.sync()
+    first_call_ms = (time.perf_counter() - t_c) * 1e3
+    for _ in range(max(args.warmup - 2, 0)):
         res = pipe.deseq2()
     # The timed region runs the production path (no per-stage synchronisation).  The dispersion
     # kernel's launch durations are still measured live in it: HIP events recorded on the engine's
@@ -313,13 +356,18 @@ def main():
     # same command, which mixes both, can still be reproduced from avg_launch_ms_all)
     klog = klog_timed
     launches = list(klog.get("k_alpha", []))
+    stages = [nm for nm, _ in klog.get("k_alpha_stage", [])]
     big = [(ms, g) for ms, g in launches if g > 0.5 * G]
+    # the genewise launches run alone; the MAP launches start while the robust-dispersion kernel of the side stream
+    # is still finishing (it no longer waits behind the trend fit): both averages are reported, the roofline object
+    # uses the one over ALL full-size launches, which is what rocprofv3's per-kernel average of this command shows
+    solo = [ms for (ms, g), nm in zip(launches, stages) if g > 0.5 * G and nm == "alpha_mle"]
     full_ms = float(np.mean([ms for ms, _ in big]))
     genes_full = float(np.mean([g for _, g in big]))
     alg_bytes = genes_full * (12.0 * N + 17.0)
     achieved = alg_bytes / (full_ms * 1e-3) / 1e9
     stage_ms = {k: round(float(np.sum([ms for ms, _ in v])), 3) for k, v in klog_prof.items()
-                if k not in ("k_alpha", "grid_fallback_genes", "nfev")}
+                if k not in ("k_alpha", "k_alpha_stage", "grid_fallback_genes", "nfev")}
     # companion bound: the fit is fp64-ALU work, ~250 flop per sample and evaluation
     # (lgamma + digamma differences, 3 logs, Cox-Reid sums); evaluations counted by the kernel itself
     nfev_full = [e for e, g in klog_prof.get("nfev", []) if g > 0.5 * G]
@@ -337,6 +385,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_ratio": None,
         "algorithmic_bytes_per_launch": int(alg_bytes), "full_launch_ms": round(full_ms, 4),
         "full_launches_timed": len(big),
+        "full_launch_ms_genewise_only": round(float(np.mean(solo)), 4) if solo else None,
         "avg_launch_ms_all": round(float(np.mean([ms for ms, _ in launches])), 4), "launches_timed": len(launches),
         "pipeline_algorithmic_GBps": round(G * 104.0 * N / (dt / args.steps) / 1e9, 2),
         "kernel_ms_per_step": stage_ms, "grid_fallback_genes_per_step": n_fallback,
@@ -358,7 +407,7 @@ def main():
     if not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         n_jobs = min(cores, 64)
-        n_sample = args.cpu_sample or {"c2": 20000, "c3": 8000, "c4": 8000, "c5": 1500}[args.config]
+        n_sample = args.cpu_sample or {"c2": 20000, "c3": 8000, "c4": 8000, "c4b": 8000, "c5": 1000}[args.config]
         n_sample = min(n_sample, G)
         try:
             v, secs, sub, ref = cpu_baseline(counts, X, n_sample, n_jobs)
@@ -399,7 +448,12 @@ def main():
                                f"{args.scaling} scaling), design {design} (p={X.shape[1]}), NB counts "
                                f"(SURVEY 8d generator)",
                    "genes_per_gpu": G, "genes_total": G_total, "samples": N, "p": int(X.shape[1]),
-                   "collectives": transport, "device": info["name"], "arch": info["arch"]},
+                   "collectives": transport, "generator": generator,
+                   "device": info["name"] or f"{info['arch']} ({info['cu_count']} CUs)", "arch": info["arch"]},
+        "first_call_ms": round(first_call_ms, 3), "cold_first_call_ms": round(cold_first_ms, 3),
+        "first_call_note": "first_call_ms: one deseq2() without the previous pass's non-zero mask (the host waits for "
+                           "the mask before compacting), pools warm; cold_first_call_ms: the very first pass of the "
+                           "process (code objects, allocations)",
         "h2d_ms": round(h2d_s * 1e3, 3),
         "value_with_h2d": round(G_total / (dt / args.steps + h2d_s), 1),
         "h2d_note": f"host int64 {N} x {G} ({counts.nbytes / 1e6:.0f} MB per GPU) -> int32 in HBM through pinned "

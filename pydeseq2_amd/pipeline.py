@@ -315,6 +315,7 @@ class DeseqPipeline:
             self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
             if kms.value >= 0.0:  # (-1: a deferred launch, nobody waited for it)
                 self.kernel_log.setdefault("k_alpha", []).append((float(kms.value), int(genes)))
+                self.kernel_log.setdefault("k_alpha_stage", []).append((name, int(genes)))
                 self.kernel_log.setdefault("grid_fallback_genes", []).append((float(ng.value), int(genes)))
 
     # ------------------------------------------------------------------ result slabs

@@ -151,3 +151,68 @@ def test_tcp_control_plane_carries_the_protocol(world):
         np.testing.assert_allclose(sf, sf_ref, rtol=1e-14)
         assert got == [bytes([r]) * (r + 1) for r in range(world)]
         assert uid == b"u" * 128 and mx == 1.5 * (world - 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's multi-GPU plan: which block of which matrix a rank works on, and the hand launcher
+@pytest.mark.parametrize("config,genes,world", [("c2", 900, 2), ("c2", 1000, 3), ("c5", 1300, 2), ("c5", 1700, 3)])
+def test_bench_strong_scaling_plan_tiles_the_named_matrix(config, genes, world, monkeypatch):
+    """--scaling strong (bench.py's default for --gpus > 1): the ranks' gene blocks tile the configuration's matrix
+    and each rank's sample block is the matching row block of that same matrix (two-collective size factors).  c5 comes
+    from the tiled generator: a rank builds its blocks without the whole matrix."""
+    import bench
+    from pydeseq2_amd.distributed import sample_block
+    from pydeseq2_amd.synth import synth_counts, synth_counts_block
+
+    N0 = bench.CONFIGS[config][1]
+    monkeypatch.setitem(bench.CONFIGS, config, (bench.CONFIGS[config][0], min(N0, 260), bench.CONFIGS[config][2]))
+    N, design = bench.CONFIGS[config][1:]
+    if config == "c5":
+        full, X = synth_counts_block(genes, N, design, bench.SEEDS[config])
+    else:
+        full, X = synth_counts(genes, N, design, bench.SEEDS[config])
+    parts, total = [], 0
+    for r in range(world):
+        counts, Xr, samp, G, G_total, gen = bench.plan_rank_data(config, genes, "strong", r, world)
+        assert np.array_equal(Xr, X) and G_total == genes and counts.shape == (N, G)
+        n0, n1 = sample_block(r, world, N)
+        assert np.array_equal(samp, full[n0:n1])
+        parts.append(counts)
+        total += G
+    assert total == genes and np.array_equal(np.concatenate(parts, axis=1), full)
+    # weak: every rank its own matrix of the configuration's size
+    c0 = bench.plan_rank_data(config, genes, "weak", 0, world)
+    c1 = bench.plan_rank_data(config, genes, "weak", 1, world)
+    assert c0[0].shape == c1[0].shape == (N, genes) and c0[4] == genes * world and not np.array_equal(c0[0], c1[0])
+    assert c0[2] is None
+
+
+def test_tiled_generator_blocks_agree_on_overlaps():
+    from pydeseq2_amd.synth import synth_counts_block
+
+    full, X = synth_counts_block(1234, 300, "mixed", 9)
+    a, _ = synth_counts_block(1234, 300, "mixed", 9, genes=(400, 1100))
+    b, _ = synth_counts_block(1234, 300, "mixed", 9, samples=(130, 251))
+    c, _ = synth_counts_block(1234, 300, "mixed", 9, genes=(499, 502), samples=(124, 127))
+    assert np.array_equal(a, full[:, 400:1100]) and np.array_equal(b, full[130:251])
+    assert np.array_equal(c, full[124:127, 499:502])
+    assert X.shape == (300, 8) and full.dtype == np.int64 and (full >= 0).all()
+
+
+def test_bench_hand_launcher_starts_one_process_per_rank(tmp_path):
+    """`python bench.py --gpus N` without a launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
+    worst exit code comes back (no torch.distributed.run in between)."""
+    import bench
+
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys\n"
+        "r = os.environ['RANK']\n"
+        "open(os.path.join(sys.argv[1], 'rank' + r), 'w').write(' '.join(os.environ[k] for k in "
+        "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+        "sys.exit(3 if (r == '1' and len(sys.argv) > 2) else 0)\n")
+    assert bench.launch_local_ranks(3, [str(tmp_path)], script=str(script)) == 0
+    got = [(tmp_path / f"rank{r}").read_text().split() for r in range(3)]
+    assert [g[0] for g in got] == ["0", "1", "2"] and all(g[2] == "3" and g[3] == "127.0.0.1" for g in got)
+    assert len({g[4] for g in got}) == 1
+    assert bench.launch_local_ranks(2, [str(tmp_path), "fail"], script=str(script)) == 3

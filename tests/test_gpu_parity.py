@@ -682,3 +682,29 @@ def test_full_size_c3_properties():
     assert_close(res.MAP_dispersions[sel][same], np.clip(m, 1e-8, 1000.0)[same], RTOL, 0, "MAP")
     beta, _, _, bc = orc.irls(c, res.size_factors, X, res.dispersions[sel], 0.5, 1e-8)
     assert_close(res.LFC[sel][bc], beta[bc], RTOL, 1e-8, "LFC")
+
+
+def test_bench_two_ranks_strong_scaling_on_one_gpu():
+    """bench.py's multi-GPU path end to end on a one-GPU box: two ranks started by its own launcher share device 0
+    (DSQ_BENCH_SHARE_GPU; RCCL refuses two ranks per device, so the collectives take the host-staged transport), strong
+    scaling (the named matrix split by genes, sample blocks for the two-collective size factors), one JSON line with
+    the collective timings, and the in-run parity of rank 0's shard against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSQ_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c2", "--genes",
+                          "3000", "--steps", "2", "--warmup", "2", "--cpu-sample", "600", "--no-extras"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["genes_total"] == 3000
+    assert d["config"]["genes_per_gpu"] == 1500 and "host-staged" in d["config"]["collectives"]
+    assert d["collectives_per_step"] >= 3 and d["collective_ms_per_step"] > 0
+    assert d["parity"]["ok"], d["parity"]

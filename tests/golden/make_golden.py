@@ -390,6 +390,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "e2e":  # round 3: end-to-end outputs at the benchmark shapes
         e2e_cases(di, sys.argv[2:])
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "narrow":  # round 3: design widths 3, 5, 6, 7
+        narrow_cases(ut, gs, pp, di)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
         wide_cases(ut, gs, pp, di)
         hard_cases(ut, gs)
@@ -418,9 +421,11 @@ def main():
     kat_case("p8", synth(48, N, X, 13), X, ut, gs, pp, di)
 
     wide_cases(ut, gs, pp, di)
+    narrow_cases(ut, gs, pp, di)
     hard_cases(ut, gs)
     bfgs_cases(ut)
     rest_of_main(ut)
+    e2e_cases(di)
 
 
 def wide_cases(ut, gs, pp, di):
@@ -434,6 +439,31 @@ def wide_cases(ut, gs, pp, di):
             cols.append(rng.normal(0, 0.6, N))
         X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
         kat_case(f"p{pw}", synth(32, N, X, seed, eff=0.35), X, ut, gs, pp, di)
+
+
+def narrow_cases(ut, gs, pp, di):
+    """cases H..K (round 3): design widths 3, 5, 6, 7 - the widths around the kernels' routing thresholds (per-cell sums
+    from 5 cells / P >= 3, sixteen-lane IRLS from P = 5, inlined cell evaluation from P = 7, split second sweep from 9):
+    p = 3: one 3-level factor (3 cells = p: linear-model mu_hat); p = 5: 2 x 4 levels (8 cells, cell path);
+    p = 6: 2 x 3 levels + a continuous covariate (no cells: register path); p = 7: 3 x 5 levels (15 cells)."""
+    specs = {3: (48, 18), 5: (64, 19), 6: (72, 20), 7: (90, 21)}
+    for pw, (N, seed) in specs.items():
+        rng = np.random.default_rng(300 + pw)
+        i = np.arange(N)
+        if pw == 3:
+            cols = [np.ones(N), (i % 3 == 1), (i % 3 == 2)]
+        elif pw == 5:
+            a, b = i % 2, (i // 2) % 4
+            cols = [np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)]
+        elif pw == 6:
+            a, b = i % 2, (i // 2) % 3
+            cols = [np.ones(N), a == 1] + [(b == k) for k in (1, 2)] + [rng.normal(0, 0.6, N), rng.normal(0, 0.6, N)]
+        else:
+            a, b = i % 3, (i // 3) % 5
+            cols = [np.ones(N)] + [(a == k) for k in (1, 2)] + [(b == k) for k in (1, 2, 3, 4)]
+        X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
+        assert X.shape[1] == pw
+        kat_case(f"p{pw}", synth(40, N, X, seed, eff=0.5), X, ut, gs, pp, di)
 
 
 def rest_of_main(ut):

@@ -266,6 +266,21 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
                        double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu);
+/* dsq_dev_alpha_mle2 with the genes of the call partitioned into two lists (device int32, indices into the G genes):
+ * those of d_rows run FOUR to a wavefront (csrc/dsq_k_alpha_rows.hip: linear-model mu_hat designs with at most 4
+ * cells, see dsq_alpha_rows_eligible), those of d_waves one to a wavefront.  Which gene may go where depends on its
+ * counts only (dsq_dev_alpha_row_split: -1 = keep it on d_waves, else the number of its samples with a count >= 512,
+ * which cost the row kernel a second sweep per evaluation: queue such genes together), so the lists are built once per
+ * data set.  The row kernel takes its genes in the order of d_rows.
+ * d_rows == NULL: as dsq_dev_alpha_mle2.  Results do not depend on the partition beyond rounding. */
+int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
+                       const int32_t* d_waves, int n_waves);
+int dsq_alpha_rows_eligible(int N, int P, int n_cells);
+int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, int32_t* d_flags);
 /* The robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960) alone: the half of dsq_dev_cooks
  * that depends on counts, size factors and design cells only (arguments as dsq_dev_cooks). */
 int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,

@@ -459,7 +459,8 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
                                double alpha_hat, double min_disp, double max_disp,
                                double prior_var, bool cr_reg, bool prior_reg, Lbfgsb1d& m,
                                const double* cst_in = nullptr, double* cst_out = nullptr,
-                               int memo_blocks = 1, const CellCtx* cell = nullptr) {
+                               int memo_blocks = 1, const CellCtx* cell = nullptr, int eval_cap = 0,
+                               bool resume = false) {
     // PAD rows are LDS-staged; the in-place grid search evaluates with PAD = false (global rows)
     static_assert(!(RUN_GRID && PAD), "the in-place grid search expects un-staged rows");
     AlphaArgs A;
@@ -472,8 +473,12 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     A.cst = cst_in != nullptr ? *cst_in : alpha_const<Wv>(y, mu, N);
     if (cst_out != nullptr && Wv::lane() == 0) *cst_out = A.cst;
     const double lo = log(min_disp), hi = log(max_disp);
-    m.start(A.la_hat, lo, hi);
-    while (!m.done) {
+    // eval_cap > 0: stop after that many evaluations in THIS call with the optimiser's state left in `m` (o.status = -1):
+    // the caller resumes the gene later (resume = true: `m` holds that state).  The sequence of iterates is unchanged.
+    if (!resume) m.start(A.la_hat, lo, hi);
+    int budget = eval_cap > 0 ? eval_cap : 0x7fffffff;
+    while (!m.done && budget > 0) {
+        --budget;
         double f, g;
         if (memo_blocks <= 1) alpha_eval<Wv, P, true, PAD, 1, CELL>(A, m.x, cr_reg, prior_reg, f, g);
         else if (memo_blocks == 2) alpha_eval<Wv, P, true, PAD, 2, CELL>(A, m.x, cr_reg, prior_reg, f, g);
@@ -484,9 +489,9 @@ DSQ_HD AlphaOut fit_alpha_gene(const int32_t* y, const double* mu, const double*
     DSQ_PHASE(7);
     AlphaOut o;
     o.converged = m.success ? 1 : 0;
-    o.nfev = m.nfev; o.nit = m.it; o.status = m.status;
+    o.nfev = m.nfev; o.nit = m.it; o.status = m.done ? m.status : -1;
     o.alpha = exp(m.x);
-    if (RUN_GRID && !m.success) {
+    if (RUN_GRID && m.done && !m.success) {
         A.cell = nullptr;  // the (rare) grid search runs the general evaluation
         o.alpha = exp(grid_fit_alpha<Wv, P>(A, lo, hi));
     }

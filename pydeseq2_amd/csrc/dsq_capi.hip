@@ -42,6 +42,8 @@ struct dsq_ctx {
     int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
     size_t ws_cap = 0;
+    void* d_resume = nullptr;     // parked optimiser states + gene list of the two-phase dispersion launch (grow-only)
+    size_t resume_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -230,8 +232,25 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
               double* d_nll_const, int const_mode, const dsq::AlphaExtras* extras) {
     if (G <= 0) return DSQ_OK;
     DSQ_HIP(ensure_list(ctx, (size_t)G));
-    int32_t* d_cnt = ctx->d_counter + 4;
-    DSQ_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+    int32_t* d_cnt = ctx->d_counter + 4;  // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes
+    DSQ_HIP(hipMemsetAsync(d_cnt, 0, 3 * sizeof(int32_t), ctx->stream));
+    // two-phase launch (dsq_launch.h, AlphaExtras): parking space for the genes phase A does not finish
+    dsq::AlphaExtras ex2{};
+    if (extras != nullptr) ex2 = *extras;
+    if (ctx->optimizer == 0) {
+        const size_t need = dsq::alpha_resume_bytes(G) + (size_t)G * sizeof(int32_t) + 256;
+        if (need > ctx->resume_cap) {
+            if (ctx->d_resume) (void)hipFree(ctx->d_resume);
+            ctx->d_resume = nullptr; ctx->resume_cap = 0;
+            DSQ_HIP(hipMalloc(&ctx->d_resume, need + need / 4));
+            ctx->resume_cap = need + need / 4;
+        }
+        ex2.eval_cap = dsq::kAlphaEvalCap;
+        ex2.resume_state = ctx->d_resume;
+        ex2.resume_list = (int32_t*)((char*)ctx->d_resume + ((dsq::alpha_resume_bytes(G) + 255) & ~(size_t)255));
+        ex2.resume_count = d_cnt + 2;
+        extras = &ex2;
+    }
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     if (ctx->optimizer == 1) {
         DSQ_CHECK_ARG(d_mu != nullptr && P <= DSQ_SHRINK_MAX_P,
@@ -243,7 +262,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     } else {
         DSQ_HIP(dsq::launch_alpha(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp,
                                   prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt, ctx->d_list,
-                                  d_nll_const, const_mode, extras));
+                                  d_nll_const, const_mode, extras, d_cnt + 1));
     }
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     int32_t* h_cnt = ctx->h_pin + 1;
@@ -344,6 +363,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_list) (void)hipFree(ctx->d_list);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_resume) (void)hipFree(ctx->d_resume);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
@@ -632,20 +652,44 @@ dsq::CellDesign to_cells(const dsq_cells* c) {
 }
 }  // namespace
 
+int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
+                       const int32_t* d_waves, int n_waves) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
+    DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr), "either mu or (coef, sf) is needed");
+    DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
+    DSQ_CHECK_ARG(d_rows == nullptr || (n_rows >= 0 && n_waves >= 0 && n_rows + n_waves == G &&
+                                        (n_waves == 0 || d_waves != nullptr)),
+                  "the two gene lists must partition the G genes of the call");
+    dsq::AlphaExtras ex{};
+    ex.cells = to_cells(cells);
+    if (d_mu == nullptr) { ex.coef = d_coef; ex.sf = d_sf; ex.min_mu = min_mu; }
+    if (d_rows != nullptr) { ex.rows = d_rows; ex.n_rows = n_rows; ex.waves = d_waves; ex.n_waves = n_waves; }
+    return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var, cr_reg,
+                     prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, &ex);
+}
+
 int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
                        int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
                        double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
-    DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
-    DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr), "either mu or (coef, sf) is needed");
-    DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
-    dsq::AlphaExtras ex{};
-    ex.cells = to_cells(cells);
-    if (d_mu == nullptr) { ex.coef = d_coef; ex.sf = d_sf; ex.min_mu = min_mu; }
-    return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var, cr_reg,
-                     prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, &ex);
+    return dsq_dev_alpha_mle3(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
+                              cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, cells, d_coef,
+                              d_sf, min_mu, nullptr, 0, nullptr, 0);
+}
+
+int dsq_alpha_rows_eligible(int N, int P, int n_cells) {
+    return dsq::alpha_rows_eligible(N, P, n_cells, true, 1) ? 1 : 0;
+}
+
+int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, int32_t* d_flags) {
+    DSQ_HIP(dsq::launch_count_big(ctx->stream, d_y, ldn, N, G, d_flags));
+    return DSQ_OK;
 }
 
 int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,

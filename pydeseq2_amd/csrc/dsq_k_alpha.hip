@@ -53,7 +53,11 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     __shared__ CellCtx cellctx[kWavesPerBlock];
     extern __shared__ __attribute__((aligned(16))) double stage[];
     const int w = threadIdx.x >> 6;
-    const int g = blockIdx.x * kWavesPerBlock + w;
+    const int gk = blockIdx.x * kWavesPerBlock + w;  // G counts the entries of ex.list when there is one
+    if (ex.n_dev != nullptr) {  // phase B of a two-phase launch: launched for a capacity, the count is on the device
+        G = min(G, *ex.n_dev);
+        if ((int)(blockIdx.x * kWavesPerBlock) >= G) return;
+    }
     log_tab_fill();  // the table of flog1p_t (dsq_math.h)
     if (!CELL) __syncthreads();
     if (CELL) {
@@ -69,7 +73,8 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
         ex.cells.XX = sXX;
         ex.cells.Xc = sXc;
     }
-    if (g >= G) return;
+    if (gk >= G) return;
+    const int g = ex.list != nullptr ? ex.list[gk] : gk;
 #if defined(DSQ_PHASE_TIMING)
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < kPhases; ++k) g_ph_acc[w][k] = 0;
@@ -130,11 +135,26 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
     }
     maxc = DeviceWave::maxi(maxc);
     const int memo_blocks = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (maxc >> 6) + 1));
+    constexpr int kStateDwords = (int)(sizeof(Lbfgsb1d) / 4);
+    static_assert(sizeof(Lbfgsb1d) % 4 == 0, "optimiser state is copied dword by dword");
+    if (ex.resume != 0) {  // phase B: the optimiser continues where phase A parked it
+        const uint32_t* src = (const uint32_t*)((const Lbfgsb1d*)ex.resume_state + g);
+        uint32_t* dst = (uint32_t*)&machine[w];
+        for (int i = threadIdx.x & 63; i < kStateDwords; i += 64) dst[i] = src[i];
+        DeviceWave::sync();
+    }
     const AlphaOut o = fit_alpha_gene<DeviceWave, P, false, STAGE, CELL>(
         yg, mg, Xt, ldx, N, alpha_hat[g], min_disp, max_disp, prior_var, cr_reg != 0, prior_reg != 0, machine[w],
-        const_mode == DSQ_CONST_LOAD ? nll_const + g : nullptr,
-        const_mode == DSQ_CONST_STORE ? nll_const + g : nullptr, memo_blocks, CELL ? &cellctx[w] : nullptr);
-    if ((threadIdx.x & 63) == 0) {
+        (const_mode == DSQ_CONST_LOAD || (ex.resume != 0 && nll_const != nullptr)) ? nll_const + g : nullptr,
+        (const_mode == DSQ_CONST_STORE && ex.resume == 0) ? nll_const + g : nullptr, memo_blocks,
+        CELL ? &cellctx[w] : nullptr, ex.resume != 0 ? 0 : ex.eval_cap, ex.resume != 0);
+    if (o.status < 0) {  // phase A ran out of its evaluation budget: park the gene for phase B
+        DeviceWave::sync();
+        uint32_t* dst = (uint32_t*)((Lbfgsb1d*)ex.resume_state + g);
+        const uint32_t* src = (const uint32_t*)&machine[w];
+        for (int i = threadIdx.x & 63; i < kStateDwords; i += 64) dst[i] = src[i];
+        if ((threadIdx.x & 63) == 0) ex.resume_list[atomicAdd(ex.resume_count, 1)] = g;
+    } else if ((threadIdx.x & 63) == 0) {
         alpha[g] = o.alpha;
         conv[g] = (uint8_t)o.converged;
         if (nfev != nullptr) nfev[g] = o.nfev;
@@ -253,6 +273,8 @@ __global__ __launch_bounds__(kBlock, alpha_min_waves(P)) void k_alpha_bfgs(const
     }
 }
 
+bool no_two_phase();
+
 hipError_t launch_alpha_bfgs(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
                              int N, int G, int P_, const double* alpha_hat, double min_disp, double max_disp,
                              double prior_var, int cr_reg, int prior_reg, double* alpha, uint8_t* conv,
@@ -269,11 +291,30 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         int ldx, int N, int G, int P_, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
-                        double* nll_const, int const_mode, const AlphaExtras* extras) {
+                        double* nll_const, int const_mode, const AlphaExtras* extras, int32_t* queue) {
     if (G <= 0) return hipSuccess;
     if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
     AlphaExtras ex{};
     if (extras != nullptr) ex = *extras;
+    ex.list = nullptr;
+    // linear-model mu_hat designs with <= 4 cells: the genes of ex.rows run four to a wavefront
+    // (dsq_k_alpha_rows.hip), the rest of them (ex.waves) below
+    bool parked = false;
+    const int G_rows = ex.n_rows;
+    if (ex.rows != nullptr && queue != nullptr && ex.n_rows + ex.n_waves == G &&
+        alpha_rows_eligible(N, P_, ex.cells.C, ex.coef != nullptr, cr_reg)) {
+        const bool park = ex.resume_state != nullptr && ex.resume_count != nullptr && ex.resume_list != nullptr &&
+                          nll_const != nullptr && ex.eval_cap > 0 && !no_two_phase();
+        const hipError_t e = launch_alpha_rows(st, y, ldn, N, ex.rows, ex.n_rows, queue, ex.coef, ex.sf, ex.cells, P_,
+                                               ex.min_mu, alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
+                                               alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode,
+                                               park ? ex.eval_cap : 0, ex.resume_state, ex.resume_count, ex.resume_list);
+        if (e != hipSuccess) return e;
+        parked = park;
+        if (ex.n_waves <= 0 && !parked) return hipSuccess;
+        ex.list = ex.waves;
+        G = ex.n_waves;
+    }
     // designs beyond the register path's width - or, on request, any design without cell structure from
     // DSQ_WIDE_MIN_P columns on - run the LDS / matrix-core kernels (dsq_k_wide.hip)
     if (ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // the dispersion kernels use cells from 5 upwards
@@ -283,7 +324,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                                  prior_reg, alpha, conv, nfev, nll_const, const_mode,
                                  ex.cells.C > 0 ? &ex.cells : nullptr);
     }
-    const dim3 grid(genes_to_blocks(G)), block(kBlock);
+    const dim3 block(kBlock);
     const int npad = (N + 63) & ~63;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
     const bool stage = smem <= 80 * 1024;  // >= 2 workgroups per CU keep their rows in LDS
@@ -299,18 +340,37 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                            max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev, grid_count, grid_list,     \
                            nll_const, const_mode, ex);                                                           \
     } while (0)
-    if (cell) {
-        const size_t smem_c = smem + (size_t)ex.cells.C * (P_ * (P_ + 1) / 2 + P_) * sizeof(double);
-        DSQ_DISPATCH_P(P_, {
-            if constexpr (P >= 3) DSQ_ALPHA_LAUNCH((k_alpha<P, true, true>), smem_c);
-        })
-    } else if (stage) {
-        DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, true, false>), smem))
-    } else {
-        DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, false, false>), (size_t)0))
+    // pass 0: the genes of this kernel (all of them, or the `waves` list beside the row kernel); pass 1: the genes
+    // the row kernel parked (AlphaExtras), continued from their optimiser states
+    ex.eval_cap = 0;
+    for (int pass = 0; pass < (parked ? 2 : 1); ++pass) {
+        if (pass == 1) {
+            ex.resume = 1;
+            ex.list = ex.resume_list;
+            ex.n_dev = ex.resume_count;
+            G = G_rows;  // capacity: every row-kernel gene could have been parked; blocks beyond the count exit at once
+        }
+        if (G <= 0) continue;
+        const dim3 grid(genes_to_blocks(G));
+        if (cell) {
+            const size_t smem_c = smem + (size_t)ex.cells.C * (P_ * (P_ + 1) / 2 + P_) * sizeof(double);
+            DSQ_DISPATCH_P(P_, {
+                if constexpr (P >= 3) DSQ_ALPHA_LAUNCH((k_alpha<P, true, true>), smem_c);
+            })
+        } else if (stage) {
+            DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, true, false>), smem))
+        } else {
+            DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, false, false>), (size_t)0))
+        }
     }
 #undef DSQ_ALPHA_LAUNCH
     return hipGetLastError();
+}
+
+size_t alpha_resume_bytes(int G) { return (size_t)G * sizeof(Lbfgsb1d); }
+bool no_two_phase() {
+    static const bool off = getenv("DSQ_NO_TWO_PHASE") != nullptr;
+    return off;
 }
 
 // does the dispersion fit of such a design take the run-time-P (LDS) kernels?  (launch_alpha's routing rule)

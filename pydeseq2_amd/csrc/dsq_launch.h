@@ -65,7 +65,36 @@ struct AlphaExtras {
     const double* coef;  // [G][P] OLS coefficients of the normalised counts (k_mom_lin_mu): mu_hat is computed
     const double* sf;    // while staging instead of being read from `mu` (which may then be null)
     double min_mu;
+    // gene lists (dsq_k_alpha_rows.hip): the genes of `rows` [n_rows] run four to a wavefront, those of `waves`
+    // [n_waves] one to a wavefront (k_alpha); together they are the G genes of the call.  nullptr: all on k_alpha.
+    const int32_t* rows;
+    const int32_t* waves;
+    int n_rows, n_waves;
+    const int32_t* list;  // (internal) k_alpha takes gene list[k] instead of gene k
+    // Parking (row kernel, dsq_k_alpha_rows.hip).  A fit whose line search ends in rounding noise takes 20-34 evaluations
+    // (0.1-0.3 % of the genes; the median is 5).  The row kernel stops a gene after eval_cap evaluations and parks it (the
+    // optimiser's state, 296 bytes) in resume_state / resume_list; k_alpha then continues the parked genes (resume != 0,
+    // genes = the parked list, count on the device), all at once, each on a wavefront of its own.  Same iterates.
+    // (For k_alpha itself the same two-phase scheme was measured and brings nothing: c3 8.31 -> 8.52 ms per step.)
+    int eval_cap;
+    int resume;
+    void* resume_state;       // [G] Lbfgsb1d records
+    int32_t* resume_count;
+    int32_t* resume_list;     // [G]
+    const int32_t* n_dev;     // (internal) phase B: number of entries of `list` on the device
 };
+constexpr int kAlphaEvalCap = 8;
+size_t alpha_resume_bytes(int G);
+// ---- dsq_k_alpha_rows.hip: four genes per wavefront for linear-model mu_hat designs with <= 4 cells
+constexpr int kRowTail = 512;    // counts below this enter a gene's tail-count table
+bool alpha_rows_eligible(int N, int P, int n_cells, bool has_coef, int cr_reg);
+hipError_t launch_alpha_rows(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, int n_list,
+                             int32_t* queue, const double* coef, const double* sf, const CellDesign& cells, int P,
+                             double min_mu, const double* alpha_hat, double min_disp, double max_disp, double prior_var,
+                             int cr_reg, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev, int32_t* grid_count,
+                             int32_t* grid_list, double* nll_const, int const_mode, int eval_cap, void* park_state,
+                             int32_t* park_count, int32_t* park_list);
+hipError_t launch_count_big(hipStream_t st, const int32_t* y, int ldn, int N, int G, int32_t* out);
 // optimizer="BFGS" variant of the dispersion fit (P <= DSQ_REG_MAX_P, mu_hat as a matrix)
 hipError_t launch_alpha_bfgs(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
                              int N, int G, int P, const double* alpha_hat, double min_disp, double max_disp,
@@ -75,7 +104,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         int ldx, int N, int G, int P, const double* alpha_hat, double min_disp,
                         double max_disp, double prior_var, int cr_reg, int prior_reg, double* alpha,
                         uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
-                        double* nll_const, int const_mode, const AlphaExtras* extras = nullptr);
+                        double* nll_const, int const_mode, const AlphaExtras* extras = nullptr, int32_t* queue = nullptr);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
                              const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev = nullptr);

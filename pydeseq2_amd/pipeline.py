@@ -206,6 +206,15 @@ class DeseqPipeline:
             self._d_Xc = DeviceArray.from_host(ctx_, D.Xc)
             self._d_XXc = DeviceArray.from_host(ctx_, D.XXc)
             self._cells = DsqCells(self._d_cell_of.ptr, self._d_Xc.ptr, self._d_XXc.ptr, int(D.n_design_cells))
+        # dispersion fits with four genes per wavefront (csrc/dsq_k_alpha_rows.hip: linear-model mu_hat, <= 4 design cells):
+        # which genes may take it depends on the counts only (1 = stays on the one-gene-per-wavefront kernel)
+        self._row_flags, self._row_lists = None, None
+        if (self._cells is not None and D.linear_mu and not os.environ.get("DSQ_NO_ALPHA_ROWS")
+                and ctx_.lib.dsq_alpha_rows_eligible(self.N, self.P, int(D.n_design_cells))):
+            d_fl = DeviceArray(ctx_, (self.G,), np.int32)
+            ctx_.call("dsq_dev_alpha_row_split", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_fl.ptr))
+            self._row_flags = d_fl.to_host()  # -1: not for the row kernel, else the gene's number of counts >= 512
+            d_fl.free()
         self.keep_layers = False   # True: the LFC fit also writes the N x G layers mu / hat diagonals (else on demand)
         self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
         self._work = None
@@ -310,7 +319,7 @@ class DeseqPipeline:
             self.kernel_log.setdefault(name, []).append((ms, int(genes)))
         else:
             self.ctx.call(cname, *args)
-        if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2"):
+        if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2", "dsq_dev_alpha_mle3"):
             kms, ng = C.c_float(), C.c_int()
             self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
             if kms.value >= 0.0:  # (-1: a deferred launch, nobody waited for it)
@@ -393,14 +402,33 @@ class DeseqPipeline:
     def _cells_arg(self):
         return C.byref(self._cells) if self._cells is not None else None
 
-    def _stage_genewise(self, d_y, Gs, d_sf, S):
+    def _row_lists_for(self, non_zero):
+        """Gene lists of the two dispersion kernels in the index space of the compacted (non-zero) genes; cached: they
+        depend on the counts only."""
+        if self._row_flags is None:
+            return None
+        c = self._row_lists
+        if c is None or not np.array_equal(c[0], non_zero):
+            fl = self._row_flags[non_zero]
+            rows, waves = np.nonzero(fl >= 0)[0], np.nonzero(fl < 0)[0].astype(np.int32)
+            # high-count genes (samples beyond the tail-count table cost a second sweep per evaluation) first and together:
+            # a wavefront then holds four of a kind, and the longer fits start early
+            rows = rows[np.argsort(-fl[rows], kind="stable")].astype(np.int32)
+            if c is not None:
+                c[1].free(); c[3].free()
+            d_rows = DeviceArray.from_host(self.ctx, rows if len(rows) else np.zeros(1, np.int32))
+            d_waves = DeviceArray.from_host(self.ctx, waves if len(waves) else np.zeros(1, np.int32))
+            c = self._row_lists = (non_zero.copy(), d_rows, len(rows), d_waves, len(waves))
+        return (c[1], c[2], c[3], c[4]) if c[2] > 0 else None
+
+    def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
         unclipped), gconv]; returns the description of mu_hat the MAP fit needs: the device matrix, or - for
         the designs with the linear-model mu_hat (dds.py:747-756) - only the per-gene OLS coefficients from
         which the dispersion kernel rebuilds mu_hat = max(sf * X coef, min_mu) while staging."""
         D = self.design
         mh = type("MuHat", (), {})()
-        mh.d_mu, mh.d_coef = None, None
+        mh.d_mu, mh.d_coef, mh.row_lists = None, None, row_lists
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
@@ -430,11 +458,14 @@ class DeseqPipeline:
     def _alpha_fit(self, name, d_y, mh, Gs, d_sf, d_start, prior_var, prior_reg, d_out, d_conv, const_mode):
         d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
         use_coef = mh.d_mu is None
-        self._k(name, Gs, "dsq_dev_alpha_mle2", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
+        rows = getattr(mh, "row_lists", None) if use_coef else None  # (d_rows, n_rows, d_waves, n_waves) or None
+        self._k(name, Gs, "dsq_dev_alpha_mle3", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
                 _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
                 c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
                 _vp(d_nfev.ptr) if d_nfev else None, _vp(mh.nll_const.ptr), const_mode, self._cells_arg(),
-                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if use_coef else None, c_double(self.min_mu))
+                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if use_coef else None, c_double(self.min_mu),
+                _vp(rows[0].ptr) if rows else None, rows[1] if rows else 0,
+                _vp(rows[2].ptr) if rows and rows[3] else None, rows[3] if rows else 0)
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
 
@@ -637,7 +668,7 @@ class DeseqPipeline:
         S = self._dev_slab(Gn)
 
         # ---- genewise dispersions (dds.py:713-797)
-        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S)
+        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero))
         if spec is not None:  # the genewise stage has synchronised behind the two read-backs
             if Gn == 0:
                 ctx.sync()

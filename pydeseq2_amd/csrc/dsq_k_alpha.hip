@@ -311,6 +311,15 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                                                park ? ex.eval_cap : 0, ex.resume_state, ex.resume_count, ex.resume_list);
         if (e != hipSuccess) return e;
         parked = park;
+        if (parked && alpha_wg_eligible(N)) {
+            // the parked fits continue one per WORKGROUP (k_alpha_wg): ~3 us per evaluation instead of ~15 with the 64
+            // lanes of k_alpha - the launch lasts as long as its longest fit (up to 26 more evaluations)
+            const hipError_t e2 = launch_alpha_wg(st, y, ldn, N, ex.resume_list, ex.resume_count, ex.n_rows, ex.coef,
+                                                  ex.sf, ex.cells, P_, ex.min_mu, alpha_hat, prior_var, prior_reg, alpha,
+                                                  conv, nfev, grid_count, grid_list, nll_const, ex.resume_state);
+            if (e2 != hipSuccess) return e2;
+            parked = false;
+        }
         if (ex.n_waves <= 0 && !parked) return hipSuccess;
         ex.list = ex.waves;
         G = ex.n_waves;

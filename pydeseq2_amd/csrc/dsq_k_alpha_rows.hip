@@ -420,6 +420,238 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Continuation of the parked genes: ONE GENE PER WORKGROUP.  The few fits that outlast the evaluation cap of the row
+// kernel need 1 .. 26 more evaluations, strictly one after the other: the launch lasts as long as the longest of them,
+// and with 64 lanes per gene (k_alpha) that was 0.4 ms per dispersion stage at N = 1000 - a fifth of the stage for 1 % of
+// the genes.  Here every thread of a workgroup owns at most kWgSpt samples in registers (N = 1000: 1024 threads, one
+// sample each), so an evaluation is ~100 instructions of per-sample work, a two-level reduction through LDS and the
+// optimiser step: about 3 us instead of 15.  Same objective as the row kernel (tail counts, per-cell mu_hat); every
+// wavefront of the workgroup keeps its own copy of the optimiser state and steps it with the same totals.
+constexpr int kWgSpt = 4;  // samples per thread at most
+
+template <int P>
+__global__ __launch_bounds__(1024) void k_alpha_wg(
+    const int32_t* __restrict__ y, int ldn, int N, const int32_t* __restrict__ list, const int32_t* __restrict__ n_dev,
+    const double* __restrict__ coef, const double* __restrict__ sf, const int32_t* __restrict__ cell_of,
+    const double* __restrict__ Xc, const double* __restrict__ XXc, double min_mu, const double* __restrict__ alpha_hat,
+    double prior_var, int prior_reg, double* __restrict__ alpha_out, uint8_t* __restrict__ conv,
+    int32_t* __restrict__ nfev, int32_t* __restrict__ grid_count, int32_t* __restrict__ grid_list,
+    const double* __restrict__ nll_const, const Lbfgsb1d* __restrict__ park_state) {
+    constexpr int C = P;
+    constexpr int T = Tri<P>::N;
+    constexpr int NV = 3 + 2 * C;  // reduced values: f (sum, compensation), g, per-cell w and dw
+    const int n_parked = *n_dev;
+    if ((int)blockIdx.x >= n_parked) return;
+    __shared__ unsigned int hist[kRowTail];
+    __shared__ int wave_tot[kRowTail / 64];
+    __shared__ double part[16][NV];
+    __shared__ Lbfgsb1d mach[16];
+    __shared__ int s_nbig;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    log_tab_fill();
+    double xx[C][T];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int k = 0; k < T; ++k) xx[c][k] = XXc[c * T + k];
+    // (launched for a fixed number of workgroups: a launch with one - mostly empty - workgroup per gene that COULD have
+    // been parked spent 0.3 ms dispatching them)
+    for (int item = blockIdx.x; item < n_parked; item += gridDim.x) {
+    const int g = list[item];
+    __syncthreads();  // the previous gene's tables are no longer in use
+    for (int i = tid; i < kRowTail; i += nthreads) hist[i] = 0u;
+    if (tid == 0) s_nbig = 0;
+    {   // this wavefront's copy of the parked optimiser state
+        constexpr int kDw = (int)(sizeof(Lbfgsb1d) / 4);
+        const uint32_t* src = (const uint32_t*)(park_state + g);
+        uint32_t* dst = (uint32_t*)&mach[w];
+        for (int i = lane; i < kDw; i += 64) dst[i] = src[i];
+    }
+    double q[C];
+    {
+        double b[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] = coef[(size_t)g * P + j];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            double yh = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) yh += Xc[c * P + j] * b[j];
+            q[c] = yh;
+        }
+    }
+    __syncthreads();
+    // this thread's samples
+    const int32_t* yg = y + (size_t)g * ldn;
+    int yi[kWgSpt], cl[kWgSpt];
+    double mu[kWgSpt];
+    int nbig = 0;
+#pragma unroll
+    for (int k = 0; k < kWgSpt; ++k) {
+        const int n = tid + k * nthreads;
+        const bool in = n < N;
+        yi[k] = in ? yg[n] : 0;
+        cl[k] = in ? cell_of[n] : 0;
+        double qq = q[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) qq = (cl[k] == c) ? q[c] : qq;
+        mu[k] = in ? dmax(sf[n] * qq, min_mu) : 0.0;
+        if (yi[k] >= kRowTail) nbig += 1;
+        else if (yi[k] > 0) atomicAdd(&hist[yi[k]], 1u);
+    }
+    nbig = DeviceWave::sumi(nbig);
+    if (lane == 0 && nbig > 0) atomicAdd(&s_nbig, nbig);
+    __syncthreads();
+    // tail count of entry tid (threads below kRowTail): T_i = #{y > i}
+    double my_tail = 0.0;
+    {
+        int h = 0, suf = 0;
+        if (tid < kRowTail) {
+            h = (int)hist[tid];
+            int v = h;  // inclusive suffix sum inside the wavefront
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_down(v, d, 64);
+                if (lane + d < 64) v += o;
+            }
+            suf = v - h;  // entries above this one in the same wavefront
+            if (lane == 0) wave_tot[w] = v;
+        }
+        __syncthreads();
+        if (tid < kRowTail) {
+            int above = s_nbig + suf;
+            for (int ww = w + 1; ww < kRowTail / 64; ++ww) above += wave_tot[ww];
+            my_tail = (double)above;
+        }
+    }
+    const double cst = nll_const[g];
+    const double la_hat = log(alpha_hat[g]);
+    Lbfgsb1d& m = mach[w];
+    DeviceWave::sync();
+    while (!m.done) {
+        const double la = m.x;
+        const double alpha = exp(la);
+        const double a = frcp(alpha);
+        const double lal = flog_t(alpha);
+        KSum accf;
+        double accg = 0.0, wc[C], dwc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { wc[c] = 0.0; dwc[c] = 0.0; }
+        if (my_tail > 0.0) {
+            const double t = a + (double)tid;
+            accf.add(-(my_tail * flog_t(t)));
+            accg -= my_tail * frcp(t);
+        }
+        double lgM = 0.0, psiM = 0.0;
+        if (s_nbig > 0) stirling_big((double)kRowTail + a, lgM, psiM);
+#pragma unroll
+        for (int k = 0; k < kWgSpt; ++k) {
+            if (tid + k * nthreads < N) {
+                const double mm = mu[k], yv = (double)yi[k];
+                const double ma = mm * alpha;
+                const double r1 = frcp(1.0 + ma);
+                const double L1 = flog1p_t(ma, r1);
+                accf.add(yv * (L1 - lal) + a * L1);
+                accg += L1 + (yv - mm) * alpha * r1;
+                const double wv = mm * r1, dwv = -(wv * wv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    wc[c] += (cl[k] == c) ? wv : 0.0;
+                    dwc[c] += (cl[k] == c) ? dwv : 0.0;
+                }
+                if (yi[k] >= kRowTail) {
+                    double lgz, psiz;
+                    stirling_big(yv + a, lgz, psiz);
+                    accf.add(lgM - lgz);
+                    accg += psiM - psiz;
+                }
+            }
+        }
+        // level 1: inside the wavefront; level 2: every wavefront adds the partials of all of them in the same order
+        {
+            KSum k1 = accf;
+            const double f1 = DeviceWave::sum_comp(k1);
+            const double g1 = DeviceWave::sum(accg);
+            double v[NV];
+            v[0] = f1; v[1] = 0.0; v[2] = g1;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { v[3 + c] = DeviceWave::sum(wc[c]); v[3 + C + c] = DeviceWave::sum(dwc[c]); }
+            if (lane == 0)
+#pragma unroll
+                for (int i = 0; i < NV; ++i) part[w][i] = v[i];
+        }
+        __syncthreads();
+        KSum fs;
+        double gs = 0.0, ws[C], dws[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { ws[c] = 0.0; dws[c] = 0.0; }
+        for (int ww = 0; ww < nwaves; ++ww) {
+            fs.add(part[ww][0]);
+            gs += part[ww][2];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { ws[c] += part[ww][3 + c]; dws[c] += part[ww][3 + C + c]; }
+        }
+        __syncthreads();
+        double f = fs.value() + cst;
+        double gr = alpha * (-(a * a * gs));
+        {
+            double M[T], dM[T];
+#pragma unroll
+            for (int k = 0; k < T; ++k) { M[k] = 0.0; dM[k] = 0.0; }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < T; ++k) { M[k] += ws[c] * xx[c][k]; dM[k] += dws[c] * xx[c][k]; }
+            chol<P>(M);
+            f += 0.5 * chol_logdet<P>(M);
+            double inv[T];
+            chol_inverse<P>(M, inv);
+            gr += 0.5 * sym_frob<P>(inv, dM) * alpha;
+        }
+        if (prior_reg != 0) {
+            const double dl = la - la_hat;
+            f += dl * dl / (2.0 * prior_var);
+            gr += dl / prior_var;
+        }
+        m.feed(f, gr);
+        DeviceWave::sync();
+    }
+    if (tid == 0) {
+        alpha_out[g] = exp(m.x);
+        conv[g] = (uint8_t)(m.success ? 1 : 0);
+        if (nfev != nullptr) nfev[g] = m.nfev;
+        if (!m.success) grid_list[atomicAdd(grid_count, 1)] = g;
+    }
+    }  // next parked gene of this workgroup
+}
+
+bool alpha_wg_eligible(int N) { return N <= 1024 * kWgSpt && getenv("DSQ_NO_ALPHA_WG") == nullptr; }
+
+// the parked genes of the row kernel (count on the device), one workgroup each; capacity = n_cap workgroups
+hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, const int32_t* n_dev,
+                           int n_cap, const double* coef, const double* sf, const CellDesign& cells, int P_,
+                           double min_mu, const double* alpha_hat, double prior_var, int prior_reg, double* alpha,
+                           uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
+                           const double* nll_const, const void* park_state) {
+    if (n_cap <= 0) return hipSuccess;
+    int threads = kRowTail;  // at least one thread per tail-count entry
+    while (threads < 1024 && threads < N) threads *= 2;  // one sample per thread up to 1024 threads, then more each
+#define DSQ_WG_LAUNCH(PP)                                                                                            \
+    hipLaunchKernelGGL(k_alpha_wg<PP>, dim3(n_cap < 768 ? n_cap : 768), dim3(threads), 0, st, y, ldn, N, list, n_dev, coef, sf, \
+                       cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var, prior_reg, alpha, conv, nfev, \
+                       grid_count, grid_list, nll_const, (const Lbfgsb1d*)park_state)
+    switch (P_) {
+        case 1: DSQ_WG_LAUNCH(1); break;
+        case 2: DSQ_WG_LAUNCH(2); break;
+        case 3: DSQ_WG_LAUNCH(3); break;
+        case 4: DSQ_WG_LAUNCH(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DSQ_WG_LAUNCH
+    return hipGetLastError();
+}
+
 size_t alpha_rows_smem(int N) {
     const int npad = (N + 63) & ~63;
     return (size_t)npad * 8 + (size_t)npad + row_slot_bytes(npad) * kRowSlots * kRowWaves +

@@ -95,6 +95,12 @@ hipError_t launch_alpha_rows(hipStream_t st, const int32_t* y, int ldn, int N, c
                              int32_t* grid_list, double* nll_const, int const_mode, int eval_cap, void* park_state,
                              int32_t* park_count, int32_t* park_list);
 hipError_t launch_count_big(hipStream_t st, const int32_t* y, int ldn, int N, int G, int32_t* out);
+bool alpha_wg_eligible(int N);
+hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, const int32_t* n_dev,
+                           int n_cap, const double* coef, const double* sf, const CellDesign& cells, int P,
+                           double min_mu, const double* alpha_hat, double prior_var, int prior_reg, double* alpha,
+                           uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
+                           const double* nll_const, const void* park_state);
 // optimizer="BFGS" variant of the dispersion fit (P <= DSQ_REG_MAX_P, mu_hat as a matrix)
 hipError_t launch_alpha_bfgs(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt, int ldx,
                              int N, int G, int P, const double* alpha_hat, double min_disp, double max_disp,

@@ -380,7 +380,9 @@ def main():
                 "flop_per_sample_eval": 250}
     n_fallback = float(np.sum([x for x, _ in klog.get("grid_fallback_genes", [])])) / args.steps
     roofline = {
-        "bound": "hbm", "kernel": "k_alpha (dispersion MLE/MAP, one gene per wavefront), full-size launches",
+        "bound": "hbm", "kernel": "dispersion MLE / MAP stage, full-size launches: k_alpha_rows (four genes per wavefront) "
+                                  "+ k_alpha_wg (continuation of the parked fits) where the design takes them, else "
+                                  "k_alpha (one gene per wavefront); HIP events around the stage's kernels",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_ratio": None,
         "algorithmic_bytes_per_launch": int(alg_bytes), "full_launch_ms": round(full_ms, 4),

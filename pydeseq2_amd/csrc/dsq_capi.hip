@@ -725,7 +725,13 @@ int dsq_side_begin(dsq_ctx* ctx) {
         const int cus = prop.multiProcessorCount;
         if (split > 0 && split < cus) {
             std::vector<uint32_t> big((size_t)(cus + 31) / 32, 0u), small((size_t)(cus + 31) / 32, 0u);
-            for (int i = 0; i < cus; ++i) (i < split ? small : big)[(size_t)i / 32] |= 1u << (i % 32);
+            // which compute units are reserved: DSQ_CU_SPLIT_MODE 0 = the first `split` mask bits, 1 = every (cus / split)-th
+            static const int mode = getenv("DSQ_CU_SPLIT_MODE") ? atoi(getenv("DSQ_CU_SPLIT_MODE")) : 0;
+            const int stride = cus / split;
+            for (int i = 0; i < cus; ++i) {
+                const bool res = mode == 0 ? i < split : (i % stride == 0 && i / stride < split);
+                (res ? small : big)[(size_t)i / 32] |= 1u << (i % 32);
+            }
             DSQ_HIP(hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)big.size(), big.data()));
             DSQ_HIP(hipExtStreamCreateWithCUMask(&ctx->small_stream, (uint32_t)small.size(), small.data()));
             DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_small0, hipEventDisableTiming));

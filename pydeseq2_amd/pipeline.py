@@ -217,6 +217,7 @@ class DeseqPipeline:
             d_fl.free()
         self.keep_layers = False   # True: the LFC fit also writes the N x G layers mu / hat diagonals (else on demand)
         self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
+        self._robust_early = bool(os.environ.get("DSQ_ROBUST_EARLY"))  # (measurement switch: fork before the genewise fit)
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -421,7 +422,7 @@ class DeseqPipeline:
             c = self._row_lists = (non_zero.copy(), d_rows, len(rows), d_waves, len(waves))
         return (c[1], c[2], c[3], c[4]) if c[2] > 0 else None
 
-    def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None):
+    def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None, pre_alpha=None):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
         unclipped), gconv]; returns the description of mu_hat the MAP fit needs: the device matrix, or - for
         the designs with the linear-model mu_hat (dds.py:747-756) - only the per-gene OLS coefficients from
@@ -452,6 +453,8 @@ class DeseqPipeline:
                     None, None, c_double(0.0), None, None, None, None, None,
                     None, None, c_double(0.0), 0, None, None, None)
         mh.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
+        if pre_alpha is not None:
+            pre_alpha()
         self._alpha_fit("alpha_mle", d_y, mh, Gs, d_sf, S["mom"], 1.0, 0, S["gw"], S["gconv"], 1)
         return mh
 
@@ -668,21 +671,12 @@ class DeseqPipeline:
         S = self._dev_slab(Gn)
 
         # ---- genewise dispersions (dds.py:713-797)
-        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero))
-        if spec is not None:  # the genewise stage has synchronised behind the two read-backs
-            if Gn == 0:
-                ctx.sync()
-            sf = np.array(spec[0])
-            if np.isnan(sf).any() or not np.array_equal(spec[1].view(np.bool_), non_zero):
-                self._nz_pred = None
-                return self.deseq2(contrast, lfc_null, alt_hypothesis, profile, stop_after_trend,
-                                   stop_after_size_factors, size_factors)
-            r.size_factors = sf
-        self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
         # the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
-        # cells only: they run on a side stream underneath the latency-bound trend / prior kernels that follow
+        # cells only: they run on a side stream underneath the latency-bound kernels of the path (the continuation of
+        # the parked dispersion fits, the grid-search pass, the trend / prior kernels on their reserved compute units)
         d_rd = S["rd"]
-        if not (stop_after_trend or stop_after_size_factors):
+
+        def launch_robust():
             if self.overlap:
                 ctx.call("dsq_side_begin")
                 self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
@@ -697,6 +691,26 @@ class DeseqPipeline:
                 raise
             if self.overlap:
                 ctx.call("dsq_side_end")
+
+        want_robust = not (stop_after_trend or stop_after_size_factors)
+        early = want_robust and self.overlap and self._robust_early
+        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero),
+                                        pre_alpha=launch_robust if early else None)
+        if spec is not None:  # the genewise stage has synchronised behind the two read-backs
+            if Gn == 0:
+                ctx.sync()
+            sf = np.array(spec[0])
+            if np.isnan(sf).any() or not np.array_equal(spec[1].view(np.bool_), non_zero):
+                self._nz_pred = None
+                if self._side_pending:
+                    ctx.call("dsq_side_abort")
+                    self._side_pending = False
+                return self.deseq2(contrast, lfc_null, alt_hypothesis, profile, stop_after_trend,
+                                   stop_after_size_factors, size_factors)
+            r.size_factors = sf
+        self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
+        if want_robust and not early:
+            launch_robust()
         t2 = tick(); T["genewise"] = t2 - t1
 
         # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
@@ -824,7 +838,7 @@ class DeseqPipeline:
                 finally:
                     if deferred:
                         ctx.call("dsq_set_deferred", 0)
-                patch = (rp, self._fetch_begin(S2, ["nm", "gw", "fit", "disp", "beta", "p", "stat", "se", "any_all"]))
+                patch = (rp, self._fetch_begin(S2))  # the sub-problem's whole (small) result block in one copy
         t7 = tick(); T["refit"] = t7 - t6
 
         # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues

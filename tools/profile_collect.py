@@ -32,15 +32,23 @@ def main():
 
     fetch = json.load(open(os.path.join(src, "pmc_FETCH_SIZE.json")))
     write = json.load(open(os.path.join(src, "pmc_WRITE_SIZE.json")))
-    # the full-size k_alpha launches are the ones with the largest grid
-    keys = [k for k in fetch if k.startswith("dsq::k_alpha<")]
-    big = max(keys, key=lambda k: int(k.split("@")[1]))
-    f_kib, w_kib = fetch[big], write.get(big, 0.0)
+    # the dispersion stage: the row kernel (four genes per wavefront) + the continuation of its parked fits where the
+    # design takes them, else the full-size k_alpha launches (largest grid)
+    rows = [k for k in fetch if k.startswith("dsq::k_alpha_rows<")]
+    if rows:
+        parts = [max(rows, key=lambda k: fetch[k])] + [k for k in fetch if k.startswith("dsq::k_alpha_wg<")][:1]
+    else:
+        keys = [k for k in fetch if k.startswith("dsq::k_alpha<")]
+        parts = [max(keys, key=lambda k: int(k.split("@")[1]))]
+    f_kib = sum(fetch[k] for k in parts)
+    w_kib = sum(write.get(k, 0.0) for k in parts)
     traffic = {
         "k_alpha_hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024),
-        "source": f"profiles/{tag}_{cfg}.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB of the full-size {big.split('@')[0]} "
-                  "launches (gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md)",
-        "fetch_kib": f_kib, "write_kib": w_kib,
+        "source": f"profiles/{tag}_{cfg}.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB of the dispersion stage's kernels "
+                  f"({' + '.join(k.split('@')[0] for k in parts)}; mean over the genewise and the MAP launch; gfx950 "
+                  "FETCH_SIZE x2 correction of MI355X_MICROARCH.md - calibrated there for 16-byte-per-lane streaming "
+                  "reads; the row kernel reads 4 bytes per lane, so the absolute is uncalibrated)",
+        "fetch_kib": f_kib, "write_kib": w_kib, "kernels": parts,
     }
     json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{cfg}.json"), "w"), indent=1)
     print(path, traffic)

@@ -272,14 +272,19 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
  * counts only (dsq_dev_alpha_row_split: -1 = keep it on d_waves, else the number of its samples with a count >= 512,
  * which cost the row kernel a second sweep per evaluation: queue such genes together), so the lists are built once per
  * data set.  The row kernel takes its genes in the order of d_rows.
- * d_rows == NULL: as dsq_dev_alpha_mle2.  Results do not depend on the partition beyond rounding. */
+ * d_rows == NULL: as dsq_dev_alpha_mle2.  Results do not depend on the partition beyond rounding.
+ * d_cell_mu != NULL (with d_mu == d_coef == NULL): mu_hat in per-cell form, see dsq_alpha_rows_eligible. */
 int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
                        int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
                        double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
-                       const int32_t* d_waves, int n_waves);
+                       const int32_t* d_waves, int n_waves, const double* d_cell_mu);
+/* 0: no row kernel for such a design; 1: at most 4 cells == columns (linear-model mu_hat); 2: up to 32 cells, p <= 8
+ * (csrc/dsq_k_alpha_rowsc.hip; both mu_hat routes - the IRLS route hands over d_cell_mu, [G][n_cells] = exp(x_c . beta) from
+ * dsq_dev_cell_mu, and mu_hat_n = sf_n * cell_mu[cell_of[n]] unclamped (utils.py:435-437) is never materialised). */
 int dsq_alpha_rows_eligible(int N, int P, int n_cells);
+int dsq_dev_cell_mu(dsq_ctx* ctx, const double* d_beta, const dsq_cells* cells, int G, int P, double* d_cell_mu);
 int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, int32_t* d_flags);
 /* The robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960) alone: the half of dsq_dev_cooks
  * that depends on counts, size factors and design cells only (arguments as dsq_dev_cooks). */

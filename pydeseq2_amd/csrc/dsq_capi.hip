@@ -288,7 +288,8 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         // everything below is stream-ordered behind the launch above and ahead of whatever the caller enqueues
         // next: no host synchronisation, no allocation (workspace carved from ctx->d_ws)
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const bool rebuild = extras != nullptr && extras->coef != nullptr;
+        const bool from_cells = extras != nullptr && extras->cell_mu != nullptr;
+        const bool rebuild = extras != nullptr && (extras->coef != nullptr || from_cells);
         const size_t b_work = up((size_t)n_grid * 102 * sizeof(double));
         const size_t b_y = rebuild ? up((size_t)n_grid * ldn * sizeof(int32_t)) : 0;
         const size_t b_mu = rebuild ? up((size_t)n_grid * ldn * sizeof(double)) : 0;
@@ -304,8 +305,12 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             int32_t* idx = (int32_t*)(w + b_work + b_y + b_mu);
             double* asub = (double*)(w + b_work + b_y + b_mu + b_idx);
             DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub, n_dev));
-            DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
-                                             ctx->d_list, n_grid, musub, ldn, idx, n_dev));
+            if (from_cells)
+                DSQ_HIP(dsq::launch_mu_from_cells(ctx->stream, extras->cell_mu, extras->cells.C, extras->sf,
+                                                  extras->cells.cell_of, N, ctx->d_list, n_grid, musub, ldn, idx, n_dev));
+            else
+                DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
+                                                 ctx->d_list, n_grid, musub, ldn, idx, n_dev));
             DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub, musub, ldn, d_Xt, ldx, N, P, min_disp, max_disp, asub,
                                            idx, n_grid, work, n_dev));
             DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub, ctx->d_list, n_grid, 1, d_alpha, n_dev));
@@ -657,17 +662,22 @@ int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
                        double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
-                       const int32_t* d_waves, int n_waves) {
+                       const int32_t* d_waves, int n_waves, const double* d_cell_mu) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
-    DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr), "either mu or (coef, sf) is needed");
+    DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr) ||
+                      (d_cell_mu != nullptr && d_sf != nullptr && cells != nullptr && cells->n_cells > 0),
+                  "mu_hat is needed as a matrix, as (coef, sf) or as (cell_mu, sf, cells)");
+    DSQ_CHECK_ARG(d_cell_mu == nullptr || (d_mu == nullptr && d_coef == nullptr && ctx->optimizer == 0 &&
+                                           !dsq::alpha_is_wide(P, cells->n_cells)),
+                  "cell_mu: alone, with the default optimizer, on the register kernels");
     DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
     DSQ_CHECK_ARG(d_rows == nullptr || (n_rows >= 0 && n_waves >= 0 && n_rows + n_waves == G &&
                                         (n_waves == 0 || d_waves != nullptr)),
                   "the two gene lists must partition the G genes of the call");
     dsq::AlphaExtras ex{};
     ex.cells = to_cells(cells);
-    if (d_mu == nullptr) { ex.coef = d_coef; ex.sf = d_sf; ex.min_mu = min_mu; }
+    if (d_mu == nullptr) { ex.coef = d_coef; ex.cell_mu = d_cell_mu; ex.sf = d_sf; ex.min_mu = min_mu; }
     if (d_rows != nullptr) { ex.rows = d_rows; ex.n_rows = n_rows; ex.waves = d_waves; ex.n_waves = n_waves; }
     return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var, cr_reg,
                      prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, &ex);
@@ -680,11 +690,18 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
                        const double* d_coef, const double* d_sf, double min_mu) {
     return dsq_dev_alpha_mle3(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
                               cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, cells, d_coef,
-                              d_sf, min_mu, nullptr, 0, nullptr, 0);
+                              d_sf, min_mu, nullptr, 0, nullptr, 0, nullptr);
 }
 
 int dsq_alpha_rows_eligible(int N, int P, int n_cells) {
-    return dsq::alpha_rows_eligible(N, P, n_cells, true, 1) ? 1 : 0;
+    if (dsq::alpha_rows_eligible(N, P, n_cells, true, 1)) return 1;  // <= 4 cells == columns: per-cell sums in registers
+    return dsq::alpha_rowsc_tail(N, P, n_cells) > 0 ? 2 : 0;         // up to 32 cells: per-cell tables in LDS
+}
+
+int dsq_dev_cell_mu(dsq_ctx* ctx, const double* d_beta, const dsq_cells* cells, int G, int P, double* d_cell_mu) {
+    DSQ_CHECK_ARG(P >= 1 && P <= 12 && cells != nullptr && cells->n_cells > 0, "cells / P out of range");
+    DSQ_HIP(dsq::launch_cell_mu(ctx->stream, d_beta, cells->d_Xc, cells->n_cells, G, P, d_cell_mu));
+    return DSQ_OK;
 }
 
 int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, int32_t* d_flags) {

@@ -102,13 +102,16 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
         const int full_d = N / 128, full_i = N / 256;  // pieces of 128 doubles / 256 ints
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
-        if (ex.coef == nullptr) {
+        if (ex.coef == nullptr && ex.cell_mu == nullptr) {
             for (int c = 0; c < full_d; ++c)
                 __builtin_amdgcn_global_load_lds((glb_void*)(mg + c * 128 + lane * 2), (lds_void*)(ms + c * 128), 16, 0, 0);
         }
         for (int c = 0; c < full_i; ++c)
             __builtin_amdgcn_global_load_lds((glb_void*)(yg + c * 256 + lane * 4), (lds_void*)(ys + c * 256), 16, 0, 0);
-        if (ex.coef != nullptr) {
+        if (ex.cell_mu != nullptr) {  // IRLS mu_hat route, per-cell form: sf_n * exp(x_c . beta), unclamped
+            const double* cm = ex.cell_mu + (size_t)g * ex.cell_mu_C;
+            for (int n = lane; n < npad; n += 64) ms[n] = n < N ? ex.sf[n] * cm[ex.cell_mu_of[n]] : 0.0;
+        } else if (ex.coef != nullptr) {
             double b[P];
 #pragma unroll
             for (int j = 0; j < P; ++j) b[j] = ex.coef[(size_t)g * P + j];
@@ -301,17 +304,30 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     // (dsq_k_alpha_rows.hip), the rest of them (ex.waves) below
     bool parked = false;
     const int G_rows = ex.n_rows;
-    if (ex.rows != nullptr && queue != nullptr && ex.n_rows + ex.n_waves == G &&
-        alpha_rows_eligible(N, P_, ex.cells.C, ex.coef != nullptr, cr_reg)) {
+    ex.cell_mu_of = ex.cells.cell_of;  // (ex.cells is cleared below for designs of <= 4 cells)
+    ex.cell_mu_C = ex.cells.C;
+    const bool have_lists = ex.rows != nullptr && queue != nullptr && ex.n_rows + ex.n_waves == G;
+    const bool rows_reg = have_lists && ex.cell_mu == nullptr &&
+                          alpha_rows_eligible(N, P_, ex.cells.C, ex.coef != nullptr, cr_reg);
+    const bool rows_lds = have_lists && !rows_reg && cr_reg != 0 && (ex.coef != nullptr || ex.cell_mu != nullptr) &&
+                          alpha_rowsc_tail(N, P_, ex.cells.C) > 0;
+    if (rows_reg || rows_lds) {
         const bool park = ex.resume_state != nullptr && ex.resume_count != nullptr && ex.resume_list != nullptr &&
                           nll_const != nullptr && ex.eval_cap > 0 && !no_two_phase();
-        const hipError_t e = launch_alpha_rows(st, y, ldn, N, ex.rows, ex.n_rows, queue, ex.coef, ex.sf, ex.cells, P_,
-                                               ex.min_mu, alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg,
-                                               alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode,
-                                               park ? ex.eval_cap : 0, ex.resume_state, ex.resume_count, ex.resume_list);
+        hipError_t e;
+        if (rows_reg)
+            e = launch_alpha_rows(st, y, ldn, N, ex.rows, ex.n_rows, queue, ex.coef, ex.sf, ex.cells, P_, ex.min_mu,
+                                  alpha_hat, min_disp, max_disp, prior_var, cr_reg, prior_reg, alpha, conv, nfev,
+                                  grid_count, grid_list, nll_const, const_mode, park ? ex.eval_cap : 0, ex.resume_state,
+                                  ex.resume_count, ex.resume_list);
+        else
+            e = launch_alpha_rows_c(st, y, ldn, N, ex.rows, ex.n_rows, queue, ex.coef, ex.cell_mu, ex.sf, ex.cells, P_,
+                                    ex.min_mu, alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv, nfev,
+                                    grid_count, grid_list, nll_const, const_mode, park ? ex.eval_cap : 0,
+                                    ex.resume_state, ex.resume_count, ex.resume_list);
         if (e != hipSuccess) return e;
         parked = park;
-        if (parked && alpha_wg_eligible(N)) {
+        if (parked && rows_reg && alpha_wg_eligible(N)) {
             // the parked fits continue one per WORKGROUP (k_alpha_wg): ~3 us per evaluation instead of ~15 with the 64
             // lanes of k_alpha - the launch lasts as long as its longest fit (up to 26 more evaluations)
             const hipError_t e2 = launch_alpha_wg(st, y, ldn, N, ex.resume_list, ex.resume_count, ex.n_rows, ex.coef,
@@ -337,7 +353,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
     const int npad = (N + 63) & ~63;
     const size_t smem = (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double);
     const bool stage = smem <= 80 * 1024;  // >= 2 workgroups per CU keep their rows in LDS
-    if (!stage && ex.coef != nullptr) return hipErrorInvalidValue;  // mu_hat on the fly needs the staged variant
+    if (!stage && (ex.coef != nullptr || ex.cell_mu != nullptr)) return hipErrorInvalidValue;  // mu_hat on the fly needs the staged variant
     const bool cell = stage && ex.cells.C > kSmallCells && P_ >= 3 && cr_reg != 0;
 #define DSQ_ALPHA_LAUNCH(KERNEL, SMEM)                                                                            \
     do {                                                                                                          \

@@ -70,6 +70,10 @@ struct AlphaExtras {
     const int32_t* rows;
     const int32_t* waves;
     int n_rows, n_waves;
+    const double* cell_mu;  // [G][cells.C] per-cell mu_hat / size factor of the IRLS mu_hat route (k_cell_mu): mu_hat_n =
+                            // sf_n * cell_mu[cell_of[n]] UNclamped, instead of `mu` or `coef`
+    const int32_t* cell_mu_of;  // (internal) cell of every sample / number of cells for cell_mu
+    int cell_mu_C;
     const int32_t* list;  // (internal) k_alpha takes gene list[k] instead of gene k
     // Parking (row kernel, dsq_k_alpha_rows.hip).  A fit whose line search ends in rounding noise takes 20-34 evaluations
     // (0.1-0.3 % of the genes; the median is 5).  The row kernel stops a gene after eval_cap evaluations and parks it (the
@@ -95,6 +99,19 @@ hipError_t launch_alpha_rows(hipStream_t st, const int32_t* y, int ldn, int N, c
                              int32_t* grid_list, double* nll_const, int const_mode, int eval_cap, void* park_state,
                              int32_t* park_count, int32_t* park_list);
 hipError_t launch_count_big(hipStream_t st, const int32_t* y, int ldn, int N, int G, int32_t* out);
+// ---- dsq_k_alpha_rowsc.hip: four genes per wavefront for designs with up to 32 cells (per-cell tables in LDS)
+int alpha_rowsc_tail(int N, int P, int n_cells);  // tail-count table size (0: not eligible)
+hipError_t launch_alpha_rows_c(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, int n_list,
+                               int32_t* queue, const double* coef, const double* cell_mu, const double* sf,
+                               const CellDesign& cells, int P, double min_mu, const double* alpha_hat, double min_disp,
+                               double max_disp, double prior_var, int prior_reg, double* alpha, uint8_t* conv,
+                               int32_t* nfev, int32_t* grid_count, int32_t* grid_list, double* nll_const,
+                               int const_mode, int eval_cap, void* park_state, int32_t* park_count,
+                               int32_t* park_list);
+hipError_t launch_cell_mu(hipStream_t st, const double* beta, const double* Xc, int C, int G, int P, double* cell_mu);
+hipError_t launch_mu_from_cells(hipStream_t st, const double* cell_mu, int C, const double* sf, const int32_t* cell_of,
+                                int N, const int32_t* list, int n_list, double* dst, int ldn, int32_t* idx_out,
+                                const int32_t* n_dev = nullptr);
 bool alpha_wg_eligible(int N);
 hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, const int32_t* n_dev,
                            int n_cap, const double* coef, const double* sf, const CellDesign& cells, int P,

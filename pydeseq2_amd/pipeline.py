@@ -209,8 +209,12 @@ class DeseqPipeline:
         # dispersion fits with four genes per wavefront (csrc/dsq_k_alpha_rows.hip: linear-model mu_hat, <= 4 design cells):
         # which genes may take it depends on the counts only (1 = stays on the one-gene-per-wavefront kernel)
         self._row_flags, self._row_lists = None, None
-        if (self._cells is not None and D.linear_mu and not os.environ.get("DSQ_NO_ALPHA_ROWS")
-                and ctx_.lib.dsq_alpha_rows_eligible(self.N, self.P, int(D.n_design_cells))):
+        # 1: <= 4 cells == columns (linear-model mu_hat), 2: up to 32 cells, p <= 8 (either mu_hat route), 0: none
+        self._row_mode = 0 if (self._cells is None or os.environ.get("DSQ_NO_ALPHA_ROWS")) else \
+            int(ctx_.lib.dsq_alpha_rows_eligible(self.N, self.P, int(D.n_design_cells)))
+        if self._row_mode == 1 and not D.linear_mu:
+            self._row_mode = 0
+        if self._row_mode:
             d_fl = DeviceArray(ctx_, (self.G,), np.int32)
             ctx_.call("dsq_dev_alpha_row_split", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_fl.ptr))
             self._row_flags = d_fl.to_host()  # -1: not for the row kernel, else the gene's number of counts >= 512
@@ -429,7 +433,7 @@ class DeseqPipeline:
         which the dispersion kernel rebuilds mu_hat = max(sf * X coef, min_mu) while staging."""
         D = self.design
         mh = type("MuHat", (), {})()
-        mh.d_mu, mh.d_coef, mh.row_lists = None, None, row_lists
+        mh.d_mu, mh.d_coef, mh.d_cell_mu, mh.row_lists = None, None, None, row_lists
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
@@ -441,7 +445,10 @@ class DeseqPipeline:
                     c_double(self.max_disp), c_double(self.min_mu), _vp(S["nm"].ptr), _vp(S["mom"].ptr),
                     _vp(mh.d_mu.ptr) if mh.d_mu else None, _vp(mh.d_coef.ptr))
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
-            mh.d_mu = self._dmat(Gs)
+            # designs the many-cell row kernel takes: mu_hat stays in its per-cell form sf_n * exp(x_c . beta)
+            # (dsq_dev_cell_mu) - the N x G matrix is neither written by the IRLS kernel nor read by the two fits
+            per_cell = self._row_mode == 2 and row_lists is not None and row_lists[3] == 0
+            mh.d_mu = None if per_cell else self._dmat(Gs)
             self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
                     _vp(S["nm"].ptr), None, None, _vp(S["mom"].ptr))
@@ -449,9 +456,12 @@ class DeseqPipeline:
             self._k("irls_mu", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
-                    _vp(d_b.ptr), _vp(mh.d_mu.ptr), None, _vp(d_c.ptr), None, self._cells_arg(),
+                    _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), None, self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
                     None, None, c_double(0.0), 0, None, None, None)
+            if per_cell:
+                mh.d_cell_mu = self._dvec(Gs * int(D.n_design_cells))
+                self.ctx.call("dsq_dev_cell_mu", _vp(d_b.ptr), self._cells_arg(), Gs, self.P, _vp(mh.d_cell_mu.ptr))
         mh.nll_const = self._dvec(Gs)  # sum lgamma(y+1) - y log(mu_hat): stored here, re-used by the MAP fit
         if pre_alpha is not None:
             pre_alpha()
@@ -460,15 +470,18 @@ class DeseqPipeline:
 
     def _alpha_fit(self, name, d_y, mh, Gs, d_sf, d_start, prior_var, prior_reg, d_out, d_conv, const_mode):
         d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
-        use_coef = mh.d_mu is None
-        rows = getattr(mh, "row_lists", None) if use_coef else None  # (d_rows, n_rows, d_waves, n_waves) or None
+        d_cell_mu = getattr(mh, "d_cell_mu", None)
+        use_coef = mh.d_mu is None and d_cell_mu is None
+        use_cell = d_cell_mu is not None
+        rows = getattr(mh, "row_lists", None) if mh.d_mu is None else None  # (d_rows, n_rows, d_waves, n_waves) or None
         self._k(name, Gs, "dsq_dev_alpha_mle3", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
                 _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
                 c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
                 _vp(d_nfev.ptr) if d_nfev else None, _vp(mh.nll_const.ptr), const_mode, self._cells_arg(),
-                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if use_coef else None, c_double(self.min_mu),
-                _vp(rows[0].ptr) if rows else None, rows[1] if rows else 0,
-                _vp(rows[2].ptr) if rows and rows[3] else None, rows[3] if rows else 0)
+                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if (use_coef or use_cell) else None,
+                c_double(self.min_mu), _vp(rows[0].ptr) if rows else None, rows[1] if rows else 0,
+                _vp(rows[2].ptr) if rows and rows[3] else None, rows[3] if rows else 0,
+                _vp(d_cell_mu.ptr) if use_cell else None)
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
 

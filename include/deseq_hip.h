@@ -284,6 +284,9 @@ int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
  * (csrc/dsq_k_alpha_rowsc.hip; both mu_hat routes - the IRLS route hands over d_cell_mu, [G][n_cells] = exp(x_c . beta) from
  * dsq_dev_cell_mu, and mu_hat_n = sf_n * cell_mu[cell_of[n]] unclamped (utils.py:435-437) is never materialised). */
 int dsq_alpha_rows_eligible(int N, int P, int n_cells);
+/* 1 when dsq_dev_alpha_mle* needs mu_hat as a matrix for such a design (run-time-P kernels, or rows too long for the staged
+ * kernel to rebuild it from d_coef / d_cell_mu), else 0: the library's own routing rule, so that callers do not mirror it. */
+int dsq_alpha_needs_mu(int N, int P, int n_cells);
 int dsq_dev_cell_mu(dsq_ctx* ctx, const double* d_beta, const dsq_cells* cells, int G, int P, double* d_cell_mu);
 int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, int G, int32_t* d_flags);
 /* The robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960) alone: the half of dsq_dev_cooks

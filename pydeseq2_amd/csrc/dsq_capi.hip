@@ -693,6 +693,8 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
                               d_sf, min_mu, nullptr, 0, nullptr, 0, nullptr);
 }
 
+int dsq_alpha_needs_mu(int N, int P, int n_cells) { return dsq::alpha_needs_mu(N, P, n_cells) ? 1 : 0; }
+
 int dsq_alpha_rows_eligible(int N, int P, int n_cells) {
     if (dsq::alpha_rows_eligible(N, P, n_cells, true, 1)) return 1;  // <= 4 cells == columns: per-cell sums in registers
     return dsq::alpha_rowsc_tail(N, P, n_cells) > 0 ? 2 : 0;         // up to 32 cells: per-cell tables in LDS

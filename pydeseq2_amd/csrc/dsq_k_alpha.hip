@@ -404,6 +404,14 @@ bool alpha_is_wide(int P_, int n_cells) {
     return P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (n_cells == 0 || wide_with_cells()));
 }
 
+// must mu_hat be handed over as a matrix?  (the LDS path reads one; rows too long for the staged kernel cannot rebuild it
+// from coefficients while staging) - launch_alpha's own routing rule, for callers that would otherwise mirror it
+bool alpha_needs_mu(int N, int P_, int n_cells) {
+    if (alpha_is_wide(P_, n_cells)) return true;
+    const int npad = (N + 63) & ~63;
+    return (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double) > 80 * 1024;
+}
+
 // work: n_grid * (2 + kGridLen) doubles of device scratch
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P_, double min_disp, double max_disp, double* alpha,

@@ -165,7 +165,8 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
                               int n_fb, const IrlsExtras* extras = nullptr, const int32_t* n_dev = nullptr);
 
 bool irls_is_wide(int P, int n_cells);
-bool alpha_is_wide(int P, int n_cells);  // the design takes the run-time-P (LDS) kernels of dsq_k_wide.hip
+bool alpha_is_wide(int P, int n_cells);
+bool alpha_needs_mu(int N, int P, int n_cells);  // the design takes the run-time-P (LDS) kernels of dsq_k_wide.hip
 
 // ---- dsq_k_stats.hip
 hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,

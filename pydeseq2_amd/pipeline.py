@@ -438,7 +438,7 @@ class DeseqPipeline:
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
             # (the LDS / matrix-core path of dsq_k_wide.hip reads mu_hat): materialise it
-            if 48 * ((self.N + 63) & ~63) > 80 * 1024 or self.P > 12:
+            if self.ctx.lib.dsq_alpha_needs_mu(self.N, self.P, int(D.n_design_cells) if self._cells is not None else 0):
                 mh.d_mu = self._dmat(Gs)
             self._k("mom_lin_mu", Gs, "dsq_dev_mom_lin_coef", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr),
                     _vp(self.d_Xt.ptr), _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp),
@@ -447,7 +447,8 @@ class DeseqPipeline:
         else:  # dds.py:757-765: IRLS with the MoM dispersions, mu only is kept
             # designs the many-cell row kernel takes: mu_hat stays in its per-cell form sf_n * exp(x_c . beta)
             # (dsq_dev_cell_mu) - the N x G matrix is neither written by the IRLS kernel nor read by the two fits
-            per_cell = self._row_mode == 2 and row_lists is not None and row_lists[3] == 0
+            per_cell = (self._row_mode == 2 and row_lists is not None and row_lists[3] == 0
+                        and not self.ctx.lib.dsq_alpha_needs_mu(self.N, self.P, int(D.n_design_cells)))
             mh.d_mu = None if per_cell else self._dmat(Gs)
             self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),

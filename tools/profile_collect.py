@@ -34,9 +34,13 @@ def main():
     write = json.load(open(os.path.join(src, "pmc_WRITE_SIZE.json")))
     # the dispersion stage: the row kernel (four genes per wavefront) + the continuation of its parked fits where the
     # design takes them, else the full-size k_alpha launches (largest grid)
-    rows = [k for k in fetch if k.startswith("dsq::k_alpha_rows<")]
+    rows = [k for k in fetch if k.startswith("dsq::k_alpha_rows<") or k.startswith("dsq::k_alpha_rows_c<")]
     if rows:
-        parts = [max(rows, key=lambda k: fetch[k])] + [k for k in fetch if k.startswith("dsq::k_alpha_wg<")][:1]
+        cont = [k for k in fetch if k.startswith("dsq::k_alpha_wg<")][:1]
+        if not cont:  # the many-cell row kernel's parked fits are continued by k_alpha (largest launch of it)
+            ka = [k for k in fetch if k.startswith("dsq::k_alpha<")]
+            cont = [max(ka, key=lambda k: int(k.split("@")[1]))] if ka else []
+        parts = [max(rows, key=lambda k: fetch[k])] + cont
     else:
         keys = [k for k in fetch if k.startswith("dsq::k_alpha<")]
         parts = [max(keys, key=lambda k: int(k.split("@")[1]))]

@@ -453,9 +453,10 @@ def main():
                    "collectives": transport, "generator": generator,
                    "device": info["name"] or f"{info['arch']} ({info['cu_count']} CUs)", "arch": info["arch"]},
         "first_call_ms": round(first_call_ms, 3), "cold_first_call_ms": round(cold_first_ms, 3),
-        "first_call_note": "first_call_ms: one deseq2() without the previous pass's non-zero mask (the host waits for "
-                           "the mask before compacting), pools warm; cold_first_call_ms: the very first pass of the "
-                           "process (code objects, allocations)",
+        "first_call_note": "cold_first_call_ms: the very first deseq2() of the process on a fresh pipeline (code objects, "
+                           "pool allocations; the non-zero mask and the row kernels' gene lists come from the upload); "
+                           "first_call_ms: a pass that waits for the non-zero mask on the host before compacting (what "
+                           "every first call did in round 2), pools warm",
         "h2d_ms": round(h2d_s * 1e3, 3),
         "value_with_h2d": round(G_total / (dt / args.steps + h2d_s), 1),
         "h2d_note": f"host int64 {N} x {G} ({counts.nbytes / 1e6:.0f} MB per GPU) -> int32 in HBM through pinned "

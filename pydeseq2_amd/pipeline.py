@@ -231,6 +231,14 @@ class DeseqPipeline:
         self._inflight = []
         self._side_pending = False
         self._pinned = _PinnedPool(ctx_)
+        # Which genes have a count at all depends on the counts only: the mask every pass compacts to is computed here, once,
+        # so that the first deseq2() call already enqueues its genewise stage without waiting for it (each pass still
+        # re-derives the mask on the device and compares), and the gene lists of the row kernels are built off the step.
+        d_lm0, d_nz0 = DeviceArray(ctx_, (self.G,), np.float64), DeviceArray(ctx_, (self.G,), np.uint8)
+        ctx_.call("dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_lm0.ptr), _vp(d_nz0.ptr))
+        self._nz_pred = d_nz0.to_host().astype(bool)
+        d_lm0.free(); d_nz0.free()
+        self._row_lists_for(self._nz_pred)
         # Cook's cutoff F.ppf(0.99, p, N - p) (dds.py:1073, 1324): a scipy call of ~0.1 ms, off the step's path
         self._cooks_cutoff = float(f_dist.ppf(0.99, self.P, self.N - self.P)) if self.N > self.P else float("nan")
         ctx_.sync()

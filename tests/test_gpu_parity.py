@@ -202,6 +202,35 @@ def test_pipeline_vs_oracle(G, N, design, seed):
         assert ref.replaced.sum() >= 2 and (res.replaced == ref.replaced).all()
 
 
+@pytest.mark.parametrize("levels,N", [(6, 90), (8, 200), (3, 75)])
+def test_pipeline_one_factor_many_levels(levels, N):
+    """One factor with `levels` levels: as many design cells as columns, so mu_hat is the linear model's (dds.py:747-756)
+    and the dispersion fits run four genes per wavefront - per-cell tables in LDS for 5 .. 32 cells (k_alpha_rows_c, linear
+    branch: clamped mu_hat from x_c . coef), registers up to 4 cells (k_alpha_rows) - against the oracle."""
+    import pydeseq2_amd
+
+    rng = np.random.default_rng(40 + levels)
+    lv = np.arange(N) % levels
+    rng.shuffle(lv)
+    X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, levels)])
+    G = 700
+    beta = np.zeros((levels, G))
+    beta[0] = rng.normal(4, 2, G)
+    beta[1:] = rng.normal(0, 0.5, (levels - 1, G))
+    disp = 4 / np.maximum(2.0 ** beta[0], 1e-3) + 0.1
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * 2.0 ** (X @ beta)
+    counts = rng.negative_binomial(1 / disp[None, :], 1 / (1 + mu * disp[None, :])).astype(np.int64)
+    counts[:, 7] = 0
+    c = np.zeros(levels)
+    c[1] = 1.0
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0)
+    assert pipe._row_mode == (1 if levels <= 4 else 2) and pipe.design.linear_mu
+    res = pipe.deseq2(contrast=c)
+    ref = orc.deseq2(counts, X, contrast=c, n_jobs=_jobs())
+    _compare(res, ref, frac_noise=0.006)
+
+
 def test_pipeline_vs_oracle_many_samples():
     """C5-shaped case (N = 2500, two categorical + three continuous covariates): rows too long for the
     LDS staging, so the dispersion kernel runs its streaming (unstaged, masked) variant, IRLS supplies

@@ -5,11 +5,22 @@
 
 #define DSQ_REG_MAX_P 12  // widest design of the register / cell kernels; wider ones: dsq_wide.h
 
+// developer builds (tools/asm_blocks.py): -DDSQ_ONLY_P=8 instantiates a single width, a unit compiles in seconds
+#if defined(DSQ_ONLY_P)
+#define DSQ_P_CASE(N_, ...)                 \
+    case N_: {                              \
+        constexpr int P = N_;               \
+        if constexpr (N_ == DSQ_ONLY_P) {   \
+            __VA_ARGS__;                    \
+        }                                   \
+    } break;
+#else
 #define DSQ_P_CASE(N_, ...) \
     case N_: {              \
         constexpr int P = N_; \
         __VA_ARGS__;        \
     } break;
+#endif
 
 #define DSQ_DISPATCH_P(p_, ...)                  \
     switch (p_) {                                \

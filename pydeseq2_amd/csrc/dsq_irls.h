@@ -31,8 +31,14 @@
 #define DSQ_PRAGMA_(x) _Pragma(#x)
 #define DSQ_PRAGMA(x) DSQ_PRAGMA_(x)
 #define DSQ_UNROLL2 DSQ_PRAGMA(unroll DSQ_IRLS_UNROLL)
+// samples per trip of the sixteen-lane (RowWave) cell loops
+#ifndef DSQ_IRLS_ROW_U
+#define DSQ_IRLS_ROW_U 4
+#endif
 
 namespace dsq {
+
+constexpr int kIrlsRowU = DSQ_IRLS_ROW_U;
 
 // Optional fused tail of the LFC fit: the per-sample part of the Cook's distances (dds.py:986-1040 and the
 // outlier bookkeeping of dds.py:1066-1110, 1325-1326; the robust dispersion comes from its own kernel, it does
@@ -63,6 +69,7 @@ struct IrlsArgs {
     int maxiter;
     bool full_rank;
     const CellDesign* cells = nullptr;  // CELL instantiations (designs with <= 64 distinct rows)
+    const double* pinvc = nullptr;      // [C][P] column of (X^T X)^-1 X^T of each cell (LDS; k_irls_row, full rank)
     void* cell_ws = nullptr;            // this wave's CellWork<P>
 };
 
@@ -92,11 +99,11 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
         const double mu = clamped ? A.min_mu : mu_raw;
         const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
-        const double rmu = frcp(mu);
         s += (yv + a) * flog_t(a + mu) - yv * lmu;
-        const double w = mu * frcp(1.0 + mu * A.disp);
-        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
-        const double wz = w * z;
+        // w = mu / (1 + mu disp), w z = w (eta + (y - mu) / mu) = (mu eta + y - mu) / (1 + mu disp): one reciprocal
+        const double rd = frcp(1.0 + mu * A.disp);
+        const double w = mu * rd;
+        const double wz = (mu * (clamped ? lmin - lsfn : eta) + (yv - mu)) * rd;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const double xw = x[i] * w;
@@ -108,6 +115,24 @@ DSQ_HD void irls_sweep(const IrlsArgs& A, const double (&beta)[P], double a, dou
     S = Wv::sum(s);
     Wv::template sum_n<T>(M);
     Wv::template sum_n<P>(r);
+}
+
+// sum_c col[c * LD] * acc[c]  (col: a column of a per-cell table in LDS, acc: per-cell sums in LDS)
+template <int LD, class Col, class Acc>
+DSQ_HD double cell_dot(Col col, const Acc& acc, int C) {
+    double v0 = 0.0, v1 = 0.0;
+    int c = 0;
+#pragma nounroll
+    for (; c + 3 < C; c += 4) {
+        v0 += col[0] * acc[c];
+        v1 += col[LD] * acc[c + 1];
+        v0 += col[2 * LD] * acc[c + 2];
+        v1 += col[3 * LD] * acc[c + 3];
+        col += 4 * LD;
+    }
+#pragma nounroll
+    for (; c < C; ++c) { v0 += col[0] * acc[c]; col += LD; }
+    return v0 + v1;
 }
 
 // The same sweep for a design with few distinct rows (dsq_linalg.h, CellDesign): the linear predictor and its
@@ -123,12 +148,10 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
     LdsWork& Wk = *(LdsWork*)A.cell_ws;
     const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
     const auto XX_ = DSQ_AS_LDS(double, D.XX);
-    for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) {
+    for (int c = Wv::lane(); c < D.C; c += Wv::W) {
         double eta = 0.0;
-        if (c < D.C) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) eta += Xc_[c * P + j] * beta[j];
-        }
+        for (int j = 0; j < P; ++j) eta += Xc_[c * P + j] * beta[j];
         Wk.tab[0][c] = eta;
         Wk.tab[1][c] = exp(eta);
         Wk.acc[0][c] = 0.0;
@@ -138,33 +161,83 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
     double s = 0.0;
     const double lmin = log(A.min_mu);
     DSQ_PHASE(3);
-    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        const double yv = (double)A.y[n];
-        const double sfn = A.sf[n];
-        const int cell = D.cell_of[n];
-        const double eta = Wk.tab[0][cell];
-        const double mu_raw = sfn * Wk.tab[1][cell];
+    // one sample: its term of the deviance sum, its weight and weight x working response
+    auto sample = [&](double yv, double sfn, double lsfn, double eta, double e, double& w, double& wz) {
+        const double mu_raw = sfn * e;
         const bool clamped = !(mu_raw > A.min_mu);
         const double mu = clamped ? A.min_mu : mu_raw;
-        const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
-        const double rmu = frcp(mu);
         s += (yv + a) * flog_t(a + mu) - yv * lmu;
-        const double w = mu * frcp(1.0 + mu * A.disp);
-        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
+        const double rd = frcp(1.0 + mu * A.disp);  // (see irls_sweep)
+        w = mu * rd;
+        wz = (mu * (clamped ? lmin - lsfn : eta) + (yv - mu)) * rd;
+    };
+    int n = Wv::lane();
+    if constexpr (Wv::W == 16) {
+        // sixteen lanes per gene take N / 16 trips: four samples per trip, loads first, so that four independent
+        // chains hide the load and the transcendental latencies (two wavefronts per SIMD do not)
+        constexpr int U = kIrlsRowU;
+        for (; n + (U - 1) * Wv::W < A.N; n += U * Wv::W) {
+            double yv[U], sfn[U], lsfn[U], eta[U], e[U], w[U], wz[U];
+            int cell[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = n + u * Wv::W;
+                yv[u] = (double)A.y[m];
+                sfn[u] = A.sf[m];
+                cell[u] = D.cell_of[m];
+                lsfn[u] = (A.lsf != nullptr) ? A.lsf[m] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { eta[u] = Wk.tab[0][cell[u]]; e[u] = Wk.tab[1][cell[u]]; }
+            if (A.lsf == nullptr) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) lsfn[u] = flog(sfn[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) sample(yv[u], sfn[u], lsfn[u], eta[u], e[u], w[u], wz[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                Wv::cell_add(&Wk.acc[0][cell[u]], w[u]);
+                Wv::cell_add(&Wk.acc[1][cell[u]], wz[u]);
+            }
+        }
+    }
+    for (; n < A.N; n += Wv::W) {
+        const double sfn = A.sf[n];
+        const int cell = D.cell_of[n];
+        const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
+        double w, wz;
+        sample((double)A.y[n], sfn, lsfn, Wk.tab[0][cell], Wk.tab[1][cell], w, wz);
         Wv::cell_add(&Wk.acc[0][cell], w);
-        Wv::cell_add(&Wk.acc[1][cell], w * z);
+        Wv::cell_add(&Wk.acc[1][cell], wz);
     }
     DSQ_PHASE(4);
     Wv::sync();
-    for (int e = Wv::lane(); e < T + P; e += Wv::W) {
-        double v = 0.0;
-        if (e < T) {
-            for (int c = 0; c < D.C; ++c) v += XX_[c * T + e] * Wk.acc[0][c];
-        } else {
-            for (int c = 0; c < D.C; ++c) v += Xc_[c * P + (e - T)] * Wk.acc[1][c];
+    // entries of X^T W X and X^T W z: a lane owns every W-th entry and walks the cells once for all of them (one
+    // broadcast read of the cell's two sums serves its (T + P) / W independent chains)
+    {
+        constexpr int NE = (T + Wv::W - 1) / Wv::W, NR = (P + Wv::W - 1) / Wv::W;
+        int em[NE], er[NR];
+        double vm[NE], vr[NR];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) { em[k] = Wv::lane() + k * Wv::W; em[k] = em[k] < T ? em[k] : T - 1; vm[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { er[k] = Wv::lane() + k * Wv::W; er[k] = er[k] < P ? er[k] : P - 1; vr[k] = 0.0; }
+#pragma unroll 4
+        for (int c = 0; c < D.C; ++c) {
+            const double a0 = Wk.acc[0][c], a1 = Wk.acc[1][c];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) vm[k] += XX_[c * T + em[k]] * a0;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) vr[k] += Xc_[c * P + er[k]] * a1;
         }
-        Wk.ent[e] = v;
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (Wv::lane() + k * Wv::W < T) Wk.ent[Wv::lane() + k * Wv::W] = vm[k];
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (Wv::lane() + k * Wv::W < P) Wk.ent[T + Wv::lane() + k * Wv::W] = vr[k];
     }
     Wv::sync();
 #pragma unroll
@@ -219,11 +292,10 @@ DSQ_HD void irls_sweep_cs(const IrlsArgs& A, const double (&beta)[P], double a, 
         const double mu = clamped ? A.min_mu : mu_raw;
         const double lsfn = (A.lsf != nullptr) ? A.lsf[n] : flog(sfn);
         const double lmu = clamped ? lmin : eta + lsfn;
-        const double rmu = frcp(mu);
         s += (yv + a) * flog_t(a + mu) - yv * lmu;
-        const double w = mu * frcp(1.0 + mu * A.disp);
-        const double z = (clamped ? lmin - lsfn : eta) + (yv - mu) * rmu;
-        const double wz = w * z;
+        const double rd = frcp(1.0 + mu * A.disp);  // (see irls_sweep)
+        const double w = mu * rd;
+        const double wz = (mu * (clamped ? lmin - lsfn : eta) + (yv - mu)) * rd;
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
             sw[c] += (cell == c) ? w : 0.0;
@@ -263,11 +335,11 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
     const auto XX_ = DSQ_AS_LDS(double, D.XX);
     double q_c[CS], swu[CS];
     {
-        double inv[T];
+        double rinv[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
         chol<P>(M);
-        chol_inverse<P>(M, inv);
+        chol_rinv<P>(M, rinv);
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
             double q = 0.0;
@@ -275,7 +347,7 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
                 double x[P];
 #pragma unroll
                 for (int j = 0; j < P; ++j) x[j] = Xc_[c * P + j];
-                q = sym_quad<P>(inv, x);
+                q = chol_quad<P>(M, rinv, x);
             }
             q_c[c] = Wv::uniform(q);
             swu[c] = 0.0;
@@ -378,6 +450,81 @@ DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst)
     if (!A.full_rank) b0[0] = b0[0] / (double)A.N;
 }
 
+// irls_init for a full-rank cell design on sixteen-lane rows: the columns of (X^T X)^-1 X^T are identical within a
+// cell, so  b0 = sum_c pinv_c * sum_{n in c} log(y_n / sf_n + 0.1): a sample adds its logarithm into its cell's
+// accumulator (no loads of the P pseudo-inverse rows per sample), the P entries of b0 are rebuilt entry-parallel.
+// Four samples per trip, loads first (see irls_sweep_cell).  A.pinvc: [C][P] in LDS.
+template <class Wv, int P>
+DSQ_HD void irls_init_cell(const IrlsArgs& A, double a, double (&b0)[P], double& cst) {
+    const CellDesign& D = *A.cells;
+    typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;
+    LdsWork& Wk = *(LdsWork*)A.cell_ws;
+    const auto pinvc_ = DSQ_AS_LDS(double, A.pinvc);
+    for (int c = Wv::lane(); c < D.C; c += Wv::W) Wk.acc[0][c] = 0.0;
+    Wv::sync();
+    double lga, dga_unused, tab_dl, tab_dd;
+    lgamma_digamma<false, true>(a, lga, dga_unused);
+    lgamma_digamma_diff<Wv, false>(Wv::lane(), a, lga, 0.0, tab_dl, tab_dd);
+    double csum = 0.0;
+    constexpr int U = kIrlsRowU;
+    for (int base = 0; base < A.N; base += U * Wv::W) {  // wave-uniform trip count (cross-lane memo reads)
+        int yi[U], cell[U];
+        double sfn[U], dl[U], lf[U];
+        bool valid[U], in_tab[U], in_fact[U];
+        bool any_big = false, any_huge = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = base + u * Wv::W + Wv::lane();
+            valid[u] = n < A.N;
+            yi[u] = valid[u] ? A.y[n] : 0;
+            sfn[u] = valid[u] ? A.sf[n] : 1.0;
+            cell[u] = valid[u] ? D.cell_of[n] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            in_tab[u] = yi[u] < Wv::W;
+            in_fact[u] = yi[u] < kLgammaIntN;
+            any_big = any_big || !in_tab[u];
+            any_huge = any_huge || !in_fact[u];
+            dl[u] = Wv::from_lane(tab_dl, in_tab[u] ? yi[u] : 0);
+            lf[u] = kLgammaInt[in_fact[u] ? yi[u] : 0];
+        }
+        if (Wv::any(any_big)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double dl2, dd2;
+                lgamma_digamma_diff<Wv, false>(in_tab[u] ? 64 : yi[u], a, lga, 0.0, dl2, dd2);
+                dl[u] = in_tab[u] ? dl[u] : dl2;
+            }
+        }
+        if (Wv::any(any_huge)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double z = in_fact[u] ? 300.0 : (double)yi[u] + 1.0;
+                const double big = (z - 0.5) * flog(z) - z + kHalfLog2Pi + stirling_tail(frcp(z));
+                lf[u] = in_fact[u] ? lf[u] : big;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            csum -= valid[u] ? dl[u] + lf[u] : 0.0;
+            const double ly = flog_t((double)yi[u] * frcp(sfn[u]) + 0.1);
+            if (valid[u]) Wv::cell_add(&Wk.acc[0][cell[u]], ly);
+        }
+    }
+    cst = Wv::sum(csum);
+    Wv::sync();
+    if (Wv::lane() < P) {
+        double v = 0.0;
+        for (int c = 0; c < D.C; ++c) v += pinvc_[c * P + Wv::lane()] * Wk.acc[0][c];
+        Wk.ent[Wv::lane()] = v;
+    }
+    Wv::sync();
+#pragma unroll
+    for (int j = 0; j < P; ++j) b0[j] = Wk.ent[j];
+    Wv::sync();  // ent and acc are rewritten by the first sweep
+}
+
 // The same quantities with the reference's own arithmetic for cst (two lgamma evaluations per
 // sample, utils.py:218-222).  The rescue of a diverged gene minimises f = nlogterm - cst + s with
 // L-BFGS-B, whose line search and stopping tests react to the rounding of f itself on these
@@ -416,12 +563,12 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
     // few design columns: the Wald matrix (X^T W X at the UNclamped mu, ds.py:320-324) is accumulated in the
     // same pass; wider designs take a second pass so that inv[] and the accumulators are not live together
     constexpr bool kWaldInLoop = P <= 4;
-    double inv[T];
+    double rinv[P];
     if (H_out != nullptr || want_cooks) {
 #pragma unroll
         for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
         chol<P>(M);
-        chol_inverse<P>(M, inv);
+        chol_rinv<P>(M, rinv);
     }
     CooksAcc<Wv> acc(want_cooks ? E->robust_disp : 0.0, want_cooks ? E->cutoff : 0.0, P);
     double Mw[T];
@@ -440,7 +587,7 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
                 const double mu = dmax(mu_raw, A.min_mu);
                 const double w = mu * frcp_g(1.0 + mu * A.disp);
                 const double sw = sqrt(w);
-                const double h = sw * sym_quad<P>(inv, x) * sw;
+                const double h = sw * chol_quad<P>(M, rinv, x) * sw;
                 if (H_out != nullptr) H_out[n] = h;
                 if (want_cooks) {
                     const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
@@ -498,49 +645,73 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
     const auto Xc_ = DSQ_AS_LDS(double, D.Xc);
     const auto XX_ = DSQ_AS_LDS(double, D.XX);
     {
-        double inv[T];
+        double rinv[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
         chol<P>(M);
-        chol_inverse<P>(M, inv);
-        for (int c = Wv::lane(); c < kMaxCells; c += Wv::W) {
-            double q = 0.0;
-            if (c < D.C) {
-                double x[P];
+        chol_rinv<P>(M, rinv);
+        for (int c = Wv::lane(); c < D.C; c += Wv::W) {
+            double x[P];
 #pragma unroll
-                for (int j = 0; j < P; ++j) x[j] = Xc_[c * P + j];
-                q = sym_quad<P>(inv, x);
-            }
-            Wk.acc[0][c] = q;     // read-only from here on
-            Wk.acc[1][c] = 0.0;   // sums of the unclamped weights (Wald)
+            for (int j = 0; j < P; ++j) x[j] = Xc_[c * P + j];
+            Wk.acc[0][c] = chol_quad<P>(M, rinv, x);  // read-only from here on
+            Wk.acc[1][c] = 0.0;                  // sums of the unclamped weights (Wald)
         }
     }
     Wv::sync();
     CooksAcc<Wv> acc(want_cooks ? E->robust_disp : 0.0, want_cooks ? E->cutoff : 0.0, P);
-    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
-        const int cell = D.cell_of[n];
-        const double mu_raw = A.sf[n] * Wk.tab[1][cell];
+    // one sample; returns its unclamped Wald weight
+    auto sample = [&](int n, int cell, double sfn, double e, double q, double yv, int fl) {
+        const double mu_raw = sfn * e;
         if (mu_out != nullptr) mu_out[n] = mu_raw;
         if (H_out != nullptr || want_cooks) {
             const double mu = dmax(mu_raw, A.min_mu);
             const double w = mu * frcp_g(1.0 + mu * A.disp);
             const double sw = sqrt(w);
-            const double h = sw * Wk.acc[0][cell] * sw;
+            const double h = sw * q * sw;
             if (H_out != nullptr) H_out[n] = h;
             if (want_cooks) {
-                const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
+                const double ck = acc.add(n, yv, mu_raw, h, fl);
                 if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
             }
         }
-        if (want_wald) Wv::cell_add(&Wk.acc[1][cell], mu_raw * frcp_g(1.0 + mu_raw * A.disp));
+        return mu_raw * frcp_g(1.0 + mu_raw * A.disp);
+    };
+    int n = Wv::lane();
+    if constexpr (Wv::W == 16) {  // four samples per trip, loads first (see irls_sweep_cell)
+        constexpr int U = kIrlsRowU;
+        for (; n + (U - 1) * Wv::W < A.N; n += U * Wv::W) {
+            int cell[U], fl[U];
+            double sfn[U], e[U], q[U], yv[U], wu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = n + u * Wv::W;
+                cell[u] = D.cell_of[m];
+                sfn[u] = A.sf[m];
+                yv[u] = want_cooks ? (double)A.y[m] : 0.0;
+                fl[u] = want_cooks ? E->flags[m] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e[u] = Wk.tab[1][cell[u]]; q[u] = Wk.acc[0][cell[u]]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) wu[u] = sample(n + u * Wv::W, cell[u], sfn[u], e[u], q[u], yv[u], fl[u]);
+            if (want_wald) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) Wv::cell_add(&Wk.acc[1][cell[u]], wu[u]);
+            }
+        }
+    }
+    for (; n < A.N; n += Wv::W) {
+        const int cell = D.cell_of[n];
+        const double wu = sample(n, cell, A.sf[n], Wk.tab[1][cell], Wk.acc[0][cell],
+                                 want_cooks ? (double)A.y[n] : 0.0, want_cooks ? E->flags[n] : 0);
+        if (want_wald) Wv::cell_add(&Wk.acc[1][cell], wu);
     }
     if (want_cooks) E->cooks = acc.finish(A.y, A.N);
     if (want_wald) {
         Wv::sync();
         for (int e = Wv::lane(); e < T; e += Wv::W) {
-            double v = 0.0;
-            for (int c = 0; c < D.C; ++c) v += XX_[c * T + e] * Wk.acc[1][c];
-            Wk.ent[e] = v;
+            Wk.ent[e] = cell_dot<T>(XX_ + e, Wk.acc[1], D.C);
         }
         Wv::sync();
         double Mw[T];
@@ -563,7 +734,12 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     const double a = 1.0 / A.disp;
     double cst;
     DSQ_PHASE(1);
-    irls_init<Wv, P>(A, a, beta, cst);
+    if constexpr (CELL == 1 && Wv::W == 16) {
+        if (A.pinvc != nullptr) irls_init_cell<Wv, P>(A, a, beta, cst);
+        else irls_init<Wv, P>(A, a, beta, cst);
+    } else {
+        irls_init<Wv, P>(A, a, beta, cst);
+    }
     const double nlogterm = A.N * a * log(A.disp);
     double M[T], r[P], S;
     constexpr int CS = CELL == 3 ? 2 : kSmallCells;

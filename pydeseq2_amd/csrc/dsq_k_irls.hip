@@ -153,13 +153,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
     const int npad = (N + 15) & ~15;
     double* s_sf = sXc + ex.cells.C * P;
     double* s_lsf = s_sf + npad;
-    int32_t* s_cell = (int32_t*)(s_lsf + npad);
+    double* s_pinvc = s_lsf + npad;
+    int32_t* s_cell = (int32_t*)(s_pinvc + ex.cells.C * P);
+    int32_t* s_rep = s_cell + npad;  // one sample of each cell
     for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
     for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
     for (int n = threadIdx.x; n < N; n += kBlock) {
         s_sf[n] = sf[n];
         s_lsf[n] = lsf != nullptr ? lsf[n] : 0.0;
-        s_cell[n] = ex.cells.cell_of[n];
+        const int c = ex.cells.cell_of[n];
+        s_cell[n] = c;
+        s_rep[c] = n;  // any sample of the cell will do
+    }
+    if (full_rank) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) s_pinvc[i] = pinvXt[(i % P) * ldx + s_rep[i / P]];
     }
     ex.cells.XX = sXX;
     ex.cells.Xc = sXc;
@@ -173,6 +181,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
     A.max_beta = max_beta; A.maxiter = maxiter; A.full_rank = full_rank != 0;
     A.cells = &ex.cells;
     A.cell_ws = (void*)&cellw[row];
+    A.pinvc = full_rank ? s_pinvc : nullptr;
+#if defined(DSQ_PHASE_TIMING)  // the timeline of the first row of each wavefront
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < kPhases; ++k) g_ph_acc[threadIdx.x >> 6][k] = 0;
+        g_ph_last[threadIdx.x >> 6] = clock64();
+        g_ph_cur[threadIdx.x >> 6] = 0;
+    }
+#endif
     LfcEpilogue E;
     epilogue_begin<P>(E, ex, g, ldn);
     double b[P];
@@ -186,6 +202,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
         if (o.fallback) fb_list[atomicAdd(fb_count, 1)] = g;
         else epilogue_store(E, ex, g);
     }
+#if defined(DSQ_PHASE_TIMING)
+    DSQ_PHASE(0);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < kPhases; ++k)
+            atomicAdd(&g_phase_total_irls[k], (unsigned long long)g_ph_acc[threadIdx.x >> 6][k]);
+#endif
 }
 
 template <int P>
@@ -311,7 +333,7 @@ static int row_min_p() {  // narrower designs: the sample loops dominate, one ge
 }
 static size_t row_lds_bytes(int C, int P, int N) {
     const int npad = (N + 15) & ~15;
-    return (size_t)C * (P * (P + 1) / 2 + P) * sizeof(double) + (size_t)npad * 20;
+    return (size_t)C * (P * (P + 1) / 2 + 2 * P) * sizeof(double) + (size_t)npad * 20 + (size_t)kMaxCells * 4;
 }
 
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,

@@ -104,6 +104,26 @@ DSQ_HD void chol_solve(const double (&l)[Tri<P>::N], double (&b)[P]) {
     }
 }
 
+// x^T (L L^T)^-1 x = |L^-1 x|^2 by one forward substitution (rinv: reciprocals of the pivots): no inverse matrix
+template <int P>
+DSQ_HD void chol_rinv(const double (&l)[Tri<P>::N], double (&rinv)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) rinv[i] = frcp(l[tri(i, i)]);
+}
+template <int P>
+DSQ_HD double chol_quad(const double (&l)[Tri<P>::N], const double (&rinv)[P], const double (&x)[P]) {
+    double t[P], q = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= l[tri(i, k)] * t[k];
+        t[i] = s * rinv[i];
+        q += t[i] * t[i];
+    }
+    return q;
+}
+
 // inv = (L L^T)^-1, packed symmetric
 template <int P>
 DSQ_HD void chol_inverse(const double (&l)[Tri<P>::N], double (&inv)[Tri<P>::N]) {

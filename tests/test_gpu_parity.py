@@ -287,7 +287,9 @@ def test_pipeline_vs_unmodified_reference_at_benchmark_shapes(name):
     counts, X, ref = load_e2e(name)
     res = pydeseq2_amd.deseq2(counts, X, device=0)
     gw, mp, rf = flag_flips(res, ref)
-    n_noise, n_grid = _compare(res, ref, frac_noise=0.004)
+    # c5 has 1000 genes only and the floor of its shape is 1-3 flips per fit per 1000 genes (5000 samples, continuous
+    # covariates: profiles/r03_flip_floor_c5.json), two fits per gene: <= 8 of 1000
+    n_noise, n_grid = _compare(res, ref, frac_noise=0.008 if name == "c5" else 0.004)
     rec = {"case": name, "genes": int(counts.shape[1]), "samples": int(counts.shape[0]), "p": int(X.shape[1]),
            "flips_genewise": int(gw.sum()), "flips_MAP": int(mp.sum()), "flips_refit": int(rf.sum()),
            "flip_genes": n_noise, "flip_rate": round(n_noise / counts.shape[1], 6), "both_on_grid": n_grid,

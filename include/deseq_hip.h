@@ -70,6 +70,12 @@ int dsq_set_optimizer(dsq_ctx* ctx, int optimizer);
  * and the kernels read the count from device memory: no host synchronisation inside dsq_dev_alpha_mle* /
  * dsq_dev_lfc_fit / dsq_dev_irls (dsq_last_alpha_kernel then reports -1 ms / -1 genes).  Results are identical. */
 int dsq_set_deferred(dsq_ctx* ctx, int on);
+/* Performance hint for the NEXT dsq_dev_lfc_fit / dsq_dev_irls of G genes on this context (one-shot): d_iters[G] are
+ * the iteration counts an earlier IRLS fit of the same genes returned (irls_solver's loop counter, utils.py:361-421;
+ * the mu_hat fit of dds.py:757-765 before the LFC fit of dds.py:908-984).  Designs fitted with sixteen lanes per gene
+ * place genes with equal counts in the same wavefront; without a hint they are grouped by dispersion.  Results do not
+ * depend on it.  The array must stay valid until that call has been enqueued. */
+int dsq_irls_order_hint(dsq_ctx* ctx, const int32_t* d_iters, int G);
 void dsq_destroy(dsq_ctx* ctx);
 const char* dsq_last_error(const dsq_ctx* ctx);
 /* name (<= name_len bytes), compute units, total device memory, gcnArchName */

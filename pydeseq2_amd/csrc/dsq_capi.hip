@@ -38,6 +38,8 @@ struct dsq_ctx {
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int optimizer = 0;            // dsq_set_optimizer: 0 L-BFGS-B (the reference's default), 1 BFGS
+    const int32_t* d_irls_hint = nullptr;  // dsq_irls_order_hint: iteration counts of an earlier fit (one-shot)
+    int irls_hint_genes = 0;
     int deferred = 0;             // dsq_set_deferred: second passes of small batches enqueued without a host round trip
     int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
@@ -597,6 +599,20 @@ int dsq_dev_alpha_mle(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int 
 }
 
 namespace {
+constexpr int kIrlsOrderMinGenes = 1024;  // below: a few workgroups, nothing to balance
+bool irls_order_enabled() {
+    static const bool v = getenv("DSQ_NO_IRLS_ORDER") == nullptr;  // A/B switch
+    return v;
+}
+}  // namespace
+
+int dsq_irls_order_hint(dsq_ctx* ctx, const int32_t* d_iters, int G) {
+    ctx->d_irls_hint = d_iters;
+    ctx->irls_hint_genes = d_iters != nullptr ? G : 0;
+    return DSQ_OK;
+}
+
+namespace {
 int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
              const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
              double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
@@ -608,7 +624,16 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     ex_local.optimizer = ctx->optimizer;
     DSQ_CHECK_ARG(ctx->optimizer == 0 || P <= DSQ_SHRINK_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
     extras = &ex_local;
-    DSQ_HIP(ensure_list(ctx, (size_t)G));
+    // sixteen-lane kernel: slots ordered by the predicted number of sweeps (the list lives behind the fallback list)
+    const bool ordered = G >= kIrlsOrderMinGenes && dsq::irls_takes_rows(N, P, ex_local.cells.C) && irls_order_enabled();
+    DSQ_HIP(ensure_list(ctx, (size_t)G * (ordered ? 2 : 1)));
+    if (ordered) {
+        int32_t* d_order = ctx->d_list + G;
+        DSQ_HIP(dsq::launch_irls_order(ctx->stream, d_disp, ctx->irls_hint_genes == G ? ctx->d_irls_hint : nullptr, G,
+                                       d_order));
+        ex_local.order = d_order;
+    }
+    ctx->d_irls_hint = nullptr; ctx->irls_hint_genes = 0;  // one-shot
     if ((size_t)N > ctx->lsf_cap) {
         if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
         ctx->d_lsf = nullptr; ctx->lsf_cap = 0;

@@ -760,11 +760,14 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
         for (int k = 0; k < T; ++k) Hm[k] = M[k];
 #pragma unroll
         for (int j = 0; j < P; ++j) Hm[tri(j, j)] += 1e-6;
+        DSQ_PHASE(7);
         chol<P>(Hm);
+        DSQ_PHASE(8);
         double bh[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) bh[j] = r[j];
         chol_solve<P>(Hm, bh);
+        DSQ_PHASE(5);
         i += 1;
         bool bad = (i >= A.maxiter);
 #pragma unroll

@@ -149,7 +149,15 @@ struct IrlsExtras {
     int alt;
     double *pvals, *stats, *se;  // [G]
     int optimizer;               // rescue of diverged genes: 0 L-BFGS-B (bounded, default), 1 BFGS (utils.py:389-399)
+    // k_irls_row: slot -> gene (launch_irls_order), so that the four genes of a wavefront need about the same
+    // number of sweeps; null: identity.  Results do not depend on it.
+    const int32_t* order;
 };
+// does launch_irls fit this design with sixteen lanes per gene (k_irls_row)?
+bool irls_takes_rows(int N, int P, int n_cells);
+// order[0..G) = genes by decreasing predicted number of IRLS sweeps: `hint_iters` (the iteration counts of an earlier
+// fit of the same genes) when given, else the dispersion (noisier genes take more sweeps)
+hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order);
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P, int full_rank,

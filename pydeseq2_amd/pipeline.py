@@ -462,10 +462,13 @@ class DeseqPipeline:
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
                     _vp(S["nm"].ptr), None, None, _vp(S["mom"].ptr))
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
+            # the iteration counts of this fit order the genes of the LFC fit (dsq_irls_order_hint)
+            S["_irls_it"] = self._dvec(Gs, np.int32)
             self._k("irls_mu", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
-                    _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), None, self._cells_arg(),
+                    _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), _vp(S["_irls_it"].ptr),
+                    self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
                     None, None, c_double(0.0), 0, None, None, None)
             if per_cell:
@@ -517,6 +520,8 @@ class DeseqPipeline:
             d_rd, cutoff, d_cooks = cooks
             ck = [_vp(d_rd.ptr), _vp(self.d_flags.ptr), c_double(cutoff), _vp(d_cooks.ptr)] + \
                  [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
+        if S.get("_irls_it") is not None:
+            self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
         self._k("lfc_fit", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,

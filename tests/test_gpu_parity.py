@@ -394,9 +394,12 @@ def test_sixteen_lane_irls_equals_the_wavefront_kernel():
         same = (a["g"] == b["g"]) & (a["m"] == b["m"]) & \
             ~(np.abs(a["d"] - b["d"]) > 1e-6 * np.abs(b["d"]))  # (a flipped dispersion-outlier decision shows here)
     assert (~same).sum() <= 3
-    assert_close(b["d"][same], a["d"][same], 1e-9, 0, "dispersions")
-    assert_close(b["l"][same], a["l"][same], 1e-8, 1e-10, "LFC")
-    assert_close(b["se"][same], a["se"][same], 1e-8, 0, "lfcSE")
+    # the two kernels order their sums differently (four samples per trip, start values from per-cell sums), so mu_hat
+    # differs in the last bits and the dispersion optimiser lands within its own resolution (4e-7 for an ulp of mu_hat,
+    # profiles/r03_flip_floor.json: max_rel_same_flag)
+    assert_close(b["d"][same], a["d"][same], 2e-6, 0, "dispersions")
+    assert_close(b["l"][same], a["l"][same], 1e-6, 1e-9, "LFC")
+    assert_close(b["se"][same], a["se"][same], 1e-6, 0, "lfcSE")
 
 
 def test_hip_inference_under_the_reference_orchestration():

@@ -43,9 +43,9 @@ def main():
         pipe.deseq2()
         ctx.sync()
         lib.dsq_debug_phase_read_irls(buf, 1)
-        tot = float(sum(buf[:8]))
+        tot = float(sum(buf[:9]))
         names = ["stage/epilogue", "init", "sweep pre (cell tables)", "sweep sample loop", "sweep reduce/rebuild",
-                 "solve + deviance", "finish (hat, cooks, wald)", "-"]
+                 "deviance, loop control", "finish (hat, cooks, wald)", "Cholesky", "solve"]
         print("k_irls (all launches of one step):")
         for k, n in enumerate(names):
             print(f"  {k} {n:26s} {buf[k] / 1e6:12.1f} Mcycles  {100.0 * buf[k] / tot:6.2f} %")

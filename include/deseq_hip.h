@@ -70,6 +70,14 @@ int dsq_set_optimizer(dsq_ctx* ctx, int optimizer);
  * and the kernels read the count from device memory: no host synchronisation inside dsq_dev_alpha_mle* /
  * dsq_dev_lfc_fit / dsq_dev_irls (dsq_last_alpha_kernel then reports -1 ms / -1 genes).  Results are identical. */
 int dsq_set_deferred(dsq_ctx* ctx, int on);
+/* One-shot hook of the NEXT dispersion fit on this context (dsq_dev_alpha_mle*): fn(arg) is called once, on the calling
+ * thread, when the full-size kernels of that fit have been enqueued and only its latency-bound tail remains (the
+ * continuation of the few long fits, the grid-search pass of utils.py:556-564) - the moment to put independent work
+ * on the side stream (dsq_side_begin ... dsq_side_end; the pipeline launches the robust dispersions of the Cook's
+ * stage, utils.py:914-960, there).  fn may call any entry point of this library except another dispersion fit.
+ * fn == NULL clears a hook that has not fired. */
+typedef void (*dsq_hook_fn)(void* arg);
+int dsq_set_alpha_hook(dsq_ctx* ctx, dsq_hook_fn fn, void* arg);
 /* Performance hint for the NEXT dsq_dev_lfc_fit / dsq_dev_irls of G genes on this context (one-shot): d_iters[G] are
  * the iteration counts an earlier IRLS fit of the same genes returned (irls_solver's loop counter, utils.py:361-421;
  * the mu_hat fit of dds.py:757-765 before the LFC fit of dds.py:908-984).  Designs fitted with sixteen lanes per gene

@@ -21,6 +21,7 @@ ALT = {None: 0, "greaterAbs": 1, "lessAbs": 2, "greater": 3, "less": 4}
 
 c_void_p, c_int, c_double, c_size_t = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _vp = c_void_p
+HOOK_FN = C.CFUNCTYPE(None, c_void_p)  # dsq_hook_fn (include/deseq_hip.h)
 
 
 class DsqCells(C.Structure):
@@ -144,6 +145,7 @@ def load():
     proto("dsq_side_abort", _vp)
     proto("dsq_set_deferred", _vp, c_int)
     proto("dsq_irls_order_hint", _vp, _vp, c_int)
+    proto("dsq_set_alpha_hook", _vp, _vp, _vp)  # (fn: a HOOK_FN cast to void*, or None)
     proto("dsq_upload_counts_i32", _vp, _vp, c_int, c_size_t, _vp, C.POINTER(c_int))
     proto("dsq_host_alloc", _vp, c_size_t, C.POINTER(_vp))
     proto("dsq_host_free", _vp, _vp)
@@ -188,7 +190,7 @@ EXPORTS = [
     "dsq_dev_sf_hist", "dsq_dev_sf_pick", "dsq_dev_sf_finish", "dsq_dev_trend_eval", "dsq_dev_trend_prior", "dsq_dev_select_dispersions",
     "dsq_dev_scatter_rows_f64", "dsq_d2d", "dsq_dev_mom_lin_mu", "dsq_dev_sf_keys_compact", "dsq_prior_mad_work_doubles", "dsq_size_factors_work_doubles", "dsq_dev_mom_raw", "dsq_dev_nll_const", "dsq_dev_nll_scaled", "dsq_dev_logmeans_poscounts", "dsq_dev_vst", "dsq_inf_lfc_shrink_nbinom_glm", "dsq_dev_lfc_shrink", "dsq_dev_padj_prepare", "dsq_dev_padj_finish", "dsq_host_alloc", "dsq_host_free", "dsq_d2h_async", "dsq_h2d_async",
     "dsq_dev_size_factors_new", "dsq_dev_mom_lin_coef", "dsq_dev_alpha_mle2", "dsq_dev_robust_disp", "dsq_dev_lfc_fit", "dsq_dev_irls_layers",
-    "dsq_side_begin", "dsq_side_end", "dsq_side_wait", "dsq_side_abort", "dsq_set_deferred", "dsq_irls_order_hint", "dsq_dev_alpha_mle3", "dsq_alpha_rows_eligible", "dsq_alpha_needs_mu", "dsq_dev_cell_mu", "dsq_dev_alpha_row_split",
+    "dsq_side_begin", "dsq_side_end", "dsq_side_wait", "dsq_side_abort", "dsq_set_deferred", "dsq_irls_order_hint", "dsq_set_alpha_hook", "dsq_dev_alpha_mle3", "dsq_alpha_rows_eligible", "dsq_alpha_needs_mu", "dsq_dev_cell_mu", "dsq_dev_alpha_row_split",
     "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",
 ]
 

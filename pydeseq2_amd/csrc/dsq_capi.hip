@@ -40,6 +40,8 @@ struct dsq_ctx {
     int optimizer = 0;            // dsq_set_optimizer: 0 L-BFGS-B (the reference's default), 1 BFGS
     const int32_t* d_irls_hint = nullptr;  // dsq_irls_order_hint: iteration counts of an earlier fit (one-shot)
     int irls_hint_genes = 0;
+    void (*alpha_hook)(void*) = nullptr;  // dsq_set_alpha_hook (one-shot)
+    void* alpha_hook_arg = nullptr;
     int deferred = 0;             // dsq_set_deferred: second passes of small batches enqueued without a host round trip
     int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
@@ -50,6 +52,17 @@ struct dsq_ctx {
     int comm_rank = 0, comm_world = 1;
     std::string err;
 };
+
+namespace {
+// the one-shot hook of dsq_set_alpha_hook (arg: the context)
+void fire_alpha_hook(void* c) {
+    dsq_ctx* ctx = (dsq_ctx*)c;
+    if (ctx->alpha_hook == nullptr) return;
+    void (*fn)(void*) = ctx->alpha_hook;
+    ctx->alpha_hook = nullptr;
+    fn(ctx->alpha_hook_arg);
+}
+}  // namespace
 
 namespace {
 
@@ -251,6 +264,8 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         ex2.resume_state = ctx->d_resume;
         ex2.resume_list = (int32_t*)((char*)ctx->d_resume + ((dsq::alpha_resume_bytes(G) + 255) & ~(size_t)255));
         ex2.resume_count = d_cnt + 2;
+        ex2.mid_hook = ctx->alpha_hook != nullptr ? fire_alpha_hook : nullptr;
+        ex2.mid_arg = ctx;
         extras = &ex2;
     }
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
@@ -267,6 +282,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
                                   d_nll_const, const_mode, extras, d_cnt + 1));
     }
     DSQ_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    fire_alpha_hook(ctx);  // (a route that did not pass the hook's point: now)
     int32_t* h_cnt = ctx->h_pin + 1;
     // Deferred mode (dsq_set_deferred; small batches on the register kernels): the grid-search pass is enqueued for
     // ALL G genes as a capacity and the kernels read the number of fallback genes from the device - no host round trip
@@ -605,6 +621,12 @@ bool irls_order_enabled() {
     return v;
 }
 }  // namespace
+
+int dsq_set_alpha_hook(dsq_ctx* ctx, dsq_hook_fn fn, void* arg) {
+    ctx->alpha_hook = fn;
+    ctx->alpha_hook_arg = arg;
+    return DSQ_OK;
+}
 
 int dsq_irls_order_hint(dsq_ctx* ctx, const int32_t* d_iters, int G) {
     ctx->d_irls_hint = d_iters;

@@ -326,6 +326,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                                     grid_count, grid_list, nll_const, const_mode, park ? ex.eval_cap : 0,
                                     ex.resume_state, ex.resume_count, ex.resume_list);
         if (e != hipSuccess) return e;
+        if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
         parked = park;
         if (parked && rows_reg && alpha_wg_eligible(N)) {
             // the parked fits continue one per WORKGROUP (k_alpha_wg): ~3 us per evaluation instead of ~15 with the 64
@@ -387,6 +388,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
         } else {
             DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, false, false>), (size_t)0))
         }
+        if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
     }
 #undef DSQ_ALPHA_LAUNCH
     return hipGetLastError();

@@ -998,7 +998,7 @@ hipError_t launch_wald(hipStream_t st, const double* mu, int ldn, const double* 
 
 // ------------------------------------------------------------------ Cook's
 // WPB waves per block share the dynamic LDS: each wave owns `cap` doubles.
-template <int WPB>
+template <int WPB, bool BIG>
 __global__ __launch_bounds__(64 * WPB) void k_cooks(const int32_t* __restrict__ y, int ldn,
                                                     const double* __restrict__ sf,
                                                     const double* __restrict__ mu,
@@ -1018,12 +1018,12 @@ __global__ __launch_bounds__(64 * WPB) void k_cooks(const int32_t* __restrict__ 
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * WPB + w;
     if (g >= G) return;
-    // per wave: cap doubles of values (+ 2 * kTrimBins histogram counters when cells are large enough
-    // to be handled by selection; `stride` is the per-wave segment in doubles)
+    // per wave: cap doubles of values (+ a BucketWork when a cell is large enough for the bucket path;
+    // `stride` is the per-wave segment in doubles)
     double* scratch = lds + (size_t)w * stride;
     unsigned int* hist = (unsigned int*)(scratch + cap);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
-    const CooksOut o = cooks_gene<DeviceWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
+    const CooksOut o = cooks_gene<DeviceWave, BIG>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,
                                               hat + (size_t)g * ldn, C, flags, N, P, cutoff, scratch,
                                               hist, LdsSorter(), cooks ? cooks + (size_t)g * ldn : nullptr);
     if ((threadIdx.x & 63) == 0) {
@@ -1040,6 +1040,14 @@ static int next_pow2(int n) {
     while (L < n) L <<= 1;
     return L;
 }
+// per-wave LDS of the trimmed statistics (dsq_stats.h, robust_disp_gene): room for the values of the largest cell
+// (a power of two for cells that are sorted) and, with a cell of kTrimBucketMin samples or more, a BucketWork behind it
+static int trim_cap(int biggest) {
+    return biggest < kTrimBucketMin ? next_pow2(biggest) : ((biggest + 15) & ~15);  // (>= 128: smaller cells of the same design)
+}
+static int trim_work_doubles(int biggest) {
+    return biggest < kTrimBucketMin ? 0 : (int)((sizeof(BucketWork) + 7) / 8);
+}
 
 hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* mu,
                         const double* hat, const int32_t* cell_offsets, const int32_t* cell_index,
@@ -1048,18 +1056,21 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
                         uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above) {
     if (G <= 0) return hipSuccess;
     const int biggest = whole ? N : max_cell;  // sorted cells need power-of-two room, selected ones do not
-    const int cap = biggest <= kTrimSortMax ? next_pow2(biggest) : ((biggest + 15) & ~15);
-    const int stride = cap + (biggest <= kTrimSortMax ? 0 : kTrimBins);
+    const int cap = trim_cap(biggest);
+    const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
+    const bool big = biggest >= kTrimBucketMin;
     if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // > ~20000 samples in one cell
-#define DSQ_COOKS_LAUNCH(WPB)                                                                          \
+#define DSQ_COOKS_LAUNCH(WPB) \
+    do { if (big) DSQ_COOKS_LAUNCH_(WPB, true); else DSQ_COOKS_LAUNCH_(WPB, false); } while (0)
+#define DSQ_COOKS_LAUNCH_(WPB, BIG)                                                                    \
     do {                                                                                               \
         if (per_wave * WPB > 48 * 1024) {                                                              \
-            (void)hipFuncSetAttribute((const void*)k_cooks<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)k_cooks<WPB, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)(per_wave * WPB));                                          \
             (void)hipGetLastError();                                                                   \
         }                                                                                              \
-        hipLaunchKernelGGL(k_cooks<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, \
+        hipLaunchKernelGGL((k_cooks<WPB, BIG>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, \
                            y, ldn, sf, mu, hat, cell_offsets, cell_index, n_cells, whole, cap, stride, flags, \
                            N, G, P, cutoff, cooks, robust_disp, any_all, any_use, any_use_nr,         \
                            few_above);                                                                \
@@ -1068,13 +1079,14 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
     else if (per_wave * 2 <= 160 * 1024) DSQ_COOKS_LAUNCH(2);
     else DSQ_COOKS_LAUNCH(1);
 #undef DSQ_COOKS_LAUNCH
+#undef DSQ_COOKS_LAUNCH_
     return hipGetLastError();
 }
 
 // The design-only half of the Cook's stage on its own (robust_disp_gene): what the fused LFC epilogue
 // (dsq_irls.h, LfcEpilogue) needs beforehand.  Independent of every fit, so the pipeline runs it on a side
 // stream underneath the latency-bound dispersion-trend / prior kernels.
-template <int WPB>
+template <int WPB, bool BIG>
 __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restrict__ y, int ldn,
                                                           const double* __restrict__ sf,
                                                           const int32_t* __restrict__ cell_offsets,
@@ -1088,7 +1100,7 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
     double* scratch = lds + (size_t)w * stride;
     unsigned int* hist = (unsigned int*)(scratch + cap);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
-    const double ar = robust_disp_gene<DeviceWave>(y + (size_t)g * ldn, sf, C, N, scratch, hist, LdsSorter());
+    const double ar = robust_disp_gene<DeviceWave, BIG>(y + (size_t)g * ldn, sf, C, N, scratch, hist, LdsSorter());
     if ((threadIdx.x & 63) == 0) robust_disp[g] = ar;
 }
 
@@ -1097,24 +1109,28 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
                               int max_cell, int N, int G, double* robust_disp) {
     if (G <= 0) return hipSuccess;
     const int biggest = whole ? N : max_cell;
-    const int cap = biggest <= kTrimSortMax ? next_pow2(biggest) : ((biggest + 15) & ~15);
-    const int stride = cap + (biggest <= kTrimSortMax ? 0 : kTrimBins);
+    const int cap = trim_cap(biggest);
+    const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
+    const bool big = biggest >= kTrimBucketMin;
     if (per_wave > 160 * 1024) return hipErrorInvalidValue;
-#define DSQ_RD_LAUNCH(WPB)                                                                                   \
+#define DSQ_RD_LAUNCH(WPB) \
+    do { if (big) DSQ_RD_LAUNCH_(WPB, true); else DSQ_RD_LAUNCH_(WPB, false); } while (0)
+#define DSQ_RD_LAUNCH_(WPB, BIG)                                                                             \
     do {                                                                                                     \
         if (per_wave * WPB > 48 * 1024) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)k_robust_disp<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)k_robust_disp<WPB, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)(per_wave * WPB));                                                \
             (void)hipGetLastError();                                                                         \
         }                                                                                                    \
-        hipLaunchKernelGGL(k_robust_disp<WPB>, dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, y, \
+        hipLaunchKernelGGL((k_robust_disp<WPB, BIG>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, y, \
                            ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, N, G, robust_disp); \
     } while (0)
     if (per_wave * 4 <= 64 * 1024) DSQ_RD_LAUNCH(4);
     else if (per_wave * 2 <= 160 * 1024) DSQ_RD_LAUNCH(2);
     else DSQ_RD_LAUNCH(1);
 #undef DSQ_RD_LAUNCH
+#undef DSQ_RD_LAUNCH_
     return hipGetLastError();
 }
 

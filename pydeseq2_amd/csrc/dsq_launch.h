@@ -86,6 +86,10 @@ struct AlphaExtras {
     int32_t* resume_count;
     int32_t* resume_list;     // [G]
     const int32_t* n_dev;     // (internal) phase B: number of entries of `list` on the device
+    // called once, on the launching thread, when the full-size kernel(s) of the fit are enqueued and the latency-bound
+    // tail (continuation of the parked fits, second passes) is about to be (dsq_set_alpha_hook); may be null
+    void (*mid_hook)(void*);
+    void* mid_arg;
 };
 constexpr int kAlphaEvalCap = 8;
 size_t alpha_resume_bytes(int G);

@@ -457,6 +457,128 @@ DSQ_HD double trimmed_sum_select(const double* buf, int n, int nt, unsigned int*
     return s + lo * (double)(below_lo + eq_lo - nt) + hi * (double)((n - nt) - below_hi);
 }
 
+// ---- trimmed sums of LARGE cells in one histogram pass
+// The values of a cell are dropped into kBuckets order-preserving buckets (linear in the bit pattern of the double
+// between the smallest and the largest value, i.e. logarithmic in the value), each bucket keeping its count and its
+// SUM.  A prefix scan of the counts finds the two buckets that hold the boundary ranks; every bucket strictly between
+// them contributes its sum, and only the (few) elements of the two boundary buckets are ranked individually.  Three
+// light passes over the cell instead of the ~50 compare-exchange passes of a bitonic sort of 512 values (or the 5+
+// passes of the radix selection above).  Samples with a ZERO count are kept out (markers < 0 in the buffer): they are
+// the one large group of ties real count data has, and the caller adds their contribution in closed form.
+constexpr int kBuckets = 512;
+constexpr int kBucketGather = 128;  // elements a boundary bucket may hold; beyond: the caller takes the selection path
+constexpr int kTrimBucketMin = 129; // cells from this size on take the bucket path (smaller ones sort in a few stages)
+struct BucketWork {                 // wave-private LDS
+    double sum[kBuckets];
+    unsigned int cnt[kBuckets];     // (2 * kTrimBins counters: doubles as the histogram of trimmed_sum_select)
+    double edge[2][kBucketGather];
+    unsigned int n_edge[2];
+    unsigned int pad[2];
+};
+static_assert(kBuckets >= 2 * kTrimBins, "the selection path borrows BucketWork::cnt");
+
+DSQ_HD unsigned long long pos_key(double v) {  // order-preserving for v >= +0
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    return b;
+}
+
+// out = sum of the elements of ranks j_lo .. j_hi (ascending, 0-based, inclusive) among the ACTIVE entries
+// (buf[k] >= 0) of buf[0..n), of which there must be n_act.  false: not applicable here (a non-finite value, a
+// boundary bucket with more than kBucketGather entries) - nothing but W has been written.
+template <class Wv>
+DSQ_HD bool bucket_rank_sum(const double* buf, int n, int n_act, int j_lo, int j_hi, BucketWork& W, double& out) {
+    out = 0.0;
+    if (n_act <= 0 || j_hi < j_lo) return true;
+    double vmin = INFINITY, vmax = -INFINITY;
+    int seen = 0;
+    for (int k = Wv::lane(); k < n; k += Wv::W) {
+        const double v = buf[k];
+        if (v >= 0.0) {
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+            seen += 1;
+        }
+    }
+    vmin = -Wv::max(-vmin);
+    vmax = Wv::max(vmax);
+    seen = Wv::sumi(seen);
+    if (seen != n_act || !(vmax < INFINITY)) return false;  // NaN (fails v >= 0) or inf among the values
+    const unsigned long long kmin = pos_key(vmin), kmax = pos_key(vmax);
+    if (kmin == kmax) { out = (double)(j_hi - j_lo + 1) * vmin; return true; }
+    int shift = 0;
+    while (((kmax - kmin) >> shift) >= (unsigned long long)kBuckets) ++shift;
+    for (int b = Wv::lane(); b < kBuckets; b += Wv::W) { W.cnt[b] = 0u; W.sum[b] = 0.0; }
+    for (int t = Wv::lane(); t < 2; t += Wv::W) W.n_edge[t] = 0u;
+    Wv::sync();
+    for (int k = Wv::lane(); k < n; k += Wv::W) {
+        const double v = buf[k];
+        if (v >= 0.0) {
+            const int b = (int)((pos_key(v) - kmin) >> shift);
+            Wv::hist_add(&W.cnt[b]);
+            Wv::cell_add(&W.sum[b], v);
+        }
+    }
+    Wv::sync();
+    // the buckets of the two boundary ranks and the sum of everything strictly between them
+    constexpr int BPL = kBuckets / (Wv::W < kBuckets ? Wv::W : kBuckets);  // consecutive buckets per lane
+    const int b0 = Wv::lane() * BPL;
+    int tot = 0;
+    for (int q = 0; q < BPL; ++q) tot += (int)W.cnt[b0 + q];
+    const int cum0 = Wv::excl_scan_i(tot);
+    int fb[2] = {0, 0}, fc[2] = {0, 0}, fn[2] = {0, 0};
+    {
+        int cum = cum0;
+        for (int q = 0; q < BPL; ++q) {
+            const int c = (int)W.cnt[b0 + q];
+            if (j_lo >= cum && j_lo < cum + c) { fb[0] = b0 + q; fc[0] = cum; fn[0] = c; }
+            if (j_hi >= cum && j_hi < cum + c) { fb[1] = b0 + q; fc[1] = cum; fn[1] = c; }
+            cum += c;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { fb[t] = Wv::sumi(fb[t]); fc[t] = Wv::sumi(fc[t]); fn[t] = Wv::sumi(fn[t]); }  // one lane hits
+    if (fn[0] > kBucketGather || fn[1] > kBucketGather) return false;
+    double inside = 0.0;
+    for (int q = 0; q < BPL; ++q) {
+        const int b = b0 + q;
+        inside += (b > fb[0] && b < fb[1]) ? W.sum[b] : 0.0;
+    }
+    inside = Wv::sum(inside);
+    // the entries of the boundary buckets, ranked one against the other
+    const bool one = fb[0] == fb[1];
+    for (int k = Wv::lane(); k < n; k += Wv::W) {
+        const double v = buf[k];
+        if (v >= 0.0) {
+            const int b = (int)((pos_key(v) - kmin) >> shift);
+            if (b == fb[0]) W.edge[0][Wv::slot_add(&W.n_edge[0])] = v;
+            else if (b == fb[1]) W.edge[1][Wv::slot_add(&W.n_edge[1])] = v;
+        }
+    }
+    Wv::sync();
+    double part = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1 && one) break;
+        const int m = fn[t];
+        // in-bucket ranks to keep
+        const int r_from = (t == 0) ? j_lo - fc[0] : 0;
+        const int r_to = (t == 1) ? j_hi - fc[1] : (one ? j_hi - fc[0] : m - 1);
+        for (int i = Wv::lane(); i < m; i += Wv::W) {
+            const double e = W.edge[t][i];
+            int r = 0;
+            for (int j = 0; j < m; ++j) {
+                const double o = W.edge[t][j];
+                r += (o < e || (o == e && j < i)) ? 1 : 0;
+            }
+            part += (r >= r_from && r <= r_to) ? e : 0.0;
+        }
+    }
+    out = inside + Wv::sum(part);
+    Wv::sync();  // W is free again
+    return true;
+}
+
 struct CooksOut {
     double robust_disp;
     int any_gt_all;      // any sample with cooks > cutoff                     (dds.py:1325-1326)
@@ -465,19 +587,19 @@ struct CooksOut {
     int few_above;       // (#samples with y > y[argmax cooks]) < 3           (dds.py:1097-1101)
 };
 
-// Trimmed statistics of a design cell: cells up to kTrimSortMax samples are SORTED in the wave's LDS
-// segment (bitonic network; measured 1.2 ms vs 1.75 ms for selection at 2 cells x 500 samples, and 6x
-// faster at 30 cells x 17), larger ones use the radix selection above (3.4 ms vs 10.2 ms for one
-// 5000-sample cell per gene).
-constexpr int kTrimSortMax = 2048;
-
-// scratch: >= max cell doubles (next power of two when the cell is sorted), hist: 2 * kTrimBins
-// counters (both wave-private LDS on the device).
+// Trimmed statistics of a design cell: cells of fewer than kTrimBucketMin samples are SORTED in the wave's LDS
+// segment (bitonic network: a few stages; 6x faster than selection at 30 cells x 17), larger ones take the bucket
+// path above, the radix selection being their fallback.
+//
+// scratch: >= max cell doubles (the next power of two for cells that are sorted), hist: a BucketWork when a cell has
+// kTrimBucketMin samples or more (both wave-private LDS on the device).
 // flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
 // Robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960): per design cell the trimmed
 // variance of the normalised counts around their trimmed mean, the largest cell variance vs the overall mean.
 // Depends on the counts, the size factors and the design cells only - not on any fit.
-template <class Wv, class Sorter>
+// BIG: the design has a cell of kTrimBucketMin samples or more (the bucket path is compiled in; without it the kernel
+// needs half the registers, which the small-cell designs turn into occupancy)
+template <class Wv, bool BIG = true, class Sorter>
 DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPlan& C, int N, double* scratch,
                                unsigned int* hist, Sorter&& sorter) {
     const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
@@ -490,13 +612,66 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
         const int n = end - beg;
         const int cls = C.whole ? 2 : trim_class(n);
         const int nt = (int)floor((double)n * ratios[cls]);
+        double tm, ts;
+        bool done = false;
+        if (BIG && n >= kTrimBucketMin) {
+            // large cell: one histogram pass per trimmed sum (bucket_rank_sum).  The samples with a zero count - the
+            // smallest values, all equal - stay out of the buckets: they add nothing to the first sum, and their squared
+            // error (0 - tm)^2 enters the second one as a block of `zeros` equal values at a known rank.
+            BucketWork& W = *(BucketWork*)hist;
+            int zeros = 0;
+            for (int k = Wv::lane(); k < n; k += Wv::W) {
+                const int sidx = C.whole ? k : C.cell_index[beg + k];
+                const int yi = y[sidx];
+                scratch[k] = yi == 0 ? -1.0 : (double)yi / sf[sidx];
+                zeros += yi == 0 ? 1 : 0;
+            }
+            zeros = Wv::sumi(zeros);
+            Wv::sync();
+            const int r_lo = nt, r_hi = n - nt - 1, n_act = n - zeros;
+            double s1 = 0.0, s2 = 0.0;
+            bool ok = bucket_rank_sum<Wv>(scratch, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1);
+            double tm2 = 0.0;
+            if (ok) {
+                tm = s1 / (double)(n - 2 * nt);
+                const double d0 = 0.0 - tm;
+                tm2 = d0 * d0;
+                int below = 0;  // values whose squared error sorts before the block of the zero counts
+                for (int k = Wv::lane(); k < n; k += Wv::W) {
+                    const double v = scratch[k];
+                    if (v >= 0.0) {
+                        const double d = v - tm;
+                        const double q = d * d;
+                        scratch[k] = q;
+                        below += q < tm2 ? 1 : 0;
+                    }
+                }
+                below = Wv::sumi(below);
+                Wv::sync();
+                // ranks among the non-zero samples that fall into [r_lo, r_hi] once the block sits at [below, below + zeros)
+                const int j_lo = r_lo < below ? r_lo : (r_lo - zeros > below ? r_lo - zeros : below);
+                const int j_hi = r_hi < below ? r_hi : (r_hi < below + zeros ? below - 1 : r_hi - zeros);
+                const int b_lo = r_lo > below ? r_lo : below, b_hi = r_hi < below + zeros - 1 ? r_hi : below + zeros - 1;
+                ok = bucket_rank_sum<Wv>(scratch, n, n_act, j_lo, j_hi, W, s2);
+                if (ok) {
+                    ts = s2 + (b_hi >= b_lo ? (double)(b_hi - b_lo + 1) * tm2 : 0.0);
+                    done = true;
+                } else {  // selection on the squared errors, the zero counts back in
+                    for (int k = Wv::lane(); k < n; k += Wv::W)
+                        if (scratch[k] < 0.0) scratch[k] = tm2;
+                    Wv::sync();
+                    ts = trimmed_sum_select<Wv>(scratch, n, nt, W.cnt);
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
         // trimmed mean of normalised counts
         for (int k = Wv::lane(); k < n; k += Wv::W) {
             const int sidx = C.whole ? k : C.cell_index[beg + k];
             scratch[k] = (double)y[sidx] / sf[sidx];
         }
-        const bool by_sort = n <= kTrimSortMax;
-        double tm;
+        const bool by_sort = n < kTrimBucketMin;
         if (by_sort) {
             sorter(scratch, n);
             tm = range_sum<Wv>(scratch, nt, n - nt) / (double)(n - 2 * nt);
@@ -511,13 +686,13 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
             const double d = scratch[k] - tm;
             scratch[k] = d * d;
         }
-        double ts;
         if (by_sort) {
             sorter.merge(scratch, n);
             ts = range_sum<Wv>(scratch, nt, n - nt);
         } else {
             Wv::sync();
             ts = trimmed_sum_select<Wv>(scratch, n, nt, hist);
+        }
         }
         const double tv = scales[cls] * (ts / (double)(n - 2 * nt));
         vmax = (tv > vmax || tv != tv) ? tv : vmax;
@@ -591,11 +766,11 @@ struct CooksAcc {
 // scratch: >= max cell doubles (next power of two when the cell is sorted), hist: 2 * kTrimBins
 // counters (both wave-private LDS on the device).
 // flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
-template <class Wv, class Sorter>
+template <class Wv, bool BIG = true, class Sorter>
 DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu, const double* H,
                            const CellPlan& C, const uint8_t* flags, int N, int P, double cutoff,
                            double* scratch, unsigned int* hist, Sorter&& sorter, double* cooks_out) {
-    const double ar = robust_disp_gene<Wv>(y, sf, C, N, scratch, hist, sorter);
+    const double ar = robust_disp_gene<Wv, BIG>(y, sf, C, N, scratch, hist, sorter);
     CooksAcc<Wv> acc(ar, cutoff, P);
     for (int n = Wv::lane(); n < N; n += Wv::W) {
         const double ck = acc.add(n, (double)y[n], mu[n], H[n], flags[n]);

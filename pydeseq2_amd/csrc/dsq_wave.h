@@ -167,6 +167,9 @@ struct DeviceWave {
     }
     // wave-private LDS histogram cell += 1; the segment is touched by this wave only
     static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
+    // ... returning the previous value (an append position; lanes of one instruction get consecutive values in lane
+    // order, so a single wave fills its list deterministically)
+    static __device__ __forceinline__ unsigned int slot_add(unsigned int* cell) { return atomicAdd(cell, 1u); }
     // wave-private LDS accumulator cell += v (several lanes may name the same cell: ds_add_f64; the segment is
     // touched by this wave only and the LDS serialises same-address lanes in a fixed order => deterministic)
     static __device__ __forceinline__ void cell_add(double* cell, double v) {
@@ -295,6 +298,7 @@ struct RowWave {
         return s - v;
     }
     static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
+    static __device__ __forceinline__ unsigned int slot_add(unsigned int* cell) { return atomicAdd(cell, 1u); }
     static __device__ __forceinline__ void cell_add(double* cell, double v) { DeviceWave::cell_add(cell, v); }
     static __device__ __forceinline__ void sync() { DeviceWave::sync(); }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }  // over the active rows: conservative
@@ -324,6 +328,7 @@ struct HostWave {
     static inline int maxi(int v) { return v; }
     static inline int excl_scan_i(int) { return 0; }
     static inline void hist_add(unsigned int* cell) { *cell += 1u; }
+    static inline unsigned int slot_add(unsigned int* cell) { return (*cell)++; }
     static inline void cell_add(double* cell, double v) { *cell += v; }
     static inline void sync() {}
     static inline bool any(bool p) { return p; }

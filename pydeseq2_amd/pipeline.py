@@ -25,7 +25,7 @@ from scipy.stats import f as f_dist
 
 from . import trend as _trend
 from ._design import DesignPack, pad16
-from ._lib import ALT, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells
+from ._lib import ALT, HOOK_FN, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells
 
 import ctypes as C
 import functools
@@ -222,6 +222,7 @@ class DeseqPipeline:
         self.keep_layers = False   # True: the LFC fit also writes the N x G layers mu / hat diagonals (else on demand)
         self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
         self._robust_early = bool(os.environ.get("DSQ_ROBUST_EARLY"))  # (measurement switch: fork before the genewise fit)
+        self._robust_late = bool(os.environ.get("DSQ_ROBUST_LATE"))    # (measurement switch: fork after the genewise stage)
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -721,8 +722,28 @@ class DeseqPipeline:
 
         want_robust = not (stop_after_trend or stop_after_size_factors)
         early = want_robust and self.overlap and self._robust_early
-        d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero),
-                                        pre_alpha=launch_robust if early else None)
+        # fork point: inside the genewise fit, when its full-size kernel is enqueued and only the continuation of the
+        # parked fits and the grid pass remain (dsq_set_alpha_hook) - the side stream then works underneath those, the
+        # trend fit and the prior; without the hook (profiling mode, DSQ_ROBUST_LATE) after the genewise stage
+        mid = want_robust and self.overlap and not early and not self.time_kernels and not self._robust_late
+        hook_state = {"fired": False, "error": None}
+        if mid:
+            def _hook(_arg):
+                hook_state["fired"] = True
+                try:
+                    launch_robust()
+                except BaseException as e:  # (a ctypes callback cannot propagate it)
+                    hook_state["error"] = e
+            self._alpha_hook = HOOK_FN(_hook)  # kept alive until the call has returned
+            ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook, C.c_void_p), None)
+        try:
+            d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero),
+                                            pre_alpha=launch_robust if early else None)
+        finally:
+            if mid:
+                ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
+        if hook_state["error"] is not None:
+            raise hook_state["error"]
         if spec is not None:  # the genewise stage has synchronised behind the two read-backs
             if Gn == 0:
                 ctx.sync()
@@ -736,7 +757,7 @@ class DeseqPipeline:
                                    stop_after_size_factors, size_factors)
             r.size_factors = sf
         self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
-        if want_robust and not early:
+        if want_robust and not early and not hook_state["fired"]:
             launch_robust()
         t2 = tick(); T["genewise"] = t2 - t1
 

@@ -403,7 +403,7 @@ int hs_cooks(const int32_t* y, int ldn, const double* sf, const double* mu, cons
              double* robust_disp, uint8_t* any_all, uint8_t* any_use, uint8_t* any_use_nr,
              uint8_t* few_above) {
     std::vector<double> scratch(N + 8);
-    std::vector<unsigned int> hist(2 * kTrimBins);
+    std::vector<unsigned int> hist(sizeof(BucketWork) / sizeof(unsigned int) + 2);  // (robust_disp_gene: a BucketWork)
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
     for (int g = 0; g < G; ++g) {
         CooksOut o = cooks_gene<HostWave>(y + (size_t)g * ldn, sf, mu + (size_t)g * ldn,

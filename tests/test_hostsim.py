@@ -438,3 +438,43 @@ def test_wide_path_vs_reference_kats(case):
         assert_close(r["p"], k["wald_p_none"], 1e-6, 1e-300, "wald p")
         ref_ck = orc.cooks_distance(counts, k["normed"], X, k["lfc_mu"], k["lfc_H"])
         assert_close(r["cooks"], ref_ck, 1e-7, 1e-300, "cooks")
+
+
+@pytest.mark.parametrize("kind", ["two_cells", "whole", "mixed_sizes", "ties"])
+def test_robust_dispersion_large_cells_bucket_path(kind):
+    """Cells of 129 samples or more take the one-pass bucket path of robust_disp_gene (dsq_stats.h, bucket_rank_sum) instead
+    of a sort: against the oracle's sort-based restatement of utils.py:914-960 on genes built to stress it - mostly zero
+    counts (the zero block sits at either trimming boundary), constant genes, two-valued genes, a single huge outlier (all
+    other values in one bucket -> the selection fallback), heavy ties from equal size factors."""
+    rng = np.random.default_rng(5)
+    if kind in ("two_cells", "ties"):
+        N = 700
+        X = np.column_stack([np.ones(N), (np.arange(N) % 2).astype(float)])
+    elif kind == "whole":
+        N = 520
+        X = np.column_stack([np.ones(N), rng.normal(size=N)])  # no cell with 3 replicates: one pseudo-cell of all samples
+    else:
+        N = 600  # cells of 300, 200 (bucket path) and 4 x 25 (sorted)
+        lv = np.concatenate([np.zeros(300), np.ones(200), 2 + np.arange(100) // 25]).astype(int)
+        X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, 6)])
+    G = 64
+    sf = np.exp(rng.normal(0, 0.3, N))
+    sf[: N // 2] = 1.0  # equal size factors: exact ties among the normalised counts
+    if kind == "ties":
+        sf[:] = 1.0     # integer values only: every bucket is a block of ties, gene 7 overflows a boundary bucket
+    mean = np.exp(rng.uniform(np.log(0.05), np.log(3000), G))
+    counts = rng.negative_binomial(2.0, 2.0 / (2.0 + mean[None, :] * sf[:, None])).astype(np.int64)
+    counts[:, 0] = 7                                     # constant
+    counts[:, 1] = np.where(rng.random(N) < 0.5, 3, 11)  # two values
+    counts[:, 2] = 0; counts[5, 2] = 1                   # all zero but one
+    counts[:, 3] = rng.poisson(100, N); counts[17, 3] = 2_000_000  # one huge outlier
+    counts[:, 4] = np.where(rng.random(N) < 0.9, 0, rng.poisson(5, N))   # zeros beyond the upper trimming boundary
+    counts[:, 5] = np.where(rng.random(N) < 0.12, 0, rng.poisson(50, N))  # zero block ends near the lower boundary
+    counts[:, 6] = np.where(rng.random(N) < 0.125, 0, 1 + rng.poisson(2, N))
+    counts[:, 7] = 100000 + rng.poisson(2, N); counts[33, 7] = 2_000_000_000  # > 128 values in a boundary bucket: selection
+    normed = counts / sf[:, None]
+    mu = np.maximum(normed.mean(0)[None, :] * sf[:, None], 0.5)
+    H = np.full((N, G), 0.01)
+    ck, rd, _ = hs.cooks(counts, sf, X, mu, H, 10.0)
+    ref = orc.robust_mom_disp(normed, X)
+    assert_close(rd, ref, 1e-10, 1e-13, "robust dispersions")

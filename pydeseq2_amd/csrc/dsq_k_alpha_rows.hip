@@ -403,8 +403,8 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows(
 // wavefront of the workgroup keeps its own copy of the optimiser state and steps it with the same totals.
 constexpr int kWgSpt = 4;  // samples per thread at most
 
-template <int P>
-__global__ __launch_bounds__(1024) void k_alpha_wg(
+template <int P, int TPB>
+__global__ __launch_bounds__(TPB) void k_alpha_wg(
     const int32_t* __restrict__ y, int ldn, int N, const int32_t* __restrict__ list, const int32_t* __restrict__ n_dev,
     const double* __restrict__ coef, const double* __restrict__ sf, const int32_t* __restrict__ cell_of,
     const double* __restrict__ Xc, const double* __restrict__ XXc, double min_mu, const double* __restrict__ alpha_hat,
@@ -500,7 +500,9 @@ __global__ __launch_bounds__(1024) void k_alpha_wg(
     }
     const double cst = nll_const[g];
     const double la_hat = log(alpha_hat[g]);
-    Lbfgsb1d& m = mach[w];
+    // the optimiser state in registers for the loop (stepping it through an LDS reference serialises on the LDS
+    // latency of every member access: ~10 us per evaluation instead of ~3)
+    Lbfgsb1d m = mach[w];
     DeviceWave::sync();
     while (!m.done) {
         const double la = m.x;
@@ -608,12 +610,22 @@ hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, con
                            uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
                            const double* nll_const, const void* park_state) {
     if (n_cap <= 0) return hipSuccess;
-    int threads = kRowTail;  // at least one thread per tail-count entry
-    while (threads < 1024 && threads < N) threads *= 2;  // one sample per thread up to 1024 threads, then more each
+    // 512 threads (one per tail-count entry, up to kWgSpt samples each) keep the optimiser state, the per-cell tables
+    // and the samples in 256 registers; with 1024 threads (longer rows) the budget is 128 and a third of it spills
+    const bool wide = N > 512 * kWgSpt;
 #define DSQ_WG_LAUNCH(PP)                                                                                            \
-    hipLaunchKernelGGL(k_alpha_wg<PP>, dim3(n_cap < 768 ? n_cap : 768), dim3(threads), 0, st, y, ldn, N, list, n_dev, coef, sf, \
-                       cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var, prior_reg, alpha, conv, nfev, \
-                       grid_count, grid_list, nll_const, (const Lbfgsb1d*)park_state)
+    do {                                                                                                             \
+        if (wide)                                                                                                    \
+            hipLaunchKernelGGL((k_alpha_wg<PP, 1024>), dim3(n_cap < 768 ? n_cap : 768), dim3(1024), 0, st, y, ldn, N, list, \
+                               n_dev, coef, sf, cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var,     \
+                               prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const,                       \
+                               (const Lbfgsb1d*)park_state);                                                         \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_alpha_wg<PP, 512>), dim3(n_cap < 768 ? n_cap : 768), dim3(512), 0, st, y, ldn, N, list, \
+                               n_dev, coef, sf, cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var,     \
+                               prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const,                       \
+                               (const Lbfgsb1d*)park_state);                                                         \
+    } while (0)
     switch (P_) {
         case 1: DSQ_WG_LAUNCH(1); break;
         case 2: DSQ_WG_LAUNCH(2); break;

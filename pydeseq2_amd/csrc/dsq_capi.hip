@@ -308,30 +308,25 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const bool from_cells = extras != nullptr && extras->cell_mu != nullptr;
         const bool rebuild = extras != nullptr && (extras->coef != nullptr || from_cells);
-        const size_t b_work = up((size_t)n_grid * 102 * sizeof(double));
-        const size_t b_y = rebuild ? up((size_t)n_grid * ldn * sizeof(int32_t)) : 0;
+        const size_t b_work = up((size_t)n_grid * dsq::kAlphaGridWorkDoubles * sizeof(double));
         const size_t b_mu = rebuild ? up((size_t)n_grid * ldn * sizeof(double)) : 0;
         const size_t b_idx = rebuild ? up((size_t)n_grid * sizeof(int32_t)) : 0;
-        const size_t b_a = rebuild ? up((size_t)n_grid * sizeof(double)) : 0;
-        DSQ_HIP(ensure_ws(ctx, b_work + b_y + b_mu + b_idx + b_a));
+        DSQ_HIP(ensure_ws(ctx, b_work + b_mu + b_idx));
         char* w = (char*)ctx->d_ws;
         double* work = (double*)w;
         if (rebuild) {
-            // no N x G mu_hat exists: rebuild the rows of the (few) fallback genes, compacted, and run the grid on them
-            int32_t* ysub = (int32_t*)(w + b_work);
-            double* musub = (double*)(w + b_work + b_y);
-            int32_t* idx = (int32_t*)(w + b_work + b_y + b_mu);
-            double* asub = (double*)(w + b_work + b_y + b_mu + b_idx);
-            DSQ_HIP(dsq::launch_gather_rows_i32(ctx->stream, d_y, ldn, ctx->d_list, n_grid, N, ysub, n_dev));
+            // no N x G mu_hat exists: rebuild the rows of the (few) fallback genes, compacted; the grid kernels read the
+            // counts and write the result through the list
+            double* musub = (double*)(w + b_work);
+            int32_t* idx = (int32_t*)(w + b_work + b_mu);
             if (from_cells)
                 DSQ_HIP(dsq::launch_mu_from_cells(ctx->stream, extras->cell_mu, extras->cells.C, extras->sf,
                                                   extras->cells.cell_of, N, ctx->d_list, n_grid, musub, ldn, idx, n_dev));
             else
                 DSQ_HIP(dsq::launch_mu_from_coef(ctx->stream, extras->coef, extras->sf, d_Xt, ldx, N, P, extras->min_mu,
                                                  ctx->d_list, n_grid, musub, ldn, idx, n_dev));
-            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, ysub, musub, ldn, d_Xt, ldx, N, P, min_disp, max_disp, asub,
-                                           idx, n_grid, work, n_dev));
-            DSQ_HIP(dsq::launch_scatter_rows(ctx->stream, asub, ctx->d_list, n_grid, 1, d_alpha, n_dev));
+            DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, musub, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
+                                           ctx->d_list, n_grid, work, n_dev, true));
         } else {
             DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, P, min_disp, max_disp, d_alpha,
                                            ctx->d_list, n_grid, work, n_dev));
@@ -1228,12 +1223,12 @@ int dsq_inf_grid_fit_alpha(dsq_ctx* ctx, const void* counts, int count_type, int
     if ((rc = upload_f64_matrix(ctx, mu, mu_layout, N, G, m, ldn))) return rc;
     if ((rc = upload_design(ctx, design, N, P, D))) return rc;
     DSQ_HIP(a.alloc((size_t)G * sizeof(double)));
-    DSQ_HIP(work.alloc((size_t)G * 102 * sizeof(double)));
+    DSQ_HIP(work.alloc((size_t)G * dsq::kAlphaGridWorkDoubles * sizeof(double)));
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     std::vector<int32_t> all((size_t)G);
     for (int g = 0; g < G; ++g) all[(size_t)g] = g;
     DSQ_HIP(hipMemcpyAsync(ctx->d_list, all.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    // the production fallback path: 100 wavefronts per gene and level (k_alpha_grid_eval / k_alpha_grid_pick)
+    // the production fallback path: 100 wavefronts per gene and level (k_alpha_grid_eval)
     DSQ_HIP(dsq::launch_alpha_grid(ctx->stream, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N, P,
                                    min_disp, max_disp, a.as<double>(), ctx->d_list, G, work.as<double>()));
     DSQ_HIP(hipMemcpyAsync(log_alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

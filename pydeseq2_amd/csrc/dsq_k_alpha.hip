@@ -173,16 +173,34 @@ __global__ __launch_bounds__(kBlock, CELL ? cell_min_waves(P) : alpha_min_waves(
 // Grid-search fallback (grid_search.py:54-142) for the (rare) genes whose L-BFGS-B run reported
 // success = False.  A gene's 100 grid evaluations are independent, so they are spread over 100
 // wavefronts (one grid point each) instead of one wave walking them serially (which cost ~2 ms of
-// pure latency per launch): eval(coarse) -> pick -> eval(fine) -> pick, four tiny launches.
+// pure latency per launch).  The wavefront that finishes a gene's level LAST (a counter per gene) picks the
+// minimum - stage 0: the refined interval, stage 1: the result - so the whole search is two launches
+// (it used to be fill -> eval -> pick -> eval -> pick, each pick a serial scan by one thread: 8 launches and
+// ~0.17 ms per dispersion stage with the gather / scatter around them).
 constexpr int kGridLen = 100;
 
+// candidate of numpy.argmin's order: the first NaN wins, else the first minimum
+struct GridBest {
+    double f;
+    int i;
+    bool nan;
+};
+__device__ __forceinline__ bool grid_better(const GridBest& a, const GridBest& b) {
+    if (a.nan != b.nan) return a.nan;
+    if (a.nan) return a.i < b.i;
+    if (a.f != b.f) return a.f < b.f;
+    return a.i < b.i;
+}
+
+// mu_compact: row k of `mu` belongs to the k-th listed gene (rows rebuilt for the list), else row grid_list[k]
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __restrict__ y,
                                                             const double* __restrict__ mu, int ldn,
                                                             const double* __restrict__ Xt, int ldx, int N,
                                                             const int32_t* __restrict__ grid_list, int n_grid,
-                                                            const double* __restrict__ lohi,
-                                                            double* __restrict__ ll,
+                                                            int mu_compact, int stage, double lo0, double hi0,
+                                                            double* __restrict__ lohi, double* __restrict__ ll,
+                                                            int32_t* __restrict__ done, double* __restrict__ alpha,
                                                             const int32_t* __restrict__ n_dev) {
     if (n_dev != nullptr) {  // capacity launch: the number of genes lives on the device
         n_grid = min(n_grid, *n_dev);
@@ -192,55 +210,59 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
     __syncthreads();
     const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (w >= n_grid * kGridLen) return;
+    const int lane = threadIdx.x & 63;
     const int k = w / kGridLen, i = w % kGridLen;
     const int g = grid_list[k];
     AlphaArgs A;
-    A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)g * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
+    A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)(mu_compact ? k : g) * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = 0.0; A.prior_var = 1.0;
     A.cst = alpha_const<DeviceWave>(A.y, A.mu, N);
     // the count memo of alpha_eval covers 64 * NB counts and relies on its caller to pick NB from the gene's
     // largest count (as k_alpha does); NB = 1 for a gene with counts >= 64 reads other counts' memo entries
     int maxc = 0;
-    for (int n = threadIdx.x & 63; n < N; n += 64) maxc = A.y[n] > maxc ? A.y[n] : maxc;
+    for (int n = lane; n < N; n += 64) maxc = A.y[n] > maxc ? A.y[n] : maxc;
     const int mb = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (DeviceWave::maxi(maxc) >> 6) + 1));
-    const double la = linspace_at(lohi[2 * k], lohi[2 * k + 1], kGridLen, i);
+    const double lo = stage == 0 ? lo0 : lohi[2 * k], hi = stage == 0 ? hi0 : lohi[2 * k + 1];
+    const double la = linspace_at(lo, hi, kGridLen, i);
     double f, gu;
     if (mb <= 1) alpha_eval<DeviceWave, P, false, false, 1>(A, la, true, false, f, gu);
     else if (mb == 2) alpha_eval<DeviceWave, P, false, false, 2>(A, la, true, false, f, gu);
     else alpha_eval<DeviceWave, P, false, false, 4>(A, la, true, false, f, gu);
-    if ((threadIdx.x & 63) == 0) ll[(size_t)k * kGridLen + i] = f;
-}
-
-// argmin over a gene's grid (numpy.argmin: first minimum, first NaN wins); stage 0 -> refine
-// interval [c - delta, c + delta] into lohi, stage 1 -> alpha = exp(best log alpha)
-__global__ void k_alpha_grid_pick(const double* __restrict__ ll, const int32_t* __restrict__ grid_list, int n_grid,
-                                  double* __restrict__ lohi, int stage, double* __restrict__ alpha,
-                                  const int32_t* __restrict__ n_dev) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev != nullptr) n_grid = min(n_grid, *n_dev);
-    if (k >= n_grid) return;
-    const double lo = lohi[2 * k], hi = lohi[2 * k + 1];
-    double best = 0.0;
-    int kb = 0;
-    bool best_nan = false;
-    for (int i = 0; i < kGridLen; ++i) {
-        const double f = ll[(size_t)k * kGridLen + i];
-        const bool isn = (f != f);
-        if (i == 0 || (!best_nan && (isn || f < best))) { best = f; kb = i; best_nan = isn; }
+    // publish, and find out whether this wavefront is the last of its gene
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&ll[(size_t)k * kGridLen + i], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(&done[k], 1) == kGridLen - 1) ? 1 : 0;
     }
-    const double c = linspace_at(lo, hi, kGridLen, kb);
-    if (stage == 0) {
-        const double delta = linspace_at(lo, hi, kGridLen, 1) - linspace_at(lo, hi, kGridLen, 0);
-        lohi[2 * k] = c - delta;
-        lohi[2 * k + 1] = c + delta;
-    } else {
-        alpha[grid_list[k]] = exp(c);
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    __threadfence();
+    GridBest best{0.0, 0x7fffffff, false};
+    for (int j = lane; j < kGridLen; j += 64) {
+        const double fj = __hip_atomic_load(&ll[(size_t)k * kGridLen + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const GridBest c{fj, j, fj != fj};
+        if (best.i == 0x7fffffff || grid_better(c, best)) best = c;
     }
-}
-
-__global__ void k_fill_lohi(double* lohi, int n, double lo, double hi) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) { lohi[2 * k] = lo; lohi[2 * k + 1] = hi; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        GridBest o;
+        o.f = __shfl_xor(best.f, m, 64);
+        o.i = __shfl_xor(best.i, m, 64);
+        o.nan = __shfl_xor((int)best.nan, m, 64) != 0;
+        if (o.i != 0x7fffffff && (best.i == 0x7fffffff || grid_better(o, best))) best = o;
+    }
+    if (lane == 0) {
+        const double c = linspace_at(lo, hi, kGridLen, best.i);
+        if (stage == 0) {
+            const double delta = linspace_at(lo, hi, kGridLen, 1) - linspace_at(lo, hi, kGridLen, 0);
+            lohi[2 * k] = c - delta;
+            lohi[2 * k + 1] = c + delta;
+            done[k] = 0;  // for the second level
+        } else {
+            alpha[g] = exp(c);
+        }
+    }
 }
 
 // optimizer="BFGS" (utils.py:546-554): one gene per wavefront, rows read from global memory (a plug-in option of
@@ -414,24 +436,26 @@ bool alpha_needs_mu(int N, int P_, int n_cells) {
     return (size_t)kWavesPerBlock * (npad + npad / 2) * sizeof(double) > 80 * 1024;
 }
 
-// work: n_grid * (2 + kGridLen) doubles of device scratch
+// work: n_grid * (3 + kGridLen) doubles of device scratch
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P_, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev) {
+                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev,
+                             bool mu_compact) {
     if (n_grid <= 0) return hipSuccess;
     if (P_ > DSQ_REG_MAX_P) {
-        if (n_dev != nullptr) return hipErrorInvalidValue;  // the LDS path takes its count from the host
+        if (n_dev != nullptr || mu_compact) return hipErrorInvalidValue;  // the LDS path takes its count from the host
         return launch_wide_alpha_grid(st, y, mu, ldn, Xt, ldx, N, P_, min_disp, max_disp, alpha, grid_list, n_grid);
     }
     double* lohi = work;
     double* ll = work + 2 * (size_t)n_grid;
-    const dim3 ge(genes_to_blocks(n_grid * kGridLen)), block(kBlock), gp((n_grid + 63) / 64), bp(64);
-    hipLaunchKernelGGL(k_fill_lohi, gp, bp, 0, st, lohi, n_grid, log(min_disp), log(max_disp));
+    int32_t* done = (int32_t*)(ll + (size_t)n_grid * kGridLen);
+    const dim3 ge(genes_to_blocks(n_grid * kGridLen)), block(kBlock);
+    hipError_t e = hipMemsetAsync(done, 0, (size_t)n_grid * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
     for (int stage = 0; stage < 2; ++stage) {
         DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_alpha_grid_eval<P>, ge, block, 0, st, y, mu, ldn, Xt, ldx, N,
-                                              grid_list, n_grid, (const double*)lohi, ll, n_dev))
-        hipLaunchKernelGGL(k_alpha_grid_pick, gp, bp, 0, st, (const double*)ll, grid_list, n_grid, lohi, stage,
-                           alpha, n_dev);
+                                              grid_list, n_grid, mu_compact ? 1 : 0, stage, log(min_disp),
+                                              log(max_disp), lohi, ll, done, alpha, n_dev))
     }
     return hipGetLastError();
 }

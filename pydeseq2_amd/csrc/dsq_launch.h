@@ -134,7 +134,9 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                         double* nll_const, int const_mode, const AlphaExtras* extras = nullptr, int32_t* queue = nullptr);
 hipError_t launch_alpha_grid(hipStream_t st, const int32_t* y, const double* mu, int ldn, const double* Xt,
                              int ldx, int N, int P, double min_disp, double max_disp, double* alpha,
-                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev = nullptr);
+                             const int32_t* grid_list, int n_grid, double* work, const int32_t* n_dev = nullptr,
+                             bool mu_compact = false);
+constexpr int kAlphaGridWorkDoubles = 103;  // per listed gene: interval, 100 grid values, the completion counter
 
 // ---- dsq_k_irls.hip
 // optional inputs / fused outputs of the IRLS kernel (zero-initialised = none)

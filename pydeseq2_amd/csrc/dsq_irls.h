@@ -358,11 +358,12 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
         const int cell = D.cell_of[n];
         const double mu_raw = A.sf[n] * cell_select<CS>(cell, e_c);
         if (mu_out != nullptr) mu_out[n] = mu_raw;
-        if (H_out != nullptr || want_cooks) {
+        double w = 0.0;
+        const bool have_w = H_out != nullptr || want_cooks;
+        if (have_w) {
             const double mu = dmax(mu_raw, A.min_mu);
-            const double w = mu * frcp_g(1.0 + mu * A.disp);
-            const double sw = sqrt(w);
-            const double h = sw * cell_select<CS>(cell, q_c) * sw;
+            w = mu * frcp_g(1.0 + mu * A.disp);
+            const double h = w * cell_select<CS>(cell, q_c);  // (sqrt(w) q sqrt(w) of utils.py:430-433, to an ulp)
             if (H_out != nullptr) H_out[n] = h;
             if (want_cooks) {
                 const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
@@ -370,7 +371,9 @@ DSQ_HD void irls_finish_cs(const IrlsArgs& A, const double (&beta)[P], double (&
             }
         }
         if (want_wald) {
-            const double wu = mu_raw * frcp_g(1.0 + mu_raw * A.disp);
+            // the Wald weight takes the UNclamped mu (ds.py:320-324): the same number unless a lane was clamped
+            double wu = w;
+            if (!have_w || Wv::any(!(mu_raw >= A.min_mu))) wu = mu_raw * frcp_g(1.0 + mu_raw * A.disp);
 #pragma unroll
             for (int c = 0; c < CS; ++c) swu[c] += (cell == c) ? wu : 0.0;
         }
@@ -427,8 +430,8 @@ DSQ_HD void irls_init(const IrlsArgs& A, double a, double (&b0)[P], double& cst)
         const bool in_fact = yi < kLgammaIntN;
         double lf = kLgammaInt[in_fact ? yi : 0];
         if (Wv::any(!in_fact)) {
-            const double z = in_fact ? 300.0 : yv + 1.0;
-            const double big = (z - 0.5) * flog(z) - z + kHalfLog2Pi + stirling_tail(frcp(z));
+            const double z = in_fact ? 300.0 : yv + 1.0;  // z >= 257: the table logarithm and the truncated tail
+            const double big = (z - 0.5) * flog_t(z) - z + kHalfLog2Pi + stirling_tail_big(frcp(z));
             lf = in_fact ? lf : big;
         }
         c -= valid ? dl + lf : 0.0;
@@ -501,7 +504,7 @@ DSQ_HD void irls_init_cell(const IrlsArgs& A, double a, double (&b0)[P], double&
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double z = in_fact[u] ? 300.0 : (double)yi[u] + 1.0;
-                const double big = (z - 0.5) * flog(z) - z + kHalfLog2Pi + stirling_tail(frcp(z));
+                const double big = (z - 0.5) * flog_t(z) - z + kHalfLog2Pi + stirling_tail_big(frcp(z));
                 lf[u] = in_fact[u] ? lf[u] : big;
             }
         }
@@ -586,8 +589,7 @@ DSQ_HD void irls_finish(const IrlsArgs& A, const double (&beta)[P], double (&M)[
             if (H_out != nullptr || want_cooks) {
                 const double mu = dmax(mu_raw, A.min_mu);
                 const double w = mu * frcp_g(1.0 + mu * A.disp);
-                const double sw = sqrt(w);
-                const double h = sw * chol_quad<P>(M, rinv, x) * sw;
+                const double h = w * chol_quad<P>(M, rinv, x);  // (sqrt(w) q sqrt(w) of utils.py:430-433, to an ulp)
                 if (H_out != nullptr) H_out[n] = h;
                 if (want_cooks) {
                     const double ck = acc.add(n, (double)A.y[n], mu_raw, h, E->flags[n]);
@@ -664,17 +666,20 @@ DSQ_HD void irls_finish_cell(const IrlsArgs& A, const double (&beta)[P], double 
     auto sample = [&](int n, int cell, double sfn, double e, double q, double yv, int fl) {
         const double mu_raw = sfn * e;
         if (mu_out != nullptr) mu_out[n] = mu_raw;
-        if (H_out != nullptr || want_cooks) {
+        double w = 0.0;
+        const bool have_w = H_out != nullptr || want_cooks;
+        if (have_w) {
             const double mu = dmax(mu_raw, A.min_mu);
-            const double w = mu * frcp_g(1.0 + mu * A.disp);
-            const double sw = sqrt(w);
-            const double h = sw * q * sw;
+            w = mu * frcp_g(1.0 + mu * A.disp);
+            const double h = w * q;  // (sqrt(w) q sqrt(w) of utils.py:430-433, to an ulp)
             if (H_out != nullptr) H_out[n] = h;
             if (want_cooks) {
                 const double ck = acc.add(n, yv, mu_raw, h, fl);
                 if (E->cooks_row != nullptr) E->cooks_row[n] = ck;
             }
         }
+        // (the same number unless a lane was clamped)
+        if (!want_wald || (have_w && !Wv::any(!(mu_raw >= A.min_mu)))) return w;
         return mu_raw * frcp_g(1.0 + mu_raw * A.disp);
     };
     int n = Wv::lane();

@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
                                                       const double* __restrict__ sf,
                                                       const uint8_t* __restrict__ flags,
                                                       const int32_t* __restrict__ gene_idx, int n_sel,
-                                                      int N, int cap, double cutoff,
+                                                      int N, int cap, int stride, double cutoff,
                                                       int32_t* __restrict__ y_out,
                                                       uint8_t* __restrict__ all_zero) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1151,8 +1151,9 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
     const int g = gene_idx[k];
     const int32_t* yr = y + (size_t)g * ldn;
     const double* ck = cooks + (size_t)g * ldn;
-    double* scratch = lds + (size_t)w * cap;
-    const double tbm = trimmed_base_mean<DeviceWave>(yr, sf, N, 0.2, scratch, LdsSorter());
+    double* scratch = lds + (size_t)w * stride;
+    const double tbm = trimmed_base_mean<DeviceWave>(yr, sf, N, 0.2, scratch, LdsSorter(),
+                                                     stride > cap ? (BucketWork*)(scratch + cap) : nullptr);
     int nonzero = 0;
     for (int n = DeviceWave::lane(); n < N; n += 64) {
         int v = yr[n];
@@ -1174,8 +1175,9 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
                           const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero) {
     if (n_sel <= 0) return hipSuccess;
-    const int cap = next_pow2(N);
-    const size_t per_wave = (size_t)cap * sizeof(double);
+    const int cap = next_pow2(N);  // (the sort is the fallback of the bucket path: power-of-two room either way)
+    const int stride = cap + trim_work_doubles(N);
+    const size_t per_wave = (size_t)stride * sizeof(double);
     if (per_wave > 160 * 1024) return hipErrorInvalidValue;
 #define DSQ_REPL_LAUNCH(WPB)                                                                         \
     do {                                                                                             \
@@ -1186,7 +1188,7 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
         }                                                                                            \
         hipLaunchKernelGGL(k_replace<WPB>, dim3((n_sel + WPB - 1) / WPB), dim3(64 * WPB),            \
                            per_wave * WPB, st, y, cooks, ldn, sf, flags, gene_idx, n_sel, N, cap,    \
-                           cutoff, y_out, all_zero);                                                 \
+                           stride, cutoff, y_out, all_zero);                                         \
     } while (0)
     if (per_wave * 4 <= 64 * 1024) DSQ_REPL_LAUNCH(4);
     else if (per_wave * 2 <= 160 * 1024) DSQ_REPL_LAUNCH(2);

@@ -780,12 +780,27 @@ DSQ_HD CooksOut cooks_gene(const int32_t* y, const double* sf, const double* mu,
 }
 
 // trimmed mean (trim 0.2) of the normalised counts over all samples (dds.py:1332-1340)
+// bw != nullptr (and N >= kTrimBucketMin): the one-pass bucket sum instead of the sort (bucket_rank_sum; the zero counts
+// are the smallest values and add nothing)
 template <class Wv, class Sorter>
 DSQ_HD double trimmed_base_mean(const int32_t* y, const double* sf, int N, double trim,
-                                double* scratch, Sorter&& sorter) {
+                                double* scratch, Sorter&& sorter, BucketWork* bw = nullptr) {
+    const int nt = (int)floor((double)N * trim);
+    if (bw != nullptr && N >= kTrimBucketMin) {
+        int zeros = 0;
+        for (int k = Wv::lane(); k < N; k += Wv::W) {
+            const int yi = y[k];
+            scratch[k] = yi == 0 ? -1.0 : (double)yi / sf[k];
+            zeros += yi == 0 ? 1 : 0;
+        }
+        zeros = Wv::sumi(zeros);
+        Wv::sync();
+        double s;
+        if (bucket_rank_sum<Wv>(scratch, N, N - zeros, nt > zeros ? nt - zeros : 0, N - nt - 1 - zeros, *bw, s))
+            return s / (double)(N - 2 * nt);
+    }
     for (int k = Wv::lane(); k < N; k += Wv::W) scratch[k] = (double)y[k] / sf[k];
     sorter(scratch, N);
-    const int nt = (int)floor((double)N * trim);
     return range_sum<Wv>(scratch, nt, N - nt) / (double)(N - 2 * nt);
 }
 

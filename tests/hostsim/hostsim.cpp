@@ -419,9 +419,10 @@ int hs_cooks(const int32_t* y, int ldn, const double* sf, const double* mu, cons
 int hs_trimmed_base_mean(const int32_t* y, int ldn, const double* sf, int N, int G, double trim,
                          double* out) {
     std::vector<double> scratch(N + 8);
+    std::vector<BucketWork> bw(1);  // (as k_replace: the bucket path from kTrimBucketMin samples on)
     for (int g = 0; g < G; ++g)
         out[g] = trimmed_base_mean<HostWave>(y + (size_t)g * ldn, sf, N, trim, scratch.data(),
-                                             HostSorter());
+                                             HostSorter(), bw.data());
     return 0;
 }
 

@@ -478,3 +478,5 @@ def test_robust_dispersion_large_cells_bucket_path(kind):
     ck, rd, _ = hs.cooks(counts, sf, X, mu, H, 10.0)
     ref = orc.robust_mom_disp(normed, X)
     assert_close(rd, ref, 1e-10, 1e-13, "robust dispersions")
+    # the replacement value of the outlier refit (dds.py:1332-1352) takes the same bucket path
+    assert_close(hs.trimmed_base_mean(counts, sf, 0.2), orc.trimmed_mean(normed, 0.2, axis=0), 1e-12, 1e-300, "trimmed mean")

@@ -139,7 +139,9 @@ DSQ_HD double cell_dot(Col col, const Acc& acc, int C) {
 // exponential are computed once per CELL, a sample fetches them by its cell index, adds its weight w and w z
 // into the cell's accumulators, and X^T W X, X^T W z are rebuilt from the <= 64 cell sums entry-parallel.  The
 // per-sample work no longer depends on P.
-template <class Wv, int P>
+// LOADM = false (sixteen-lane rows): X^T W X and X^T W z stay in the workspace (Wk.ent), where row_chol_solve and the
+// finish read them - no lane holds the whole matrix
+template <class Wv, int P, bool LOADM = true>
 DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a, double& S,
                             double (&M)[Tri<P>::N], double (&r)[P]) {
     constexpr int T = Tri<P>::N;
@@ -240,11 +242,13 @@ DSQ_HD void irls_sweep_cell(const IrlsArgs& A, const double (&beta)[P], double a
             if (Wv::lane() + k * Wv::W < P) Wk.ent[T + Wv::lane() + k * Wv::W] = vr[k];
     }
     Wv::sync();
+    if constexpr (LOADM) {
 #pragma unroll
-    for (int k = 0; k < T; ++k) M[k] = Wk.ent[k];
+        for (int k = 0; k < T; ++k) M[k] = Wk.ent[k];
 #pragma unroll
-    for (int j = 0; j < P; ++j) r[j] = Wk.ent[T + j];
-    Wv::sync();  // ent is rewritten by the next sweep
+        for (int j = 0; j < P; ++j) r[j] = Wk.ent[T + j];
+        Wv::sync();  // ent is rewritten by the next sweep
+    }
     S = Wv::sum(s);
 }
 
@@ -749,9 +753,12 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     double M[T], r[P], S;
     constexpr int CS = CELL == 3 ? 2 : kSmallCells;
     double e_c[CS];  // CELL == 2, 3: exp(x_c . beta) of the last sweep
+    // sixteen-lane rows solve the normal equations cooperatively (row_chol_solve: two registers per design column and
+    // lane instead of the whole matrix in every lane)
+    constexpr bool kRowSolve = CELL == 1 && Wv::W == 16;
     auto sweep = [&]() {
         DSQ_PHASE(2);
-        if constexpr (CELL == 1) irls_sweep_cell<Wv, P>(A, beta, a, S, M, r);
+        if constexpr (CELL == 1) irls_sweep_cell<Wv, P, !kRowSolve>(A, beta, a, S, M, r);
         else if constexpr (CELL >= 2) irls_sweep_cs<Wv, P, CS>(A, beta, a, S, M, r, e_c);
         else irls_sweep<Wv, P>(A, beta, a, S, M, r);
         DSQ_PHASE(5);
@@ -760,18 +767,25 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     double dev = 1000.0, ratio = 1.0;
     int i = 0;
     while (ratio > A.beta_tol) {
-        double Hm[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) Hm[k] = M[k];
-#pragma unroll
-        for (int j = 0; j < P; ++j) Hm[tri(j, j)] += 1e-6;
-        DSQ_PHASE(7);
-        chol<P>(Hm);
-        DSQ_PHASE(8);
         double bh[P];
+        if constexpr (kRowSolve) {
+            typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;
+            DSQ_PHASE(7);
+            row_chol_solve<Wv, P>(((LdsWork*)A.cell_ws)->ent, 1e-6, bh);
+            Wv::sync();  // ent is rewritten by the next sweep
+        } else {
+            double Hm[T];
 #pragma unroll
-        for (int j = 0; j < P; ++j) bh[j] = r[j];
-        chol_solve<P>(Hm, bh);
+            for (int k = 0; k < T; ++k) Hm[k] = M[k];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Hm[tri(j, j)] += 1e-6;
+            DSQ_PHASE(7);
+            chol<P>(Hm);
+            DSQ_PHASE(8);
+#pragma unroll
+            for (int j = 0; j < P; ++j) bh[j] = r[j];
+            chol_solve<P>(Hm, bh);
+        }
         DSQ_PHASE(5);
         i += 1;
         bool bad = (i >= A.maxiter);
@@ -790,6 +804,13 @@ DSQ_HD IrlsOut irls_gene(const IrlsArgs& A, double (&beta)[P], double* mu_out, d
     }
     out.iters = i;
     DSQ_PHASE(6);
+    if constexpr (kRowSolve) {  // X^T W X of the last sweep
+        typedef DSQ_LDS_STRUCT(CellWork<P>) LdsWork;
+        LdsWork& Wk = *(LdsWork*)A.cell_ws;
+#pragma unroll
+        for (int k = 0; k < T; ++k) M[k] = Wk.ent[k];
+        Wv::sync();  // (the finish reuses ent)
+    }
     if constexpr (CELL == 1) irls_finish_cell<Wv, P>(A, beta, M, mu_out, H_out, E);
     else if constexpr (CELL >= 2) irls_finish_cs<Wv, P, CS>(A, beta, M, e_c, mu_out, H_out, E);
     else irls_finish<Wv, P>(A, beta, M, mu_out, H_out, E);

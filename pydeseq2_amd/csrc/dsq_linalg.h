@@ -7,6 +7,7 @@
 // Replaces numpy.linalg.slogdet / inv and scipy.linalg.solve(assume_a="pos")
 // at pydeseq2/utils.py:370-371, 428-430, 515, 532, 772-776.
 #pragma once
+#include <type_traits>
 #include <cstdint>
 
 #include "dsq_math.h"
@@ -65,6 +66,60 @@ DSQ_HD void chol(double (&a)[Tri<P>::N]) {
             a[tri(i, j)] = s * r;
         }
     }
+}
+
+// compile-time loop (the index reaches DPP controls, which are immediates)
+template <int I, int N, class F>
+DSQ_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Solve (A + ridge I) x = b for one gene held by a SIXTEEN-LANE ROW (RowWave, P <= 16): lane i keeps row i of the
+// lower triangle (P registers) and its entry of b; pivots, columns and solution entries travel by row broadcasts.
+// The register kernels keep the whole p x p matrix in every lane (p (p + 1) registers at fp64 - the reason k_irls_row
+// spilled from p = 6 on); here the matrix costs 2 p registers per lane for the same ~p^3 / 3 instructions.
+//   ent: packed lower triangle of A followed by b (T + P doubles, LDS);  x: the solution, in every lane
+template <class Wv, int P, class Ent>
+DSQ_HD void row_chol_solve(const Ent& ent, double ridge, double (&x)[P]) {
+    constexpr int T = Tri<P>::N;
+    const int rl = Wv::lane();
+    const int ri = rl < P ? rl : P - 1;  // (lanes beyond the matrix shadow its last row)
+    double a[P], rinv[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) a[j] = ent[tri(ri, j <= ri ? j : ri)] + (j == ri ? ridge : 0.0);
+    double b = ent[T + ri];
+    // right-looking Cholesky: after step j, a[j] of lane i >= j is L_ij
+    static_for<0, P>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const double r = frsq(Wv::template row_bcast<j>(a[j]));
+        rinv[j] = r;
+        a[j] *= r;
+        static_for<j + 1, P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a[k] -= a[j] * Wv::template row_bcast<k>(a[j]);  // (meaningful in lanes i >= k)
+        });
+    });
+    // forward substitution: y_k is final in lane k, every later row takes its term
+    static_for<0, P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const double yk = Wv::template row_bcast<k>(b) * rinv[k];
+        b = rl == k ? yk : (rl > k ? b - a[k] * yk : b);
+    });
+    // back substitution with L^T: x_i final in lane i, lane k < i takes L_ik x_i (L_ik lives in lane i)
+    static_for<0, P>([&](auto I) {
+        constexpr int i = P - 1 - decltype(I)::value;
+        const double xi = Wv::template row_bcast<i>(b) * rinv[i];
+        x[i] = xi;
+        b = rl == i ? xi : b;
+        static_for<0, i>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const double lik = Wv::template row_bcast<i>(a[k]);
+            b = rl == k ? b - lik * xi : b;
+        });
+    });
 }
 
 // log det(L L^T) = 2 log prod_j L_jj.  The pivots are square roots of weighted sums of squares of design entries

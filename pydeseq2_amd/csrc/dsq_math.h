@@ -54,6 +54,7 @@ DSQ_HD double flog_t(double x);
 DSQ_HD double flog1p(double u);
 DSQ_HD double frcp(double x);
 DSQ_HD double frcp_g(double x);
+DSQ_HD double frsq(double x);
 
 constexpr double kHalfLog2Pi = 0.91893853320467274178032973640562;
 constexpr double kEps = 2.220446049250313e-16;
@@ -160,6 +161,18 @@ DSQ_HD double frcp(double x) {
     return r;
 #else
     return 1.0 / x;
+#endif
+}
+
+// 1/sqrt(x): v_rsq_f64 + two Newton steps (<= 1 ulp), positive normal x; NaN for negative x as sqrt gives
+DSQ_HD double frsq(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(r * fma(-x * r, r, 1.0), 0.5, r);
+    r = fma(r * fma(-x * r, r, 1.0), 0.5, r);
+    return r;
+#else
+    return 1.0 / sqrt(x);
 #endif
 }
 

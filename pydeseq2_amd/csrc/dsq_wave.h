@@ -299,6 +299,9 @@ struct RowWave {
     }
     static __device__ __forceinline__ void hist_add(unsigned int* cell) { atomicAdd(cell, 1u); }
     static __device__ __forceinline__ unsigned int slot_add(unsigned int* cell) { return atomicAdd(cell, 1u); }
+    // the value lane L of the row holds, in every lane of the row (DPP row_newbcast: no LDS crossbar)
+    template <int L>
+    static __device__ __forceinline__ double row_bcast(double v) { return detail::dpp_d<0x150 + L>(v); }
     static __device__ __forceinline__ void cell_add(double* cell, double v) { DeviceWave::cell_add(cell, v); }
     static __device__ __forceinline__ void sync() { DeviceWave::sync(); }
     static __device__ __forceinline__ bool any(bool p) { return __any(p); }  // over the active rows: conservative

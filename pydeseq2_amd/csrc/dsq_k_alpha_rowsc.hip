@@ -34,7 +34,7 @@ struct RowGeneC {  // per-slot record in LDS (many-cell designs)
 };
 
 DSQ_HD size_t rowc_slot_bytes(int npad, int ntail, int P) {
-    return (sizeof(RowGeneC) + (size_t)npad * 2 + (size_t)ntail * 2 + (size_t)P * (P + 1) * 8 + 15) & ~(size_t)15;
+    return (sizeof(RowGeneC) + (size_t)npad * 2 + (size_t)ntail * 2 + (size_t)P * (P + 1) * 4 + 15) & ~(size_t)15;
 }
 
 // packed lower triangle of L^-1 for L from chol<P> (in place is not possible: rows are read while columns are written)
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows_c(
     const bool linear = coef != nullptr;  // mu_hat = max(sf q_c, min_mu); else sf * cell_mu (unclamped, dds.py:757-771)
     double* const sf_s = dyn;                                       // [npad], 0 beyond N
     double* const xx_s = sf_s + npad;                               // [C][T] outer products of the cells' rows
-    uint8_t* const cell_s = (uint8_t*)(xx_s + (size_t)kRcCells * T);  // [npad]
+    double* const xc_s = xx_s + (size_t)kRcCells * T;               // [C][P] the cells' design rows
+    uint8_t* const cell_s = (uint8_t*)(xc_s + (size_t)kRcCells * P);  // [npad]
     char* const slots0 = (char*)(cell_s + npad);
     const size_t slot_bytes = rowc_slot_bytes(npad, ntail, P);
     unsigned int* const hist0 = (unsigned int*)(slots0 + slot_bytes * kRowSlots * kRowWaves);  // [waves][ntail]
@@ -100,13 +101,14 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows_c(
         cell_s[n] = (uint8_t)(n < N ? cell_of[n] : 0);
     }
     for (int i = threadIdx.x; i < C * T; i += kRowBlock) xx_s[i] = XXc[i];
+    for (int i = threadIdx.x; i < C * P; i += kRowBlock) xc_s[i] = Xc[i];
     __syncthreads();
 
     auto slot_of = [&](int r) { return (RowGeneC*)(slots0 + slot_bytes * (size_t)(w * kRowSlots + r)); };
     RowGeneC* const S = slot_of(row);
     uint16_t* const cnt = (uint16_t*)((char*)S + sizeof(RowGeneC));
     uint16_t* const tail = cnt + npad;
-    double* const ent = (double*)(((uintptr_t)(tail + ntail) + 7) & ~(uintptr_t)7);  // [2 T] matrix entries in transit
+    double* const ent = (double*)(((uintptr_t)(tail + ntail) + 7) & ~(uintptr_t)7);  // [T] X^T W X, then its factor
     unsigned int* const hist = hist0 + (size_t)w * ntail;
     if (rl == 0) { S->g = -1; S->n_tail = 0; S->n_big = 0; }
     DeviceWave::sync();
@@ -317,33 +319,81 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows_c(
         double f = sumf + S->cst;
         double gr = alpha * (-(a * a * accg));
         DeviceWave::sync();  // all adds of the row have landed
-        // X^T W X and X^T dW X entry by entry: lane e of the row walks the cells for entries e, e + 16, ...
-        for (int e = rl; e < T; e += kRowLanes) {
-            double me = 0.0, de = 0.0;
+        // Cox-Reid term and its derivative without a p x p matrix in any lane:
+        //   M = X^T W X = sum_c w_c x_c x_c^T entry by entry (a lane owns entries e, e + 16, ... and walks the cells once),
+        //   its Cholesky factor with lane i keeping row i (row broadcasts, as row_chol_solve of the IRLS kernel),
+        //   log det M from the pivots, and  tr(M^-1 X^T dW X) = sum_c dw_c x_c^T M^-1 x_c = sum_c dw_c |L^-1 x_c|^2
+        //   cell-parallel by forward substitution against the factor in LDS - X^T dW X is never formed.
+        {
+            constexpr int NE = (T + kRowLanes - 1) / kRowLanes;
+            int em[NE];
+            double vm[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) { em[k] = rl + k * kRowLanes; em[k] = em[k] < T ? em[k] : T - 1; vm[k] = 0.0; }
+#pragma unroll 4
             for (int c = 0; c < C; ++c) {
-                const double xx = xx_s[c * T + e];
-                me += xx * S->acc[0][c];
-                de += xx * S->acc[1][c];
+                const double a0 = S->acc[0][c];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) vm[k] += xx_s[c * T + em[k]] * a0;
             }
-            ent[e] = me;
-            ent[T + e] = de;
+#pragma unroll
+            for (int k = 0; k < NE; ++k)
+                if (rl + k * kRowLanes < T) ent[rl + k * kRowLanes] = vm[k];
         }
         DeviceWave::sync();
         {
-            double li[T];
-            {
-                double M[T];
+            const int ri = rl < P ? rl : P - 1;
+            double arow[P], rinv[P];
 #pragma unroll
-                for (int k = 0; k < T; ++k) M[k] = ent[k];
-                chol<P>(M);
-                f += 0.5 * chol_logdet<P>(M);
-                tri_inverse<P>(M, li);
+            for (int j = 0; j < P; ++j) arow[j] = ent[tri(ri, j <= ri ? j : ri)];
+            static_for<0, P>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const double r = frsq(RowWave::row_bcast<j>(arow[j]));
+                rinv[j] = r;
+                arow[j] *= r;
+                static_for<j + 1, P>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    arow[k] -= arow[j] * RowWave::row_bcast<k>(arow[j]);
+                });
+            });
+            {   // 0.5 log det M = sum_j log L_jj = -log prod_j (1 / L_jj)   (one logarithm, as chol_logdet)
+                double p1 = 1.0, p2 = 1.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    if (j < (P + 1) / 2) p1 *= rinv[j];
+                    else p2 *= rinv[j];
+                }
+                const double pr = p1 * p2;
+                double hl;
+                if (pr > 1e-140 && pr < 1e140) hl = -flog(pr);
+                else if (!(p1 > 0.0 && p1 < INFINITY && p2 > 0.0 && p2 < INFINITY)) hl = NAN;  // NaN / zero pivot
+                else hl = -(flog(p1) + flog(p2));
+                f += hl;
             }
-            __builtin_amdgcn_sched_barrier(0);  // X^T dW X is fetched only now: factor and inverse factor are the peak
-            double dM[T];
+            DeviceWave::sync();  // every lane has read its row of M: the factor may take its place
+            if (rl < P) {
+                const int base = rl * (rl + 1) / 2;
 #pragma unroll
-            for (int k = 0; k < T; ++k) dM[k] = ent[T + k];
-            gr += 0.5 * trace_inv_times<P>(li, dM) * alpha;
+                for (int j = 0; j < P; ++j)
+                    if (j <= rl) ent[base + j] = arow[j];
+            }
+            DeviceWave::sync();
+            double trp = 0.0;
+            for (int c = rl; c < C; c += kRowLanes) {
+                double t[P], q = 0.0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) t[i] = xc_s[c * P + i];
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    t[k] *= rinv[k];
+                    q += t[k] * t[k];
+#pragma unroll
+                    for (int i = k + 1; i < P; ++i) t[i] -= ent[tri(i, k)] * t[k];
+                }
+                trp += S->acc[1][c] * q;
+            }
+            gr += 0.5 * RowWave::sum(trp) * alpha;
+            DeviceWave::sync();  // ent is rewritten by the next evaluation
         }
         if (prior_reg != 0) {
             const double dl = la - S->la_hat;
@@ -380,7 +430,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows_c(
 // LDS of one workgroup for (N, P, table size)
 static size_t rowsc_smem(int N, int P, int ntail) {
     const int npad = (N + 63) & ~63;
-    return (size_t)npad * 8 + (size_t)kRcCells * (P * (P + 1) / 2) * 8 + (size_t)npad +
+    return (size_t)npad * 8 + (size_t)kRcCells * (P * (P + 1) / 2 + P) * 8 + (size_t)npad +
            rowc_slot_bytes(npad, ntail, P) * kRowSlots * kRowWaves + (size_t)kRowWaves * ntail * 4 + 64;
 }
 

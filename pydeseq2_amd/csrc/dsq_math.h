@@ -47,6 +47,13 @@ __device__ __forceinline__ void phase_mark(int k) {
 #define DSQ_PHASE(k) ((void)0)
 #endif
 
+// a rarely taken branch that must not be hoisted above its test (an empty volatile asm is a side effect)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSQ_NO_SPECULATE asm volatile("")
+#else
+#define DSQ_NO_SPECULATE ((void)0)
+#endif
+
 namespace dsq {
 
 DSQ_HD double flog(double x);

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
                                                           const double* __restrict__ sf,
                                                           const int32_t* __restrict__ cell_offsets,
                                                           const int32_t* __restrict__ cell_index, int n_cells,
-                                                          int whole, int cap, int stride, int N, int G,
+                                                          int whole, int cap, int stride, int seg_len, int N, int G,
                                                           double* __restrict__ robust_disp) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int w = threadIdx.x >> 6;
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
     double* scratch = lds + (size_t)w * stride;
     unsigned int* hist = (unsigned int*)(scratch + cap);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
-    const double ar = robust_disp_gene<DeviceWave, BIG>(y + (size_t)g * ldn, sf, C, N, scratch, hist, LdsSorter());
+    const double ar = robust_disp_gene<DeviceWave, BIG>(y + (size_t)g * ldn, sf, C, N, scratch, hist, LdsSorter(), seg_len);
     if ((threadIdx.x & 63) == 0) robust_disp[g] = ar;
 }
 
@@ -1109,7 +1109,10 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
                               int max_cell, int N, int G, double* robust_disp) {
     if (G <= 0) return hipSuccess;
     const int biggest = whole ? N : max_cell;
-    const int cap = trim_cap(biggest);
+    // designs whose cells all have at most kSegMaxCell samples: several cells per sorting pass (seg_trimmed_variances)
+    static const bool seg_off = getenv("DSQ_NO_SEG_CELLS") != nullptr;  // A/B switch
+    const int seg_len = (!whole && !seg_off && biggest <= kSegMaxCell) ? next_pow2(biggest < 2 ? 2 : biggest) : 0;
+    const int cap = seg_len > 0 ? kSegBatch + kSegBatch / 2 : trim_cap(biggest);
     const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
     const bool big = biggest >= kTrimBucketMin;
@@ -1124,7 +1127,7 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
             (void)hipGetLastError();                                                                         \
         }                                                                                                    \
         hipLaunchKernelGGL((k_robust_disp<WPB, BIG>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, y, \
-                           ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, N, G, robust_disp); \
+                           ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, seg_len, N, G, robust_disp); \
     } while (0)
     if (per_wave * 4 <= 64 * 1024) DSQ_RD_LAUNCH(4);
     else if (per_wave * 2 <= 160 * 1024) DSQ_RD_LAUNCH(2);

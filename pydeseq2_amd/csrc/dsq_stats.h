@@ -593,20 +593,130 @@ struct CooksOut {
 //
 // scratch: >= max cell doubles (the next power of two for cells that are sorted), hist: a BucketWork when a cell has
 // kTrimBucketMin samples or more (both wave-private LDS on the device).
+// ---- trimmed variances of SMALL cells, several cells per pass
+// A design with many small cells (c4: 30 cells of 16-17 samples) leaves most of a wavefront idle when the cells are
+// sorted one after the other (a 32-element bitonic stage has 16 compare-exchanges for 64 lanes).  Here kSegBatch / L
+// cells - L = the power of two that holds the largest cell - sit side by side in the wave's buffer as segments of L and
+// are sorted by ONE network (every stage: kSegBatch / 2 compare-exchanges, one per lane); the trimmed sums are
+// per-segment accumulators in LDS.  Same arithmetic per cell as the one-by-one path, up to the order of the additions
+// inside a trimmed sum.
+constexpr int kSegBatch = 128;   // elements per pass
+constexpr int kSegMaxCell = 64;  // cells up to this size take the batched path
+
+template <class Wv>
+DSQ_HD void seg_bitonic_stage(double* buf, int L, int k, int j, bool merge_only) {
+    const int half = L >> 1;
+    for (int p = Wv::lane(); p < kSegBatch / 2; p += Wv::W) {
+        const int seg = p / half, ii = p % half;
+        const int lo_l = ((ii & ~(j - 1)) << 1) | (ii & (j - 1));
+        const int lo = seg * L + lo_l, hi = lo | j;
+        const bool up = merge_only || ((lo_l & k) == 0);
+        const double a = buf[lo], b = buf[hi];
+        const bool gt = (a > b) || (a != a && b == b);  // NaNs sort last (numpy.sort)
+        if (gt == up) { buf[lo] = b; buf[hi] = a; }
+    }
+    Wv::sync();
+}
+
+// max over the cells c0 .. c0 + kSegBatch / L - 1 of scale * trimmed mean of squared errors (NaN wins, as the caller's max)
+// segsum: kSegBatch / L doubles (LDS)
+template <class Wv>
+DSQ_HD double seg_trimmed_variances(const int32_t* y, const double* sf, const CellPlan& C, int c0, int L, double* buf,
+                                    double* segsum, double vmax) {
+    const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
+    const double scales[3] = {2.04, 1.86, 1.51};
+    const int nseg = kSegBatch / L;
+    // this lane's elements e = lane, lane + W, ...: segment, position, and the trimming ranks of the segment's cell
+    auto cell_of_elem = [&](int e, int& k, int& n, int& nt, int& cls, int& beg) {
+        const int c = c0 + e / L;
+        k = e % L;
+        beg = 0; n = 0; nt = 0; cls = 0;
+        if (c < C.n_cells) {
+            beg = C.cell_offsets[c];
+            n = C.cell_offsets[c + 1] - beg;
+            cls = trim_class(n);
+            nt = (int)floor((double)n * ratios[cls]);
+        }
+    };
+    for (int e = Wv::lane(); e < kSegBatch; e += Wv::W) {
+        int k, n, nt, cls, beg;
+        cell_of_elem(e, k, n, nt, cls, beg);
+        double v = INFINITY;
+        if (k < n) {
+            const int sidx = C.cell_index[beg + k];
+            v = (double)y[sidx] / sf[sidx];
+        }
+        buf[e] = v;
+    }
+    for (int q = Wv::lane(); q < nseg; q += Wv::W) segsum[q] = 0.0;
+    Wv::sync();
+    for (int k = 2; k <= L; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) seg_bitonic_stage<Wv>(buf, L, k, j, false);
+    for (int e = Wv::lane(); e < kSegBatch; e += Wv::W) {
+        int k, n, nt, cls, beg;
+        cell_of_elem(e, k, n, nt, cls, beg);
+        if (k >= nt && k < n - nt) Wv::cell_add(&segsum[e / L], buf[e]);
+    }
+    Wv::sync();
+    // squared errors around the segment's trimmed mean (ascending -> decreasing-then-increasing: one merge sorts them)
+    for (int e = Wv::lane(); e < kSegBatch; e += Wv::W) {
+        int k, n, nt, cls, beg;
+        cell_of_elem(e, k, n, nt, cls, beg);
+        if (k < n) {
+            const double d = buf[e] - segsum[e / L] / (double)(n - 2 * nt);
+            buf[e] = d * d;
+        }
+    }
+    Wv::sync();
+    for (int q = Wv::lane(); q < nseg; q += Wv::W) segsum[q] = 0.0;
+    Wv::sync();
+    for (int j = L >> 1; j > 0; j >>= 1) seg_bitonic_stage<Wv>(buf, L, L, j, true);
+    for (int e = Wv::lane(); e < kSegBatch; e += Wv::W) {
+        int k, n, nt, cls, beg;
+        cell_of_elem(e, k, n, nt, cls, beg);
+        if (k >= nt && k < n - nt) Wv::cell_add(&segsum[e / L], buf[e]);
+    }
+    Wv::sync();
+    for (int q = Wv::lane(); q < nseg; q += Wv::W) {
+        if (c0 + q < C.n_cells) {
+            const int n = C.cell_offsets[c0 + q + 1] - C.cell_offsets[c0 + q];
+            const int cls = trim_class(n);
+            const int nt = (int)floor((double)n * ratios[cls]);
+            const double tv = scales[cls] * (segsum[q] / (double)(n - 2 * nt));
+            vmax = (tv > vmax || tv != tv) ? tv : vmax;
+        }
+    }
+    Wv::sync();  // buf and segsum are free again
+    return vmax;
+}
+
 // flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
 // Robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960): per design cell the trimmed
 // variance of the normalised counts around their trimmed mean, the largest cell variance vs the overall mean.
 // Depends on the counts, the size factors and the design cells only - not on any fit.
 // BIG: the design has a cell of kTrimBucketMin samples or more (the bucket path is compiled in; without it the kernel
 // needs half the registers, which the small-cell designs turn into occupancy)
+// seg_len > 0: every cell has at most seg_len <= kSegMaxCell samples (a power of two) and scratch holds kSegBatch values
+// followed by kSegBatch / seg_len sums: the cells go through seg_trimmed_variances, several per pass
 template <class Wv, bool BIG = true, class Sorter>
 DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPlan& C, int N, double* scratch,
-                               unsigned int* hist, Sorter&& sorter) {
+                               unsigned int* hist, Sorter&& sorter, int seg_len = 0) {
     const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
     const double scales[3] = {2.04, 1.86, 1.51};
     double vmax = -INFINITY;
     const int ncell = C.whole ? 1 : C.n_cells;
-    for (int c = 0; c < ncell; ++c) {
+    const bool batched = !BIG && seg_len > 0 && !C.whole;
+    if (batched) {
+        for (int c0 = 0; c0 < ncell; c0 += kSegBatch / seg_len) {
+            const double v = seg_trimmed_variances<Wv>(y, sf, C, c0, seg_len, scratch, scratch + kSegBatch, vmax);
+            vmax = v;
+        }
+        // (per-lane partial maxima: combine; a NaN anywhere wins)
+        const double any_nan = Wv::max(vmax != vmax ? 1.0 : 0.0);
+        vmax = Wv::max(vmax != vmax ? -INFINITY : vmax);
+        if (any_nan > 0.0) vmax = NAN;
+    }
+    for (int c = batched ? ncell : 0; c < ncell; ++c) {
         const int beg = C.whole ? 0 : C.cell_offsets[c];
         const int end = C.whole ? N : C.cell_offsets[c + 1];
         const int n = end - beg;

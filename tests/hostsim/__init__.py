@@ -220,6 +220,20 @@ def cooks(counts, sf, X, mu, H, cutoff, min_replicates=7):
     return ck.T, rd, [a.astype(bool) for a in fl]
 
 
+def robust_disp_seg(counts, sf, X, seg_len):
+    """robust_disp_gene with the batched small-cell path (seg_len = power of two >= the largest cell, 0: one cell at a time)"""
+    y = gene_major(counts)
+    G, N = y.shape
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    off, idx, ncell, whole, flags = cell_plan(X, 7)
+    out = np.empty(G)
+    rc = lib().hs_robust_disp_seg(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(off, C.c_int32),
+                                  _p(idx, C.c_int32), C.c_int(ncell), C.c_int(whole), C.c_int(N), C.c_int(G),
+                                  C.c_int(seg_len), _p(out, C.c_double))
+    assert rc == 0
+    return out
+
+
 def trimmed_base_mean(counts, sf, trim=0.2):
     y = gene_major(counts)
     G, N = y.shape

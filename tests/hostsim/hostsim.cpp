@@ -416,6 +416,17 @@ int hs_cooks(const int32_t* y, int ldn, const double* sf, const double* mu, cons
     return 0;
 }
 
+// robust dispersions with the small cells sorted several per pass (seg_len > 0: k_robust_disp<.., false>'s path)
+int hs_robust_disp_seg(const int32_t* y, int ldn, const double* sf, const int32_t* cell_offsets,
+                       const int32_t* cell_index, int n_cells, int whole, int N, int G, int seg_len, double* out) {
+    std::vector<double> scratch((size_t)(N + 8 > 256 ? N + 8 : 256));
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    for (int g = 0; g < G; ++g)
+        out[g] = robust_disp_gene<HostWave, false>(y + (size_t)g * ldn, sf, C, N, scratch.data(), nullptr, HostSorter(),
+                                                   seg_len);
+    return 0;
+}
+
 int hs_trimmed_base_mean(const int32_t* y, int ldn, const double* sf, int N, int G, double trim,
                          double* out) {
     std::vector<double> scratch(N + 8);

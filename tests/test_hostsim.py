@@ -480,3 +480,37 @@ def test_robust_dispersion_large_cells_bucket_path(kind):
     assert_close(rd, ref, 1e-10, 1e-13, "robust dispersions")
     # the replacement value of the outlier refit (dds.py:1332-1352) takes the same bucket path
     assert_close(hs.trimmed_base_mean(counts, sf, 0.2), orc.trimmed_mean(normed, 0.2, axis=0), 1e-12, 1e-300, "trimmed mean")
+
+
+@pytest.mark.parametrize("shape", ["3factor_500", "3factor_90", "ragged"])
+def test_robust_dispersion_small_cells_batched(shape):
+    """Designs whose cells all have at most 64 samples sort several cells per pass (dsq_stats.h, seg_trimmed_variances):
+    against the oracle's restatement of utils.py:914-960 and against the one-cell-at-a-time path, for 30 cells of 16-17
+    samples (the c4 benchmark design), 30 cells of 3 samples, and cells of 3 ... 64 samples side by side (one of them
+    excluded for having 2 replicates), with all-zero, constant and outlier genes."""
+    rng = np.random.default_rng(11)
+    if shape == "ragged":
+        sizes = [3, 4, 5, 7, 8, 9, 16, 17, 23, 24, 31, 32, 33, 64, 2]
+        lv = np.repeat(np.arange(len(sizes)), sizes)
+        rng.shuffle(lv)
+        N = len(lv)
+        X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, len(sizes))])
+    else:
+        N = int(shape.split("_")[1])
+        _, X = orc.synth_counts(4, N, "3factor", 3)
+    G = 48
+    sf = np.exp(rng.normal(0, 0.3, N))
+    mean = np.exp(rng.uniform(np.log(0.05), np.log(3000), G))
+    counts = rng.negative_binomial(2.0, 2.0 / (2.0 + mean[None, :] * sf[:, None])).astype(np.int64)
+    counts[:, 0] = 0; counts[3, 0] = 2
+    counts[:, 1] = 9
+    counts[:, 2] = rng.poisson(40, N); counts[1, 2] = 3_000_000
+    normed = counts / sf[:, None]
+    ref = orc.robust_mom_disp(normed, X)
+    _, cnt = orc.design_cells(X)
+    seg = 1
+    while seg < max(c for c in cnt if c >= 3):
+        seg *= 2
+    got = hs.robust_disp_seg(counts, sf, X, max(seg, 2))
+    assert_close(got, ref, 1e-11, 1e-13, "batched cells")
+    assert_close(hs.robust_disp_seg(counts, sf, X, 0), ref, 1e-11, 1e-13, "one cell at a time")

@@ -211,16 +211,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
 #endif
 }
 
-// Genes by decreasing predicted number of sweeps (counting sort, one workgroup).  The four genes of a k_irls_row
-// wavefront iterate until the slowest has converged: in input order that costs 40 % more sweeps than the genes need
-// (mean 4.5, mean of the maximum of four 6.3 on the c4 benchmark shape); ordered by the dispersion 13 %, ordered by
-// the iteration counts of an earlier fit of the same genes (the mu_hat fit before the LFC fit) 1.4 %.
+// Genes by decreasing predicted number of sweeps, in chunks of 1024 (a counting sort per workgroup).  The four genes of a
+// k_irls_row wavefront iterate until the slowest has converged: in input order that costs 40 % more sweeps than the genes
+// need (mean 4.5, mean of the maximum of four 6.3 on the c4 benchmark shape); ordered by the dispersion 13 %, ordered by
+// the iteration counts of an earlier fit of the same genes (the mu_hat fit before the LFC fit) 1.4 %.  Ordering inside
+// chunks keeps the kernel parallel (one sort over all genes in a single workgroup took 46 us) and costs a few mixed
+// wavefronts per chunk at the class boundaries.
 constexpr int kOrderBins = 512;
-__global__ __launch_bounds__(1024) void k_irls_order(const double* __restrict__ disp, const int32_t* __restrict__ hint,
-                                                     int G, int32_t* __restrict__ order) {
+constexpr int kOrderChunk = 1024;
+__global__ __launch_bounds__(kOrderChunk) void k_irls_order(const double* __restrict__ disp, const int32_t* __restrict__ hint,
+                                                            int G, int32_t* __restrict__ order) {
     __shared__ int bins[kOrderBins];
     __shared__ int scan[kOrderBins];
-    auto key = [&](int g) -> int {
+    const int base = blockIdx.x * kOrderChunk, g = base + threadIdx.x;
+    int key = -1;
+    if (g < G) {
         int k;
         if (hint != nullptr) {
             k = hint[g];
@@ -230,11 +235,11 @@ __global__ __launch_bounds__(1024) void k_irls_order(const double* __restrict__ 
             k = (b >> 63) ? 0 : (e < 0 ? 0 : (e > 63 ? 63 : e)) * 8 + (int)((b >> 49) & 7);
         }
         k = k < 0 ? 0 : (k >= kOrderBins ? kOrderBins - 1 : k);
-        return kOrderBins - 1 - k;  // decreasing
-    };
+        key = kOrderBins - 1 - k;  // decreasing
+    }
     for (int i = threadIdx.x; i < kOrderBins; i += blockDim.x) bins[i] = 0;
     __syncthreads();
-    for (int g = threadIdx.x; g < G; g += blockDim.x) atomicAdd(&bins[key(g)], 1);
+    if (key >= 0) atomicAdd(&bins[key], 1);
     __syncthreads();
     // exclusive scan of the bins (Hillis-Steele on the first kOrderBins threads)
     int v = threadIdx.x < kOrderBins ? bins[threadIdx.x] : 0;
@@ -247,12 +252,13 @@ __global__ __launch_bounds__(1024) void k_irls_order(const double* __restrict__ 
     }
     if (threadIdx.x < kOrderBins) bins[threadIdx.x] = v - own;
     __syncthreads();
-    for (int g = threadIdx.x; g < G; g += blockDim.x) order[atomicAdd(&bins[key(g)], 1)] = g;
+    if (key >= 0) order[base + atomicAdd(&bins[key], 1)] = g;
 }
 
 hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order) {
     if (G <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_irls_order, dim3(1), dim3(1024), 0, st, disp, hint_iters, G, order);
+    hipLaunchKernelGGL(k_irls_order, dim3((G + kOrderChunk - 1) / kOrderChunk), dim3(kOrderChunk), 0, st, disp, hint_iters,
+                       G, order);
     return hipGetLastError();
 }
 

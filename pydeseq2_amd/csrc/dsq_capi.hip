@@ -643,11 +643,11 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     extras = &ex_local;
     // sixteen-lane kernel: slots ordered by the predicted number of sweeps (the list lives behind the fallback list)
     const bool ordered = G >= kIrlsOrderMinGenes && dsq::irls_takes_rows(N, P, ex_local.cells.C) && irls_order_enabled();
-    DSQ_HIP(ensure_list(ctx, (size_t)G * (ordered ? 2 : 1)));
+    DSQ_HIP(ensure_list(ctx, (size_t)G * (ordered ? 2 : 1) + (ordered ? (size_t)dsq::irls_order_work_ints() : 0)));
     if (ordered) {
         int32_t* d_order = ctx->d_list + G;
         DSQ_HIP(dsq::launch_irls_order(ctx->stream, d_disp, ctx->irls_hint_genes == G ? ctx->d_irls_hint : nullptr, G,
-                                       d_order));
+                                       d_order, d_order + G));
         ex_local.order = d_order;
     }
     ctx->d_irls_hint = nullptr; ctx->irls_hint_genes = 0;  // one-shot

@@ -476,26 +476,37 @@ __global__ __launch_bounds__(TPB) void k_alpha_wg(
     nbig = DeviceWave::sumi(nbig);
     if (lane == 0 && nbig > 0) atomicAdd(&s_nbig, nbig);
     __syncthreads();
-    // tail count of entry tid (threads below kRowTail): T_i = #{y > i}
-    double my_tail = 0.0;
+    // tail counts of this thread's entries i = tid + k * TPB: T_i = #{y > i}
+    constexpr int TPT = (kRowTail + TPB - 1) / TPB;  // entries per thread
+    double my_tail[TPT];
     {
-        int h = 0, suf = 0;
-        if (tid < kRowTail) {
-            h = (int)hist[tid];
-            int v = h;  // inclusive suffix sum inside the wavefront
+        int suf[TPT];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_down(v, d, 64);
-                if (lane + d < 64) v += o;
+        for (int k = 0; k < TPT; ++k) {
+            const int i = tid + k * TPB;
+            suf[k] = 0;
+            if (i < kRowTail) {  // (whole wavefronts: TPB and kRowTail are multiples of 64)
+                const int h = (int)hist[i];
+                int v = h;  // inclusive suffix sum inside the chunk of 64 entries
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_down(v, d, 64);
+                    if (lane + d < 64) v += o;
+                }
+                suf[k] = v - h;  // entries above this one in the same chunk
+                if (lane == 0) wave_tot[i >> 6] = v;
             }
-            suf = v - h;  // entries above this one in the same wavefront
-            if (lane == 0) wave_tot[w] = v;
         }
         __syncthreads();
-        if (tid < kRowTail) {
-            int above = s_nbig + suf;
-            for (int ww = w + 1; ww < kRowTail / 64; ++ww) above += wave_tot[ww];
-            my_tail = (double)above;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int i = tid + k * TPB;
+            my_tail[k] = 0.0;
+            if (i < kRowTail) {
+                int above = s_nbig + suf[k];
+                for (int cc = (i >> 6) + 1; cc < kRowTail / 64; ++cc) above += wave_tot[cc];
+                my_tail[k] = (double)above;
+            }
         }
     }
     const double cst = nll_const[g];
@@ -513,10 +524,13 @@ __global__ __launch_bounds__(TPB) void k_alpha_wg(
         double accg = 0.0, wc[C], dwc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) { wc[c] = 0.0; dwc[c] = 0.0; }
-        if (my_tail > 0.0) {
-            const double t = a + (double)tid;
-            accf.add(-(my_tail * flog_t(t)));
-            accg -= my_tail * frcp(t);
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            if (my_tail[k] > 0.0) {
+                const double t = a + (double)(tid + k * TPB);
+                accf.add(-(my_tail[k] * flog_t(t)));
+                accg -= my_tail[k] * frcp(t);
+            }
         }
         double lgM = 0.0, psiM = 0.0;
         if (s_nbig > 0) stirling_big((double)kRowTail + a, lgM, psiM);
@@ -601,6 +615,10 @@ __global__ __launch_bounds__(TPB) void k_alpha_wg(
     }  // next parked gene of this workgroup
 }
 
+static bool wg_narrow_enabled() {
+    static const bool v = getenv("DSQ_WG_512") == nullptr;  // A/B switch: 512 threads also for rows of <= 1024 samples
+    return v;
+}
 bool alpha_wg_eligible(int N) { return N <= 1024 * kWgSpt && getenv("DSQ_NO_ALPHA_WG") == nullptr; }
 
 // the parked genes of the row kernel (count on the device), one workgroup each; capacity = n_cap workgroups
@@ -610,12 +628,19 @@ hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, con
                            uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
                            const double* nll_const, const void* park_state) {
     if (n_cap <= 0) return hipSuccess;
-    // 512 threads (one per tail-count entry, up to kWgSpt samples each) keep the optimiser state, the per-cell tables
-    // and the samples in 256 registers; with 1024 threads (longer rows) the budget is 128 and a third of it spills
-    const bool wide = N > 512 * kWgSpt;
+    // 256 threads with four samples each (rows of <= 1024 samples): one wavefront per SIMD - most of an evaluation is the
+    // wave-uniform part (reductions, algebra, optimiser step), which two resident wavefronts per SIMD only interleave.
+    // 512 threads (up to 2048 samples) still keep the optimiser state, the tables and the samples in 256 registers;
+    // with 1024 threads (longer rows) the budget is 128 and a third of it spills
+    const bool wide = N > 512 * kWgSpt, narrow = N <= 256 * kWgSpt && wg_narrow_enabled();
 #define DSQ_WG_LAUNCH(PP)                                                                                            \
     do {                                                                                                             \
-        if (wide)                                                                                                    \
+        if (narrow)                                                                                                  \
+            hipLaunchKernelGGL((k_alpha_wg<PP, 256>), dim3(n_cap < 768 ? n_cap : 768), dim3(256), 0, st, y, ldn, N, list, \
+                               n_dev, coef, sf, cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var,     \
+                               prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const,                       \
+                               (const Lbfgsb1d*)park_state);                                                         \
+        else if (wide)                                                                                               \
             hipLaunchKernelGGL((k_alpha_wg<PP, 1024>), dim3(n_cap < 768 ? n_cap : 768), dim3(1024), 0, st, y, ldn, N, list, \
                                n_dev, coef, sf, cells.cell_of, cells.Xc, cells.XX, min_mu, alpha_hat, prior_var,     \
                                prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const,                       \

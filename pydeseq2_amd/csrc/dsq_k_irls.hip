@@ -211,38 +211,54 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
 #endif
 }
 
-// Genes by decreasing predicted number of sweeps, in chunks of 1024 (a counting sort per workgroup).  The four genes of a
-// k_irls_row wavefront iterate until the slowest has converged: in input order that costs 40 % more sweeps than the genes
-// need (mean 4.5, mean of the maximum of four 6.3 on the c4 benchmark shape); ordered by the dispersion 13 %, ordered by
-// the iteration counts of an earlier fit of the same genes (the mu_hat fit before the LFC fit) 1.4 %.  Ordering inside
-// chunks keeps the kernel parallel (one sort over all genes in a single workgroup took 46 us) and costs a few mixed
-// wavefronts per chunk at the class boundaries.
+// Genes by decreasing predicted number of sweeps (a counting sort over all genes).  The four genes of a k_irls_row
+// wavefront iterate until the slowest has converged: in input order that costs 40 % more sweeps than the genes need
+// (mean 4.5, mean of the maximum of four 6.3 on the c4 benchmark shape); ordered by the dispersion 13 %, ordered by the
+// iteration counts of an earlier fit of the same genes (the mu_hat fit before the LFC fit) 1.4 %.  The order is GLOBAL and
+// decreasing on purpose: the long fits start first and the launch ends with short ones (sorting chunks of 1024 genes
+// independently evened out the wavefronts just as well and lost a quarter of the launch to its tail).  Two kernels:
+// per-workgroup histograms added into a global one, then every workgroup scans the global histogram itself, reserves its
+// share of each class with one atomic per class and places its genes (the order inside a class does not matter).
 constexpr int kOrderBins = 512;
 constexpr int kOrderChunk = 1024;
-__global__ __launch_bounds__(kOrderChunk) void k_irls_order(const double* __restrict__ disp, const int32_t* __restrict__ hint,
-                                                            int G, int32_t* __restrict__ order) {
-    __shared__ int bins[kOrderBins];
-    __shared__ int scan[kOrderBins];
-    const int base = blockIdx.x * kOrderChunk, g = base + threadIdx.x;
-    int key = -1;
-    if (g < G) {
-        int k;
-        if (hint != nullptr) {
-            k = hint[g];
-        } else {  // exponent and three mantissa bits of the dispersion: eight classes per octave
-            const unsigned long long b = (unsigned long long)__double_as_longlong(disp[g]);
-            const int e = (int)((b >> 52) & 0x7ff) - 1023 + 40;
-            k = (b >> 63) ? 0 : (e < 0 ? 0 : (e > 63 ? 63 : e)) * 8 + (int)((b >> 49) & 7);
-        }
-        k = k < 0 ? 0 : (k >= kOrderBins ? kOrderBins - 1 : k);
-        key = kOrderBins - 1 - k;  // decreasing
+__device__ __forceinline__ int irls_order_key(const double* __restrict__ disp, const int32_t* __restrict__ hint, int g) {
+    int k;
+    if (hint != nullptr) {
+        k = hint[g];
+    } else {  // exponent and three mantissa bits of the dispersion: eight classes per octave
+        const unsigned long long b = (unsigned long long)__double_as_longlong(disp[g]);
+        const int e = (int)((b >> 52) & 0x7ff) - 1023 + 40;
+        k = (b >> 63) ? 0 : (e < 0 ? 0 : (e > 63 ? 63 : e)) * 8 + (int)((b >> 49) & 7);
     }
+    k = k < 0 ? 0 : (k >= kOrderBins ? kOrderBins - 1 : k);
+    return kOrderBins - 1 - k;  // decreasing
+}
+// work: [0, kOrderBins) global histogram, [kOrderBins, 2 kOrderBins) per-class cursors - zeroed before the launch
+__global__ __launch_bounds__(kOrderChunk) void k_irls_order_hist(const double* __restrict__ disp,
+                                                                 const int32_t* __restrict__ hint, int G,
+                                                                 int32_t* __restrict__ work) {
+    __shared__ int bins[kOrderBins];
+    const int g = blockIdx.x * kOrderChunk + threadIdx.x;
+    for (int i = threadIdx.x; i < kOrderBins; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    if (g < G) atomicAdd(&bins[irls_order_key(disp, hint, g)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kOrderBins; i += blockDim.x)
+        if (bins[i] != 0) atomicAdd(&work[i], bins[i]);
+}
+__global__ __launch_bounds__(kOrderChunk) void k_irls_order_place(const double* __restrict__ disp,
+                                                                  const int32_t* __restrict__ hint, int G,
+                                                                  int32_t* __restrict__ work, int32_t* __restrict__ order) {
+    __shared__ int bins[kOrderBins];   // this workgroup's class counts, then its running positions
+    __shared__ int scan[kOrderBins];
+    const int g = blockIdx.x * kOrderChunk + threadIdx.x;
+    const int key = g < G ? irls_order_key(disp, hint, g) : -1;
     for (int i = threadIdx.x; i < kOrderBins; i += blockDim.x) bins[i] = 0;
     __syncthreads();
     if (key >= 0) atomicAdd(&bins[key], 1);
     __syncthreads();
-    // exclusive scan of the bins (Hillis-Steele on the first kOrderBins threads)
-    int v = threadIdx.x < kOrderBins ? bins[threadIdx.x] : 0;
+    // exclusive scan of the GLOBAL histogram (Hillis-Steele on the first kOrderBins threads)
+    int v = threadIdx.x < kOrderBins ? work[threadIdx.x] : 0;
     const int own = v;
     for (int d = 1; d < kOrderBins; d <<= 1) {
         if (threadIdx.x < kOrderBins) scan[threadIdx.x] = v;
@@ -250,17 +266,25 @@ __global__ __launch_bounds__(kOrderChunk) void k_irls_order(const double* __rest
         if (threadIdx.x < kOrderBins && threadIdx.x >= d) v += scan[threadIdx.x - d];
         __syncthreads();
     }
-    if (threadIdx.x < kOrderBins) bins[threadIdx.x] = v - own;
+    if (threadIdx.x < kOrderBins) {
+        const int mine = bins[threadIdx.x];
+        bins[threadIdx.x] = (v - own) + (mine != 0 ? atomicAdd(&work[kOrderBins + threadIdx.x], mine) : 0);
+    }
     __syncthreads();
-    if (key >= 0) order[base + atomicAdd(&bins[key], 1)] = g;
+    if (key >= 0) order[atomicAdd(&bins[key], 1)] = g;
 }
 
-hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order) {
+hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order,
+                             int32_t* work) {
     if (G <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_irls_order, dim3((G + kOrderChunk - 1) / kOrderChunk), dim3(kOrderChunk), 0, st, disp, hint_iters,
-                       G, order);
+    hipError_t e = hipMemsetAsync(work, 0, 2 * kOrderBins * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    const dim3 grid((G + kOrderChunk - 1) / kOrderChunk), block(kOrderChunk);
+    hipLaunchKernelGGL(k_irls_order_hist, grid, block, 0, st, disp, hint_iters, G, work);
+    hipLaunchKernelGGL(k_irls_order_place, grid, block, 0, st, disp, hint_iters, G, work, order);
     return hipGetLastError();
 }
+int irls_order_work_ints() { return 2 * kOrderBins; }
 
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restrict__ y, int ldn,

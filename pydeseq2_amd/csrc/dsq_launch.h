@@ -163,7 +163,10 @@ struct IrlsExtras {
 bool irls_takes_rows(int N, int P, int n_cells);
 // order[0..G) = genes by decreasing predicted number of IRLS sweeps: `hint_iters` (the iteration counts of an earlier
 // fit of the same genes) when given, else the dispersion (noisier genes take more sweeps)
-hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order);
+// work: irls_order_work_ints() int32 of device scratch
+hipError_t launch_irls_order(hipStream_t st, const double* disp, const int32_t* hint_iters, int G, int32_t* order,
+                             int32_t* work);
+int irls_order_work_ints();
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P, int full_rank,

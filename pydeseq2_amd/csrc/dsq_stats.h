@@ -486,24 +486,31 @@ DSQ_HD unsigned long long pos_key(double v) {  // order-preserving for v >= +0
 // out = sum of the elements of ranks j_lo .. j_hi (ascending, 0-based, inclusive) among the ACTIVE entries
 // (buf[k] >= 0) of buf[0..n), of which there must be n_act.  false: not applicable here (a non-finite value, a
 // boundary bucket with more than kBucketGather entries) - nothing but W has been written.
+// range: the smallest and the largest active value when the caller already knows them (and that every active entry is
+// finite) - saves the pass that finds them
 template <class Wv>
-DSQ_HD bool bucket_rank_sum(const double* buf, int n, int n_act, int j_lo, int j_hi, BucketWork& W, double& out) {
+DSQ_HD bool bucket_rank_sum(const double* buf, int n, int n_act, int j_lo, int j_hi, BucketWork& W, double& out,
+                            const double* range = nullptr) {
     out = 0.0;
     if (n_act <= 0 || j_hi < j_lo) return true;
     double vmin = INFINITY, vmax = -INFINITY;
-    int seen = 0;
-    for (int k = Wv::lane(); k < n; k += Wv::W) {
-        const double v = buf[k];
-        if (v >= 0.0) {
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-            seen += 1;
+    if (range != nullptr) {
+        vmin = range[0]; vmax = range[1];
+    } else {
+        int seen = 0;
+        for (int k = Wv::lane(); k < n; k += Wv::W) {
+            const double v = buf[k];
+            if (v >= 0.0) {
+                vmin = v < vmin ? v : vmin;
+                vmax = v > vmax ? v : vmax;
+                seen += 1;
+            }
         }
+        vmin = -Wv::max(-vmin);
+        vmax = Wv::max(vmax);
+        seen = Wv::sumi(seen);
+        if (seen != n_act || !(vmax < INFINITY)) return false;  // NaN (fails v >= 0) or inf among the values
     }
-    vmin = -Wv::max(-vmin);
-    vmax = Wv::max(vmax);
-    seen = Wv::sumi(seen);
-    if (seen != n_act || !(vmax < INFINITY)) return false;  // NaN (fails v >= 0) or inf among the values
     const unsigned long long kmin = pos_key(vmin), kmax = pos_key(vmax);
     if (kmin == kmax) { out = (double)(j_hi - j_lo + 1) * vmin; return true; }
     int shift = 0;
@@ -705,6 +712,8 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
     const double scales[3] = {2.04, 1.86, 1.51};
     double vmax = -INFINITY;
     const int ncell = C.whole ? 1 : C.n_cells;
+    double cell_total = 0.0;  // per-lane sum of the normalised counts of the cells that took the bucket path ...
+    int cells_summed = 0;     // ... and how many samples those cells hold
     const bool batched = !BIG && seg_len > 0 && !C.whole;
     if (batched) {
         for (int c0 = 0; c0 < ncell; c0 += kSegBatch / seg_len) {
@@ -728,25 +737,42 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
             // large cell: one histogram pass per trimmed sum (bucket_rank_sum).  The samples with a zero count - the
             // smallest values, all equal - stay out of the buckets: they add nothing to the first sum, and their squared
             // error (0 - tm)^2 enters the second one as a block of `zeros` equal values at a known rank.
+            // (the normalised count as y * (1 / sf): a reciprocal with two Newton steps instead of an IEEE division - an ulp
+            // of difference in values that only enter trimmed sums; the same pass finds the range of the non-zero values
+            // and adds up the cell for the overall mean of utils.py:954)
             BucketWork& W = *(BucketWork*)hist;
-            int zeros = 0;
+            int zeros = 0, bad = 0;
+            double lo1 = INFINITY, hi1 = -INFINITY;
             for (int k = Wv::lane(); k < n; k += Wv::W) {
                 const int sidx = C.whole ? k : C.cell_index[beg + k];
                 const int yi = y[sidx];
-                scratch[k] = yi == 0 ? -1.0 : (double)yi / sf[sidx];
+                const double v = (double)yi * frcp_g(sf[sidx]);
+                scratch[k] = yi == 0 ? -1.0 : v;
                 zeros += yi == 0 ? 1 : 0;
+                if (yi != 0) {
+                    bad |= (v >= 0.0 && v < INFINITY) ? 0 : 1;
+                    lo1 = v < lo1 ? v : lo1;
+                    hi1 = v > hi1 ? v : hi1;
+                    cell_total += v;
+                }
             }
             zeros = Wv::sumi(zeros);
+            bad = Wv::sumi(bad);
+            double range[2] = {-Wv::max(-lo1), Wv::max(hi1)};
+            cells_summed += n;
             Wv::sync();
             const int r_lo = nt, r_hi = n - nt - 1, n_act = n - zeros;
             double s1 = 0.0, s2 = 0.0;
-            bool ok = bucket_rank_sum<Wv>(scratch, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1);
+            bool ok = bucket_rank_sum<Wv>(scratch, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1,
+                                          bad == 0 ? range : nullptr);
             double tm2 = 0.0;
             if (ok) {
                 tm = s1 / (double)(n - 2 * nt);
                 const double d0 = 0.0 - tm;
                 tm2 = d0 * d0;
                 int below = 0;  // values whose squared error sorts before the block of the zero counts
+                double lo2 = INFINITY, hi2 = -INFINITY;
+                bad = 0;
                 for (int k = Wv::lane(); k < n; k += Wv::W) {
                     const double v = scratch[k];
                     if (v >= 0.0) {
@@ -754,15 +780,20 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
                         const double q = d * d;
                         scratch[k] = q;
                         below += q < tm2 ? 1 : 0;
+                        bad |= (q >= 0.0 && q < INFINITY) ? 0 : 1;
+                        lo2 = q < lo2 ? q : lo2;
+                        hi2 = q > hi2 ? q : hi2;
                     }
                 }
                 below = Wv::sumi(below);
+                bad = Wv::sumi(bad);
+                range[0] = -Wv::max(-lo2); range[1] = Wv::max(hi2);
                 Wv::sync();
                 // ranks among the non-zero samples that fall into [r_lo, r_hi] once the block sits at [below, below + zeros)
                 const int j_lo = r_lo < below ? r_lo : (r_lo - zeros > below ? r_lo - zeros : below);
                 const int j_hi = r_hi < below ? r_hi : (r_hi < below + zeros ? below - 1 : r_hi - zeros);
                 const int b_lo = r_lo > below ? r_lo : below, b_hi = r_hi < below + zeros - 1 ? r_hi : below + zeros - 1;
-                ok = bucket_rank_sum<Wv>(scratch, n, n_act, j_lo, j_hi, W, s2);
+                ok = bucket_rank_sum<Wv>(scratch, n, n_act, j_lo, j_hi, W, s2, bad == 0 ? range : nullptr);
                 if (ok) {
                     ts = s2 + (b_hi >= b_lo ? (double)(b_hi - b_lo + 1) * tm2 : 0.0);
                     done = true;
@@ -807,10 +838,15 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
         const double tv = scales[cls] * (ts / (double)(n - 2 * nt));
         vmax = (tv > vmax || tv != tv) ? tv : vmax;
     }
-    // mean of normalised counts over ALL samples (utils.py:954)
-    double s = 0.0;
-    for (int n = Wv::lane(); n < N; n += Wv::W) s += (double)y[n] / sf[n];
-    const double m = Wv::sum(s) / (double)N;
+    // mean of normalised counts over ALL samples (utils.py:954): already summed when the bucket path saw every sample
+    double m;
+    if (BIG && cells_summed == N) {
+        m = Wv::sum(cell_total) / (double)N;
+    } else {
+        double s = 0.0;
+        for (int n = Wv::lane(); n < N; n += Wv::W) s += (double)y[n] / sf[n];
+        m = Wv::sum(s) / (double)N;
+    }
     double ar = (vmax - m) / (m * m);
     ar = (ar > 0.04) ? ar : 0.04;  // np.maximum(alpha, 0.04) (NaN -> stays NaN in numpy; see below)
     if (vmax != vmax) ar = vmax;

@@ -465,17 +465,23 @@ DSQ_HD double trimmed_sum_select(const double* buf, int n, int nt, unsigned int*
 // light passes over the cell instead of the ~50 compare-exchange passes of a bitonic sort of 512 values (or the 5+
 // passes of the radix selection above).  Samples with a ZERO count are kept out (markers < 0 in the buffer): they are
 // the one large group of ties real count data has, and the caller adds their contribution in closed form.
-constexpr int kBuckets = 512;
-constexpr int kBucketGather = 128;  // elements a boundary bucket may hold; beyond: the caller takes the selection path
+#ifndef DSQ_BUCKETS
+#define DSQ_BUCKETS 512
+#endif
+#ifndef DSQ_BUCKET_GATHER
+#define DSQ_BUCKET_GATHER 128
+#endif
+constexpr int kBuckets = DSQ_BUCKETS;
+constexpr int kBucketGather = DSQ_BUCKET_GATHER;  // elements a boundary bucket may hold; beyond: the caller takes the selection path
 constexpr int kTrimBucketMin = 129; // cells from this size on take the bucket path (smaller ones sort in a few stages)
 struct BucketWork {                 // wave-private LDS
-    double sum[kBuckets];
-    unsigned int cnt[kBuckets];     // (2 * kTrimBins counters: doubles as the histogram of trimmed_sum_select)
+    double sum[kBuckets];           // (doubles as the 2 * kTrimBins counters of trimmed_sum_select, the fallback)
+    unsigned int cnt[kBuckets];
     double edge[2][kBucketGather];
     unsigned int n_edge[2];
     unsigned int pad[2];
 };
-static_assert(kBuckets >= 2 * kTrimBins, "the selection path borrows BucketWork::cnt");
+static_assert(kBuckets * sizeof(double) >= 2 * kTrimBins * sizeof(unsigned int), "the selection path borrows BucketWork::sum");
 
 DSQ_HD unsigned long long pos_key(double v) {  // order-preserving for v >= +0
     unsigned long long b;
@@ -801,7 +807,7 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
                     for (int k = Wv::lane(); k < n; k += Wv::W)
                         if (scratch[k] < 0.0) scratch[k] = tm2;
                     Wv::sync();
-                    ts = trimmed_sum_select<Wv>(scratch, n, nt, W.cnt);
+                    ts = trimmed_sum_select<Wv>(scratch, n, nt, (unsigned int*)W.sum);
                     done = true;
                 }
             }

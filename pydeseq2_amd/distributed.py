@@ -157,7 +157,7 @@ class TcpControl:
                 c, _a = srv.accept()
                 c.settimeout(timeout)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.sendall(self.MAGIC)
+                c.sendall(self.MAGIC + int(port).to_bytes(4, "little"))  # (the job's base port: two jobs with overlapping port ranges do not adopt each other's ranks)
                 r = int.from_bytes(self._recvn(c, 4), "little")
                 peers[r] = c
             srv.close()
@@ -169,7 +169,7 @@ class TcpControl:
                     try:
                         c = socket.create_connection((addr, pt), timeout=2)
                         c.settimeout(5)
-                        if self._recvn(c, len(self.MAGIC)) == self.MAGIC:
+                        if self._recvn(c, len(self.MAGIC) + 4) == self.MAGIC + int(port).to_bytes(4, "little"):
                             c.settimeout(timeout)
                             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             c.sendall(int(rank).to_bytes(4, "little"))

@@ -7,8 +7,13 @@
 
 namespace dsq {
 
+// resident wavefronts per SIMD asked of the compiler (0: whatever the registers allow): the optimiser between two
+// objective evaluations is serial code on an LDS workspace, i.e. LDS latency that only other wavefronts can cover
+#ifndef DSQ_SHRINK_WAVES
+#define DSQ_SHRINK_WAVES 0
+#endif
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_shrink(const int32_t* __restrict__ y, int ldn,
+__global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1) void k_shrink(const int32_t* __restrict__ y, int ldn,
                                                    const double* __restrict__ offset,
                                                    const double* __restrict__ Xt, int ldx, int N, int G,
                                                    const double* __restrict__ size, double sigma0, double sigma,

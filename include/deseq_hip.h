@@ -35,7 +35,8 @@ extern "C" {
 #endif
 
 #define DSQ_MAX_P 32        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path */
-#define DSQ_SHRINK_MAX_P 12 /* apeGLM shrinkage (dsq_*_lfc_shrink*) */
+#define DSQ_SHRINK_MAX_P 32 /* apeGLM shrinkage (dsq_*_lfc_shrink*): up to 12 columns in registers, 13 ... 32 run-time p */
+#define DSQ_BFGS_MAX_P 12   /* optimizer = "BFGS" of the dispersion fit / the IRLS rescue: register kernels only */
 
 typedef struct dsq_ctx dsq_ctx;
 

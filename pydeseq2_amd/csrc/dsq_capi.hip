@@ -270,7 +270,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     }
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     if (ctx->optimizer == 1) {
-        DSQ_CHECK_ARG(d_mu != nullptr && P <= DSQ_SHRINK_MAX_P,
+        DSQ_CHECK_ARG(d_mu != nullptr && P <= DSQ_BFGS_MAX_P,
                       "optimizer=\"BFGS\" takes mu_hat as a matrix and designs of at most 12 columns");
         DSQ_HIP(dsq::launch_alpha_bfgs(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp,
                                        max_disp, prior_var, cr_reg, prior_reg, d_alpha, d_conv, d_nfev, d_cnt,
@@ -639,7 +639,7 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     dsq::IrlsExtras ex_local{};
     if (extras != nullptr) ex_local = *extras;
     ex_local.optimizer = ctx->optimizer;
-    DSQ_CHECK_ARG(ctx->optimizer == 0 || P <= DSQ_SHRINK_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
+    DSQ_CHECK_ARG(ctx->optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
     extras = &ex_local;
     // sixteen-lane kernel: slots ordered by the predicted number of sweeps (the list lives behind the fallback list)
     const bool ordered = G >= kIrlsOrderMinGenes && dsq::irls_takes_rows(N, P, ex_local.cells.C) && irls_order_enabled();
@@ -923,7 +923,7 @@ int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                        uint8_t* d_converged) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
                                prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged));
@@ -1364,7 +1364,7 @@ int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_ty
                                   const double* design, const double* size, const double* offset, int N, int G,
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
                                   double* beta_out, double* inv_hessian_out, uint8_t* converged) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 12 design columns)");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);

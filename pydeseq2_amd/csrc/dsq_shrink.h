@@ -226,4 +226,166 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
     return res.success ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Designs of 13 ... 32 columns (the reference has no limit, utils.py:990-1142): the same fit with a RUN-TIME number of
+// coefficients p <= PMAX.  The optimiser is the same lbfgsb_nd (its workspace is sized by PMAX), the Hessian is built
+// one row per pass over the samples (p passes: the p (p + 1) / 2 accumulators of the narrow path would not fit the
+// register file), and the inverse runs on two p x p matrices in the wave's LDS workspace, column-parallel.  One gene per
+// wavefront; not tuned - what matters here is that wide designs run at all.
+template <int PMAX>
+struct ShrinkWorkWide {  // wave-private LDS on the device
+    LbfgsbWork<PMAX> lb;
+    double x[PMAX], l[PMAX], u[PMAX];
+    int nbd[PMAX];
+    double Hm[PMAX * PMAX], Iv[PMAX * PMAX];
+};
+
+template <class Wv, int PMAX>
+DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, double* g) {
+    const double lsz = log(A.size);
+    double b[PMAX], gr[PMAX];
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) { b[j] = j < p ? xb[j] : 0.0; gr[j] = 0.0; }
+    double s = 0.0;
+    for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+        const double yv = (double)A.y[n];
+        double x[PMAX];
+        double eta = 0.0;
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) {
+            x[j] = j < p ? A.Xt[j * A.ldx + n] : 0.0;
+            eta += x[j] * b[j];  // (x[j] b[j] = 0 exactly beyond p: the sum's value and rounding are those of p terms)
+        }
+        const double eo = eta + A.offset[n];
+        const double d = eo - lsz;
+        const double e = exp(-fabs(d));
+        const double lae = (d > 0 ? eo : lsz) + flog1p(e);
+        s += yv * eta - (yv + A.size) * lae;
+        if (g != nullptr) {
+            const double gk = yv - (yv + A.size) * ((d > 0 ? 1.0 : e) * frcp(1.0 + e));
+#pragma unroll
+            for (int j = 0; j < PMAX; ++j) gr[j] += gk * x[j];
+        }
+    }
+    s = Wv::sum(s);
+    double prior = 0.0, bs = 0.0;
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        if (j < p && j != A.shrink_index) prior += (b[j] * b[j]) / (2.0 * A.sigma0 * A.sigma0);
+        bs = (j == A.shrink_index) ? b[j] : bs;
+    }
+    const double q = bs / A.sigma;
+    prior += log1p(q * q);
+    if (g != nullptr) {
+        Wv::template sum_n<PMAX>(gr);
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) {
+            if (j < p) {
+                const double dp = (j == A.shrink_index) ? 2.0 * b[j] / (A.sigma * A.sigma + bs * bs)
+                                                        : b[j] / (A.sigma0 * A.sigma0);
+                g[j] = dp - gr[j];
+            }
+        }
+    }
+    return prior - s;
+}
+
+// beta[p] (out), inv_hessian[p*p] row-major (out, nullable); returns scipy's res.success
+template <class Wv, int PMAX>
+DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, ShrinkWorkWide<PMAX>& Wk, double* beta, double* inv_hessian) {
+    for (int j = 0; j < p; ++j) Wk.x[j] = 0.0;
+    Wv::sync();
+    const double f0 = shrink_fn_wide<Wv, PMAX>(A, p, Wk.x, nullptr);
+    const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
+    const double cn = (f0 != f0) ? f0 : cnst;
+    for (int j = 0; j < p; ++j) {
+        Wk.x[j] = (j & 1) ? -0.1 : 0.1;
+        Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+    }
+    Wv::sync();
+    auto fg = [&](const double* xb, double& f, double* g) {
+        double gg[PMAX];
+        f = shrink_fn_wide<Wv, PMAX>(A, p, xb, gg) / cn;
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j)
+            if (j < p) g[j] = gg[j] / cn;
+    };
+    const LbfgsbResult res =
+        lbfgsb_nd<PMAX>(fg, p, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    Wv::sync();
+    if (Wv::lane() == 0)
+        for (int j = 0; j < p; ++j) beta[j] = Wk.x[j];
+    if (inv_hessian == nullptr) return res.success ? 1 : 0;
+    // Hessian (cnst = 1), one row per pass:  X^T diag(frac) X + h  with the reference's broadcasting quirk (h_j is added
+    // to every row of column j, utils.py:1099-1110; see shrink_gene)
+    double b[PMAX];
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) b[j] = j < p ? Wk.x[j] : 0.0;
+    const double bs = Wk.x[A.shrink_index];
+    const double s2 = A.sigma * A.sigma, b2 = bs * bs;
+    for (int i = 0; i < p; ++i) {
+        double r[PMAX];
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) r[j] = 0.0;
+        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            const double yv = (double)A.y[n];
+            double x[PMAX];
+            double eta = 0.0;
+#pragma unroll
+            for (int j = 0; j < PMAX; ++j) {
+                x[j] = j < p ? A.Xt[j * A.ldx + n] : 0.0;
+                eta += x[j] * b[j];
+            }
+            const double e = exp(eta + A.offset[n]);
+            const double fr = (yv + A.size) * A.size * e / ((A.size + e) * (A.size + e));
+            const double xw = A.Xt[i * A.ldx + n] * fr;
+#pragma unroll
+            for (int j = 0; j < PMAX; ++j) r[j] += xw * x[j];
+        }
+        Wv::template sum_n<PMAX>(r);
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) {
+            if (j < p && Wv::lane() == 0) {
+                const double hd = (j == A.shrink_index) ? 2.0 * (s2 - b2) / ((s2 + b2) * (s2 + b2))
+                                                        : 1.0 / (A.sigma0 * A.sigma0);
+                Wk.Hm[i * p + j] = r[j] + hd;
+                Wk.Iv[i * p + j] = (i == j) ? 1.0 : 0.0;
+            }
+        }
+    }
+    Wv::sync();
+    // inverse by Gauss-Jordan with partial pivoting (as shrink_gene), the row operations spread over the lanes
+    for (int c = 0; c < p; ++c) {
+        int pv = c;
+        double mx = fabs(Wk.Hm[c * p + c]);
+        for (int r = c + 1; r < p; ++r) {
+            const double v = fabs(Wk.Hm[r * p + c]);
+            if (v > mx) { mx = v; pv = r; }
+        }
+        if (pv != c) {
+            for (int k = Wv::lane(); k < p; k += Wv::W) {
+                double t = Wk.Hm[c * p + k]; Wk.Hm[c * p + k] = Wk.Hm[pv * p + k]; Wk.Hm[pv * p + k] = t;
+                t = Wk.Iv[c * p + k]; Wk.Iv[c * p + k] = Wk.Iv[pv * p + k]; Wk.Iv[pv * p + k] = t;
+            }
+            Wv::sync();
+        }
+        const double d = 1.0 / Wk.Hm[c * p + c];
+        Wv::sync();  // (every lane has read the pivot before its column's owner scales it)
+        for (int k = Wv::lane(); k < p; k += Wv::W) { Wk.Hm[c * p + k] *= d; Wk.Iv[c * p + k] *= d; }
+        Wv::sync();
+        for (int r = 0; r < p; ++r) {
+            if (r == c) continue;
+            const double fct = Wk.Hm[r * p + c];
+            Wv::sync();  // (read by every lane before the owner of column c overwrites it)
+            for (int k = Wv::lane(); k < p; k += Wv::W) {
+                Wk.Hm[r * p + k] -= fct * Wk.Hm[c * p + k];
+                Wk.Iv[r * p + k] -= fct * Wk.Iv[c * p + k];
+            }
+        }
+        Wv::sync();
+    }
+    for (int k = Wv::lane(); k < p * p; k += Wv::W) inv_hessian[k] = Wk.Iv[k];
+    return res.success ? 1 : 0;
+}
+
 }  // namespace dsq

@@ -401,6 +401,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "bfgs":
         bfgs_cases(ut)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shrink_wide":  # round 3: apeGLM shrinkage for designs of 13 ... 32 columns
+        shrink_wide_cases(ut)
+        return
     # case A: 2-level factor (linear-mu route), p = 2
     N = 40
     X = np.column_stack([np.ones(N), (np.arange(N) % 2).astype(float)])
@@ -464,6 +467,25 @@ def narrow_cases(ut, gs, pp, di):
         X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
         assert X.shape[1] == pw
         kat_case(f"p{pw}", synth(40, N, X, seed, eff=0.5), X, ut, gs, pp, di)
+
+
+def shrink_wide_cases(ut):
+    """utils.nbinomGLM (the unmodified reference, L-BFGS-B as ds.py:407 calls it) on the wide-design KAT inputs:
+    p = 16 (one factor with 16 levels) and p = 24 -> kat_shrink_wide.npz"""
+    sh = {}
+    for case, sidx in (("p16", 1), ("p24", 3)):
+        k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
+        counts, X, sf = k["counts"], k["X"], k["sf"]
+        size = 1.0 / np.clip(k["map_alpha"], 1e-8, max(10, counts.shape[0]))
+        G = min(counts.shape[1], 24)
+        for tag, ps in (("a", 1.0), ("b", 0.3)):
+            r = [ut.nbinomGLM(X, counts[:, i], size[i], np.log(sf), 15, ps, "L-BFGS-B", sidx) for i in range(G)]
+            sh[f"{case}{tag}_beta"] = np.stack([x[0] for x in r])
+            sh[f"{case}{tag}_invh"] = np.stack([x[1] for x in r])
+            sh[f"{case}{tag}_conv"] = np.array([x[2] for x in r], dtype=bool)
+            sh[f"{case}{tag}_scale"] = np.array(ps)
+        sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
+    np.savez(os.path.join(HERE, "kat_shrink_wide.npz"), **sh)
 
 
 def rest_of_main(ut):

@@ -95,6 +95,27 @@ def test_lfc_shrink_inference_vs_reference_kats(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["p16", "p24"])
+def test_lfc_shrink_wide_designs_vs_reference_kats(case):
+    """13 ... 32 design columns (k_shrink_wide: run-time p) against outputs of the unmodified utils.nbinomGLM."""
+    import os
+
+    from pydeseq2_amd import HipInference
+    from tests.helpers import load_kat
+
+    inf = HipInference(device=0)
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_wide.npz"))
+    kk = load_kat(case)
+    G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
+    for tag in "ab":
+        b, ih, cv = inf.lfc_shrink_nbinom_glm(kk["X"], kk["counts"][:, :G], k[f"{case}_size"], np.log(kk["sf"]), 15,
+                                              float(k[f"{case}{tag}_scale"]), "L-BFGS-B", sidx)
+        assert (cv == k[f"{case}{tag}_conv"]).all()
+        np.testing.assert_allclose(b, k[f"{case}{tag}_beta"], rtol=1e-5, atol=1e-8)
+        scale = np.abs(k[f"{case}{tag}_invh"]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
+
+
 def test_lfc_shrink_pipeline_vs_oracle_and_r():
     import pydeseq2_amd
     from pydeseq2_amd import summary as sm

@@ -116,6 +116,27 @@ def test_lfc_shrink_wide_designs_vs_reference_kats(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
 
 
+def test_lfc_shrink_pipeline_wide_design_vs_oracle():
+    """DeseqStats.lfc_shrink's device path on a 14-column design (two factors + nine continuous covariates): the
+    pipeline-level shrinkage (prior scale from the MLE LFCs, k_shrink_wide, shrunken LFC and lfcSE) against the oracle."""
+    import pydeseq2_amd
+    from pydeseq2_amd import summary as sm
+    from tests.test_gpu_parity import _wide_case
+
+    counts, X = _wide_case("mixed14", 160, 120, 41)
+    counts[:, 3] = 0
+    c = np.zeros(X.shape[1])
+    c[1] = 1.0
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0)
+    res = pipe.deseq2(contrast=c)
+    lfc, se, conv, scale = sm.lfc_shrink(pipe, res, 1)
+    rl, rs, rc, rscale = orc.lfc_shrink(counts, X, res, 1)
+    assert abs(scale - rscale) < 1e-12
+    assert (np.isnan(conv) == np.isnan(rc)).all() and (conv[~np.isnan(rc)] == rc[~np.isnan(rc)]).all()
+    _same(lfc, rl, rtol=1e-5)
+    _same(se, rs, rtol=1e-5)
+
+
 def test_lfc_shrink_pipeline_vs_oracle_and_r():
     import pydeseq2_amd
     from pydeseq2_amd import summary as sm

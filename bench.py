@@ -142,7 +142,7 @@ def cpu_baseline(counts, X, n_sample, n_jobs):
 # the p-value error is reported in that unit ("pvalue_per_z2") and the statistic itself at 1e-5
 PARITY_TOL = {"dispersions": 1e-5, "LFC": 1e-5, "lfcSE": 1e-5, "stat": 1e-5, "pvalue_per_z2": 1e-5}
 # Genes whose L-BFGS-B success flag differs between the two sides.  Floor: a ONE-ULP change of mu_hat flips 0.09-0.18 % of
-# the reference's own fits per fit (tools/flip_floor.py -> profiles/r03_flip_floor.json; two fits per gene here);
+# the reference's own fits per fit (tests/tools/flip_floor.py -> profiles/r03_flip_floor.json; two fits per gene here);
 # measured engine vs reference 0.14-0.23 % over both fits.
 PARITY_MAX_NOISE_FRAC = 0.0035
 

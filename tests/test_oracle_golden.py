@@ -301,7 +301,7 @@ def test_oracle_end_to_end_is_the_unmodified_reference_at_benchmark_shapes(name)
     routines repeat the reference's operation sequence (same scipy / numpy / LAPACK calls on the same operands), so on
     the machine that generated the files every output is BIT-IDENTICAL.  Another CPU's BLAS kernels may round a dot
     product differently; a last-bit change of mu_hat moves the stopping point of ~0.1 % of the L-BFGS-B runs
-    (tools/flip_floor.py, profiles/r03_flip_floor.json), so the portable assertion is: at most 0.4 % of the genes
+    (tests/tools/flip_floor.py, profiles/r03_flip_floor.json), so the portable assertion is: at most 0.4 % of the genes
     change a success flag, every other gene agrees to 2e-6, and the cross-gene quantities to 1e-6."""
     import os
     import warnings

@@ -8,7 +8,7 @@ shim as tests/golden/make_golden.py and driven, in dds.py / ds.py call order, by
 oracle's own kernels are timed on the same slice and the same cores, which gives the factor by which bench.py's
 "port" baseline differs from the reference's kernels.
 
-    python tools/cpu_reference_slice.py [genes]     ->  profiles/cpu_reference_slice.json
+    python tests/tests/tools/cpu_reference_slice.py [genes]     ->  profiles/cpu_reference_slice.json
 """
 import json
 import os
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 

@@ -8,8 +8,8 @@ genewise fits of the first genes of the c3 golden case are repeated with mu_hat 
 and the genes whose flag or value changes are counted.  Any implementation whose loss differs from the reference's in
 the last bits - another summation order, another lgamma - sits at some point of this curve.
 
-    python tools/flip_floor.py [genes]      ->  profiles/r03_flip_floor.json      (c3 shape: 1000 samples, two groups)
-    python tools/flip_floor.py 1000 c5      ->  profiles/r03_flip_floor_c5.json   (c5 shape: 5000 samples, continuous
+    python tests/tools/flip_floor.py [genes]      ->  profiles/r03_flip_floor.json      (c3 shape: 1000 samples, two groups)
+    python tests/tools/flip_floor.py 1000 c5      ->  profiles/r03_flip_floor_c5.json   (c5 shape: 5000 samples, continuous
                                                 covariates, mu_hat from the IRLS fit)
 """
 import json
@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import nbglm_oracle as orc  # noqa: E402

@@ -60,11 +60,6 @@ enum dsq_alt { DSQ_ALT_NONE = 0, DSQ_ALT_GREATER_ABS = 1, DSQ_ALT_LESS_ABS = 2,
 
 /* ------------------------------------------------------------------ context */
 int dsq_create(int device_id, dsq_ctx** out);
-/* optimizer of the two per-gene fits that take one in the reference (utils.py:343 irls_solver's rescue,
- * utils.py:546-554 fit_alpha_mle): 0 = "L-BFGS-B" (the default and the only one dds.py / ds.py use), 1 = "BFGS"
- * (scipy's unbounded BFGS restated, csrc/dsq_bfgs.h; designs of at most 12 columns, mu_hat given as a matrix).
- * Sticky per context until set again. */
-int dsq_set_optimizer(dsq_ctx* ctx, int optimizer);
 /* Deferred second passes (sticky until set again).  The dispersion fit's grid-search pass (utils.py:556-564) and the
  * IRLS rescue (utils.py:374-413) normally wait for the host to read how many genes need them.  With on != 0, batches of
  * at most 2048 genes on the register kernels (P <= 12) enqueue those passes for every gene of the batch as a capacity
@@ -126,21 +121,23 @@ int dsq_inf_lin_reg_mu(dsq_ctx* ctx, const void* counts, int count_type, int cou
 
 /* Inference.irls (inference.py:46-119; default_inference.py:83-124 -> utils.irls_solver
  * utils.py:273-438).  beta_out[G*P]; mu_out, hat_out: G x N gene-major; converged[G].
- * `optimizer` of the reference is fixed to "L-BFGS-B" semantics (bounded). */
+ * optimizer (utils.py:343, the rescue of diverged genes utils.py:389-399): 0 = "L-BFGS-B" (bounded; the default and the
+ * only one dds.py / ds.py pass), 1 = "BFGS" (scipy's unbounded BFGS restated, csrc/dsq_bfgs.h; at most 12 columns). */
 int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                  const double* size_factors, const double* design, const double* disp, int N,
                  int G, int P, double min_mu, double beta_tol, double min_beta, double max_beta,
                  int maxiter, double* beta_out, double* mu_out, double* hat_out,
-                 uint8_t* converged);
+                 uint8_t* converged, int optimizer);
 
 /* Inference.alpha_mle (inference.py:121-178; default_inference.py:126-161 ->
  * utils.fit_alpha_mle utils.py:441-564, grid_search.grid_fit_alpha grid_search.py:54-142).
- * mu given in `mu_layout`; prior_disp_var ignored unless prior_reg. */
+ * mu given in `mu_layout`; prior_disp_var ignored unless prior_reg; optimizer (utils.py:546-554): 0 = "L-BFGS-B",
+ * 1 = "BFGS" (at most 12 design columns). */
 int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                       const double* design, const double* mu, int mu_layout,
                       const double* alpha_hat, int N, int G, int P, double min_disp,
                       double max_disp, double prior_disp_var, int cr_reg, int prior_reg,
-                      double* alpha_out, uint8_t* converged);
+                      double* alpha_out, uint8_t* converged, int optimizer);
 
 /* Inference.wald_test (inference.py:180-235; default_inference.py:163-198 ->
  * utils.wald_test utils.py:718-811).  lfc[G*P] natural log; ridge[P*P]; contrast[P];

@@ -60,7 +60,6 @@ def load():
     proto("dsq_last_error", _vp, res=C.c_char_p)
     proto("dsq_device_info", _vp, C.c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_size_t), C.c_char_p, c_int)
     proto("dsq_sync", _vp)
-    proto("dsq_set_optimizer", _vp, c_int)
     proto("dsq_debug_pending_error", res=C.c_char_p)
     proto("dsq_timer_start", _vp)
     proto("dsq_timer_stop", _vp, C.POINTER(C.c_float))
@@ -75,9 +74,9 @@ def load():
     # Inference level
     proto("dsq_inf_lin_reg_mu", _vp, _vp, c_int, c_int, _vp, _vp, c_int, c_int, c_int, c_double, _vp)
     proto("dsq_inf_irls", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double, c_double,
-          c_double, c_double, c_int, _vp, _vp, _vp, _vp)
+          c_double, c_double, c_int, _vp, _vp, _vp, _vp, c_int)
     proto("dsq_inf_alpha_mle", _vp, _vp, c_int, c_int, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_double,
-          c_double, c_double, c_int, c_int, _vp, _vp)
+          c_double, c_double, c_int, c_int, _vp, _vp, c_int)
     proto("dsq_inf_wald_test", _vp, _vp, _vp, _vp, _vp, c_int, _vp, _vp, c_double, c_int, c_int, c_int,
           c_int, _vp, _vp, _vp)
     proto("dsq_inf_fit_rough_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, c_int, _vp)
@@ -178,7 +177,7 @@ def load():
 
 
 EXPORTS = [
-    "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_set_optimizer", "dsq_debug_pending_error", "dsq_timer_start",
+    "dsq_create", "dsq_destroy", "dsq_last_error", "dsq_device_info", "dsq_sync", "dsq_debug_pending_error", "dsq_timer_start",
     "dsq_timer_stop", "dsq_last_alpha_kernel", "dsq_malloc", "dsq_free", "dsq_memset", "dsq_h2d", "dsq_d2h", "dsq_h2d_2d",
     "dsq_d2h_2d", "dsq_inf_lin_reg_mu", "dsq_inf_irls", "dsq_inf_alpha_mle", "dsq_inf_wald_test",
     "dsq_inf_fit_rough_dispersions", "dsq_inf_fit_moments_dispersions", "dsq_dev_trend_loss_grad", "dsq_dev_trend_fit", "dsq_dev_prior_mad",

@@ -216,16 +216,17 @@ class DeseqDataSet:
         X = self.obsm["design_matrix"].to_numpy() if use_design else np.ones((self.n_obs, 1))
         pipe = p0 if use_design else DeseqPipeline(self.X, X, ctx=p0.ctx, min_mu=p0.min_mu, min_disp=p0.min_disp,
                                                     max_disp=p0.max_disp, beta_tol=p0.beta_tol, fit_type=self.vst_fit_type,
-                                                    size_factors_fit_type=p0.size_factors_fit_type)
+                                                    size_factors_fit_type=p0.size_factors_fit_type,
+                                                    control_genes=self._control_genes)
         # The reference tests `"size_factors" not in self.obsm` (dds.py:404) - size factors live in .obs, so the test is
-        # always true: vst_fit() ALWAYS refits them with size_factors_fit_type and WITHOUT control genes
-        # (fit_size_factors' default) and overwrites obs["size_factors"].  Mirrored as is.
+        # always true: vst_fit() ALWAYS refits them with size_factors_fit_type and overwrites obs["size_factors"];
+        # fit_size_factors falls back to the data set's control_genes (dds.py:628-631, set in __init__, dds.py:319),
+        # so the control-gene mask stays in force.  Mirrored as is.
         old_ft, pipe.fit_type = pipe.fit_type, self.vst_fit_type
-        old_cm, pipe._control_mask = pipe._control_mask, None
         try:
             r = pipe.deseq2(stop_after_trend=True)
         finally:
-            pipe.fit_type, pipe._control_mask = old_ft, old_cm
+            pipe.fit_type = old_ft
             if pipe is not p0:
                 pipe.close()
         if pipe is p0:

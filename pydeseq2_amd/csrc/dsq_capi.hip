@@ -37,7 +37,6 @@ struct dsq_ctx {
     size_t lsf_cap = 0;
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    int optimizer = 0;            // dsq_set_optimizer: 0 L-BFGS-B (the reference's default), 1 BFGS
     const int32_t* d_irls_hint = nullptr;  // dsq_irls_order_hint: iteration counts of an earlier fit (one-shot)
     int irls_hint_genes = 0;
     void (*alpha_hook)(void*) = nullptr;  // dsq_set_alpha_hook (one-shot)
@@ -116,7 +115,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
               int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
               double* d_nll_const = nullptr, int const_mode = DSQ_CONST_COMPUTE,
-              const dsq::AlphaExtras* extras = nullptr);
+              const dsq::AlphaExtras* extras = nullptr, int optimizer = 0);
 
 // RAII device buffer for the Inference-level calls
 struct DevBuf {
@@ -244,15 +243,17 @@ int download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N
 int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx, int N,
               int G, int P, const double* d_alpha_hat, double min_disp, double max_disp, double prior_var,
               int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_conv, int32_t* d_nfev,
-              double* d_nll_const, int const_mode, const dsq::AlphaExtras* extras) {
+              double* d_nll_const, int const_mode, const dsq::AlphaExtras* extras, int optimizer) {
+    // optimizer: 0 = "L-BFGS-B" (the reference's default and the only one dds.py / ds.py use), 1 = "BFGS" (utils.py:546-554)
     if (G <= 0) return DSQ_OK;
+    DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     int32_t* d_cnt = ctx->d_counter + 4;  // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes
     DSQ_HIP(hipMemsetAsync(d_cnt, 0, 3 * sizeof(int32_t), ctx->stream));
     // two-phase launch (dsq_launch.h, AlphaExtras): parking space for the genes phase A does not finish
     dsq::AlphaExtras ex2{};
     if (extras != nullptr) ex2 = *extras;
-    if (ctx->optimizer == 0) {
+    if (optimizer == 0) {
         const size_t need = dsq::alpha_resume_bytes(G) + (size_t)G * sizeof(int32_t) + 256;
         if (need > ctx->resume_cap) {
             if (ctx->d_resume) (void)hipFree(ctx->d_resume);
@@ -269,7 +270,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         extras = &ex2;
     }
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
-    if (ctx->optimizer == 1) {
+    if (optimizer == 1) {
         DSQ_CHECK_ARG(d_mu != nullptr && P <= DSQ_BFGS_MAX_P,
                       "optimizer=\"BFGS\" takes mu_hat as a matrix and designs of at most 12 columns");
         DSQ_HIP(dsq::launch_alpha_bfgs(ctx->stream, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp,
@@ -288,7 +289,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     // ALL G genes as a capacity and the kernels read the number of fallback genes from the device - no host round trip
     // between the fit and its second pass (the refit of the outlier genes is a chain of ~15 tiny launches whose
     // synchronisations cost more than its kernels).
-    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && ctx->optimizer == 0 &&
+    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && optimizer == 0 &&
                           !dsq::alpha_is_wide(P, extras != nullptr ? extras->cells.C : 0);
     const int32_t* n_dev = deferred ? d_cnt : nullptr;
     int32_t n_grid = G;
@@ -365,12 +366,6 @@ int dsq_create(int device_id, dsq_ctx** out) {
 
 int dsq_set_deferred(dsq_ctx* ctx, int on) {
     ctx->deferred = on ? 1 : 0;
-    return DSQ_OK;
-}
-
-int dsq_set_optimizer(dsq_ctx* ctx, int optimizer) {
-    DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
-    ctx->optimizer = optimizer;
     return DSQ_OK;
 }
 
@@ -634,12 +629,14 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
              const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
              double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
              double* d_beta, double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters,
-             const dsq::IrlsExtras* extras) {
+             const dsq::IrlsExtras* extras, int optimizer = 0) {
+    // optimizer of the rescue of diverged genes (utils.py:343, 389-399): 0 = bounded L-BFGS-B (default), 1 = BFGS
     if (G <= 0) return DSQ_OK;
+    DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     dsq::IrlsExtras ex_local{};
     if (extras != nullptr) ex_local = *extras;
-    ex_local.optimizer = ctx->optimizer;
-    DSQ_CHECK_ARG(ctx->optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
+    ex_local.optimizer = optimizer;
+    DSQ_CHECK_ARG(optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
     extras = &ex_local;
     // sixteen-lane kernel: slots ordered by the predicted number of sweeps (the list lives behind the fallback list)
     const bool ordered = G >= kIrlsOrderMinGenes && dsq::irls_takes_rows(N, P, ex_local.cells.C) && irls_order_enabled();
@@ -664,7 +661,7 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
                              d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
     int32_t* h_cnt = ctx->h_pin;
     // deferred mode (see run_alpha): the rescue pass is enqueued for all G genes as a capacity, count on the device
-    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && ctx->optimizer == 0 &&
+    const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && optimizer == 0 &&
                           !dsq::irls_is_wide(P, extras->cells.C);
     int32_t n_fb = G;
     if (!deferred) {
@@ -710,9 +707,8 @@ int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
     DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr) ||
                       (d_cell_mu != nullptr && d_sf != nullptr && cells != nullptr && cells->n_cells > 0),
                   "mu_hat is needed as a matrix, as (coef, sf) or as (cell_mu, sf, cells)");
-    DSQ_CHECK_ARG(d_cell_mu == nullptr || (d_mu == nullptr && d_coef == nullptr && ctx->optimizer == 0 &&
-                                           !dsq::alpha_is_wide(P, cells->n_cells)),
-                  "cell_mu: alone, with the default optimizer, on the register kernels");
+    DSQ_CHECK_ARG(d_cell_mu == nullptr || (d_mu == nullptr && d_coef == nullptr && !dsq::alpha_is_wide(P, cells->n_cells)),
+                  "cell_mu: alone, on the register kernels");
     DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
     DSQ_CHECK_ARG(d_rows == nullptr || (n_rows >= 0 && n_waves >= 0 && n_rows + n_waves == G &&
                                         (n_waves == 0 || d_waves != nullptr)),
@@ -780,14 +776,16 @@ int dsq_side_begin(dsq_ctx* ctx) {
         // use only those K: both then run at their stand-alone speed side by side, instead of the barrier kernel's
         // workgroups time-slicing CUs with the other kernel's waves (measured: 0.51 ms alone, 1.32 ms co-scheduled).
         // (c3: 9.10 -> 8.52 ms per step at K = 32, 8.58 at 64, no gain at 16 - two barrier workgroups per CU)
-        static const int split = getenv("DSQ_CU_SPLIT") ? atoi(getenv("DSQ_CU_SPLIT")) : 32;
+        // (read per context; the 32 was tuned on a 256-CU part: a device with fewer than 4 x split compute units keeps
+        // one unmasked side stream - a robust-dispersion kernel squeezed onto cus - 32 units would serialise the stage)
+        const int split = getenv("DSQ_CU_SPLIT") ? atoi(getenv("DSQ_CU_SPLIT")) : 32;
         hipDeviceProp_t prop;
         DSQ_HIP(hipGetDeviceProperties(&prop, ctx->device));
         const int cus = prop.multiProcessorCount;
-        if (split > 0 && split < cus) {
+        if (split > 0 && cus >= 4 * split) {
             std::vector<uint32_t> big((size_t)(cus + 31) / 32, 0u), small((size_t)(cus + 31) / 32, 0u);
             // which compute units are reserved: DSQ_CU_SPLIT_MODE 0 = the first `split` mask bits, 1 = every (cus / split)-th
-            static const int mode = getenv("DSQ_CU_SPLIT_MODE") ? atoi(getenv("DSQ_CU_SPLIT_MODE")) : 0;
+            const int mode = getenv("DSQ_CU_SPLIT_MODE") ? atoi(getenv("DSQ_CU_SPLIT_MODE")) : 0;
             const int stride = cus / split;
             for (int i = 0; i < cus; ++i) {
                 const bool res = mode == 0 ? i < split : (i % stride == 0 && i / stride < split);
@@ -1305,7 +1303,7 @@ int dsq_inf_lin_reg_mu(dsq_ctx* ctx, const void* counts, int count_type, int cou
 int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                  const double* size_factors, const double* design, const double* disp, int N, int G, int P,
                  double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter,
-                 double* beta_out, double* mu_out, double* hat_out, uint8_t* converged) {
+                 double* beta_out, double* mu_out, double* hat_out, uint8_t* converged, int optimizer) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);
@@ -1320,10 +1318,10 @@ int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_lay
     DSQ_HIP(mu.alloc((size_t)G * ldn * sizeof(double)));
     DSQ_HIP(hat.alloc((size_t)G * ldn * sizeof(double)));
     DSQ_HIP(conv.alloc((size_t)G));
-    rc = dsq_dev_irls(ctx, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(), D.pinv.as<double>(),
-                      D.ldx, N, G, P, D.full_rank, d.as<double>(), min_mu, beta_tol, min_beta, max_beta,
-                      maxiter, beta.as<double>(), mu.as<double>(), hat.as<double>(), conv.as<uint8_t>(),
-                      nullptr);
+    rc = run_irls(ctx, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(), D.pinv.as<double>(),
+                  D.ldx, N, G, P, D.full_rank, d.as<double>(), min_mu, beta_tol, min_beta, max_beta,
+                  maxiter, beta.as<double>(), mu.as<double>(), hat.as<double>(), conv.as<uint8_t>(),
+                  nullptr, nullptr, optimizer);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(beta_out, beta.p, (size_t)G * P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
@@ -1336,7 +1334,7 @@ int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_lay
 int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                       const double* design, const double* mu, int mu_layout, const double* alpha_hat, int N,
                       int G, int P, double min_disp, double max_disp, double prior_disp_var, int cr_reg,
-                      int prior_reg, double* alpha_out, uint8_t* converged) {
+                      int prior_reg, double* alpha_out, uint8_t* converged, int optimizer) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);
@@ -1352,7 +1350,7 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
     DSQ_HIP(conv.alloc((size_t)G));
     if ((rc = run_alpha(ctx, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N, G, P,
                         ah.as<double>(), min_disp, max_disp, prior_disp_var, cr_reg, prior_reg, a.as<double>(),
-                        conv.as<uint8_t>(), nullptr)))
+                        conv.as<uint8_t>(), nullptr, nullptr, DSQ_CONST_COMPUTE, nullptr, optimizer)))
         return rc;
     DSQ_HIP(hipMemcpyAsync(alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));

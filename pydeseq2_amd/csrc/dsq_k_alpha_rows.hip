@@ -683,13 +683,8 @@ hipError_t launch_alpha_rows(hipStream_t st, const int32_t* y, int ldn, int N, c
                              int32_t* grid_list, double* nll_const, int const_mode, int eval_cap, void* park_state,
                              int32_t* park_count, int32_t* park_list) {
     if (n_list <= 0) return hipSuccess;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = current_device_cus();
+    if (n_cu <= 0) return hipGetLastError();
     const size_t smem = alpha_rows_smem(N);
     const int per_block = kRowSlots * kRowWaves;
     int blocks = (n_list + per_block - 1) / per_block;

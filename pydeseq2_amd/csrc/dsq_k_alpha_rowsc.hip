@@ -453,13 +453,8 @@ hipError_t launch_alpha_rows_c(hipStream_t st, const int32_t* y, int ldn, int N,
     if (n_list <= 0) return hipSuccess;
     const int ntail = alpha_rowsc_tail(N, P_, cells.C);
     if (ntail == 0 || (coef == nullptr) == (cell_mu == nullptr)) return hipErrorInvalidValue;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = current_device_cus();
+    if (n_cu <= 0) return hipGetLastError();
     const size_t smem = rowsc_smem(N, P_, ntail);
     const int per_block = kRowSlots * kRowWaves;
     int blocks = (n_list + per_block - 1) / per_block;

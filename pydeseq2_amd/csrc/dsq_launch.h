@@ -15,6 +15,19 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 
 inline int genes_to_blocks(int G) { return (G + kWavesPerBlock - 1) / kWavesPerBlock; }
 
+// compute units of the CURRENT device (the persistent kernels size their grids by it; a process may drive several
+// different GPUs, one context each: cached per device ordinal, not per process); 0 on error
+inline int current_device_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cache[dev] = prop.multiProcessorCount;
+    return prop.multiProcessorCount;
+}
+
 // waves per SIMD requested for the cell-path kernels: their sample loops need few registers at any P, but the
 // p x p algebra between the loops (Cholesky, inverse, Wald) holds 2-3 packed matrices
 #ifndef DSQ_CELL_WAVES_WIDE

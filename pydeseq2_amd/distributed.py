@@ -153,12 +153,32 @@ class TcpControl:
             srv.listen(world)
             srv.settimeout(timeout)
             peers = {}
+            deadline = time.time() + timeout
             while len(peers) < world - 1:
-                c, _a = srv.accept()
-                c.settimeout(timeout)
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.sendall(self.MAGIC + int(port).to_bytes(4, "little"))  # (the job's base port: two jobs with overlapping port ranges do not adopt each other's ranks)
-                r = int.from_bytes(self._recvn(c, 4), "little")
+                left = deadline - time.time()
+                if left <= 0:
+                    srv.close()
+                    raise TimeoutError(f"control plane: {world - 1 - len(peers)} rank(s) did not connect")
+                srv.settimeout(left)
+                try:
+                    c, _a = srv.accept()
+                except socket.timeout:
+                    continue
+                # A connection that is not one of this job's ranks (a rank of another job probing the port range reads
+                # the greeting, sees another base port and hangs up; a port scanner; a health probe) must not take the
+                # hub down: its handshake fails, the socket is closed, the hub keeps accepting until the deadline.
+                try:
+                    c.settimeout(min(5.0, max(left, 0.1)))
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    # (the job's base port: two jobs with overlapping port ranges do not adopt each other's ranks)
+                    c.sendall(self.MAGIC + int(port).to_bytes(4, "little"))
+                    r = int.from_bytes(self._recvn(c, 4), "little")
+                    if not (1 <= r < world) or r in peers:
+                        raise ConnectionError(f"control plane: unexpected rank {r}")
+                    c.settimeout(timeout)
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
                 peers[r] = c
             srv.close()
             self.peers = [peers[r] for r in range(1, world)]

@@ -17,6 +17,7 @@ import numpy as np
 from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context
 
 _vp, c_int, c_double = C.c_void_p, C.c_int, C.c_double
+_OPTIMIZER = {"L-BFGS-B": 0, "BFGS": 1}  # the `optimizer` argument of dsq_inf_irls / dsq_inf_alpha_mle
 
 
 def _counts_arg(counts):
@@ -104,28 +105,12 @@ class HipInference:
         sf, d = _vec(size_factors), _vec(disp)
         beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
         conv = np.empty(G, dtype=np.uint8)
-        with self._optimizer(optimizer):  # the rescue of diverged genes: bounded L-BFGS-B or scipy's BFGS restated
-            self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
-                          _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
-                          c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
-                          _vp(H.ctypes.data), _vp(conv.ctypes.data))
+        # last argument: the rescue of diverged genes - bounded L-BFGS-B (0) or scipy's BFGS restated (1)
+        self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
+                      _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
+                      c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
+                      _vp(H.ctypes.data), _vp(conv.ctypes.data), _OPTIMIZER[optimizer])
         return beta, mu.T, H.T, conv.astype(bool)
-
-    def _optimizer(self, name):
-        """Context manager: optimizer="BFGS" for the C calls inside (utils.py:343, 546-554), back to the default after."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def cm():
-            if name == "BFGS":
-                self.ctx.call("dsq_set_optimizer", 1)
-            try:
-                yield
-            finally:
-                if name == "BFGS":
-                    self.ctx.call("dsq_set_optimizer", 0)
-
-        return cm()
 
     # ------------------------------------------------------------------ alpha_mle
     def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
@@ -140,11 +125,10 @@ class HipInference:
         m, mlay = _matrix_arg(mu)
         ah = _vec(alpha_hat)
         out, conv = np.empty(G), np.empty(G, dtype=np.uint8)
-        with self._optimizer(optimizer):
-            self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
-                          mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
-                          c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
-                          int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data))
+        self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
+                      mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
+                      c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
+                      int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data), _OPTIMIZER[optimizer])
         return out, conv.astype(bool)
 
     # ------------------------------------------------------------------ wald_test

@@ -346,7 +346,8 @@ class DeseqPipeline:
     # host buffer, so that they come back with two DMA copies at the end of the step instead of ~20
     # pageable round trips in between.  _F64 / _U8 name the vectors (each Gs long; "beta" is Gs x P).
     _F64 = ("nm", "mom", "gw", "fit", "map", "disp", "p", "stat", "se", "rd")
-    _U8 = ("gconv", "mconv", "outl", "lconv", "any_all", "any_use", "any_use_nr", "few_above")
+    # ("naz": all counts zero after the outlier replacement - written by k_replace for the refit's sub-problem only)
+    _U8 = ("gconv", "mconv", "outl", "lconv", "any_all", "any_use", "any_use_nr", "few_above", "naz")
 
     def _slab_layout(self, Gs):
         off, o = {}, 0
@@ -870,7 +871,7 @@ class DeseqPipeline:
                 d_rp = self._up(rp.astype(np.int32), np.int32)
                 d_ysub = self._dmat(Gr, np.int32)
                 S2 = self._dev_slab(Gr)
-                d_az = S2["any_all"]  # (a flag vector the sub-problem does not use)
+                d_az = S2["naz"]  # its own field: no stage of the sub-problem writes it
                 ctx.call("dsq_dev_replace_outliers", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
                          _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(cutoff), _vp(d_ysub.ptr),
                          _vp(d_az.ptr))
@@ -910,7 +911,7 @@ class DeseqPipeline:
         pv, st, se = H["p"], H["stat"], H["se"]
         if patch is not None:  # dds.py:1368-1458: the refitted genes take their new values
             rp, h2 = patch[0], self._fetch_end(patch[1])
-            naz = h2["any_all"].astype(bool)  # all counts zero after the replacement (dds.py:1368-1383)
+            naz = h2["naz"].astype(bool)  # all counts zero after the replacement (dds.py:1368-1383)
             new_zero_nz[rp[naz]] = True
             refitted_nz[rp[~naz]] = True
             rf, k = rp[~naz], np.nonzero(~naz)[0]

@@ -143,7 +143,7 @@ def kat_case(name, counts, X, ut, gs, pp, di, n_grid=3):
     mu_w = np.exp(X @ beta.T) * sf[:, None]
     ridge = np.diag(np.repeat(1e-6, p))
     contrast = np.zeros(p)
-    contrast[1] = 1.0
+    contrast[min(1, p - 1)] = 1.0
     out["contrast"] = contrast
     for alt, null in ((None, 0.0), ("greater", 0.5), ("less", -0.5), ("greaterAbs", 0.5),
                       ("lessAbs", 0.5)):
@@ -393,6 +393,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "narrow":  # round 3: design widths 3, 5, 6, 7
         narrow_cases(ut, gs, pp, di)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "widths":  # round 4: design widths 1, 9, 11 and the mixed p = 8 design
+        width_cases(ut, gs, pp, di)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
         wide_cases(ut, gs, pp, di)
         hard_cases(ut, gs)
@@ -425,6 +428,7 @@ def main():
 
     wide_cases(ut, gs, pp, di)
     narrow_cases(ut, gs, pp, di)
+    width_cases(ut, gs, pp, di)
     hard_cases(ut, gs)
     bfgs_cases(ut)
     rest_of_main(ut)
@@ -467,6 +471,27 @@ def narrow_cases(ut, gs, pp, di):
         X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
         assert X.shape[1] == pw
         kat_case(f"p{pw}", synth(40, N, X, seed, eff=0.5), X, ut, gs, pp, di)
+
+
+def width_cases(ut, gs, pp, di):
+    """cases L..O (round 4): the design widths that had no reference KAT - p = 1 (intercept only: what vst() fits), p = 9 and
+    p = 11 (register path with the split second sweep) - and "p8m", the benchmark's MIXED design shape (BASELINE
+    configs[4]: a 2-level and a 4-level factor + three continuous covariates, p = 8) for the kernels that split
+    X^T W X into a per-cell block and a small continuous block."""
+    specs = {"p1": (1, 24, 31), "p9": (9, 100, 32), "p11": (11, 110, 33), "p8m": (8, 160, 34)}
+    for name, (pw, N, seed) in specs.items():
+        rng = np.random.default_rng(400 + pw + (50 if name == "p8m" else 0))
+        i = np.arange(N)
+        if pw == 1:
+            cols = [np.ones(N)]
+        else:
+            a, b = i % 2, (i // 2) % 4
+            cols = [np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)]
+            while len(cols) < pw:
+                cols.append(rng.normal(0, 0.6 if name != "p8m" else 1.0, N))
+        X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
+        assert X.shape[1] == pw
+        kat_case(name, synth(40, N, X, seed, eff=0.4), X, ut, gs, pp, di)
 
 
 def shrink_wide_cases(ut):

@@ -153,6 +153,59 @@ def test_tcp_control_plane_carries_the_protocol(world):
         assert uid == b"u" * 128 and mx == 1.5 * (world - 1)
 
 
+def test_tcp_hub_survives_connections_that_are_not_its_ranks():
+    """A rank of another job that probes this hub's port range (reads the greeting, sees another base port, hangs up), a
+    port scanner or a health probe must not take rank 0 down: the failed handshake is dropped and the hub keeps
+    accepting; a connection that claims a rank outside 1..world-1 or a rank that is already connected is refused."""
+    import socket
+    import threading
+    import time
+
+    port = _free_port()
+    out = {}
+
+    def hub():
+        try:
+            out["ctl"] = D.TcpControl(0, 2, "127.0.0.1", port, timeout=30)
+        except BaseException as e:  # noqa: BLE001
+            out["err"] = e
+
+    th = threading.Thread(target=hub)
+    th.start()
+
+    def connect():
+        for _ in range(200):
+            for pt in range(port + 1, port + 32):
+                try:
+                    return socket.create_connection(("127.0.0.1", pt), timeout=1)
+                except OSError:
+                    continue
+            time.sleep(0.02)
+        raise AssertionError("hub not reachable")
+
+    c = connect()
+    c.close()                                   # a probe that hangs up at once
+    c = connect()
+    c.recv(12)
+    c.close()                                   # another job's rank: reads the greeting, hangs up
+    c = connect()
+    c.recv(12)
+    c.sendall((7).to_bytes(4, "little"))        # a rank this job does not have
+    time.sleep(0.1)
+    c.close()
+    real = D.TcpControl(1, 2, "127.0.0.1", port, timeout=30)
+    th.join(timeout=30)
+    assert "err" not in out, out.get("err")
+    got = {}
+    t2 = threading.Thread(target=lambda: got.setdefault("v", out["ctl"].allgather_bytes(b"a")))
+    t2.start()
+    assert real.allgather_bytes(b"b") == [b"a", b"b"]
+    t2.join(timeout=30)
+    assert got["v"] == [b"a", b"b"]
+    real.close()
+    out["ctl"].close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bench.py's multi-GPU plan: which block of which matrix a rank works on, and the hand launcher
 @pytest.mark.parametrize("config,genes,world", [("c2", 900, 2), ("c2", 1000, 3), ("c5", 1300, 2), ("c5", 1700, 3)])

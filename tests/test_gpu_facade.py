@@ -104,6 +104,14 @@ def test_size_factor_modes():
     np.testing.assert_array_almost_equal(dds.obs["size_factors"], expect)
     dds.fit_size_factors(fit_type="poscounts")
     np.testing.assert_array_almost_equal(dds.obs["size_factors"], expect)
+    # vst_fit() refits the size factors through fit_size_factors, which falls back to the data set's control genes
+    # (dds.py:404-407, 628-631): both vst routes keep them
+    mask = np.zeros(c.shape[1], dtype=bool)
+    mask[[1, 3, 6]] = True
+    for use_design in (False, True):
+        dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition", control_genes=np.nonzero(mask)[0])
+        dds.vst_fit(use_design=use_design)
+        np.testing.assert_allclose(dds.obs["size_factors"], orc.size_factors_control(c, mask), rtol=1e-12)
     # zeros in the matrix: poscounts uses the positive entries only
     z = c.copy()
     z[::3, ::2] = 0

@@ -62,7 +62,7 @@ def test_dispersion_kernel_every_design_width(inf, P):
         assert (rel > 1e-6).mean() <= 0.03 and rel.max() < 5e-3, (P, bool(kw), np.sort(rel)[-5:])
 
 
-@pytest.mark.parametrize("case", ["p2", "p3", "p4", "p5", "p6", "p7", "p8", "p10", "p12", "p16", "p24"])
+@pytest.mark.parametrize("case", ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12", "p16", "p24"])
 def test_inference_vs_reference_kats(inf, case):
     """Every Inference method on the device against the outputs of the unmodified reference kernels.
     p = 10, 12: the split second sweep of the register path; p = 16, 24: the LDS / MFMA path for designs

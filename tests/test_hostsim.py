@@ -15,7 +15,7 @@ from oracle import nbglm_oracle as orc
 from tests import hostsim as hs
 from tests.helpers import assert_close, check_hard_dispersion_genes, check_hard_lfc_genes, load_kat
 
-CASES = ["p2", "p3", "p4", "p5", "p6", "p7", "p8", "p10", "p12"]
+CASES = ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12"]
 
 
 def test_special_functions():

@@ -292,6 +292,33 @@ int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
                        const int32_t* d_waves, int n_waves, const double* d_cell_mu);
+/* MIXED designs: a few categorical columns (at most 32 distinct rows: "cells") + one to three continuous covariates,
+ * at most 8 columns (BASELINE configs[4]; csrc/dsq_mix.h, dsq_k_alpha_mix.hip).  The reference treats every design alike
+ * (utils.py:441-564, 273-438: N outer products x_n x_n^T per evaluation); here X^T W X splits into a per-cell block, a
+ * per-cell x covariate block and a small covariate block, and the samples are walked sorted by cell.
+ * dsq_mix_create analyses a design (host, row-major N x P) once and keeps its slot order, cell table and sorted
+ * covariates on the device; *out = NULL with DSQ_OK when the design is not one these kernels take (no continuous column
+ * needed, too many covariates / columns / cells, mostly padding, rows too long) - the caller then stays on the other
+ * paths.  Environment: DSQ_NO_ALPHA_MIX=1 disables the family, DSQ_MIX_FORCE=1 lifts the padding limit (tests). */
+typedef struct dsq_mix dsq_mix;
+int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** out);
+void dsq_mix_destroy(dsq_mix* mix);
+int dsq_mix_info(const dsq_mix* mix, int* n_slots, int* n_cells, int* n_continuous);
+/* diagnostics: launches of the mixed-design dispersion kernel by this process so far */
+int dsq_mix_launch_count(void);
+/* dsq_dev_alpha_mle3 with a mixed design: the genes of d_rows run k_alpha_mix (one gene per wavefront, counts staged as
+ * uint16: dsq_dev_alpha_row_split says which genes fit), those of d_waves the general kernel (they need d_mu).
+ * d_beta != NULL (with d_mu == d_coef == d_cell_mu == NULL, n_waves == 0): mu_hat = d_sf * exp(X d_beta), the UNclamped
+ * mean of the IRLS mu_hat route (dds.py:757-771, utils.py:435-437), rebuilt inside the kernel from the [G][P]
+ * coefficients - the N x G matrix is neither written nor read.  d_beta == NULL: mu_hat gathered from d_mu.  mix == NULL:
+ * as dsq_dev_alpha_mle3. */
+int dsq_dev_alpha_mle4(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
+                       const int32_t* d_waves, int n_waves, const double* d_cell_mu, const dsq_mix* mix,
+                       const double* d_beta);
 /* 0: no row kernel for such a design; 1: at most 4 cells == columns (linear-model mu_hat); 2: up to 32 cells, p <= 8
  * (csrc/dsq_k_alpha_rowsc.hip; both mu_hat routes - the IRLS route hands over d_cell_mu, [G][n_cells] = exp(x_c . beta) from
  * dsq_dev_cell_mu, and mu_hat_n = sf_n * cell_mu[cell_of[n]] unclamped (utils.py:435-437) is never materialised). */

@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,13 @@
 
 #include "../../include/deseq_hip.h"
 #include "dsq_launch.h"
+
+// a mixed design on the device (dsq_mix_create): csrc/dsq_mix.h
+struct dsq_mix {
+    dsq::MixDesign d{};
+    void* d_block = nullptr;  // one allocation behind all of d's pointers
+    int device = 0;
+};
 
 struct dsq_ctx {
     int device = 0;
@@ -47,6 +55,8 @@ struct dsq_ctx {
     size_t ws_cap = 0;
     void* d_resume = nullptr;     // parked optimiser states + gene list of the two-phase dispersion launch (grow-only)
     size_t resume_cap = 0;
+    void* d_mix = nullptr;        // wave-private mu_hat rows of the mixed-design dispersion kernel (grow-only)
+    size_t mix_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -248,8 +258,9 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     if (G <= 0) return DSQ_OK;
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     DSQ_HIP(ensure_list(ctx, (size_t)G));
-    int32_t* d_cnt = ctx->d_counter + 4;  // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes
-    DSQ_HIP(hipMemsetAsync(d_cnt, 0, 3 * sizeof(int32_t), ctx->stream));
+    // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes, [3] gene queue of the continuation launch
+    int32_t* d_cnt = ctx->d_counter + 4;
+    DSQ_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int32_t), ctx->stream));
     // two-phase launch (dsq_launch.h, AlphaExtras): parking space for the genes phase A does not finish
     dsq::AlphaExtras ex2{};
     if (extras != nullptr) ex2 = *extras;
@@ -267,6 +278,24 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         ex2.resume_count = d_cnt + 2;
         ex2.mid_hook = ctx->alpha_hook != nullptr ? fire_alpha_hook : nullptr;
         ex2.mid_arg = ctx;
+        if (ex2.mix != nullptr && ex2.rows != nullptr && ex2.n_rows > 0) {
+            // wave-private mu_hat rows of the mixed-design kernel (persistent launch: a fixed number of wavefronts)
+            const size_t need_d = dsq::alpha_mix_scratch_doubles(*ex2.mix, ex2.n_rows);
+            if (need_d == 0) {
+                ex2.mix = nullptr;  // rows too long for that kernel: the general one takes every gene
+            } else {
+                if (need_d * sizeof(double) > ctx->mix_cap) {
+                    if (ctx->d_mix) (void)hipFree(ctx->d_mix);
+                    ctx->d_mix = nullptr; ctx->mix_cap = 0;
+                    DSQ_HIP(hipMalloc(&ctx->d_mix, need_d * sizeof(double)));
+                    ctx->mix_cap = need_d * sizeof(double);
+                }
+                ex2.mix_scratch = (double*)ctx->d_mix;
+                ex2.mix_scratch_doubles = ctx->mix_cap / sizeof(double);
+            }
+        }
+        if (ex2.mix == nullptr && d_mu == nullptr && ex2.mix_beta != nullptr)
+            return fail(ctx, DSQ_ERR_ARG, "mu_hat from IRLS coefficients needs the mixed-design kernel (rows too long)");
         extras = &ex2;
     }
     DSQ_HIP(hipEventRecord(ctx->evk0, ctx->stream));
@@ -308,7 +337,8 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         // next: no host synchronisation, no allocation (workspace carved from ctx->d_ws)
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const bool from_cells = extras != nullptr && extras->cell_mu != nullptr;
-        const bool rebuild = extras != nullptr && (extras->coef != nullptr || from_cells);
+        const bool from_beta = extras != nullptr && extras->mix_beta != nullptr && d_mu == nullptr;
+        const bool rebuild = extras != nullptr && (extras->coef != nullptr || from_cells || from_beta);
         const size_t b_work = up((size_t)n_grid * dsq::kAlphaGridWorkDoubles * sizeof(double));
         const size_t b_mu = rebuild ? up((size_t)n_grid * ldn * sizeof(double)) : 0;
         const size_t b_idx = rebuild ? up((size_t)n_grid * sizeof(int32_t)) : 0;
@@ -320,7 +350,10 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             // counts and write the result through the list
             double* musub = (double*)(w + b_work);
             int32_t* idx = (int32_t*)(w + b_work + b_mu);
-            if (from_cells)
+            if (from_beta)
+                DSQ_HIP(dsq::launch_mu_from_beta(ctx->stream, extras->mix_beta, extras->sf, d_Xt, ldx, N, P, ctx->d_list,
+                                                 n_grid, musub, ldn, idx, n_dev));
+            else if (from_cells)
                 DSQ_HIP(dsq::launch_mu_from_cells(ctx->stream, extras->cell_mu, extras->cells.C, extras->sf,
                                                   extras->cells.cell_of, N, ctx->d_list, n_grid, musub, ldn, idx, n_dev));
             else
@@ -377,6 +410,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_list) (void)hipFree(ctx->d_list);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_resume) (void)hipFree(ctx->d_resume);
+    if (ctx->d_mix) (void)hipFree(ctx->d_mix);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
@@ -696,17 +730,24 @@ dsq::CellDesign to_cells(const dsq_cells* c) {
 }
 }  // namespace
 
-int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+int dsq_dev_alpha_mle4(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
                        int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
                        double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
                        int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
                        const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
-                       const int32_t* d_waves, int n_waves, const double* d_cell_mu) {
+                       const int32_t* d_waves, int n_waves, const double* d_cell_mu, const dsq_mix* mix,
+                       const double* d_beta) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(const_mode >= DSQ_CONST_COMPUTE && const_mode <= DSQ_CONST_LOAD, "const_mode out of range");
     DSQ_CHECK_ARG(d_mu != nullptr || (d_coef != nullptr && d_sf != nullptr) ||
-                      (d_cell_mu != nullptr && d_sf != nullptr && cells != nullptr && cells->n_cells > 0),
-                  "mu_hat is needed as a matrix, as (coef, sf) or as (cell_mu, sf, cells)");
+                      (d_cell_mu != nullptr && d_sf != nullptr && cells != nullptr && cells->n_cells > 0) ||
+                      (mix != nullptr && d_beta != nullptr && d_sf != nullptr),
+                  "mu_hat is needed as a matrix, as (coef, sf), as (cell_mu, sf, cells) or as (mix, beta, sf)");
+    DSQ_CHECK_ARG(mix == nullptr || (mix->d.P == P && mix->d.N == N && d_rows != nullptr),
+                  "mix: built for another design, or the gene lists are missing");
+    DSQ_CHECK_ARG(d_beta == nullptr || (mix != nullptr && d_mu == nullptr && d_coef == nullptr && d_cell_mu == nullptr &&
+                                        n_waves == 0),
+                  "beta: with mix only, alone, and every gene on the mixed-design kernel");
     DSQ_CHECK_ARG(d_cell_mu == nullptr || (d_mu == nullptr && d_coef == nullptr && !dsq::alpha_is_wide(P, cells->n_cells)),
                   "cell_mu: alone, on the register kernels");
     DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
@@ -717,8 +758,20 @@ int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
     ex.cells = to_cells(cells);
     if (d_mu == nullptr) { ex.coef = d_coef; ex.cell_mu = d_cell_mu; ex.sf = d_sf; ex.min_mu = min_mu; }
     if (d_rows != nullptr) { ex.rows = d_rows; ex.n_rows = n_rows; ex.waves = d_waves; ex.n_waves = n_waves; }
+    if (mix != nullptr) { ex.mix = &mix->d; ex.mix_beta = d_beta; ex.sf = d_sf; }
     return run_alpha(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var, cr_reg,
                      prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, &ex);
+}
+
+int dsq_dev_alpha_mle3(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
+                       int N, int G, int P, const double* d_alpha_hat, double min_disp, double max_disp,
+                       double prior_disp_var, int cr_reg, int prior_reg, double* d_alpha, uint8_t* d_converged,
+                       int32_t* d_nfev, double* d_nll_const, int const_mode, const dsq_cells* cells,
+                       const double* d_coef, const double* d_sf, double min_mu, const int32_t* d_rows, int n_rows,
+                       const int32_t* d_waves, int n_waves, const double* d_cell_mu) {
+    return dsq_dev_alpha_mle4(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
+                              cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, cells, d_coef,
+                              d_sf, min_mu, d_rows, n_rows, d_waves, n_waves, d_cell_mu, nullptr, nullptr);
 }
 
 int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, const double* d_Xt, int ldx,
@@ -729,6 +782,180 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
     return dsq_dev_alpha_mle3(ctx, d_y, d_mu, ldn, d_Xt, ldx, N, G, P, d_alpha_hat, min_disp, max_disp, prior_disp_var,
                               cr_reg, prior_reg, d_alpha, d_converged, d_nfev, d_nll_const, const_mode, cells, d_coef,
                               d_sf, min_mu, nullptr, 0, nullptr, 0, nullptr);
+}
+
+// ------------------------------------------------------------------ mixed designs (csrc/dsq_mix.h)
+// Analysis of a design matrix (row-major N x P), once per design: which columns are continuous covariates, the cells
+// of the remaining (categorical) columns, the slot order of the samples.  *out = NULL (and DSQ_OK): not a mixed
+// design the kernels take - the caller stays on the general path.
+int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** out) {
+    DSQ_CHECK_ARG(out != nullptr && design != nullptr, "null argument");
+    *out = nullptr;
+    if (P < 1 || P > dsq::kMixMaxP || N < 2 || N > 65535 || !dsq::alpha_mix_enabled()) return DSQ_OK;
+    const bool force = getenv("DSQ_MIX_FORCE") != nullptr;  // tests: also designs whose padding exceeds the waste limit
+    // columns by decreasing number of distinct values
+    std::vector<int> nd((size_t)P), order((size_t)P);
+    for (int j = 0; j < P; ++j) {
+        std::vector<double> col((size_t)N);
+        for (int n = 0; n < N; ++n) col[(size_t)n] = design[(size_t)n * P + j];
+        std::sort(col.begin(), col.end());
+        nd[(size_t)j] = (int)(std::unique(col.begin(), col.end()) - col.begin());
+        order[(size_t)j] = j;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nd[(size_t)a] > nd[(size_t)b]; });
+    std::vector<char> cont((size_t)P, 0);
+    std::vector<int> idx((size_t)N), cell((size_t)N);
+    int C = 0;
+    auto less_cat = [&](int a, int b) {  // lexicographic on the categorical columns, then by sample index
+        for (int j = 0; j < P; ++j) {
+            if (cont[(size_t)j]) continue;
+            const double va = design[(size_t)a * P + j], vb = design[(size_t)b * P + j];
+            if (va != vb) return va < vb;
+        }
+        return a < b;
+    };
+    auto same_cat = [&](int a, int b) {
+        for (int j = 0; j < P; ++j)
+            if (!cont[(size_t)j] && design[(size_t)a * P + j] != design[(size_t)b * P + j]) return false;
+        return true;
+    };
+    auto find_cells = [&]() {
+        for (int n = 0; n < N; ++n) idx[(size_t)n] = n;
+        std::sort(idx.begin(), idx.end(), less_cat);
+        C = 0;
+        for (int k = 0; k < N; ++k) {
+            if (k > 0 && !same_cat(idx[(size_t)k - 1], idx[(size_t)k])) ++C;
+            cell[(size_t)idx[(size_t)k]] = C;
+        }
+        ++C;
+    };
+    int Q = 0;
+    find_cells();
+    while (C > dsq::kMixMaxCells && Q < dsq::kMixMaxQ && Q < P) {
+        cont[(size_t)order[(size_t)Q]] = 1;
+        ++Q;
+        find_cells();
+    }
+    if (Q == 0 || C > dsq::kMixMaxCells) return DSQ_OK;  // purely categorical (the cell kernels), or too many covariates
+    // slot order: cells one after the other (idx is sorted by cell, then sample), each padded to whole loop iterations
+    // of the kernels (kMixU trips of 64 slots)
+    std::vector<int> count((size_t)C, 0);
+    for (int n = 0; n < N; ++n) ++count[(size_t)cell[(size_t)n]];
+    const int blk = 64 * dsq::kMixU;
+    int Ns = 0;
+    for (int c = 0; c < C; ++c) Ns += (count[(size_t)c] + blk - 1) / blk * blk;
+    if (!force && Ns > N + N / 2 + blk) return DSQ_OK;  // mostly padding (small cells): the general kernels do less work
+    dsq::MixDesign M{};
+    M.Ns = Ns; M.C = C; M.Q = Q; M.P = P; M.N = N;
+    {
+        int q = 0;
+        for (int j = 0; j < P; ++j) {
+            M.colq[j] = cont[(size_t)j] ? q : -1;
+            if (cont[(size_t)j]) M.zcol[q++] = j;
+        }
+    }
+    if (dsq::alpha_mix_scratch_doubles(M, 4) == 0) return DSQ_OK;  // rows too long for the kernel's LDS staging
+    std::vector<int32_t> perm((size_t)Ns, -1);
+    std::vector<uint8_t> trip_cell((size_t)(Ns / 64), (uint8_t)(C - 1));
+    std::vector<double> Zs((size_t)Q * Ns, 0.0), Xc((size_t)C * P, 0.0), Ginv;
+    {
+        int s = 0, k = 0;
+        for (int c = 0; c < C; ++c) {
+            const int s0 = s;
+            for (int i = 0; i < count[(size_t)c]; ++i, ++k, ++s) {
+                const int n = idx[(size_t)k];
+                perm[(size_t)s] = n;
+                for (int q = 0; q < Q; ++q) Zs[(size_t)q * Ns + s] = design[(size_t)n * P + M.zcol[q]];
+                if (i == 0)
+                    for (int j = 0; j < P; ++j) Xc[(size_t)c * P + j] = cont[(size_t)j] ? 0.0 : design[(size_t)n * P + j];
+            }
+            s = s0 + (count[(size_t)c] + blk - 1) / blk * blk;
+            for (int t = s0 / 64; t < s / 64; ++t) trip_cell[(size_t)t] = (uint8_t)c;
+        }
+    }
+    {   // (X^T X)^-1 by Cholesky in extended precision (start values of the IRLS kernel); skipped when rank deficient
+        std::vector<long double> A((size_t)P * P, 0.0L), Li((size_t)P * P, 0.0L);
+        for (int n = 0; n < N; ++n)
+            for (int i = 0; i < P; ++i)
+                for (int j = 0; j <= i; ++j) A[(size_t)i * P + j] += (long double)design[(size_t)n * P + i] * design[(size_t)n * P + j];
+        bool ok = true;
+        long double dmax_ = 0.0L;
+        for (int i = 0; i < P; ++i) dmax_ = std::max(dmax_, A[(size_t)i * P + i]);
+        for (int j = 0; j < P && ok; ++j) {
+            long double d = A[(size_t)j * P + j];
+            for (int k = 0; k < j; ++k) d -= A[(size_t)j * P + k] * A[(size_t)j * P + k];
+            if (!(d > dmax_ * 1e-13L)) { ok = false; break; }
+            d = std::sqrt(d);
+            A[(size_t)j * P + j] = d;
+            for (int i = j + 1; i < P; ++i) {
+                long double v = A[(size_t)i * P + j];
+                for (int k = 0; k < j; ++k) v -= A[(size_t)i * P + k] * A[(size_t)j * P + k];
+                A[(size_t)i * P + j] = v / d;
+            }
+        }
+        if (ok) {
+            for (int j = 0; j < P; ++j) {  // L^-1, column by column
+                Li[(size_t)j * P + j] = 1.0L / A[(size_t)j * P + j];
+                for (int i = j + 1; i < P; ++i) {
+                    long double v = 0.0L;
+                    for (int k = j; k < i; ++k) v -= A[(size_t)i * P + k] * Li[(size_t)k * P + j];
+                    Li[(size_t)i * P + j] = v / A[(size_t)i * P + i];
+                }
+            }
+            Ginv.assign((size_t)P * P, 0.0);
+            for (int i = 0; i < P; ++i)
+                for (int j = 0; j < P; ++j) {
+                    long double v = 0.0L;
+                    for (int k = std::max(i, j); k < P; ++k) v += Li[(size_t)k * P + i] * Li[(size_t)k * P + j];
+                    Ginv[(size_t)i * P + j] = (double)v;
+                }
+        }
+    }
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_perm = up((size_t)Ns * 4), b_tc = up((size_t)Ns / 64), b_z = up((size_t)Q * Ns * 8),
+                 b_xc = up((size_t)C * P * 8), b_g = up((size_t)P * P * 8);
+    dsq_mix* m = new dsq_mix();
+    m->device = ctx->device;
+    hipError_t e = hipMalloc(&m->d_block, b_perm + b_tc + b_z + b_xc + b_g);
+    if (e != hipSuccess) { delete m; return fail(ctx, DSQ_ERR_HIP, std::string("dsq_mix_create: ") + hipGetErrorString(e)); }
+    char* p = (char*)m->d_block;
+    auto put = [&](const void* src, size_t bytes, size_t slot) {
+        char* dst = p;
+        if (e == hipSuccess && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+        p += slot;
+        return dst;
+    };
+    M.perm = (const int32_t*)put(perm.data(), (size_t)Ns * 4, b_perm);
+    M.trip_cell = (const uint8_t*)put(trip_cell.data(), (size_t)Ns / 64, b_tc);
+    M.Zs = (const double*)put(Zs.data(), (size_t)Q * Ns * 8, b_z);
+    M.Xc = (const double*)put(Xc.data(), (size_t)C * P * 8, b_xc);
+    const char* g = put(Ginv.empty() ? nullptr : Ginv.data(), Ginv.empty() ? 0 : (size_t)P * P * 8, b_g);
+    M.Ginv = Ginv.empty() ? nullptr : (const double*)g;
+    if (e != hipSuccess) {
+        (void)hipFree(m->d_block);
+        delete m;
+        return fail(ctx, DSQ_ERR_HIP, std::string("dsq_mix_create: ") + hipGetErrorString(e));
+    }
+    m->d = M;
+    *out = m;
+    return DSQ_OK;
+}
+
+void dsq_mix_destroy(dsq_mix* mix) {
+    if (mix == nullptr) return;
+    (void)hipSetDevice(mix->device);
+    if (mix->d_block) (void)hipFree(mix->d_block);
+    delete mix;
+}
+
+int dsq_mix_launch_count(void) { return dsq::alpha_mix_launches(); }
+
+int dsq_mix_info(const dsq_mix* mix, int* n_slots, int* n_cells, int* n_continuous) {
+    if (mix == nullptr) return DSQ_ERR_ARG;
+    if (n_slots) *n_slots = mix->d.Ns;
+    if (n_cells) *n_cells = mix->d.C;
+    if (n_continuous) *n_continuous = mix->d.Q;
+    return DSQ_OK;
 }
 
 int dsq_alpha_needs_mu(int N, int P, int n_cells) { return dsq::alpha_needs_mu(N, P, n_cells) ? 1 : 0; }
@@ -1348,9 +1575,36 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
     if ((rc = upload_vec(ctx, alpha_hat, (size_t)G * sizeof(double), ah))) return rc;
     DSQ_HIP(a.alloc((size_t)G * sizeof(double)));
     DSQ_HIP(conv.alloc((size_t)G));
+    // mixed designs (categorical columns + up to three continuous covariates, csrc/dsq_mix.h): the kernel family of
+    // the pipeline, here with mu gathered from the caller's matrix; genes with a count beyond its 16-bit staging stay on
+    // the general kernel
+    struct MixGuard {
+        dsq_mix* m = nullptr;
+        ~MixGuard() { dsq_mix_destroy(m); }
+    } mg;
+    dsq::AlphaExtras ex{};
+    DevBuf flags, d_rows, d_waves;
+    if (cr_reg != 0 && optimizer == 0) {
+        if ((rc = dsq_mix_create(ctx, design, N, P, &mg.m))) return rc;
+    }
+    if (mg.m != nullptr) {
+        DSQ_HIP(flags.alloc((size_t)G * sizeof(int32_t)));
+        DSQ_HIP(dsq::launch_count_big(ctx->stream, y.as<int32_t>(), ldn, N, G, flags.as<int32_t>()));
+        std::vector<int32_t> fl((size_t)G), rows, waves;
+        DSQ_HIP(hipMemcpyAsync(fl.data(), flags.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < G; ++g) (fl[(size_t)g] >= 0 ? rows : waves).push_back(g);
+        if ((rc = upload_vec(ctx, rows.data(), rows.size() * sizeof(int32_t), d_rows))) return rc;
+        if ((rc = upload_vec(ctx, waves.data(), waves.size() * sizeof(int32_t), d_waves))) return rc;
+        DSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host lists go out of scope
+        ex.mix = &mg.m->d;
+        ex.rows = d_rows.as<int32_t>(); ex.n_rows = (int)rows.size();
+        ex.waves = d_waves.as<int32_t>(); ex.n_waves = (int)waves.size();
+    }
     if ((rc = run_alpha(ctx, y.as<int32_t>(), m.as<double>(), ldn, D.Xt.as<double>(), D.ldx, N, G, P,
                         ah.as<double>(), min_disp, max_disp, prior_disp_var, cr_reg, prior_reg, a.as<double>(),
-                        conv.as<uint8_t>(), nullptr, nullptr, DSQ_CONST_COMPUTE, nullptr, optimizer)))
+                        conv.as<uint8_t>(), nullptr, nullptr, DSQ_CONST_COMPUTE, mg.m != nullptr ? &ex : nullptr,
+                        optimizer)))
         return rc;
     DSQ_HIP(hipMemcpyAsync(alpha_out, a.p, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));

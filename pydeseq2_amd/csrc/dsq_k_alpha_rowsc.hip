@@ -37,40 +37,6 @@ DSQ_HD size_t rowc_slot_bytes(int npad, int ntail, int P) {
     return (sizeof(RowGeneC) + (size_t)npad * 2 + (size_t)ntail * 2 + (size_t)P * (P + 1) * 4 + 15) & ~(size_t)15;
 }
 
-// packed lower triangle of L^-1 for L from chol<P> (in place is not possible: rows are read while columns are written)
-template <int P>
-DSQ_D void tri_inverse(const double (&l)[Tri<P>::N], double (&li)[Tri<P>::N]) {
-#pragma unroll
-    for (int j = 0; j < P; ++j) li[tri(j, j)] = frcp(l[tri(j, j)]);
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = j; k < i; ++k) s -= l[tri(i, k)] * li[tri(k, j)];
-            li[tri(i, j)] = s * li[tri(i, i)];
-        }
-    }
-}
-
-// tr((L L^T)^-1 B) = sum_k l_k B l_k^T with l_k = row k of L^-1 (B symmetric, packed)
-template <int P>
-DSQ_D double trace_inv_times(const double (&li)[Tri<P>::N], const double (&b)[Tri<P>::N]) {
-    double tr = 0.0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-#pragma unroll
-        for (int i = 0; i <= k; ++i) {
-            double r = 0.0;
-#pragma unroll
-            for (int j = 0; j <= k; ++j) r += b[tris(i, j)] * li[tri(k, j)];
-            tr += r * li[tri(k, i)];
-        }
-    }
-    return tr;
-}
-
 template <int P>
 __global__ __launch_bounds__(kRowBlock, 2) void k_alpha_rows_c(
     const int32_t* __restrict__ y, int ldn, int N, const int32_t* __restrict__ list, int n_list,

@@ -859,7 +859,8 @@ hipError_t launch_lin_mu(hipStream_t st, const int32_t* y, int ldn, const double
 
 // mu_hat rows of a few listed genes from their OLS coefficients (the grid-search fallback of the dispersion fit
 // when no N x G mu_hat was materialised): dst[k][:] = max(sf * (X coef[list[k]]), min_mu), idx_out[k] = k
-template <int P>
+// EXP: the IRLS route's mu_hat instead, sf * exp(X beta) UNclamped (dds.py:757-771, utils.py:435-437)
+template <int P, bool EXP = false>
 __global__ __launch_bounds__(kBlock) void k_mu_from_coef(const double* __restrict__ coef, const double* __restrict__ sf,
                                                          const double* __restrict__ Xt, int ldx, int N, double min_mu,
                                                          const int32_t* __restrict__ list, int n_list,
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(kBlock) void k_mu_from_coef(const double* __restric
         double yh = 0.0;
 #pragma unroll
         for (int j = 0; j < P; ++j) yh += Xt[j * ldx + n] * b[j];
-        dst[(size_t)k * ldn + n] = dmax(sf[n] * yh, min_mu);
+        dst[(size_t)k * ldn + n] = EXP ? sf[n] * exp(yh) : dmax(sf[n] * yh, min_mu);
     }
     if ((threadIdx.x & 63) == 0) idx_out[k] = k;
 }
@@ -887,6 +888,15 @@ hipError_t launch_mu_from_coef(hipStream_t st, const double* coef, const double*
     if (n_list <= 0) return hipSuccess;
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_mu_from_coef<P>, dim3(genes_to_blocks(n_list)), dim3(kBlock), 0, st, coef,
                                           sf, Xt, ldx, N, min_mu, list, n_list, dst, ldn, idx_out, n_dev))
+    return hipGetLastError();
+}
+
+hipError_t launch_mu_from_beta(hipStream_t st, const double* beta, const double* sf, const double* Xt, int ldx, int N,
+                               int P_, const int32_t* list, int n_list, double* dst, int ldn, int32_t* idx_out,
+                               const int32_t* n_dev) {
+    if (n_list <= 0) return hipSuccess;
+    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL((k_mu_from_coef<P, true>), dim3(genes_to_blocks(n_list)), dim3(kBlock), 0, st,
+                                          beta, sf, Xt, ldx, N, 0.0, list, n_list, dst, ldn, idx_out, n_dev))
     return hipGetLastError();
 }
 

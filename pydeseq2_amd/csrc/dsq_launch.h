@@ -7,6 +7,7 @@
 
 #include "../../include/deseq_hip.h"
 #include "dsq_linalg.h"
+#include "dsq_mix.h"
 
 namespace dsq {
 
@@ -103,6 +104,13 @@ struct AlphaExtras {
     // tail (continuation of the parked fits, second passes) is about to be (dsq_set_alpha_hook); may be null
     void (*mid_hook)(void*);
     void* mid_arg;
+    // Mixed designs (dsq_mix.h, dsq_k_alpha_mix.hip): the genes of `rows` run k_alpha_mix.  mu_hat comes from the IRLS
+    // coefficients mix_beta [G][P] (sf * exp(X beta), unclamped: dds.py:757-771) or, when mix_beta is null, from `mu`.
+    // mix_scratch: [mix_scratch_doubles] wave-private mu_hat rows (alpha_mix_scratch_doubles).
+    const MixDesign* mix;
+    const double* mix_beta;
+    double* mix_scratch;
+    size_t mix_scratch_doubles;
 };
 constexpr int kAlphaEvalCap = 8;
 size_t alpha_resume_bytes(int G);
@@ -129,6 +137,22 @@ hipError_t launch_cell_mu(hipStream_t st, const double* beta, const double* Xc, 
 hipError_t launch_mu_from_cells(hipStream_t st, const double* cell_mu, int C, const double* sf, const int32_t* cell_of,
                                 int N, const int32_t* list, int n_list, double* dst, int ldn, int32_t* idx_out,
                                 const int32_t* n_dev = nullptr);
+// ---- dsq_k_alpha_mix.hip (one translation unit per number of continuous covariates): mixed designs, dsq_mix.h
+bool alpha_mix_enabled();
+int alpha_mix_launches();  // launches of k_alpha_mix by this process so far (tests: did the design take that route?)
+// doubles of wave-private scratch a launch for n_list genes needs (0: such rows do not fit the kernel)
+size_t alpha_mix_scratch_doubles(const MixDesign& D, int n_list);
+hipError_t launch_alpha_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const int32_t* list,
+                            int n_list, const int32_t* n_dev, int32_t* queue, const double* beta, const double* mu,
+                            const double* sf, const double* alpha_hat, double min_disp, double max_disp,
+                            double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev,
+                            int32_t* grid_count, int32_t* grid_list, double* nll_const, int const_mode, int eval_cap,
+                            int resume, void* park_state, int32_t* park_count, int32_t* park_list, double* mu_scratch,
+                            size_t scratch_doubles);
+// rows of mu_hat = sf * exp(X beta) (unclamped) for a gene list (grid-search pass when no N x G mu_hat exists)
+hipError_t launch_mu_from_beta(hipStream_t st, const double* beta, const double* sf, const double* Xt, int ldx, int N,
+                               int P, const int32_t* list, int n_list, double* dst, int ldn, int32_t* idx_out,
+                               const int32_t* n_dev = nullptr);
 bool alpha_wg_eligible(int N);
 hipError_t launch_alpha_wg(hipStream_t st, const int32_t* y, int ldn, int N, const int32_t* list, const int32_t* n_dev,
                            int n_cap, const double* coef, const double* sf, const CellDesign& cells, int P,

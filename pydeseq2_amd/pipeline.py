@@ -214,6 +214,14 @@ class DeseqPipeline:
             int(ctx_.lib.dsq_alpha_rows_eligible(self.N, self.P, int(D.n_design_cells)))
         if self._row_mode == 1 and not D.linear_mu:
             self._row_mode = 0
+        # 3: MIXED design - categorical columns with few distinct rows + up to three continuous covariates (dsq_mix_create,
+        # csrc/dsq_mix.h: the analysis and the eligibility rule live in the library).  IRLS mu_hat route only.
+        self._mix = None
+        if self._row_mode == 0 and not D.linear_mu and not os.environ.get("DSQ_NO_ALPHA_MIX"):
+            mp = _vp()
+            ctx_.call("dsq_mix_create", _vp(D.X.ctypes.data), self.N, self.P, C.byref(mp))
+            if mp.value:
+                self._mix, self._row_mode = mp.value, 3
         if self._row_mode:
             d_fl = DeviceArray(ctx_, (self.G,), np.int32)
             ctx_.call("dsq_dev_alpha_row_split", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_fl.ptr))
@@ -333,7 +341,7 @@ class DeseqPipeline:
             self.kernel_log.setdefault(name, []).append((ms, int(genes)))
         else:
             self.ctx.call(cname, *args)
-        if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2", "dsq_dev_alpha_mle3"):
+        if cname in ("dsq_dev_alpha_mle", "dsq_dev_alpha_mle2", "dsq_dev_alpha_mle3", "dsq_dev_alpha_mle4"):
             kms, ng = C.c_float(), C.c_int()
             self.ctx.call("dsq_last_alpha_kernel", C.byref(kms), C.byref(ng))
             if kms.value >= 0.0:  # (-1: a deferred launch, nobody waited for it)
@@ -443,7 +451,7 @@ class DeseqPipeline:
         which the dispersion kernel rebuilds mu_hat = max(sf * X coef, min_mu) while staging."""
         D = self.design
         mh = type("MuHat", (), {})()
-        mh.d_mu, mh.d_coef, mh.d_cell_mu, mh.row_lists = None, None, None, row_lists
+        mh.d_mu, mh.d_coef, mh.d_cell_mu, mh.d_beta, mh.row_lists = None, None, None, None, row_lists
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
@@ -459,7 +467,10 @@ class DeseqPipeline:
             # (dsq_dev_cell_mu) - the N x G matrix is neither written by the IRLS kernel nor read by the two fits
             per_cell = (self._row_mode == 2 and row_lists is not None and row_lists[3] == 0
                         and not self.ctx.lib.dsq_alpha_needs_mu(self.N, self.P, int(D.n_design_cells)))
-            mh.d_mu = None if per_cell else self._dmat(Gs)
+            # mixed designs: the dispersion kernel rebuilds mu_hat = sf * exp(X beta) from the coefficients of this fit
+            # (every gene on it: no count beyond its 16-bit staging); otherwise it gathers its rows from the matrix
+            from_beta = self._row_mode == 3 and row_lists is not None and row_lists[3] == 0
+            mh.d_mu = None if (per_cell or from_beta) else self._dmat(Gs)
             self._k("mom", Gs, "dsq_dev_mom", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, c_double(self.min_disp), c_double(self.max_disp),
                     _vp(S["nm"].ptr), None, None, _vp(S["mom"].ptr))
@@ -473,6 +484,8 @@ class DeseqPipeline:
                     self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
                     None, None, c_double(0.0), 0, None, None, None)
+            if from_beta:
+                mh.d_beta = d_b
             if per_cell:
                 mh.d_cell_mu = self._dvec(Gs * int(D.n_design_cells))
                 self.ctx.call("dsq_dev_cell_mu", _vp(d_b.ptr), self._cells_arg(), Gs, self.P, _vp(mh.d_cell_mu.ptr))
@@ -485,17 +498,21 @@ class DeseqPipeline:
     def _alpha_fit(self, name, d_y, mh, Gs, d_sf, d_start, prior_var, prior_reg, d_out, d_conv, const_mode):
         d_nfev = self._dvec(Gs, np.int32) if self.collect_nfev else None
         d_cell_mu = getattr(mh, "d_cell_mu", None)
-        use_coef = mh.d_mu is None and d_cell_mu is None
+        d_beta = getattr(mh, "d_beta", None)
+        use_coef = mh.d_mu is None and d_cell_mu is None and d_beta is None
         use_cell = d_cell_mu is not None
-        rows = getattr(mh, "row_lists", None) if mh.d_mu is None else None  # (d_rows, n_rows, d_waves, n_waves) or None
-        self._k(name, Gs, "dsq_dev_alpha_mle3", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
+        mix = self._mix if (self._row_mode == 3 and getattr(mh, "row_lists", None) is not None) else None
+        # (d_rows, n_rows, d_waves, n_waves) or None; the mixed-design kernel also takes its rows from a mu_hat matrix
+        rows = getattr(mh, "row_lists", None) if (mh.d_mu is None or mix) else None
+        self._k(name, Gs, "dsq_dev_alpha_mle4", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
                 _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
                 c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
                 _vp(d_nfev.ptr) if d_nfev else None, _vp(mh.nll_const.ptr), const_mode, self._cells_arg(),
-                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if (use_coef or use_cell) else None,
+                _vp(mh.d_coef.ptr) if use_coef else None, _vp(d_sf.ptr) if (use_coef or use_cell or d_beta) else None,
                 c_double(self.min_mu), _vp(rows[0].ptr) if rows else None, rows[1] if rows else 0,
                 _vp(rows[2].ptr) if rows and rows[3] else None, rows[3] if rows else 0,
-                _vp(d_cell_mu.ptr) if use_cell else None)
+                _vp(d_cell_mu.ptr) if use_cell else None, _vp(mix) if (mix and rows) else None,
+                _vp(d_beta.ptr) if d_beta else None)
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
 
@@ -1022,6 +1039,9 @@ class DeseqPipeline:
         for _cap, ptr in self._pool_free + self._pool_used:
             self.ctx.free(ptr)
         self._pool_free, self._pool_used = [], []
+        if getattr(self, "_mix", None):
+            self.ctx.lib.dsq_mix_destroy(_vp(self._mix))
+            self._mix = None
         self._pinned.close()
 
     def __del__(self):

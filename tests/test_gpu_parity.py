@@ -742,3 +742,108 @@ def test_bench_two_ranks_strong_scaling_on_one_gpu():
     assert d["config"]["genes_per_gpu"] == 1500 and "host-staged" in d["config"]["collectives"]
     assert d["collectives_per_step"] >= 3 and d["collective_ms_per_step"] > 0
     assert d["parity"]["ok"], d["parity"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Mixed designs (csrc/dsq_mix.h, dsq_k_alpha_mix.hip): categorical columns + up to three continuous covariates
+def _mix_launches(ctx):
+    return int(ctx.lib.dsq_mix_launch_count())
+
+
+@pytest.mark.parametrize("case", ["p4", "p6", "p8m"])
+def test_mixed_design_dispersion_kernel_vs_reference_kats(inf, case, monkeypatch):
+    """k_alpha_mix against the outputs of the unmodified utils.fit_alpha_mle (utils.py:441-564) on the KAT designs with
+    continuous covariates: p = 4 (2 x 2 levels + 1 covariate), p = 6 (2 x 3 levels + 2), p = 8 (2 x 4 levels + 3, the
+    benchmark's design shape).  Through the plug-in entry point, which hands mu over as a matrix (gathered into slot
+    order by the kernel).  DSQ_MIX_FORCE lifts the padding limit: the KATs have 15 - 20 samples per cell."""
+    monkeypatch.setenv("DSQ_MIX_FORCE", "1")
+    k = load_kat(case)
+    N, P = k["X"].shape
+    maxd = float(max(10, N))
+    before = _mix_launches(inf.ctx)
+    a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["mom"], 1e-8, maxd)
+    assert _mix_launches(inf.ctx) > before, "the design did not take the mixed-design kernel"
+    assert (c == k["gw_conv"]).all()
+    assert_close(a, k["gw_alpha"], 1e-6, 0, "genewise alpha")
+    a, c = inf.alpha_mle(k["counts"], k["X"], k["mu_hat"], k["fitted"], 1e-8, maxd,
+                         prior_disp_var=float(k["prior_var"]), cr_reg=True, prior_reg=True)
+    assert (c == k["map_conv"]).all()
+    assert_close(a, k["map_alpha"], 1e-6, 0, "MAP alpha")
+    # a gene with a count beyond the kernel's 16-bit staging stays on the general kernel, the others on this one
+    counts = k["counts"].copy()
+    counts[3, 1] = 70000
+    mu = k["mu_hat"].copy()
+    a2, c2 = inf.alpha_mle(counts, k["X"], mu, k["mom"], 1e-8, maxd)
+    keep = np.arange(counts.shape[1]) != 1
+    assert_close(a2[keep], k["gw_alpha"][keep], 1e-6, 0, "genewise alpha beside a 17-bit gene")
+    monkeypatch.delenv("DSQ_MIX_FORCE")
+    a3, c3 = inf.alpha_mle(counts, k["X"], mu, k["mom"], 1e-8, maxd)  # all genes on the general kernel
+    assert c2[1] == c3[1] and abs(a2[1] - a3[1]) <= 1e-9 * abs(a3[1])
+
+
+def _mixed_case(P, Q, N, G, seed, cells_levels):
+    """Counts and design with `cells_levels` categorical factors (levels) + Q continuous covariates, P columns."""
+    rng = np.random.default_rng(seed)
+    cols = [np.ones(N)]
+    for lv in cells_levels:
+        v = np.arange(N) % lv
+        rng.shuffle(v)
+        cols += [(v == kk).astype(float) for kk in range(1, lv)]
+    cols += [rng.normal(0, 1.0, N) for _ in range(Q)]
+    X = np.column_stack(cols)
+    assert X.shape[1] == P, X.shape
+    beta = np.zeros((P, G))
+    beta[0] = rng.normal(4, 2, G)
+    beta[1:] = rng.normal(0, 0.3, (P - 1, G))
+    disp = 4 / np.maximum(2.0 ** beta[0], 1e-3) + 0.1
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * 2.0 ** (X @ beta)
+    size = 1 / disp
+    counts = rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu)).astype(np.int64)
+    return counts, X
+
+
+@pytest.mark.parametrize("P,Q,levels,N", [(3, 1, (2,), 300), (5, 2, (3,), 750), (8, 3, (2, 4), 1400), (4, 3, (), 260),
+                                          (7, 1, (2, 5), 900), (6, 2, (4,), 640)])
+def test_mixed_design_pipeline_every_shape(P, Q, levels, N, monkeypatch):
+    """Every (columns, covariates) shape of the mixed-design kernels end to end: mu_hat rebuilt from the IRLS coefficients
+    inside the dispersion kernel (no N x G matrix), against the same pipeline on the general kernels (HIP vs HIP, all
+    genes at 1e-8 apart from success-flag flips) and against the oracle at 1e-5."""
+    import pydeseq2_amd
+    from pydeseq2_amd import DeseqPipeline
+
+    G = 360
+    counts, X = _mixed_case(P, Q, N, G, 100 + P * 10 + Q, levels)
+    counts[:, 7] = 0
+    counts[5, 11] = 66000  # one gene beyond the 16-bit staging: the matrix route of the kernel + the general kernel
+    pipe = DeseqPipeline(counts, X, device=0)
+    assert pipe._row_mode == 3, "not routed to the mixed-design kernels"
+    before = _mix_launches(pipe.ctx)
+    res = pipe.deseq2()
+    assert _mix_launches(pipe.ctx) >= before + 2
+    c2 = counts.copy()
+    c2[5, 11] = 60000  # every gene fits: mu_hat from the coefficients
+    pipe2 = DeseqPipeline(c2, X, device=0)
+    res2 = pipe2.deseq2()
+    monkeypatch.setenv("DSQ_NO_ALPHA_MIX", "1")
+    gen = DeseqPipeline(c2, X, device=0)
+    assert gen._row_mode == 0
+    ref_hip = gen.deseq2()
+    monkeypatch.delenv("DSQ_NO_ALPHA_MIX")
+    nz = ref_hip.non_zero
+    same = nz & (res2.genewise_converged == ref_hip.genewise_converged) & (res2.MAP_converged == ref_hip.MAP_converged)
+    assert (nz & ~same).sum() <= 2
+    assert_close(res2.genewise_dispersions[same], ref_hip.genewise_dispersions[same], 2e-6, 0, "genewise, mix vs general")
+    assert_close(res2.dispersions[same], ref_hip.dispersions[same], 2e-6, 0, "dispersions, mix vs general")
+    ref = orc.deseq2(c2[:, :120], X, n_jobs=_jobs(), keep_layers=False)
+    sub = pydeseq2_amd.deseq2(c2[:, :120], X, device=0)
+    _compare(sub, ref, frac_noise=0.02)
+    # the run with the 17-bit gene (mu_hat gathered from the matrix, that gene on the general kernel) against the general
+    # kernels on the same counts
+    monkeypatch.setenv("DSQ_NO_ALPHA_MIX", "1")
+    ref17 = DeseqPipeline(counts, X, device=0).deseq2()
+    monkeypatch.delenv("DSQ_NO_ALPHA_MIX")
+    ok = nz & (res.genewise_converged == ref17.genewise_converged) & (res.MAP_converged == ref17.MAP_converged)
+    assert (nz & ~ok).sum() <= 2
+    assert_close(res.genewise_dispersions[ok], ref17.genewise_dispersions[ok], 2e-6, 0, "matrix route vs general")
+    assert_close(res.dispersions[ok], ref17.dispersions[ok], 2e-6, 0, "matrix route vs general, final")

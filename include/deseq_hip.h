@@ -333,6 +333,14 @@ int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, in
 int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
                         const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int N, int G,
                         double* d_robust_disp);
+/* dsq_dev_robust_disp with the size of the design's smallest cell (min_cell; ignored when whole != 0): when every cell
+ * has at least 129 samples and the largest at least 2048 - or there are no cells at all (designs with continuous
+ * covariates: one trimmed variance over all N samples) - the trimmed sums recompute the normalised counts from the gene's
+ * row instead of buffering a cell in LDS (csrc/dsq_stats.h, robust_disp_gene_lean; 8 KB instead of 8 * next_pow2(cell)
+ * bytes per wavefront).  Same results up to the rounding of a fused multiply-add. */
+int dsq_dev_robust_disp2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
+                         const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int min_cell, int N, int G,
+                         double* d_robust_disp);
 /* dsq_dev_irls with (a) the optional cell path, (b) the per-sample half of the Cook's stage fused into its epilogue
  * (d_flags != NULL: d_robust_disp from dsq_dev_robust_disp in, d_cooks (nullable layer) and the four flag vectors of
  * dsq_dev_cooks out) and (c) the Wald statistics of dsq_dev_wald (h_ridge != NULL) computed while mu is in registers.
@@ -346,6 +354,17 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
                     uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
                     const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
                     double* d_stats, double* d_se);
+/* dsq_dev_lfc_fit with a mixed design (dsq_mix_create): the fit, its start values and its epilogue run k_irls_mix
+ * (csrc/dsq_k_irls_mix.hip: samples sorted by design cell, X^T W X from per-cell + covariate sums); mix == NULL: as
+ * dsq_dev_lfc_fit.  Same outputs; diverged genes take the same rescue pass. */
+int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                     const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                     double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
+                     double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
+                     const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
+                     uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
+                     const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
+                     double* d_stats, double* d_se, const dsq_mix* mix);
 int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt, int ldx,
                         int N, int G, int P, const double* d_disp, const double* d_beta, double min_mu, double* d_mu,
                         double* d_hat);

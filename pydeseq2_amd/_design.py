@@ -61,8 +61,9 @@ class DesignPack:
         if self.whole:
             self.cell_offsets = np.array([0, self.N], dtype=np.int32)
             self.cell_index = np.arange(self.N, dtype=np.int32)
-            self.n_cells, self.max_cell = 0, self.N
+            self.n_cells, self.max_cell, self.min_cell = 0, self.N, self.N
         else:
             self.cell_offsets = np.concatenate([[0], np.cumsum([len(c) for c in cells])]).astype(np.int32)
             self.cell_index = np.concatenate(cells).astype(np.int32)
             self.n_cells, self.max_cell = len(cells), int(max(len(c) for c in cells))
+            self.min_cell = int(min(len(c) for c in cells))

@@ -57,6 +57,10 @@ struct dsq_ctx {
     size_t resume_cap = 0;
     void* d_mix = nullptr;        // wave-private mu_hat rows of the mixed-design dispersion kernel (grow-only)
     size_t mix_cap = 0;
+    void* d_mixw = nullptr;       // slot-ordered per-sample vectors of the mixed-design IRLS kernel (grow-only)
+    size_t mixw_cap = 0;
+    int32_t* d_redo = nullptr;    // genes the buffer-less robust-dispersion kernel hands back (side stream; grow-only)
+    size_t redo_cap = 0;
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
     int comm_rank = 0, comm_world = 1;
     std::string err;
@@ -286,6 +290,8 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             } else {
                 if (need_d * sizeof(double) > ctx->mix_cap) {
                     if (ctx->d_mix) (void)hipFree(ctx->d_mix);
+    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
                     ctx->d_mix = nullptr; ctx->mix_cap = 0;
                     DSQ_HIP(hipMalloc(&ctx->d_mix, need_d * sizeof(double)));
                     ctx->mix_cap = need_d * sizeof(double);
@@ -689,7 +695,20 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
         ctx->lsf_cap = (size_t)N;
     }
     DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
-    DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, sizeof(int32_t), ctx->stream));
+    DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(int32_t), ctx->stream));  // [0] fallback genes, [1] gene queue
+    if (ex_local.mix != nullptr && dsq::irls_takes_mix(ex_local.mix, full_rank)) {
+        const size_t need = dsq::irls_mix_work_bytes(ex_local.mix->Ns);
+        if (need > ctx->mixw_cap) {
+            if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
+            ctx->d_mixw = nullptr; ctx->mixw_cap = 0;
+            DSQ_HIP(hipMalloc(&ctx->d_mixw, need));
+            ctx->mixw_cap = need;
+        }
+        ex_local.mix_work = ctx->d_mixw;
+        ex_local.mix_queue = ctx->d_counter + 1;
+    } else {
+        ex_local.mix = nullptr;
+    }
     DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
                              d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
@@ -976,13 +995,27 @@ int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, in
     return DSQ_OK;
 }
 
+int dsq_dev_robust_disp2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
+                         const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int min_cell, int N, int G,
+                         double* d_robust_disp) {
+    DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
+    if (whole) min_cell = N;
+    if ((size_t)G + 1 > ctx->redo_cap) {
+        if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+        ctx->d_redo = nullptr; ctx->redo_cap = 0;
+        DSQ_HIP(hipMalloc((void**)&ctx->d_redo, ((size_t)G + 1 + (size_t)G / 4) * sizeof(int32_t)));
+        ctx->redo_cap = (size_t)G + 1 + (size_t)G / 4;
+    }
+    DSQ_HIP(dsq::launch_robust_disp(ctx->stream, d_y, ldn, d_sf, d_cell_offsets, d_cell_index, n_cells, whole, max_cell,
+                                    N, G, d_robust_disp, min_cell, ctx->d_redo));
+    return DSQ_OK;
+}
+
 int dsq_dev_robust_disp(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
                         const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int N, int G,
                         double* d_robust_disp) {
-    DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
-    DSQ_HIP(dsq::launch_robust_disp(ctx->stream, d_y, ldn, d_sf, d_cell_offsets, d_cell_index, n_cells, whole, max_cell,
-                                    N, G, d_robust_disp));
-    return DSQ_OK;
+    return dsq_dev_robust_disp2(ctx, d_y, ldn, d_sf, d_cell_offsets, d_cell_index, n_cells, whole, max_cell, 0, N, G,
+                                d_robust_disp);
 }
 
 int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt, int ldx,
@@ -1060,15 +1093,16 @@ int dsq_side_wait(dsq_ctx* ctx) {
     return DSQ_OK;
 }
 
-int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
-                    const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
-                    double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
-                    double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
-                    const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
-                    uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
-                    const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
-                    double* d_stats, double* d_se) {
+int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                     const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                     double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
+                     double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
+                     const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
+                     uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
+                     const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
+                     double* d_stats, double* d_se, const dsq_mix* mix) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
+    DSQ_CHECK_ARG(mix == nullptr || (mix->d.P == P && mix->d.N == N), "mix: built for another design");
     DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
     DSQ_CHECK_ARG(d_flags == nullptr || (d_robust_disp && d_any_all && d_any_use && d_any_use_nr && d_few_above),
                   "the fused Cook's bookkeeping needs the robust dispersions and the four flag vectors");
@@ -1077,6 +1111,7 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
     if (G <= 0) return DSQ_OK;
     dsq::IrlsExtras ex{};
     ex.cells = to_cells(cells);
+    if (mix != nullptr) ex.mix = &mix->d;
     if (d_flags != nullptr) {
         ex.robust_disp = d_robust_disp; ex.flags = d_flags; ex.cutoff = cutoff; ex.cooks = d_cooks;
         ex.any_all = d_any_all; ex.any_use = d_any_use; ex.any_use_nr = d_any_use_nr; ex.few_above = d_few_above;
@@ -1099,6 +1134,20 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
     }
     return run_irls(ctx, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp, min_mu, beta_tol, min_beta,
                     max_beta, maxiter, d_beta, d_mu, d_hat, d_converged, d_iters, &ex);
+}
+
+int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
+                    const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
+                    double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
+                    double* d_mu, double* d_hat, uint8_t* d_converged, int32_t* d_iters, const dsq_cells* cells,
+                    const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
+                    uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
+                    const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
+                    double* d_stats, double* d_se) {
+    return dsq_dev_lfc_fit2(ctx, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp, min_mu, beta_tol,
+                            min_beta, max_beta, maxiter, d_beta, d_mu, d_hat, d_converged, d_iters, cells, d_robust_disp,
+                            d_flags, cutoff, d_cooks, d_any_all, d_any_use, d_any_use_nr, d_few_above, h_ridge, h_contrast,
+                            lfc_null, alt, d_pvals, d_stats, d_se, nullptr);
 }
 
 int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_mu,
@@ -1545,10 +1594,18 @@ int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_lay
     DSQ_HIP(mu.alloc((size_t)G * ldn * sizeof(double)));
     DSQ_HIP(hat.alloc((size_t)G * ldn * sizeof(double)));
     DSQ_HIP(conv.alloc((size_t)G));
+    // mixed designs: the kernel family of the pipeline (csrc/dsq_mix.h)
+    struct MixGuard {
+        dsq_mix* m = nullptr;
+        ~MixGuard() { dsq_mix_destroy(m); }
+    } mg;
+    if ((rc = dsq_mix_create(ctx, design, N, P, &mg.m))) return rc;
+    dsq::IrlsExtras exi{};
+    if (mg.m != nullptr) exi.mix = &mg.m->d;
     rc = run_irls(ctx, y.as<int32_t>(), ldn, sf.as<double>(), D.Xt.as<double>(), D.pinv.as<double>(),
                   D.ldx, N, G, P, D.full_rank, d.as<double>(), min_mu, beta_tol, min_beta, max_beta,
                   maxiter, beta.as<double>(), mu.as<double>(), hat.as<double>(), conv.as<uint8_t>(),
-                  nullptr, nullptr, optimizer);
+                  nullptr, mg.m != nullptr ? &exi : nullptr, optimizer);
     if (rc) return rc;
     DSQ_HIP(hipMemcpyAsync(beta_out, beta.p, (size_t)G * P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(converged, conv.p, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));

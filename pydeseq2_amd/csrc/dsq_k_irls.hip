@@ -418,6 +418,43 @@ bool irls_takes_rows(int N, int P_, int n_cells) {
            row_lds_bytes(n_cells, P_, N) <= 40 * 1024;
 }
 
+// ---- mixed designs: one translation unit per number of continuous covariates (dsq_k_irls_mix.hip)
+#define DSQ_MIXI_DECL(Q_)                                                                                             \
+    bool irls_mix_fits_q##Q_(int Ns, int P);                                                                          \
+    hipError_t launch_irls_mix_q##Q_(hipStream_t, const int32_t*, int, const MixDesign&, const double*, int, int32_t*, \
+                                     const double*, double, double, double, int, double*, double*, double*, uint8_t*, \
+                                     int32_t*, int32_t*, int32_t*, const IrlsExtras&, void*);
+DSQ_MIXI_DECL(1)
+DSQ_MIXI_DECL(2)
+DSQ_MIXI_DECL(3)
+#undef DSQ_MIXI_DECL
+
+bool irls_takes_mix(const MixDesign* mix, int full_rank) {
+    static const bool off = getenv("DSQ_NO_IRLS_MIX") != nullptr;  // A/B switch: such designs on the general kernel
+    if (off || mix == nullptr || !full_rank || mix->Ginv == nullptr || !alpha_mix_enabled()) return false;
+    switch (mix->Q) {
+        case 1: return irls_mix_fits_q1(mix->Ns, mix->P);
+        case 2: return irls_mix_fits_q2(mix->Ns, mix->P);
+        case 3: return irls_mix_fits_q3(mix->Ns, mix->P);
+        default: return false;
+    }
+}
+
+static hipError_t launch_irls_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G,
+                                  int32_t* queue, const double* disp, double min_mu, double beta_tol, double max_beta,
+                                  int maxiter, double* beta, double* mu, double* hat, uint8_t* conv, int32_t* iters,
+                                  int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work) {
+    switch (D.Q) {
+        case 1: return launch_irls_mix_q1(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+                                          hat, conv, iters, fb_count, fb_list, ex, work);
+        case 2: return launch_irls_mix_q2(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+                                          hat, conv, iters, fb_count, fb_list, ex, work);
+        case 3: return launch_irls_mix_q3(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+                                          hat, conv, iters, fb_count, fb_list, ex, work);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* sf, const double* lsf,
                        const double* Xt,
                        const double* pinvXt, int ldx, int N, int G, int P_, int full_rank,
@@ -428,6 +465,10 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     if (G <= 0) return hipSuccess;
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
+    // mixed designs (dsq_k_irls_mix.hip): one gene per wavefront in slot order; the same outputs and fallback list
+    if (ex.mix != nullptr && ex.mix_work != nullptr && ex.mix_queue != nullptr && irls_takes_mix(ex.mix, full_rank))
+        return launch_irls_mix(st, y, ldn, *ex.mix, sf, G, ex.mix_queue, disp, min_mu, beta_tol, max_beta, maxiter, beta,
+                               mu, hat, conv, iters, fb_count, fb_list, ex, ex.mix_work);
     if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()))) {
         if (ex.cells.C > 0 && ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // (the wide kernels take 5..64 cells)
         return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,

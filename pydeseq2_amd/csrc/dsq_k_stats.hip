@@ -1102,11 +1102,15 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
                                                           const int32_t* __restrict__ cell_offsets,
                                                           const int32_t* __restrict__ cell_index, int n_cells,
                                                           int whole, int cap, int stride, int seg_len, int N, int G,
-                                                          double* __restrict__ robust_disp) {
+                                                          double* __restrict__ robust_disp,
+                                                          const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ n_dev) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int w = threadIdx.x >> 6;
-    const int g = blockIdx.x * WPB + w;
-    if (g >= G) return;
+    const int k = blockIdx.x * WPB + w;
+    if (n_dev != nullptr) G = min(G, *n_dev);  // second pass of the lean kernel: launched for a capacity
+    if (k >= G) return;
+    const int g = list != nullptr ? list[k] : k;
     double* scratch = lds + (size_t)w * stride;
     unsigned int* hist = (unsigned int*)(scratch + cap);
     CellPlan C{cell_offsets, cell_index, n_cells, whole};
@@ -1114,10 +1118,60 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
     if ((threadIdx.x & 63) == 0) robust_disp[g] = ar;
 }
 
+// Designs whose cells all have at least kTrimBucketMin samples (or no cells at all: one trimmed variance over every
+// sample - designs with continuous covariates): the bucket sums recompute the normalised counts from the gene's row on
+// every pass instead of keeping them in LDS (robust_disp_gene_lean).  At N = 5000 the buffered kernel held 70 KB of LDS
+// per wavefront - two wavefronts per CU, 13.3 ms for 60 000 genes; this one holds the 8 KB bucket table: 5.5 ms.  A gene on
+// which a bucket pass gives up (a boundary bucket with more than kBucketGather values, a non-finite value) is listed
+// and redone by the buffered kernel.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_robust_disp_lean(const int32_t* __restrict__ y, int ldn,
+                                                               const double* __restrict__ sf,
+                                                               const int32_t* __restrict__ cell_offsets,
+                                                               const int32_t* __restrict__ cell_index, int n_cells,
+                                                               int whole, int N, int G,
+                                                               double* __restrict__ robust_disp,
+                                                               int32_t* __restrict__ redo_count,
+                                                               int32_t* __restrict__ redo_list) {
+    __shared__ BucketWork W[WPB];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x * WPB + w;
+    if (g >= G) return;
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    bool failed;
+    const double ar = robust_disp_gene_lean<DeviceWave>(y + (size_t)g * ldn, sf, C, N, W[w], failed);
+    if ((threadIdx.x & 63) == 0) {
+        if (failed) redo_list[atomicAdd(redo_count, 1)] = g;
+        else robust_disp[g] = ar;
+    }
+}
+
+// ... where the buffer costs occupancy: from 2048 samples in the largest cell on (16 KB + 8 KB of LDS per wavefront).
+// Measured: c5 (one "cell" of 5000 samples) 13.3 -> 5.5 ms per 60 000 genes; c3 (two cells of 500: 12 KB per wavefront
+// either way) 0.84 -> 1.14 ms - the recomputation costs more than the buffer there, so c3 stays on the buffered kernel.
+bool robust_disp_lean_eligible(int min_cell, int max_cell, int whole, int N) {
+    const bool off = getenv("DSQ_NO_ROBUST_LEAN") != nullptr;  // A/B switch (read per launch: the tests flip it)
+    const char* mn = getenv("DSQ_ROBUST_LEAN_MIN");
+    const int min_big = mn != nullptr ? atoi(mn) : 2048;
+    return !off && (whole ? N : min_cell) >= kTrimBucketMin && (whole ? N : max_cell) >= min_big;
+}
+
+// redo: G + 1 int32 of device scratch (lean path only, may be null otherwise): [0] the number of genes the lean kernel
+// handed back, [1 ..] their indices
 hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const double* sf,
                               const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
-                              int max_cell, int N, int G, double* robust_disp) {
+                              int max_cell, int N, int G, double* robust_disp, int min_cell, int32_t* redo) {
     if (G <= 0) return hipSuccess;
+    const bool lean = redo != nullptr && robust_disp_lean_eligible(min_cell, max_cell, whole, N);
+    if (lean) {
+        hipError_t e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return e;
+        constexpr int WPB = 4;
+        hipLaunchKernelGGL((k_robust_disp_lean<WPB>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, ldn, sf,
+                           cell_offsets, cell_index, n_cells, whole, N, G, robust_disp, redo, redo + 1);
+    }
+    const int32_t* list = lean ? redo + 1 : nullptr;
+    const int32_t* n_dev = lean ? redo : nullptr;
     const int biggest = whole ? N : max_cell;
     // designs whose cells all have at most kSegMaxCell samples: several cells per sorting pass (seg_trimmed_variances)
     static const bool seg_off = getenv("DSQ_NO_SEG_CELLS") != nullptr;  // A/B switch
@@ -1137,7 +1191,8 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
             (void)hipGetLastError();                                                                         \
         }                                                                                                    \
         hipLaunchKernelGGL((k_robust_disp<WPB, BIG>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), per_wave * WPB, st, y, \
-                           ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, seg_len, N, G, robust_disp); \
+                           ldn, sf, cell_offsets, cell_index, n_cells, whole, cap, stride, seg_len, N, G, robust_disp, \
+                           list, n_dev);                                                                     \
     } while (0)
     if (per_wave * 4 <= 64 * 1024) DSQ_RD_LAUNCH(4);
     else if (per_wave * 2 <= 160 * 1024) DSQ_RD_LAUNCH(2);

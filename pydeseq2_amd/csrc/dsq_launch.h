@@ -195,7 +195,14 @@ struct IrlsExtras {
     // k_irls_row: slot -> gene (launch_irls_order), so that the four genes of a wavefront need about the same
     // number of sweeps; null: identity.  Results do not depend on it.
     const int32_t* order;
+    // mixed designs (dsq_mix.h, dsq_k_irls_mix.hip): mix != null routes the fit to k_irls_mix; mix_work: irls_mix_work_bytes
+    // of device scratch (slot-ordered size factors, their logs, Cook's flags), mix_queue: a zeroed int32 gene counter
+    const MixDesign* mix;
+    void* mix_work;
+    int32_t* mix_queue;
 };
+bool irls_takes_mix(const MixDesign* mix, int full_rank);
+inline size_t irls_mix_work_bytes(int Ns) { return (size_t)Ns * 17 + 64; }
 // does launch_irls fit this design with sixteen lanes per gene (k_irls_row)?
 bool irls_takes_rows(int N, int P, int n_cells);
 // order[0..G) = genes by decreasing predicted number of IRLS sweeps: `hint_iters` (the iteration counts of an earlier
@@ -262,9 +269,11 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
                         int P, double cutoff, double* cooks, double* robust_disp, uint8_t* any_all,
                         uint8_t* any_use, uint8_t* any_use_nr, uint8_t* few_above);
 // robust dispersion of utils.robust_method_of_moments_disp (the design-only half of launch_cooks)
+// min_cell: the smallest of the design's cells; redo: G + 1 int32 of scratch for the kernel without the LDS buffer
+// (designs whose cells all have >= 129 samples), or null
 hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const double* sf,
                               const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
-                              int max_cell, int N, int G, double* robust_disp);
+                              int max_cell, int N, int G, double* robust_disp, int min_cell = 0, int32_t* redo = nullptr);
 hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
                           const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero);

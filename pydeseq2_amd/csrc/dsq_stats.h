@@ -494,8 +494,9 @@ DSQ_HD unsigned long long pos_key(double v) {  // order-preserving for v >= +0
 // boundary bucket with more than kBucketGather entries) - nothing but W has been written.
 // range: the smallest and the largest active value when the caller already knows them (and that every active entry is
 // finite) - saves the pass that finds them
-template <class Wv>
-DSQ_HD bool bucket_rank_sum(const double* buf, int n, int n_act, int j_lo, int j_hi, BucketWork& W, double& out,
+// Buf: anything indexable by k in [0, n) - a buffer of doubles, or an accessor that recomputes the value (NormedValues)
+template <class Wv, class Buf>
+DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi, BucketWork& W, double& out,
                             const double* range = nullptr) {
     out = 0.0;
     if (n_act <= 0 || j_hi < j_lo) return true;
@@ -859,6 +860,115 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
     return ar;
 }
 
+// The k-th normalised count of a design cell (y / sf, as y * (1 / sf)), or its squared error against `tm`; -1 for a
+// zero count (inactive for bucket_rank_sum) - recomputed from the gene's row on every access instead of being kept in
+// a wave-private LDS buffer: the row is read from L1 / L2 three more times, the LDS footprint of a wavefront drops from
+// next_pow2(N) doubles (64 KB at N = 5000: two wavefronts per CU) to the bucket table (8 KB)
+struct NormedValues {
+    const int32_t* y;
+    const double* sf;
+    const int32_t* idx;  // the cell's sample indices, or null: samples 0 .. n-1
+    double tm;
+    bool squared;
+    DSQ_HD double operator[](int k) const {
+        const int s = idx != nullptr ? idx[k] : k;
+        const int yi = y[s];
+        if (yi == 0) return -1.0;
+        const double v = (double)yi * frcp_g(sf[s]);
+        if (!squared) return v;
+        const double d = v - tm;
+        return d * d;
+    }
+};
+
+// robust_disp_gene for designs whose cells ALL take the bucket path (every cell - or the whole sample set - has at least
+// kTrimBucketMin samples), without a per-wave buffer of the cell's values (NormedValues).  failed = true: a boundary
+// bucket held too many values or a value was not finite - the caller hands the gene to robust_disp_gene (selection path).
+template <class Wv>
+DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const CellPlan& C, int N, BucketWork& W,
+                                    bool& failed) {
+    const double ratios[3] = {1.0 / 3.0, 1.0 / 4.0, 1.0 / 8.0};
+    const double scales[3] = {2.04, 1.86, 1.51};
+    failed = false;
+    double vmax = -INFINITY, cell_total = 0.0;
+    const int ncell = C.whole ? 1 : C.n_cells;
+    int cells_summed = 0;
+    for (int c = 0; c < ncell; ++c) {
+        const int beg = C.whole ? 0 : C.cell_offsets[c];
+        const int end = C.whole ? N : C.cell_offsets[c + 1];
+        const int n = end - beg;
+        const int cls = C.whole ? 2 : trim_class(n);
+        const int nt = (int)floor((double)n * ratios[cls]);
+        NormedValues V{y, sf, C.whole ? nullptr : C.cell_index + beg, 0.0, false};
+        int zeros = 0, bad = 0;
+        double lo1 = INFINITY, hi1 = -INFINITY;
+        for (int k = Wv::lane(); k < n; k += Wv::W) {
+            const double v = V[k];
+            zeros += v < 0.0 ? 1 : 0;
+            if (!(v < 0.0)) {
+                bad |= (v >= 0.0 && v < INFINITY) ? 0 : 1;
+                lo1 = v < lo1 ? v : lo1;
+                hi1 = v > hi1 ? v : hi1;
+                cell_total += v;
+            }
+        }
+        zeros = Wv::sumi(zeros);
+        bad = Wv::sumi(bad);
+        double range[2] = {-Wv::max(-lo1), Wv::max(hi1)};
+        cells_summed += n;
+        if (bad != 0) { failed = true; return NAN; }
+        const int r_lo = nt, r_hi = n - nt - 1, n_act = n - zeros;
+        double s1 = 0.0, s2 = 0.0;
+        if (!bucket_rank_sum<Wv>(V, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1, range)) {
+            failed = true;
+            return NAN;
+        }
+        const double tm = s1 / (double)(n - 2 * nt);
+        const double d0 = 0.0 - tm;
+        const double tm2 = d0 * d0;
+        V.tm = tm;
+        V.squared = true;
+        int below = 0;  // values whose squared error sorts before the block of the zero counts
+        double lo2 = INFINITY, hi2 = -INFINITY;
+        for (int k = Wv::lane(); k < n; k += Wv::W) {
+            const double q = V[k];
+            if (q >= 0.0) {
+                below += q < tm2 ? 1 : 0;
+                bad |= (q < INFINITY) ? 0 : 1;
+                lo2 = q < lo2 ? q : lo2;
+                hi2 = q > hi2 ? q : hi2;
+            }
+        }
+        below = Wv::sumi(below);
+        bad = Wv::sumi(bad);
+        range[0] = -Wv::max(-lo2); range[1] = Wv::max(hi2);
+        if (bad != 0) { failed = true; return NAN; }
+        // ranks among the non-zero samples that fall into [r_lo, r_hi] once the block sits at [below, below + zeros)
+        const int j_lo = r_lo < below ? r_lo : (r_lo - zeros > below ? r_lo - zeros : below);
+        const int j_hi = r_hi < below ? r_hi : (r_hi < below + zeros ? below - 1 : r_hi - zeros);
+        const int b_lo = r_lo > below ? r_lo : below, b_hi = r_hi < below + zeros - 1 ? r_hi : below + zeros - 1;
+        if (!bucket_rank_sum<Wv>(V, n, n_act, j_lo, j_hi, W, s2, range)) {
+            failed = true;
+            return NAN;
+        }
+        const double ts = s2 + (b_hi >= b_lo ? (double)(b_hi - b_lo + 1) * tm2 : 0.0);
+        const double tv = scales[cls] * (ts / (double)(n - 2 * nt));
+        vmax = (tv > vmax || tv != tv) ? tv : vmax;
+    }
+    double m;
+    if (cells_summed == N) {
+        m = Wv::sum(cell_total) / (double)N;
+    } else {
+        double s = 0.0;
+        for (int n = Wv::lane(); n < N; n += Wv::W) s += (double)y[n] / sf[n];
+        m = Wv::sum(s) / (double)N;
+    }
+    double ar = (vmax - m) / (m * m);
+    ar = (ar > 0.04) ? ar : 0.04;
+    if (vmax != vmax) ar = vmax;
+    return ar;
+}
+
 // Per-sample accumulator of the Cook's bookkeeping (dds.py:1034-1040, 1066-1110, 1325-1326): feed every
 // sample's (y, mu, hat) once, finish() reduces over the wave.  Used by cooks_gene (mu / hat rows from memory)
 // and by the epilogue of the LFC fit (mu / hat straight from the IRLS registers).
@@ -880,11 +990,15 @@ struct CooksAcc {
         const bool gt = ck > cutoff;
         g_all |= gt ? 1 : 0;
         if (gt && (fl & 1)) { g_use = 1; if (!(fl & 2)) g_use_nr = 1; }
-        // np.argmax: first NaN wins, else first maximum (samples arrive in ascending order per lane)
+        // np.argmax: first NaN wins, else first maximum - whatever order the samples arrive in (the mixed-design kernels
+        // walk them sorted by design cell): ties go to the smaller sample index
         const bool isn = (ck != ck);
-        if (!best_nan) {
-            if (isn) { best_nan = true; best_idx = n; }
-            else if (ck > best) { best = ck; best_idx = n; }
+        if (isn) {
+            best_idx = (best_nan && best_idx < n) ? best_idx : n;
+            best_nan = true;
+        } else if (!best_nan && (ck > best || (ck == best && n < best_idx))) {
+            best = ck;
+            best_idx = n;
         }
         return ck;
     }

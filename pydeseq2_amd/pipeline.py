@@ -477,13 +477,13 @@ class DeseqPipeline:
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
             # the iteration counts of this fit order the genes of the LFC fit (dsq_irls_order_hint)
             S["_irls_it"] = self._dvec(Gs, np.int32)
-            self._k("irls_mu", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+            self._k("irls_mu", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                     _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), _vp(S["_irls_it"].ptr),
                     self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
-                    None, None, c_double(0.0), 0, None, None, None)
+                    None, None, c_double(0.0), 0, None, None, None, _vp(self._mix) if self._mix else None)
             if from_beta:
                 mh.d_beta = d_b
             if per_cell:
@@ -541,13 +541,13 @@ class DeseqPipeline:
                  [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
         if S.get("_irls_it") is not None:
             self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
-        self._k("lfc_fit", Gs, "dsq_dev_lfc_fit", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
+        self._k("lfc_fit", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
                 _vp(S["beta"].ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
                 _vp(S["lconv"].ptr), None, self._cells_arg(), *ck,
                 _vp(ridge.ctypes.data), _vp(contrast.ctypes.data), c_double(lfc_null), alt,
-                _vp(S["p"].ptr), _vp(S["stat"].ptr), _vp(S["se"].ptr))
+                _vp(S["p"].ptr), _vp(S["stat"].ptr), _vp(S["se"].ptr), _vp(self._mix) if self._mix else None)
         return d_mu, d_hat
 
     # ------------------------------------------------------------------ cross-gene steps (hooks)
@@ -727,9 +727,9 @@ class DeseqPipeline:
                 ctx.call("dsq_side_begin")
                 self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
             try:
-                self._k("robust_disp", Gn, "dsq_dev_robust_disp", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
-                        _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell, N, Gn,
-                        _vp(d_rd.ptr))
+                self._k("robust_disp", Gn, "dsq_dev_robust_disp2", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
+                        _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
+                        D.min_cell, N, Gn, _vp(d_rd.ptr))
             except BaseException:
                 if self.overlap:  # back on the main stream, both streams drained (a shared Context stays usable)
                     ctx.call("dsq_side_abort")

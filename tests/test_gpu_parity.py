@@ -847,3 +847,64 @@ def test_mixed_design_pipeline_every_shape(P, Q, levels, N, monkeypatch):
     assert (nz & ~ok).sum() <= 2
     assert_close(res.genewise_dispersions[ok], ref17.genewise_dispersions[ok], 2e-6, 0, "matrix route vs general")
     assert_close(res.dispersions[ok], ref17.dispersions[ok], 2e-6, 0, "matrix route vs general, final")
+
+
+@pytest.mark.parametrize("design,N", [("2level", 600), ("mixed", 700), ("2factor", 1200)])
+def test_robust_dispersions_without_the_lds_buffer(design, N, monkeypatch):
+    """Designs whose cells all hold >= 129 samples (or that have no cells: continuous covariates) take
+    k_robust_disp_lean - the trimmed sums recompute the normalised counts from the gene's row instead of buffering the
+    cell in LDS.  Same values up to the contraction of a multiply-add (the recomputed value is not rounded through
+    memory): the Cook's layer (which the robust dispersion scales) agrees to 1e-12 with the buffered kernel's; genes with
+    heavy ties / huge counts exercise the hand-back to the buffered kernel."""
+    from pydeseq2_amd import DeseqPipeline
+
+    monkeypatch.setenv("DSQ_ROBUST_LEAN_MIN", "0")  # (the default leaves cells below 2048 samples to the buffered kernel)
+    counts, X = orc.synth_counts(500, N, design, 21)
+    counts[:, 3] = 0
+    counts[:, 4] = 1            # one value: every boundary bucket holds all samples
+    counts[::2, 5] = 7          # two values
+    counts[:, 6] = np.where(np.arange(N) % 50 == 0, 10 ** 9, 3)  # huge range
+    counts[7, 8] = 300000       # an outlier (refit path)
+    pipe = DeseqPipeline(counts, X, device=0)
+    res = pipe.deseq2()
+    cooks = pipe.layer("cooks")
+    monkeypatch.setenv("DSQ_NO_ROBUST_LEAN", "1")
+    pipe2 = DeseqPipeline(counts, X, device=0)
+    res2 = pipe2.deseq2()
+    cooks2 = pipe2.layer("cooks")
+    assert np.array_equal(np.isnan(cooks), np.isnan(cooks2))
+    ok = ~np.isnan(cooks)
+    assert_close(cooks[ok], cooks2[ok], 1e-12, 0, "Cook's distances, lean vs buffered robust dispersions")
+    assert np.array_equal(res.cooks_outlier, res2.cooks_outlier) and np.array_equal(res.refitted, res2.refitted)
+
+
+@pytest.mark.parametrize("case", ["p4", "p6", "p8m"])
+def test_mixed_design_irls_kernel_vs_reference_kats(inf, case, monkeypatch):
+    """k_irls_mix against the unmodified utils.irls_solver (utils.py:273-438) on the KAT designs with continuous
+    covariates: coefficients, the unclamped mu, hat diagonals, convergence flags - for the mu_hat fit (method-of-moments
+    dispersions) and for the LFC fit; then the Wald statistics of the fused epilogue through the pipeline are covered by
+    test_mixed_design_pipeline_every_shape."""
+    monkeypatch.setenv("DSQ_MIX_FORCE", "1")
+    k = load_kat(case)
+    N, P = k["X"].shape
+    b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], k["mom"], 0.5, 1e-8)
+    assert (conv == k["irls_conv"]).all()
+    assert_close(b, k["irls_beta"], 1e-8, 1e-10, "irls beta")
+    assert_close(mu, k["irls_mu"], 1e-8, 1e-10, "irls mu")
+    assert_close(H, k["irls_H"], 1e-8, 1e-12, "irls H")
+    disp = np.clip(k["map_alpha"], 1e-8, float(max(10, N)))
+    b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], disp, 0.5, 1e-8)
+    assert (conv == k["lfc_conv"]).all()
+    assert_close(b, k["lfc_beta"], 1e-8, 1e-10, "lfc beta")
+    assert_close(mu, k["lfc_mu"], 1e-8, 1e-10, "lfc mu")
+    assert_close(H, k["lfc_H"], 1e-8, 1e-12, "lfc H")
+    # a gene with a count beyond the 16-bit staging: gathered from its row inside the same kernel
+    counts = k["counts"].copy()
+    counts[2, 1] = 70001
+    monkeypatch.delenv("DSQ_MIX_FORCE")
+    b0, mu0, H0, c0 = inf.irls(counts, k["sf"], k["X"], disp, 0.5, 1e-8)   # general kernel
+    monkeypatch.setenv("DSQ_MIX_FORCE", "1")
+    b1, mu1, H1, c1 = inf.irls(counts, k["sf"], k["X"], disp, 0.5, 1e-8)   # mixed-design kernel
+    assert (c0 == c1).all()
+    assert_close(b1, b0, 1e-8, 1e-10, "beta, 17-bit gene")
+    assert_close(H1, H0, 1e-8, 1e-12, "hat, 17-bit gene")

@@ -304,6 +304,12 @@ typedef struct dsq_mix dsq_mix;
 int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** out);
 void dsq_mix_destroy(dsq_mix* mix);
 int dsq_mix_info(const dsq_mix* mix, int* n_slots, int* n_cells, int* n_continuous);
+/* h_slot_of[N]: the slot of every sample (the kernels walk the samples sorted by design cell, cells padded to whole
+ * loop iterations; a slot-ordered N x G layer - see dsq_dev_lfc_fit2 - is read through this map) */
+int dsq_mix_slots(const dsq_mix* mix, int32_t* h_slot_of);
+/* 1 when dsq_dev_lfc_fit2 runs such a design on k_irls_mix (and may therefore be given a slot-ordered Cook's layer), else
+ * 0: the library's own routing rule */
+int dsq_mix_takes_irls(const dsq_mix* mix, int full_rank);
 /* diagnostics: launches of the mixed-design dispersion kernel by this process so far */
 int dsq_mix_launch_count(void);
 /* dsq_dev_alpha_mle3 with a mixed design: the genes of d_rows run k_alpha_mix (one gene per wavefront, counts staged as
@@ -356,7 +362,10 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
                     double* d_stats, double* d_se);
 /* dsq_dev_lfc_fit with a mixed design (dsq_mix_create): the fit, its start values and its epilogue run k_irls_mix
  * (csrc/dsq_k_irls_mix.hip: samples sorted by design cell, X^T W X from per-cell + covariate sums); mix == NULL: as
- * dsq_dev_lfc_fit.  Same outputs; diverged genes take the same rescue pass. */
+ * dsq_dev_lfc_fit.  Same outputs; diverged genes take the same rescue pass.
+ * cooks_ld != 0 (>= the design's slots, dsq_mix_info; needs mix): d_cooks is written in SLOT order with that row pitch -
+ * coalesced stores instead of a scatter over the row (which cost 5 x the layer's bytes in HBM writes); its readers are
+ * dsq_dev_replace_outliers2 and dsq_mix_slots.  cooks_ld == 0: sample order, pitch ldn, as dsq_dev_lfc_fit. */
 int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt,
                      const double* d_pinvXt, int ldx, int N, int G, int P, int full_rank, const double* d_disp,
                      double min_mu, double beta_tol, double min_beta, double max_beta, int maxiter, double* d_beta,
@@ -364,7 +373,12 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
                      const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
                      uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
                      const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
-                     double* d_stats, double* d_se, const dsq_mix* mix);
+                     double* d_stats, double* d_se, const dsq_mix* mix, int cooks_ld);
+/* dsq_dev_replace_outliers for a Cook's layer in slot order (cooks_ld, mix as given to dsq_dev_lfc_fit2); cooks_ld == 0:
+ * as dsq_dev_replace_outliers. */
+int dsq_dev_replace_outliers2(dsq_ctx* ctx, const int32_t* d_y, const double* d_cooks, int ldn, const double* d_sf,
+                              const uint8_t* d_flags, const int32_t* d_gene_idx, int n_sel, int N, double cutoff,
+                              int32_t* d_y_out, uint8_t* d_all_zero, int cooks_ld, const dsq_mix* mix);
 int dsq_dev_irls_layers(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_Xt, int ldx,
                         int N, int G, int P, const double* d_disp, const double* d_beta, double min_mu, double* d_mu,
                         double* d_hat);

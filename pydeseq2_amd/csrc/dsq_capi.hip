@@ -290,8 +290,6 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             } else {
                 if (need_d * sizeof(double) > ctx->mix_cap) {
                     if (ctx->d_mix) (void)hipFree(ctx->d_mix);
-    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
-    if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
                     ctx->d_mix = nullptr; ctx->mix_cap = 0;
                     DSQ_HIP(hipMalloc(&ctx->d_mix, need_d * sizeof(double)));
                     ctx->mix_cap = need_d * sizeof(double);
@@ -697,7 +695,9 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
     DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(int32_t), ctx->stream));  // [0] fallback genes, [1] gene queue
     if (ex_local.mix != nullptr && dsq::irls_takes_mix(ex_local.mix, full_rank)) {
-        const size_t need = dsq::irls_mix_work_bytes(ex_local.mix->Ns);
+        const int n_layers = ((ex_local.flags != nullptr && ex_local.cooks != nullptr) ? 1 : 0) + (d_mu != nullptr ? 1 : 0) +
+                             (d_hat != nullptr ? 1 : 0);
+        const size_t need = dsq::irls_mix_work_bytes(*ex_local.mix, G, n_layers);
         if (need > ctx->mixw_cap) {
             if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
             ctx->d_mixw = nullptr; ctx->mixw_cap = 0;
@@ -705,6 +705,7 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
             ctx->mixw_cap = need;
         }
         ex_local.mix_work = ctx->d_mixw;
+        ex_local.mix_work_bytes = ctx->mixw_cap;
         ex_local.mix_queue = ctx->d_counter + 1;
     } else {
         ex_local.mix = nullptr;
@@ -863,7 +864,8 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
     const int blk = 64 * dsq::kMixU;
     int Ns = 0;
     for (int c = 0; c < C; ++c) Ns += (count[(size_t)c] + blk - 1) / blk * blk;
-    if (!force && Ns > N + N / 2 + blk) return DSQ_OK;  // mostly padding (small cells): the general kernels do less work
+    Ns = (Ns + 255) & ~255;  // whole blocks of four trips (the staging passes walk four at a time); the tail is padding
+    if (!force && Ns > N + N / 2 + 256) return DSQ_OK;  // mostly padding (small cells): the general kernels do less work
     dsq::MixDesign M{};
     M.Ns = Ns; M.C = C; M.Q = Q; M.P = P; M.N = N;
     {
@@ -874,7 +876,7 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
         }
     }
     if (dsq::alpha_mix_scratch_doubles(M, 4) == 0) return DSQ_OK;  // rows too long for the kernel's LDS staging
-    std::vector<int32_t> perm((size_t)Ns, -1);
+    std::vector<int32_t> perm((size_t)Ns, -1), slot_of((size_t)N, 0);
     std::vector<uint8_t> trip_cell((size_t)(Ns / 64), (uint8_t)(C - 1));
     std::vector<double> Zs((size_t)Q * Ns, 0.0), Xc((size_t)C * P, 0.0), Ginv;
     {
@@ -884,6 +886,7 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
             for (int i = 0; i < count[(size_t)c]; ++i, ++k, ++s) {
                 const int n = idx[(size_t)k];
                 perm[(size_t)s] = n;
+                slot_of[(size_t)n] = s;
                 for (int q = 0; q < Q; ++q) Zs[(size_t)q * Ns + s] = design[(size_t)n * P + M.zcol[q]];
                 if (i == 0)
                     for (int j = 0; j < P; ++j) Xc[(size_t)c * P + j] = cont[(size_t)j] ? 0.0 : design[(size_t)n * P + j];
@@ -932,10 +935,10 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
     }
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_perm = up((size_t)Ns * 4), b_tc = up((size_t)Ns / 64), b_z = up((size_t)Q * Ns * 8),
-                 b_xc = up((size_t)C * P * 8), b_g = up((size_t)P * P * 8);
+                 b_xc = up((size_t)C * P * 8), b_g = up((size_t)P * P * 8), b_so = up((size_t)N * 4);
     dsq_mix* m = new dsq_mix();
     m->device = ctx->device;
-    hipError_t e = hipMalloc(&m->d_block, b_perm + b_tc + b_z + b_xc + b_g);
+    hipError_t e = hipMalloc(&m->d_block, b_perm + b_tc + b_z + b_xc + b_g + b_so);
     if (e != hipSuccess) { delete m; return fail(ctx, DSQ_ERR_HIP, std::string("dsq_mix_create: ") + hipGetErrorString(e)); }
     char* p = (char*)m->d_block;
     auto put = [&](const void* src, size_t bytes, size_t slot) {
@@ -950,6 +953,7 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
     M.Xc = (const double*)put(Xc.data(), (size_t)C * P * 8, b_xc);
     const char* g = put(Ginv.empty() ? nullptr : Ginv.data(), Ginv.empty() ? 0 : (size_t)P * P * 8, b_g);
     M.Ginv = Ginv.empty() ? nullptr : (const double*)g;
+    M.slot_of = (const int32_t*)put(slot_of.data(), (size_t)N * 4, b_so);
     if (e != hipSuccess) {
         (void)hipFree(m->d_block);
         delete m;
@@ -965,6 +969,17 @@ void dsq_mix_destroy(dsq_mix* mix) {
     (void)hipSetDevice(mix->device);
     if (mix->d_block) (void)hipFree(mix->d_block);
     delete mix;
+}
+
+int dsq_mix_slots(const dsq_mix* mix, int32_t* h_slot_of) {
+    if (mix == nullptr || h_slot_of == nullptr) return DSQ_ERR_ARG;
+    return hipMemcpy(h_slot_of, mix->d.slot_of, (size_t)mix->d.N * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess
+               ? DSQ_OK
+               : DSQ_ERR_HIP;
+}
+
+int dsq_mix_takes_irls(const dsq_mix* mix, int full_rank) {
+    return (mix != nullptr && dsq::irls_takes_mix(&mix->d, full_rank)) ? 1 : 0;
 }
 
 int dsq_mix_launch_count(void) { return dsq::alpha_mix_launches(); }
@@ -1000,6 +1015,11 @@ int dsq_dev_robust_disp2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double
                          double* d_robust_disp) {
     DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
     if (whole) min_cell = N;
+    {   // (runs on the side stream from inside another call: attribute an error left behind by an earlier launch to it)
+        const hipError_t pend = hipGetLastError();
+        if (pend != hipSuccess)
+            return fail(ctx, DSQ_ERR_HIP, std::string("HIP error pending before dsq_dev_robust_disp2: ") + hipGetErrorString(pend));
+    }
     if ((size_t)G + 1 > ctx->redo_cap) {
         if (ctx->d_redo) (void)hipFree(ctx->d_redo);
         ctx->d_redo = nullptr; ctx->redo_cap = 0;
@@ -1100,9 +1120,11 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
                      const double* d_robust_disp, const uint8_t* d_flags, double cutoff, double* d_cooks,
                      uint8_t* d_any_all, uint8_t* d_any_use, uint8_t* d_any_use_nr, uint8_t* d_few_above,
                      const double* h_ridge, const double* h_contrast, double lfc_null, int alt, double* d_pvals,
-                     double* d_stats, double* d_se, const dsq_mix* mix) {
+                     double* d_stats, double* d_se, const dsq_mix* mix, int cooks_ld) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(mix == nullptr || (mix->d.P == P && mix->d.N == N), "mix: built for another design");
+    DSQ_CHECK_ARG(cooks_ld == 0 || (mix != nullptr && cooks_ld >= mix->d.Ns && dsq::irls_takes_mix(&mix->d, full_rank)),
+                  "cooks_ld: a slot-ordered Cook's layer needs a mixed design the kernel takes and a pitch >= its slots");
     DSQ_CHECK_ARG(cells == nullptr || cells->n_cells <= dsq::kMaxCells, "too many design cells for the cell path");
     DSQ_CHECK_ARG(d_flags == nullptr || (d_robust_disp && d_any_all && d_any_use && d_any_use_nr && d_few_above),
                   "the fused Cook's bookkeeping needs the robust dispersions and the four flag vectors");
@@ -1112,6 +1134,7 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
     dsq::IrlsExtras ex{};
     ex.cells = to_cells(cells);
     if (mix != nullptr) ex.mix = &mix->d;
+    ex.cooks_ld = cooks_ld;
     if (d_flags != nullptr) {
         ex.robust_disp = d_robust_disp; ex.flags = d_flags; ex.cutoff = cutoff; ex.cooks = d_cooks;
         ex.any_all = d_any_all; ex.any_use = d_any_use; ex.any_use_nr = d_any_use_nr; ex.few_above = d_few_above;
@@ -1147,7 +1170,7 @@ int dsq_dev_lfc_fit(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_s
     return dsq_dev_lfc_fit2(ctx, d_y, ldn, d_sf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp, min_mu, beta_tol,
                             min_beta, max_beta, maxiter, d_beta, d_mu, d_hat, d_converged, d_iters, cells, d_robust_disp,
                             d_flags, cutoff, d_cooks, d_any_all, d_any_use, d_any_use_nr, d_few_above, h_ridge, h_contrast,
-                            lfc_null, alt, d_pvals, d_stats, d_se, nullptr);
+                            lfc_null, alt, d_pvals, d_stats, d_se, nullptr, 0);
 }
 
 int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const double* d_mu,
@@ -1162,13 +1185,23 @@ int dsq_dev_cooks(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf,
     return DSQ_OK;
 }
 
+int dsq_dev_replace_outliers2(dsq_ctx* ctx, const int32_t* d_y, const double* d_cooks, int ldn,
+                              const double* d_sf, const uint8_t* d_flags, const int32_t* d_gene_idx,
+                              int n_sel, int N, double cutoff, int32_t* d_y_out, uint8_t* d_all_zero, int cooks_ld,
+                              const dsq_mix* mix) {
+    DSQ_CHECK_ARG(N <= 16384, "more than 16384 samples is not supported by the outlier replacement");
+    DSQ_CHECK_ARG(cooks_ld == 0 || (mix != nullptr && mix->d.N == N && cooks_ld >= mix->d.Ns),
+                  "cooks_ld: a slot-ordered Cook's layer comes with the mixed design that wrote it");
+    DSQ_HIP(dsq::launch_replace(ctx->stream, d_y, d_cooks, ldn, d_sf, d_flags, d_gene_idx, n_sel, N, cutoff,
+                                d_y_out, d_all_zero, cooks_ld, cooks_ld != 0 ? mix->d.slot_of : nullptr));
+    return DSQ_OK;
+}
+
 int dsq_dev_replace_outliers(dsq_ctx* ctx, const int32_t* d_y, const double* d_cooks, int ldn,
                              const double* d_sf, const uint8_t* d_flags, const int32_t* d_gene_idx,
                              int n_sel, int N, double cutoff, int32_t* d_y_out, uint8_t* d_all_zero) {
-    DSQ_CHECK_ARG(N <= 16384, "more than 16384 samples is not supported by the outlier replacement");
-    DSQ_HIP(dsq::launch_replace(ctx->stream, d_y, d_cooks, ldn, d_sf, d_flags, d_gene_idx, n_sel, N, cutoff,
-                                d_y_out, d_all_zero));
-    return DSQ_OK;
+    return dsq_dev_replace_outliers2(ctx, d_y, d_cooks, ldn, d_sf, d_flags, d_gene_idx, n_sel, N, cutoff, d_y_out,
+                                     d_all_zero, 0, nullptr);
 }
 
 int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, const double* d_Xt, int ldx,

@@ -327,7 +327,7 @@ size_t alpha_mix_scratch_doubles(const MixDesign& D, int n_list) {
     if (D.Q == 1) alpha_mix_grid_q1(D.Ns, D.P, n_list, &blocks, &nw);
     else if (D.Q == 2) alpha_mix_grid_q2(D.Ns, D.P, n_list, &blocks, &nw);
     else if (D.Q == 3) alpha_mix_grid_q3(D.Ns, D.P, n_list, &blocks, &nw);
-    return (size_t)blocks * nw * D.Ns;
+    return blocks > 0 ? (size_t)blocks * nw * D.Ns + (size_t)D.Ns : 0;  // the rows + the slot-ordered size factors
 }
 
 hipError_t launch_alpha_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const int32_t* list,

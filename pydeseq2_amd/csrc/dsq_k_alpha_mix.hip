@@ -28,6 +28,25 @@
 
 namespace dsq {
 
+// developer build (make mixph, tools/mix_phase_probe.py): per-phase cycle accounting of k_alpha_mix
+#if defined(DSQ_MIX_PHASES) && DSQ_MIX_Q == 3
+__device__ unsigned long long g_mix_phase[12];
+#endif
+#if defined(DSQ_MIX_PHASES)
+#if DSQ_MIX_Q != 3
+extern __device__ unsigned long long g_mix_phase[12];
+#endif
+#define MIX_PH(k)                                                       \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const long long t_ = clock64();                                 \
+        ph_acc[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (k);     \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#else
+#define MIX_PH(k) ((void)0)
+#endif
+
 struct MixWaveLds {  // wave-private LDS record (followed by the gene's counts, uint16 [Ns])
     Lbfgsb1d m;
     double cellv[kMixMaxCells];                      // x_c . beta of the categorical part, per cell
@@ -101,13 +120,19 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
     constexpr int q1 = Q > 1 ? 1 : 0, q2 = Q > 2 ? 2 : 0;  // (clamped indices: the unused operands of a pick)
 
     const double lo = log(min_disp), hi = log(max_disp);
+#if defined(DSQ_MIX_PHASES)
+    long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = clock64();
+    int ph_cur = 0;
+#endif
     for (;;) {
+        MIX_PH(0);
         int k = 0;
         if (lane == 0) k = atomicAdd(queue, 1);
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= n_list) break;
         const int g = list != nullptr ? list[k] : k;
         // ------------------------------------------------------------------------------------------ stage the gene
+        MIX_PH(2);
         for (int i = lane; i < kMixTail; i += 64) L->hist[i] = 0u;
         double bz[Q];
 #pragma unroll
@@ -178,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                 if (want_cst && valid) cs.add(-((double)v * flog_t(m)));
             }
         }
+        MIX_PH(3);
         maxc = DeviceWave::maxi(maxc);
         DeviceWave::sync();
         {   // tail counts T_i = #{y > i}; sum_n lgamma(y_n + 1) = sum_i T_i log(i + 1) from the same walk
@@ -216,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
         int budget = (eval_cap > 0 && resume == 0) ? eval_cap : 0x7fffffff;
         while (!L->m.done && budget > 0) {
             --budget;
+            MIX_PH(4);
             const double la = DeviceWave::uniform(L->m.x);
             const double alpha = DeviceWave::uniform(exp(la));
             const double a = DeviceWave::uniform(frcp(alpha));
@@ -279,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                     for (int q = 0; q < Q; ++q) zn[u][q] = D.Zs[(size_t)q * Ns + s];
                 }
             };
+            MIX_PH(5);
             issue(0);
             for (int t0 = 0; t0 < ntrips; t0 += U) {
                 int yi[U];
@@ -338,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                     }
                 }
             }
+            MIX_PH(6);
             fold(cur);
             DeviceWave::template sum_n<2 * QQ>(zz);
             if (kind == 2) {
@@ -354,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
             double gr = alpha * (-(a * a * accg));
             if (lane < T) { L->ent[lane] = Me; L->ent[T + lane] = dMe; }
             DeviceWave::sync();
+            MIX_PH(7);
             {   // Cox-Reid term 0.5 log det M and its derivative 0.5 alpha tr(M^-1 dM): the factor, its inverse factor and
                 // then dM are the register peak (two packed matrices, not four: tr(M^-1 dM) = sum_k l_k dM l_k^T, l_k the
                 // rows of L^-1 - no inverse matrix)
@@ -373,9 +403,11 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                 f += dl * dl / (2.0 * prior_var);
                 gr += dl / prior_var;
             }
+            MIX_PH(8);
             L->m.feed(f, gr);
             DeviceWave::sync();
         }
+        MIX_PH(9);
         // ------------------------------------------------------------------------------------------ result / parking
         if (!L->m.done) {  // out of this launch's evaluation budget: the continuation launch resumes the gene
             constexpr int kDw = (int)(sizeof(Lbfgsb1d) / 4);
@@ -391,6 +423,15 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
         }
         DeviceWave::sync();
     }
+#if defined(DSQ_MIX_PHASES)
+    MIX_PH(0);
+    if (lane == 0) {
+        unsigned long long life = 0;
+        for (int i = 0; i < 10; ++i) { atomicAdd(&g_mix_phase[i], (unsigned long long)ph_acc[i]); life += ph_acc[i]; }
+        atomicMax(&g_mix_phase[10], life);
+        atomicAdd(&g_mix_phase[11], 1ull);
+    }
+#endif
 }
 
 // wavefronts per workgroup for rows of Ns slots: four when two workgroups still share a CU's LDS, else fewer (0: too long)
@@ -472,3 +513,14 @@ hipError_t DSQ_MIX_CAT(launch_alpha_mix_q, DSQ_MIX_Q)(
 }
 
 }  // namespace dsq
+
+#if defined(DSQ_MIX_PHASES) && DSQ_MIX_Q == 3
+extern "C" int dsq_debug_mix_phase_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dsq::g_mix_phase), 12 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[12] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dsq::g_mix_phase), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

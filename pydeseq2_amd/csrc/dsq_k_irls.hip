@@ -421,9 +421,10 @@ bool irls_takes_rows(int N, int P_, int n_cells) {
 // ---- mixed designs: one translation unit per number of continuous covariates (dsq_k_irls_mix.hip)
 #define DSQ_MIXI_DECL(Q_)                                                                                             \
     bool irls_mix_fits_q##Q_(int Ns, int P);                                                                          \
+    void irls_mix_grid_q##Q_(int Ns, int P, int G, int* blocks, int* nw);                                             \
     hipError_t launch_irls_mix_q##Q_(hipStream_t, const int32_t*, int, const MixDesign&, const double*, int, int32_t*, \
                                      const double*, double, double, double, int, double*, double*, double*, uint8_t*, \
-                                     int32_t*, int32_t*, int32_t*, const IrlsExtras&, void*);
+                                     int32_t*, int32_t*, int32_t*, const IrlsExtras&, void*, size_t);
 DSQ_MIXI_DECL(1)
 DSQ_MIXI_DECL(2)
 DSQ_MIXI_DECL(3)
@@ -440,17 +441,27 @@ bool irls_takes_mix(const MixDesign* mix, int full_rank) {
     }
 }
 
+size_t irls_mix_work_bytes(const MixDesign& D, int G, int n_layers) {
+    int blocks = 0, nw = 0;
+    if (D.Q == 1) irls_mix_grid_q1(D.Ns, D.P, G, &blocks, &nw);
+    else if (D.Q == 2) irls_mix_grid_q2(D.Ns, D.P, G, &blocks, &nw);
+    else if (D.Q == 3) irls_mix_grid_q3(D.Ns, D.P, G, &blocks, &nw);
+    (void)blocks; (void)nw; (void)n_layers; (void)G;  // (no per-wavefront rows: the layers are written in place)
+    return (size_t)D.Ns * 17 + 64;
+}
+
 static hipError_t launch_irls_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G,
                                   int32_t* queue, const double* disp, double min_mu, double beta_tol, double max_beta,
                                   int maxiter, double* beta, double* mu, double* hat, uint8_t* conv, int32_t* iters,
-                                  int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work) {
+                                  int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work,
+                                  size_t work_bytes) {
     switch (D.Q) {
         case 1: return launch_irls_mix_q1(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
-                                          hat, conv, iters, fb_count, fb_list, ex, work);
+                                          hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
         case 2: return launch_irls_mix_q2(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
-                                          hat, conv, iters, fb_count, fb_list, ex, work);
+                                          hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
         case 3: return launch_irls_mix_q3(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
-                                          hat, conv, iters, fb_count, fb_list, ex, work);
+                                          hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
         default: return hipErrorInvalidValue;
     }
 }
@@ -468,7 +479,7 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     // mixed designs (dsq_k_irls_mix.hip): one gene per wavefront in slot order; the same outputs and fallback list
     if (ex.mix != nullptr && ex.mix_work != nullptr && ex.mix_queue != nullptr && irls_takes_mix(ex.mix, full_rank))
         return launch_irls_mix(st, y, ldn, *ex.mix, sf, G, ex.mix_queue, disp, min_mu, beta_tol, max_beta, maxiter, beta,
-                               mu, hat, conv, iters, fb_count, fb_list, ex, ex.mix_work);
+                               mu, hat, conv, iters, fb_count, fb_list, ex, ex.mix_work, ex.mix_work_bytes);
     if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()))) {
         if (ex.cells.C > 0 && ex.cells.C <= kSmallCells) ex.cells = CellDesign{};  // (the wide kernels take 5..64 cells)
         return launch_wide_irls(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, G, P_, full_rank, disp, min_mu, beta_tol,

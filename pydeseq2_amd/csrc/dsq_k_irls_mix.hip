@@ -389,7 +389,14 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
         const bool want_cooks = ex.flags != nullptr, want_wald = ex.ridge != nullptr;
         double* const mu_row = mu_out != nullptr ? mu_out + (size_t)g * ldn : nullptr;
         double* const hat_row = hat_out != nullptr ? hat_out + (size_t)g * ldn : nullptr;
-        double* const cooks_row = (want_cooks && ex.cooks != nullptr) ? ex.cooks + (size_t)g * ldn : nullptr;
+        // the Cook's layer: ex.cooks_ld == 0: sample order, pitch ldn; else SLOT order with that pitch (>= Ns) - one
+        // coalesced 512-byte store per trip instead of 64 scattered 8-byte stores (which, over the 40 KB rows of 2048
+        // wavefronts, evicted half-written lines from L2: rocprofv3 showed 5 x the layer's bytes written to HBM); the
+        // readers (outlier replacement, DeseqPipeline.layer) go through MixDesign::slot_of
+        const bool cooks_slots = ex.cooks_ld > 0;
+        double* const cooks_row = (want_cooks && ex.cooks != nullptr)
+                                      ? ex.cooks + (size_t)g * (cooks_slots ? (size_t)ex.cooks_ld : (size_t)ldn)
+                                      : nullptr;
         CooksOut cko{};
         WaldOut wo{};
         if (mu_row != nullptr || hat_row != nullptr || want_cooks || want_wald) {
@@ -501,9 +508,13 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                         }
                         const double h = wv * qf;
                         if (valid && hat_row != nullptr) hat_row[n] = h;
-                        if (want_cooks && valid) {
-                            const double ck = acc.add(n, (double)yi, mu_raw, h, flags_s[s]);
-                            if (cooks_row != nullptr) cooks_row[n] = ck;
+                        if (want_cooks) {
+                            double ck = 0.0;
+                            if (valid) ck = acc.add(n, (double)yi, mu_raw, h, flags_s[s]);
+                            if (cooks_row != nullptr) {
+                                if (cooks_slots) cooks_row[s] = ck;
+                                else if (valid) cooks_row[n] = ck;
+                            }
                         }
                     }
                     if (want_wald) {
@@ -564,28 +575,44 @@ static int mixi_waves_per_block(int Ns, int P) {
 #define DSQ_MIX_CAT_(a, b) a##b
 #define DSQ_MIX_CAT(a, b) DSQ_MIX_CAT_(a, b)
 
-// work: 2 * Ns doubles + Ns bytes of device scratch for the slot-ordered per-sample vectors (irls_mix_work_bytes)
-hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
-    hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G, int32_t* queue,
-    const double* disp, double min_mu, double beta_tol, double max_beta, int maxiter, double* beta, double* mu,
-    double* hat, uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work) {
-    constexpr int Q = DSQ_MIX_Q;
-    if (G <= 0) return hipSuccess;
-    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || D.Ginv == nullptr || work == nullptr) return hipErrorInvalidValue;
-    const int nw = mixi_waves_per_block(D.Ns, D.P);
+// persistent grid for G genes: (workgroups, wavefronts per workgroup); 0 workgroups: rows too long
+void DSQ_MIX_CAT(irls_mix_grid_q, DSQ_MIX_Q)(int Ns, int P, int G, int* blocks, int* nw_out) {
+    *blocks = 0; *nw_out = 0;
+    const int nw = mixi_waves_per_block(Ns, P);
     const int n_cu = current_device_cus();
-    if (nw == 0 || n_cu <= 0) return hipErrorInvalidValue;
-    const size_t smem = mixi_shared_bytes(D.Ns, D.P) + mixi_wave_bytes(D.Ns) * nw + 64;
+    if (nw == 0 || n_cu <= 0 || G <= 0) return;
+    const size_t smem = mixi_shared_bytes(Ns, P) + mixi_wave_bytes(Ns) * nw + 64;
     int per_cu = (int)((156 * 1024) / smem);
     if (per_cu * nw > 8) per_cu = 8 / nw;
     if (per_cu < 1) per_cu = 1;
-    int blocks = (G + nw - 1) / nw;
-    if (blocks > per_cu * n_cu) blocks = per_cu * n_cu;
+    int b = (G + nw - 1) / nw;
+    if (b > per_cu * n_cu) b = per_cu * n_cu;
+    *blocks = b; *nw_out = nw;
+}
+
+// work (irls_mix_work_bytes): slot-ordered size factors, their logs, Cook's flags
+hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
+    hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G, int32_t* queue,
+    const double* disp, double min_mu, double beta_tol, double max_beta, int maxiter, double* beta, double* mu,
+    double* hat, uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work,
+    size_t work_bytes) {
+    constexpr int Q = DSQ_MIX_Q;
+    if (G <= 0) return hipSuccess;
+    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || D.Ginv == nullptr || work == nullptr) return hipErrorInvalidValue;
+    if (ex.cooks_ld != 0 && ex.cooks_ld < D.Ns) return hipErrorInvalidValue;
+    int blocks = 0, nw = 0;
+    DSQ_MIX_CAT(irls_mix_grid_q, DSQ_MIX_Q)(D.Ns, D.P, G, &blocks, &nw);
+    if (blocks == 0 || (size_t)D.Ns * 17 + 64 > work_bytes) return hipErrorInvalidValue;
+    const size_t smem = mixi_shared_bytes(D.Ns, D.P) + mixi_wave_bytes(D.Ns) * nw + 64;
     double* sfs = (double*)work;
     double* lsfs = sfs + D.Ns;
     uint8_t* flags_s = (uint8_t*)(lsfs + D.Ns);
     hipLaunchKernelGGL(k_mix_prep<Q>, dim3((D.Ns + 255) / 256), dim3(256), 0, st, sf, ex.flags, D.perm, D.Ns, sfs, lsfs,
                        flags_s);
+    {
+        const hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+    }
     unsigned cont_mask = 0;
     for (int q = 0; q < Q; ++q) cont_mask |= 1u << D.zcol[q];
 #define DSQ_MIXI_LAUNCH(PP)                                                                                             \

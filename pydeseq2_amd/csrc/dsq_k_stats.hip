@@ -9,6 +9,8 @@
 #include <cfloat>
 #include <hip/hip_cooperative_groups.h>
 
+#include <cstdio>
+
 #include "dsq_dispatch.h"
 #include "dsq_launch.h"
 #include "dsq_stats.h"
@@ -1165,10 +1167,18 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     const bool lean = redo != nullptr && robust_disp_lean_eligible(min_cell, max_cell, whole, N);
     if (lean) {
         hipError_t e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            fprintf(stderr, "[launch_robust_disp] hipMemsetAsync(%p): %s\n", (void*)redo, hipGetErrorString(e));
+            return e;
+        }
         constexpr int WPB = 4;
         hipLaunchKernelGGL((k_robust_disp_lean<WPB>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, ldn, sf,
                            cell_offsets, cell_index, n_cells, whole, N, G, robust_disp, redo, redo + 1);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            fprintf(stderr, "[launch_robust_disp] k_robust_disp_lean launch: %s (G %d N %d)\n", hipGetErrorString(e), G, N);
+            return e;
+        }
     }
     const int32_t* list = lean ? redo + 1 : nullptr;
     const int32_t* n_dev = lean ? redo : nullptr;
@@ -1180,7 +1190,10 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
     const bool big = biggest >= kTrimBucketMin;
-    if (per_wave > 160 * 1024) return hipErrorInvalidValue;
+    if (per_wave > 160 * 1024) {
+        fprintf(stderr, "[launch_robust_disp] %zu bytes of LDS per wavefront (cell of %d samples)\n", per_wave, biggest);
+        return hipErrorInvalidValue;
+    }
 #define DSQ_RD_LAUNCH(WPB) \
     do { if (big) DSQ_RD_LAUNCH_(WPB, true); else DSQ_RD_LAUNCH_(WPB, false); } while (0)
 #define DSQ_RD_LAUNCH_(WPB, BIG)                                                                             \
@@ -1199,7 +1212,13 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     else DSQ_RD_LAUNCH(1);
 #undef DSQ_RD_LAUNCH
 #undef DSQ_RD_LAUNCH_
-    return hipGetLastError();
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            fprintf(stderr, "[launch_robust_disp] buffered kernel launch: %s (G %d, %zu B of LDS per wavefront, lean %d)\n",
+                    hipGetErrorString(e), G, per_wave, (int)lean);
+        return e;
+    }
 }
 
 // ------------------------------------------------------------------ outlier replacement
@@ -1211,21 +1230,23 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
                                                       const int32_t* __restrict__ gene_idx, int n_sel,
                                                       int N, int cap, int stride, double cutoff,
                                                       int32_t* __restrict__ y_out,
-                                                      uint8_t* __restrict__ all_zero) {
+                                                      uint8_t* __restrict__ all_zero, int cooks_ld,
+                                                      const int32_t* __restrict__ slot_of) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int w = threadIdx.x >> 6;
     const int k = blockIdx.x * WPB + w;
     if (k >= n_sel) return;
     const int g = gene_idx[k];
     const int32_t* yr = y + (size_t)g * ldn;
-    const double* ck = cooks + (size_t)g * ldn;
+    // (mixed designs: the Cook's layer is in slot order with its own pitch, see k_irls_mix)
+    const double* ck = cooks + (size_t)g * (slot_of != nullptr ? (size_t)cooks_ld : (size_t)ldn);
     double* scratch = lds + (size_t)w * stride;
     const double tbm = trimmed_base_mean<DeviceWave>(yr, sf, N, 0.2, scratch, LdsSorter(),
                                                      stride > cap ? (BucketWork*)(scratch + cap) : nullptr);
     int nonzero = 0;
     for (int n = DeviceWave::lane(); n < N; n += 64) {
         int v = yr[n];
-        if ((flags[n] & 2) && ck[n] > cutoff) v = (int)(tbm * sf[n]);  // truncation (astype(int))
+        if ((flags[n] & 2) && ck[slot_of != nullptr ? slot_of[n] : n] > cutoff) v = (int)(tbm * sf[n]);  // truncation (astype(int))
         y_out[(size_t)k * ldn + n] = v;
         nonzero |= (v != 0);
     }
@@ -1241,7 +1262,8 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
 
 hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
                           const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
-                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero) {
+                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero, int cooks_ld,
+                          const int32_t* slot_of) {
     if (n_sel <= 0) return hipSuccess;
     const int cap = next_pow2(N);  // (the sort is the fallback of the bucket path: power-of-two room either way)
     const int stride = cap + trim_work_doubles(N);
@@ -1256,7 +1278,7 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
         }                                                                                            \
         hipLaunchKernelGGL(k_replace<WPB>, dim3((n_sel + WPB - 1) / WPB), dim3(64 * WPB),            \
                            per_wave * WPB, st, y, cooks, ldn, sf, flags, gene_idx, n_sel, N, cap,    \
-                           stride, cutoff, y_out, all_zero);                                         \
+                           stride, cutoff, y_out, all_zero, cooks_ld, slot_of);                      \
     } while (0)
     if (per_wave * 4 <= 64 * 1024) DSQ_REPL_LAUNCH(4);
     else if (per_wave * 2 <= 160 * 1024) DSQ_REPL_LAUNCH(2);

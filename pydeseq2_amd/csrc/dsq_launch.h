@@ -184,6 +184,7 @@ struct IrlsExtras {
     const uint8_t* flags;        // [N]
     double cutoff;
     double* cooks;               // [G][ldn] or null
+    int cooks_ld;                // mixed designs: != 0: the layer is written in SLOT order with this pitch (>= mix->Ns)
     uint8_t *any_all, *any_use, *any_use_nr, *few_above;  // [G]
     // fused Wald statistics: on when ridge != nullptr (device pointers)
     const double* ridge;         // [P*P]
@@ -199,10 +200,16 @@ struct IrlsExtras {
     // of device scratch (slot-ordered size factors, their logs, Cook's flags), mix_queue: a zeroed int32 gene counter
     const MixDesign* mix;
     void* mix_work;
+    size_t mix_work_bytes;
     int32_t* mix_queue;
 };
 bool irls_takes_mix(const MixDesign* mix, int full_rank);
-inline size_t irls_mix_work_bytes(int Ns) { return (size_t)Ns * 17 + 64; }
+// device scratch of a mixed-design fit of G genes that writes n_layers N x G layers (Cook's distances, mu, hat diagonal)
+size_t irls_mix_work_bytes(const MixDesign& D, int G, int n_layers);
+hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
+                          const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
+                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero, int cooks_ld,
+                          const int32_t* slot_of);
 // does launch_irls fit this design with sixteen lanes per gene (k_irls_row)?
 bool irls_takes_rows(int N, int P, int n_cells);
 // order[0..G) = genes by decreasing predicted number of IRLS sweeps: `hint_iters` (the iteration counts of an earlier
@@ -274,9 +281,6 @@ hipError_t launch_cooks(hipStream_t st, const int32_t* y, int ldn, const double*
 hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const double* sf,
                               const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
                               int max_cell, int N, int G, double* robust_disp, int min_cell = 0, int32_t* redo = nullptr);
-hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
-                          const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
-                          int N, double cutoff, int32_t* y_out, uint8_t* all_zero);
 hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, const int32_t* idx,
                                   int n_idx, int ncols, double* dst);
 // ---- dsq_k_shrink.hip (apeGLM MAP LFC)

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "dsq_exp_table.h"
 #include "dsq_log_table.h"
 
 #if defined(__HIPCC__)
@@ -308,6 +309,53 @@ DSQ_HD double flog_t(double x) {
     const double p = detail::log1p_tail(r);
     const double dk = (double)k;
     return fma(dk, detail::kLn2Hi, T + (r + (p + dk * detail::kLn2Lo)));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Table-driven exponential for the per-sample loops (mu = sf exp(x . beta): one per sample and IRLS sweep).  The library
+// exp costs ~40 instructions; here x = k ln2/128 + r with |r| <= ln2/256, exp(x) = 2^(k >> 7) * 2^((k & 127)/128) * e^r:
+// the middle factor from a 128-entry table (correctly rounded), e^r - 1 by a degree-5 polynomial (truncation < 6e-19
+// relative), the power of two applied as two exact scale factors so that overflow gives inf and underflow is gradual.
+// Measured against math.exp over [-745, 710]: <= 1 ulp (tests/test_hostsim.py).  ~22 instructions, one LDS read.
+// On the device the table lives in LDS: a kernel that reaches fexp_t calls exp_tab_fill() with all of its threads and
+// synchronises before the first use.
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ double g_exp_tab[kExpTabN];
+#endif
+DSQ_D void exp_tab_fill() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = threadIdx.x; i < kExpTabN; i += blockDim.x) g_exp_tab[i] = kExpTab[i];
+#endif
+}
+DSQ_HD double fexp_t(double x) {
+    // beyond +-800 the result is inf / 0 anyway: clamping keeps the integer arithmetic in range (NaN passes through)
+    const double xc = x > 800.0 ? 800.0 : (x < -800.0 ? -800.0 : x);
+    const double kd = rint(xc * kExpInvStep);
+    double r = fma(-kd, kExpStepHi, xc);
+    r = fma(-kd, kExpStepLo, r);
+    const int ki = (xc == xc) ? (int)kd : 0;
+    const int j = ki & (kExpTabN - 1), m = ki >> 7;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const double lds_d;
+    const double t = ((lds_d*)g_exp_tab)[j];
+#else
+    const double t = kExpTab[j];
+#endif
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    const double p = fma(r * r, q, r);
+    const double e = fma(t, p, t);
+    const int m1 = m >> 1, m2 = m - m1;  // |m| <= 1155: both scale factors are normal numbers
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double s1 = __hiloint2double((1023 + m1) << 20, 0), s2 = __hiloint2double((1023 + m2) << 20, 0);
+#else
+    const uint64_t b1 = (uint64_t)(1023 + m1) << 52, b2 = (uint64_t)(1023 + m2) << 52;
+    double s1, s2;
+    std::memcpy(&s1, &b1, 8);
+    std::memcpy(&s2, &b2, 8);
+#endif
+    return (e * s1) * s2;
 }
 
 // log(1 + u), u >= 0 finite; rw = 1 / (1 + u) (the callers have it)

@@ -23,10 +23,12 @@ constexpr int kMixMaxP = 8;      // design columns at most
 constexpr int kMixMaxCells = 32; // distinct categorical rows at most
 constexpr int kMixTail = 512;    // counts below this enter a gene's tail-count table (as kRowTail)
 constexpr int kMixU = 2;         // 64-sample trips per loop iteration; every cell is padded to whole iterations
+                                 // (and the row to a multiple of 256 slots: the staging passes walk four trips at a time)
 
 // Device-resident description of one mixed design (built once per design by dsq_mix_create, include/deseq_hip.h).
 struct MixDesign {
     const int32_t* perm;       // [Ns] slot -> sample index, -1: padding
+    const int32_t* slot_of;    // [N] sample index -> slot (the inverse of perm)
     const uint8_t* trip_cell;  // [Ns / 64] design cell of every 64-slot trip
     const double* Zs;          // [Q][Ns] continuous covariates in slot order, 0 in padding slots
     const double* Xc;          // [C][P] the cells' design rows with the continuous columns set to 0

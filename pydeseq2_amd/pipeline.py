@@ -216,12 +216,19 @@ class DeseqPipeline:
             self._row_mode = 0
         # 3: MIXED design - categorical columns with few distinct rows + up to three continuous covariates (dsq_mix_create,
         # csrc/dsq_mix.h: the analysis and the eligibility rule live in the library).  IRLS mu_hat route only.
-        self._mix = None
+        self._mix, self._mix_slots, self._slot_of = None, 0, None
         if self._row_mode == 0 and not D.linear_mu and not os.environ.get("DSQ_NO_ALPHA_MIX"):
             mp = _vp()
             ctx_.call("dsq_mix_create", _vp(D.X.ctypes.data), self.N, self.P, C.byref(mp))
             if mp.value:
                 self._mix, self._row_mode = mp.value, 3
+                ns = C.c_int()
+                ctx_.lib.dsq_mix_info(mp, C.byref(ns), None, None)
+                self._mix_slots = int(ns.value)
+                # the Cook's layer of such a design is written in slot order (coalesced rows, csrc/dsq_k_irls_mix.hip):
+                # whoever reads it - the outlier replacement on the device, layer() on the host - goes through this map
+                self._slot_of = np.empty(self.N, dtype=np.int32)
+                ctx_.lib.dsq_mix_slots(mp, _vp(self._slot_of.ctypes.data))
         if self._row_mode:
             d_fl = DeviceArray(ctx_, (self.G,), np.int32)
             ctx_.call("dsq_dev_alpha_row_split", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_fl.ptr))
@@ -483,7 +490,7 @@ class DeseqPipeline:
                     _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), _vp(S["_irls_it"].ptr),
                     self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
-                    None, None, c_double(0.0), 0, None, None, None, _vp(self._mix) if self._mix else None)
+                    None, None, c_double(0.0), 0, None, None, None, _vp(self._mix) if self._mix else None, 0)
             if from_beta:
                 mh.d_beta = d_b
             if per_cell:
@@ -535,8 +542,10 @@ class DeseqPipeline:
         d_hat = self._dmat(Gs) if want else None
         ridge, contrast, lfc_null, alt = wald
         ck = [None, None, c_double(0.0), None, None, None, None, None]
+        cooks_ld = 0
         if cooks is not None:
             d_rd, cutoff, d_cooks = cooks
+            cooks_ld = self._cooks_ld()
             ck = [_vp(d_rd.ptr), _vp(self.d_flags.ptr), c_double(cutoff), _vp(d_cooks.ptr)] + \
                  [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
         if S.get("_irls_it") is not None:
@@ -547,8 +556,14 @@ class DeseqPipeline:
                 _vp(S["beta"].ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
                 _vp(S["lconv"].ptr), None, self._cells_arg(), *ck,
                 _vp(ridge.ctypes.data), _vp(contrast.ctypes.data), c_double(lfc_null), alt,
-                _vp(S["p"].ptr), _vp(S["stat"].ptr), _vp(S["se"].ptr), _vp(self._mix) if self._mix else None)
+                _vp(S["p"].ptr), _vp(S["stat"].ptr), _vp(S["se"].ptr), _vp(self._mix) if self._mix else None, cooks_ld)
         return d_mu, d_hat
+
+    def _cooks_ld(self):
+        """Row pitch of a slot-ordered Cook's layer (mixed designs the IRLS kernel takes), else 0: sample order, pitch ldn."""
+        if self._mix and self.ctx.lib.dsq_mix_takes_irls(_vp(self._mix), int(self.design.full_rank)):
+            return self._mix_slots
+        return 0
 
     # ------------------------------------------------------------------ cross-gene steps (hooks)
     # The only places where a gene needs other genes; DistDeseqPipeline (distributed.py) overrides
@@ -840,7 +855,8 @@ class DeseqPipeline:
         cutoff = self._cooks_cutoff
         ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
         wald_args = (ridge, contrast, float(np.log(2) * lfc_null), ALT[alt_hypothesis])
-        d_cooks = self._dmat(Gn)
+        cld = self._cooks_ld()
+        d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
         if self.overlap:
             ctx.call("dsq_side_wait")
             self._side_pending = False
@@ -866,7 +882,7 @@ class DeseqPipeline:
         # otherwise layer() rebuilds them on demand from the fit's coefficients / dispersions (S is not patched by the
         # refit any more, so its vectors ARE those of this fit)
         self.layers = {"nz_idx": self._arange_G if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
-                       "cooks": d_cooks, "_fit": (d_ynz, d_sf, S["beta"], S["disp"], Gn)}
+                       "cooks": d_cooks, "_cooks_ld": cld, "_fit": (d_ynz, d_sf, S["beta"], S["disp"], Gn)}
         t5 = tick(); T["LFC_cooks_wald"] = t5 - t4
         t6 = t5
 
@@ -889,9 +905,9 @@ class DeseqPipeline:
                 d_ysub = self._dmat(Gr, np.int32)
                 S2 = self._dev_slab(Gr)
                 d_az = S2["naz"]  # its own field: no stage of the sub-problem writes it
-                ctx.call("dsq_dev_replace_outliers", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
+                ctx.call("dsq_dev_replace_outliers2", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
                          _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(cutoff), _vp(d_ysub.ptr),
-                         _vp(d_az.ptr))
+                         _vp(d_az.ptr), cld, _vp(self._mix) if cld else None)
                 deferred = not (profile or self.time_kernels or self.collect_nfev)
                 if deferred:
                     ctx.call("dsq_set_deferred", 1)
@@ -1063,7 +1079,11 @@ class DeseqPipeline:
                           _vp(self.layers["mu_LFC"].ptr), _vp(self.layers["hat_diagonals"].ptr))
             d = self.layers[name]
         nzi = self.layers["nz_idx"]
-        rows = self.ctx.d2h_rows(d.ptr, len(nzi), self.N, self.ldn)
+        if name == "cooks" and self.layers.get("_cooks_ld"):  # slot order on the device: back to sample order here
+            cld = self.layers["_cooks_ld"]
+            rows = self.ctx.d2h_rows(d.ptr, len(nzi), cld, cld)[:, self._slot_of]
+        else:
+            rows = self.ctx.d2h_rows(d.ptr, len(nzi), self.N, self.ldn)
         out = np.full((self.N, self.G), np.nan)
         out[:, nzi] = rows.T
         return out

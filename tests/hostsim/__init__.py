@@ -328,6 +328,13 @@ def flog(x):
     return a, b, c
 
 
+def fexp(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().hs_fexp(_p(x, C.c_double), C.c_int(x.size), _p(out, C.c_double))
+    return out
+
+
 def trimmed_sum(buf, nt):
     """sum(sorted(buf)[nt : len - nt]) through the device's selection routine (host instantiation)."""
     b = np.ascontiguousarray(buf, dtype=np.float64)

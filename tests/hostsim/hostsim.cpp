@@ -44,6 +44,10 @@ void hs_flog(const double* x, int n, double* lg, double* l1p, double* rc) {
     for (int i = 0; i < n; ++i) { lg[i] = flog(x[i]); l1p[i] = flog1p(x[i]); rc[i] = frcp(x[i]); }
 }
 
+void hs_fexp(const double* x, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = fexp_t(x[i]);
+}
+
 void hs_norm_sf(const double* x, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = norm_sf(x[i]);
 }

@@ -279,6 +279,25 @@ def test_lean_log_matches_libm():
     assert np.max(np.abs(l1 - np.log1p(u)) / (np.spacing(np.log1p(u)) + 1e-320)) <= 1.0
 
 
+def test_table_exponential_matches_libm():
+    """fexp_t (dsq_math.h): the exponential of the mixed-design kernels' per-sample loops, <= 1 ulp against the C
+    library over the whole range, exact limits, gradual underflow, NaN."""
+    import math
+
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-745, 709.7, 200000), rng.normal(0, 3, 200000), rng.uniform(-1e-3, 1e-3, 20000),
+                        np.arange(-100, 100) * (math.log(2) / 128), [0.0, -0.0, 1.0, -1.0, 709.78, -708.4, -744.0]])
+    e = hs.fexp(x)
+    ref = np.exp(x)
+    ulp = np.spacing(ref)
+    assert np.max(np.abs(e - ref) / ulp) <= 1.0, np.max(np.abs(e - ref) / ulp)
+    assert hs.fexp([0.0])[0] == 1.0
+    with np.errstate(over="ignore"):
+        assert np.isinf(hs.fexp([710.0, 1e300, np.inf])).all()
+    assert (hs.fexp([-746.0, -1e300, -np.inf]) == 0.0).all()
+    assert np.isnan(hs.fexp([np.nan])[0])
+
+
 def test_lbfgsb_dense_matches_scipy():
     """Dense-matrix L-BFGS-B (n <= 4) used by the trend fit: same iterates as scipy."""
     rng = np.random.default_rng(8)

@@ -6,16 +6,17 @@
 set -u
 TAG=${1:-r01_x}
 CFG=${2:-c3}
+shift 2 2>/dev/null || true   # anything else goes to bench.py (e.g. --genes 7500)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- \
-    python "$REPO/bench.py" --config "$CFG" --steps 5 --warmup 2 > "$OUT/bench_prof.log" 2> "$OUT/bench_prof.err"
+    python "$REPO/bench.py" --config "$CFG" --steps 5 --warmup 2 "$@" > "$OUT/bench_prof.log" 2> "$OUT/bench_prof.err"
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o run -- \
-        python "$REPO/bench.py" --config "$CFG" --steps 1 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/pmc_$C.log" 2>&1
+        python "$REPO/bench.py" --config "$CFG" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > "$OUT/pmc_$C.log" 2>&1
 done
 cd "$REPO"
 for f in $(find "$OUT" -name "*_results.db"); do echo "$f"; done

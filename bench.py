@@ -190,6 +190,59 @@ def parity_report(res, ref):
             "ok": bool(good)}
 
 
+def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs):
+    """One more configuration on the same device (extras of the default run, so that the driver's record carries every
+    BASELINE configuration, not only the headline one): ms per step of the resident path, the dispersion stage's launch
+    time and HBM-roofline fraction (HIP events, as for the main line) and an in-run parity object against the oracle on
+    a slice of the same matrix."""
+    import warnings
+
+    import pydeseq2_amd
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.synth import synth_counts_block
+
+    G_cfg, N, design = CONFIGS[name]
+    G = genes or G_cfg
+    if name == "c5":
+        counts, X = synth_counts_block(G, N, design, SEEDS[name])
+    else:
+        counts, X = synth_fast(G, N, design, seed=SEEDS[name])
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx)
+    for _ in range(warmup + 1):
+        pipe.deseq2()
+    pipe.kernel_log = {}
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.deseq2()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    big = [(ms, g) for ms, g in pipe.kernel_log.get("k_alpha", []) if g > 0.5 * G]
+    full_ms = float(np.mean([ms for ms, _ in big])) if big else None
+    alg = G * (12.0 * N + 17.0)
+    out = {"workload": f"{name}: {G} genes x {N} samples, design {design} (p={X.shape[1]})"
+                       + (" - one of eight GPUs' share of BASELINE configs[4]" if (name == "c5" and G < G_cfg) else ""),
+           "ms_per_step": round(dt * 1e3, 3), "genes_per_s": round(G / dt, 1),
+           "dispersion_stage": None if full_ms is None else {
+               "full_launch_ms": round(full_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+               "achieved_GBps": round(alg / (full_ms * 1e-3) / 1e9, 2),
+               "frac": round(alg / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    if parity_genes:
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sub = np.ascontiguousarray(counts[:, :parity_genes])
+                ref = orc.deseq2(sub, X, n_jobs=n_jobs, keep_layers=False)
+            psub = pydeseq2_amd.DeseqPipeline(sub, X, ctx=ctx)
+            out["parity"] = parity_report(psub.deseq2(), ref)
+            out["parity"]["slice"] = f"first {parity_genes} genes of this matrix"
+            psub.close()
+        except Exception as e:  # noqa: BLE001
+            out["parity_error"] = repr(e)
+    pipe.close()
+    return out
+
+
 class _TimedComm:
     """Wraps a communicator for the profiled step: HIP-event time of every collective on the engine's stream."""
 
@@ -232,7 +285,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.scaling is None:
-        args.scaling = "strong" if world > 1 else "weak"
+        args.scaling = "strong"  # (one GPU: the named configuration, whole - the N = 1 point of the strong-scaling curve)
     N, design = CONFIGS[args.config][1:]
     counts, X, samp, G, G_total, generator = plan_rank_data(args.config, args.genes, args.scaling, rank, world)
 
@@ -436,6 +489,17 @@ def main():
                 extras["parity_c4"] = parity_report(p4.deseq2(), ref4)
                 extras["parity_c4"]["slice"] = "2000 genes x 500 samples, design 3factor (p=8), seed 3"
                 p4.close()
+                # the other BASELINE configurations on the same device (configs[1], [3] at full size, and one GPU's share
+                # of configs[4]): each with its step time, its dispersion-stage roofline fraction and an in-run parity check
+                oc = {}
+                for nm, gn, pg in (("c2", 0, 2000), ("c4", 0, 0), ("c5", 7500, 300)):
+                    try:
+                        oc[nm if gn == 0 else f"{nm}_shard"] = measure_other_config(nm, gn, ctx, 5, 2, pg, n_jobs)
+                    except Exception as e:  # noqa: BLE001
+                        oc[nm] = {"error": repr(e)}
+                if "c4" in oc and "parity_c4" in extras:
+                    oc["c4"]["parity"] = extras["parity_c4"]
+                extras["other_configs"] = oc
         except Exception as e:  # noqa: BLE001 - the GPU measurement above stands on its own
             print(f"[bench] cpu_baseline / parity failed: {e!r}", file=sys.stderr)
     parity_ok = bool(parity and parity["ok"] and extras.get("parity_c4", {"ok": True})["ok"])
@@ -447,10 +511,10 @@ def main():
         "metric": "genes/sec end-to-end deseq2() (size factors->dispersion->IRLS->Wald)",
         "value": round(value, 1), "unit": "genes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {G_total} genes x {N} samples in total ({G} per GPU, "
-                               f"{args.scaling} scaling), design {design} (p={X.shape[1]}), NB counts "
-                               f"(SURVEY 8d generator)",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {G_total} genes x {N} samples in total"
+                               + (f" ({G} per GPU, {args.scaling} scaling)" if world > 1 else "")
+                               + f", design {design} (p={X.shape[1]}), NB counts (SURVEY 8d generator)",
                    "genes_per_gpu": G, "genes_total": G_total, "samples": N, "p": int(X.shape[1]),
                    "collectives": transport, "generator": generator,
                    "device": info["name"] or f"{info['arch']} ({info['cu_count']} CUs)", "arch": info["arch"]},

@@ -474,6 +474,13 @@ int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* 
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                        uint8_t* d_converged);
+/* dsq_dev_lfc_shrink that may also (or only) return d_ih_entry[G] = inv_hessian[g][shrink_index][shrink_index] - all that
+ * DeseqStats.lfc_shrink derives the shrunken lfcSE from (ds.py:424-433): 8 bytes per gene back instead of 8 p^2.
+ * d_inv_hessian and d_ih_entry may each be NULL; d_ih_entry needs P <= 12. */
+int dsq_dev_lfc_shrink2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                        uint8_t* d_converged, double* d_ih_entry);
 /* Adjusted p-values of DeseqStats.summary() (ds.py:486-542).
  * prepare: sorts the p-values once, derives the 50 baseMean cut-offs (np.quantile of base_mean at
  *   theta = linspace(mean(base_mean == 0), 0.95 or 1, 50)), assigns every gene the number of cut-offs it

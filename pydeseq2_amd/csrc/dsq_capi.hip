@@ -1226,15 +1226,24 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
     return DSQ_OK;
 }
 
+int dsq_dev_lfc_shrink2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                        uint8_t* d_converged, double* d_ih_entry) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
+    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
+    DSQ_CHECK_ARG(d_ih_entry == nullptr || P <= DSQ_BFGS_MAX_P, "d_ih_entry: designs of at most 12 columns (wider: d_inv_hessian)");
+    DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
+                               prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged, d_ih_entry));
+    return DSQ_OK;
+}
+
 int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                        uint8_t* d_converged) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
-    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
-    DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
-                               prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged));
-    return DSQ_OK;
+    return dsq_dev_lfc_shrink2(ctx, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale, prior_scale,
+                               shrink_index, d_beta, d_inv_hessian, d_converged, nullptr);
 }
 
 int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, int G, const double* d_sf, int mode,

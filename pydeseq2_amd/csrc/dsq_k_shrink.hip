@@ -18,7 +18,8 @@ __global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1
                                                    const double* __restrict__ Xt, int ldx, int N, int G,
                                                    const double* __restrict__ size, double sigma0, double sigma,
                                                    int shrink_index, double* __restrict__ beta,
-                                                   double* __restrict__ invh, uint8_t* __restrict__ conv) {
+                                                   double* __restrict__ invh, uint8_t* __restrict__ conv,
+                                                   double* __restrict__ ih_entry) {
     __shared__ ShrinkWork<P> work[kWavesPerBlock];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1
     A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
     double b[P];
-    const int ok = shrink_gene<DeviceWave, P>(A, work[w], b, invh ? invh + (size_t)g * P * P : nullptr);
+    const int ok = shrink_gene<DeviceWave, P>(A, work[w], b, invh ? invh + (size_t)g * P * P : nullptr,
+                                              ih_entry ? ih_entry + g : nullptr);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ 
 
 hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx,
                          int N, int G, int P_, const double* size, double sigma0, double sigma, int shrink_index,
-                         double* beta, double* invh, uint8_t* conv) {
+                         double* beta, double* invh, uint8_t* conv, double* ih_entry) {
     if (G <= 0) return hipSuccess;
     if (P_ > DSQ_REG_MAX_P) {
-        if (P_ > 32) return hipErrorInvalidValue;
+        if (P_ > 32 || ih_entry != nullptr) return hipErrorInvalidValue;  // (the run-time-p kernel writes the whole inverse)
         if (P_ <= 16)
             hipLaunchKernelGGL(k_shrink_wide<16>, dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size, sigma0,
                                sigma, shrink_index, beta, invh, conv);
@@ -70,7 +72,7 @@ hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double
     }
     const dim3 grid(genes_to_blocks(G)), block(kBlock);
     DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_shrink<P>, grid, block, 0, st, y, ldn, offset, Xt, ldx, N, G, size,
-                                          sigma0, sigma, shrink_index, beta, invh, conv))
+                                          sigma0, sigma, shrink_index, beta, invh, conv, ih_entry))
     return hipGetLastError();
 }
 

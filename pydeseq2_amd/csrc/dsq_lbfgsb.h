@@ -18,6 +18,7 @@
 // scalar code on it, function/gradient evaluations are the only wave-parallel part).
 #pragma once
 #include "dsq_lbfgsb1d.h"
+#include "dsq_lbfgsb_par.h"
 
 namespace dsq {
 
@@ -28,6 +29,7 @@ struct LbfgsbWork {
     double wn[4 * M * M], wn1[4 * M * M];
     double z[NMAX], r[NMAX], d[NMAX], t[NMAX], xp[NMAX], wa[8 * M];
     double g[NMAX];
+    double sacc[2 * M];  // per-lane accumulators of the lane-parallel factorisations / solves (dsq_lbfgsb_par.h)
     int index[NMAX], iwhere[NMAX], indx2[NMAX];
 };
 
@@ -136,7 +138,11 @@ DSQ_HD void hpsolb(int n, double* t, int* iorder, int iheap) {
 }  // namespace lb
 
 // FG: void(const double* x, double& f, double* g)
-template <int NMAX, class FG, int M = 10>
+// Wv: how the dense linear algebra between two evaluations is executed (dsq_lbfgsb_par.h).  OneLane: every lane of the
+// calling wavefront runs all of it redundantly (the scalar routines as written); a wave policy (DeviceWave): the outputs of
+// formk / subsm / matupd / formt are spread over the lanes, each with its scalar arithmetic - same iterates.  The rare
+// paths (Cauchy point with its bmv products, projections at bounds) stay scalar in either mode.
+template <int NMAX, class FG, int M = 10, class Wv = OneLane>
 DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const double* u,
                               const int* nbd, LbfgsbWork<NMAX, M>& W, double factr = 1e7,
                               double pgtol = 1e-5, int maxls = 20, int maxiter = 15000,
@@ -247,7 +253,9 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
         while (!done_dir) {  // label 222
             int info = 0;
             if (!cnstnd && col > 0) {
-                for (int i = 0; i < n; ++i) z[i] = x[i];
+                Wv::sync();
+                for (int i = Wv::lane(); i < n; i += Wv::W) z[i] = x[i];
+                Wv::sync();
                 wrk = updatd;
                 nseg = 0;
             } else {
@@ -442,22 +450,57 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
             if (nfree != 0 && col != 0) {
                 if (wrk) {
                     // -------------------------------------------------------- formk
+                    // (lane-parallel: every output entry keeps the scalar routine's operations and their order; see
+                    // dsq_lbfgsb_par.h.  The barriers separate steps whose inputs other lanes wrote.)
+                    Wv::sync();
                     if (updatd) {
                         if (iupdat > m) {
-                            for (int jy = 1; jy <= m - 1; ++jy) {
-                                const int js = m + jy;
-                                for (int q = 0; q < m - jy; ++q) WN1(jy + q, jy) = WN1(jy + 1 + q, jy + 1);
-                                for (int q = 0; q < m - jy; ++q) WN1(js + q, js) = WN1(js + 1 + q, js + 1);
-                                for (int q = 0; q < m - 1; ++q) WN1(m + 1 + q, jy) = WN1(m + 2 + q, jy + 1);
+                            // the three blocks of WN1 move one row up and one column left: new(r, c) = old(r + 1, c + 1) -
+                            // the sequential loops never read an entry they have already overwritten, so this is a
+                            // simultaneous move: read, barrier, write
+                            constexpr int NSH = ((M - 1) * M + (M - 1) * (M - 1) + Wv::W - 1) / Wv::W;
+                            double tmp[NSH];
+                            auto walk = [&](auto&& fn) {
+                                int e = 0, slot = 0;
+                                for (int jy = 1; jy <= m - 1; ++jy) {
+                                    const int js = m + jy;
+                                    for (int q = 0; q < m - jy; ++q, ++e)
+                                        if (e % Wv::W == Wv::lane()) fn(slot++, jy + q, jy, jy + 1 + q, jy + 1);
+                                    for (int q = 0; q < m - jy; ++q, ++e)
+                                        if (e % Wv::W == Wv::lane()) fn(slot++, js + q, js, js + 1 + q, js + 1);
+                                    for (int q = 0; q < m - 1; ++q, ++e)
+                                        if (e % Wv::W == Wv::lane()) fn(slot++, m + 1 + q, jy, m + 2 + q, jy + 1);
+                                }
+                            };
+                            if constexpr (Wv::W == 1) {
+                                (void)tmp;
+                                walk([&](int, int dr_, int dc_, int sr_, int sc_) { WN1(dr_, dc_) = WN1(sr_, sc_); });
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < NSH; ++i) tmp[i] = 0.0;
+                                walk([&](int slot, int, int, int sr_, int sc_) {
+#pragma unroll
+                                    for (int i = 0; i < NSH; ++i)
+                                        if (i == slot) tmp[i] = WN1(sr_, sc_);
+                                });
+                                Wv::sync();
+                                walk([&](int slot, int dr_, int dc_, int, int) {
+                                    double v = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < NSH; ++i)
+                                        if (i == slot) v = tmp[i];
+                                    WN1(dr_, dc_) = v;
+                                });
+                                Wv::sync();
                             }
                         }
                         const int pbegin = 1, pend = nfree, dbegin = nfree + 1, dend = n;
-                        int iy = col, is = m + col;
+                        const int iy = col, is0 = m + col;
                         int ipntr = head + col - 1;
                         if (ipntr > m) ipntr -= m;
-                        int jpntr = head;
-                        for (int jy = 1; jy <= col; ++jy) {
+                        for (int jy = 1 + Wv::lane(); jy <= col; jy += Wv::W) {  // row `col` of the Y'Y, S'S and R blocks
                             const int js = m + jy;
+                            const int jpntr = (head + jy - 2) % m + 1;
                             double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
                             for (int k = pbegin; k <= pend; ++k) { const int k1 = index[k - 1]; temp1 += WY(k1, ipntr) * WY(k1, jpntr); }
                             for (int k = dbegin; k <= dend; ++k) {
@@ -466,63 +509,57 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                                 temp3 += WS(k1, ipntr) * WY(k1, jpntr);
                             }
                             WN1(iy, jy) = temp1;
-                            WN1(is, js) = temp2;
-                            WN1(is, jy) = temp3;
-                            jpntr = jpntr % m + 1;
+                            WN1(is0, js) = temp2;
+                            WN1(is0, jy) = temp3;
                         }
-                        const int jy = col;
-                        jpntr = head + col - 1;
+                        Wv::sync();  // (the next loop overwrites WN1(m + col, col))
+                        const int jyc = col;
+                        int jpntr = head + col - 1;
                         if (jpntr > m) jpntr -= m;
-                        ipntr = head;
-                        for (int i = 1; i <= col; ++i) {
-                            is = m + i;
+                        for (int i = 1 + Wv::lane(); i <= col; i += Wv::W) {  // column `col` of the R block
+                            const int is = m + i;
+                            const int ip = (head + i - 2) % m + 1;
                             double temp3 = 0.0;
-                            for (int k = pbegin; k <= pend; ++k) { const int k1 = index[k - 1]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
-                            ipntr = ipntr % m + 1;
-                            WN1(is, jy) = temp3;
+                            for (int k = pbegin; k <= pend; ++k) { const int k1 = index[k - 1]; temp3 += WS(k1, ip) * WY(k1, jpntr); }
+                            WN1(is, jyc) = temp3;
                         }
-                        (void)iy;
+                        Wv::sync();
                     }
                     const int upcl = updatd ? col - 1 : col;
                     {
-                        int ipntr = head;
-                        for (int iy = 1; iy <= upcl; ++iy) {
-                            const int is = m + iy;
-                            int jpntr = head;
-                            for (int jy = 1; jy <= iy; ++jy) {
-                                const int js = m + jy;
-                                double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
-                                for (int k = 1; k <= nenter; ++k) {
-                                    const int k1 = indx2[k - 1];
-                                    temp1 += WY(k1, ipntr) * WY(k1, jpntr);
-                                    temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-                                }
-                                for (int k = ileave; k <= n; ++k) {
-                                    const int k1 = indx2[k - 1];
-                                    temp3 += WY(k1, ipntr) * WY(k1, jpntr);
-                                    temp4 += WS(k1, ipntr) * WS(k1, jpntr);
-                                }
-                                WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
-                                WN1(is, js) = WN1(is, js) - temp2 + temp4;
-                                jpntr = jpntr % m + 1;
+                        // variables that entered / left the free set since the last iteration (none without bounds: the
+                        // sums are empty, the entries still take their "+ 0 - 0")
+                        for (int e = Wv::lane(); e < upcl * upcl; e += Wv::W) {
+                            const int iy = e / upcl + 1, jy = e % upcl + 1;
+                            if (jy > iy) continue;
+                            const int is = m + iy, js = m + jy;
+                            const int ipntr = (head + iy - 2) % m + 1, jpntr = (head + jy - 2) % m + 1;
+                            double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+                            for (int k = 1; k <= nenter; ++k) {
+                                const int k1 = indx2[k - 1];
+                                temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+                                temp2 += WS(k1, ipntr) * WS(k1, jpntr);
                             }
-                            ipntr = ipntr % m + 1;
-                        }
-                        ipntr = head;
-                        for (int is = m + 1; is <= m + upcl; ++is) {
-                            int jpntr = head;
-                            for (int jy = 1; jy <= upcl; ++jy) {
-                                double temp1 = 0.0, temp3 = 0.0;
-                                for (int k = 1; k <= nenter; ++k) { const int k1 = indx2[k - 1]; temp1 += WS(k1, ipntr) * WY(k1, jpntr); }
-                                for (int k = ileave; k <= n; ++k) { const int k1 = indx2[k - 1]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
-                                if (is <= jy + m) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
-                                else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
-                                jpntr = jpntr % m + 1;
+                            for (int k = ileave; k <= n; ++k) {
+                                const int k1 = indx2[k - 1];
+                                temp3 += WY(k1, ipntr) * WY(k1, jpntr);
+                                temp4 += WS(k1, ipntr) * WS(k1, jpntr);
                             }
-                            ipntr = ipntr % m + 1;
+                            WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
+                            WN1(is, js) = WN1(is, js) - temp2 + temp4;
                         }
+                        for (int e = Wv::lane(); e < upcl * upcl; e += Wv::W) {
+                            const int is = m + e / upcl + 1, jy = e % upcl + 1;
+                            const int ipntr = (head + (is - m) - 2) % m + 1, jpntr = (head + jy - 2) % m + 1;
+                            double temp1 = 0.0, temp3 = 0.0;
+                            for (int k = 1; k <= nenter; ++k) { const int k1 = indx2[k - 1]; temp1 += WS(k1, ipntr) * WY(k1, jpntr); }
+                            for (int k = ileave; k <= n; ++k) { const int k1 = indx2[k - 1]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
+                            if (is <= jy + m) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
+                            else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
+                        }
+                        Wv::sync();
                     }
-                    for (int iy = 1; iy <= col; ++iy) {
+                    for (int iy = 1 + Wv::lane(); iy <= col; iy += Wv::W) {  // the columns iy and col + iy of WN
                         const int is = col + iy, is1 = m + iy;
                         for (int jy = 1; jy <= iy; ++jy) {
                             const int js = col + jy, js1 = m + jy;
@@ -533,26 +570,33 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                         for (int jy = iy; jy <= col; ++jy) WN(jy, is) = WN1(is1, jy);
                         WN(iy, iy) = WN(iy, iy) + SY(iy, iy);
                     }
-                    info = lb::dpofa(W.wn, m2, col);
+                    Wv::sync();
+                    info = lbp::dpofa<Wv>(W.wn, m2, col, W.sacc);
                     if (info != 0) {
                         info = -1;
                     } else {
                         const int col2 = 2 * col;
-                        for (int js = col + 1; js <= col2; ++js) (void)lb::dtrsl_upper(W.wn, m2, col, &WN(1, js), 11);
-                        for (int is = col + 1; is <= col2; ++is)
-                            for (int js = is; js <= col2; ++js) {
-                                double s = 0.0;
-                                for (int q = 1; q <= col; ++q) s += WN(q, is) * WN(q, js);
-                                WN(is, js) = WN(is, js) + s;
-                            }
-                        info = lb::dpofa(&WN(col + 1, col + 1), m2, col);
+                        // col right-hand sides, one per lane (each solve is the scalar one)
+                        for (int js = col + 1 + Wv::lane(); js <= col2; js += Wv::W) lbp::dtrsl_upper_t_own(W.wn, m2, col, &WN(1, js));
+                        Wv::sync();
+                        for (int e = Wv::lane(); e < col * col; e += Wv::W) {  // Schur complement, one entry per lane
+                            const int is = col + 1 + e / col, js = col + 1 + e % col;
+                            if (js < is) continue;
+                            double sacc_ = 0.0;
+                            for (int q = 1; q <= col; ++q) sacc_ += WN(q, is) * WN(q, js);
+                            WN(is, js) = WN(is, js) + sacc_;
+                        }
+                        Wv::sync();
+                        info = lbp::dpofa<Wv>(&WN(col + 1, col + 1), m2, col, W.sacc);
                         if (info != 0) info = -2;
                     }
                 }
                 if (info != 0) { refresh(); continue; }
                 // ------------------------------------------------------------ cmprlb
                 if (!cnstnd && col > 0) {
-                    for (int i = 0; i < n; ++i) r[i] = -g[i];
+                    Wv::sync();
+                    for (int i = Wv::lane(); i < n; i += Wv::W) r[i] = -g[i];
+                    Wv::sync();
                 } else {
                     for (int i = 1; i <= nfree; ++i) {
                         const int k = index[i - 1];
@@ -579,8 +623,9 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                     double* wv = wa;
                     double* ds = r;   // Newton direction on the free variables
                     double* xs = z;   // Cauchy point in, subspace minimiser out
-                    int pointr = head;
-                    for (int i = 1; i <= col; ++i) {
+                    Wv::sync();
+                    for (int i = 1 + Wv::lane(); i <= col; i += Wv::W) {  // W' r: one pair of entries per lane
+                        const int pointr = (head + i - 2) % m + 1;
                         double temp1 = 0.0, temp2 = 0.0;
                         for (int j = 1; j <= nsub; ++j) {
                             const int k = index[j - 1];
@@ -589,27 +634,38 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                         }
                         wv[i - 1] = temp1;
                         wv[col + i - 1] = theta * temp2;
-                        pointr = pointr % m + 1;
                     }
+                    Wv::sync();
                     const int col2 = 2 * col;
-                    info = lb::dtrsl_upper(W.wn, m2, col2, wv, 11);
+                    info = lbp::dtrsl_upper<Wv>(W.wn, m2, col2, wv, 11, W.sacc);
                     if (info == 0) {
-                        for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-                        info = lb::dtrsl_upper(W.wn, m2, col2, wv, 1);
+                        for (int i = Wv::lane(); i < col; i += Wv::W) wv[i] = -wv[i];
+                        Wv::sync();
+                        info = lbp::dtrsl_upper<Wv>(W.wn, m2, col2, wv, 1, W.sacc);
                     }
                     if (info == 0) {
-                        pointr = head;
-                        for (int jy = 1; jy <= col; ++jy) {
-                            const int js = col + jy;
-                            for (int i = 1; i <= nsub; ++i) {
-                                const int k = index[i - 1];
-                                ds[i - 1] = ds[i - 1] + WY(k, pointr) * wv[jy - 1] / theta + WS(k, pointr) * wv[js - 1];
+                        for (int i = 1 + Wv::lane(); i <= nsub; i += Wv::W) {  // the Newton step, one component per lane
+                            const int k = index[i - 1];
+                            double dsi = ds[i - 1];
+                            int pointr = head;
+                            for (int jy = 1; jy <= col; ++jy) {
+                                const int js = col + jy;
+                                dsi = dsi + WY(k, pointr) * wv[jy - 1] / theta + WS(k, pointr) * wv[js - 1];
+                                pointr = pointr % m + 1;
                             }
-                            pointr = pointr % m + 1;
+                            ds[i - 1] = dsi * (1.0 / theta);
                         }
-                        for (int i = 0; i < nsub; ++i) ds[i] *= (1.0 / theta);
+                        Wv::sync();
                         int iword = 0;
-                        for (int i = 0; i < n; ++i) xp[i] = xs[i];
+                        for (int i = Wv::lane(); i < n; i += Wv::W) xp[i] = xs[i];
+                        Wv::sync();
+                        if (!cnstnd) {  // no bounds: the projection is the plain step, one component per lane
+                            for (int i = 1 + Wv::lane(); i <= nsub; i += Wv::W) {
+                                const int k = index[i - 1];
+                                xs[k - 1] = xs[k - 1] + ds[i - 1];
+                            }
+                            Wv::sync();
+                        } else
                         for (int i = 1; i <= nsub; ++i) {
                             const int k = index[i - 1];
                             const double dk = ds[i - 1];
@@ -670,7 +726,9 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                 if (info != 0) { refresh(); continue; }
             }
             // ---------------------------------------------------------------- 555: line search
-            for (int i = 0; i < n; ++i) d[i] = z[i] - x[i];
+            Wv::sync();
+            for (int i = Wv::lane(); i < n; i += Wv::W) d[i] = z[i] - x[i];
+            Wv::sync();
             dtd = 0.0;
             for (int i = 0; i < n; ++i) dtd += d[i] * d[i];
             const double dnorm = sqrt(dtd);
@@ -697,7 +755,8 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
             }
             if (iter == 0 && !boxed) stp = dmin(1.0 / dnorm, stpmx);
             else stp = 1.0;
-            for (int i = 0; i < n; ++i) { t[i] = x[i]; r[i] = g[i]; }
+            for (int i = Wv::lane(); i < n; i += Wv::W) { t[i] = x[i]; r[i] = g[i]; }
+            Wv::sync();
             fold = f;
             int ifun = 0;
             bool lsfail = false;
@@ -712,16 +771,20 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                 while (!lsfail) {
                     ifun += 1;
                     if (ifun - 1 >= maxls) { lsfail = true; break; }
+                    Wv::sync();
                     if (stp == 1.0) {
-                        for (int i = 0; i < n; ++i) x[i] = z[i];
+                        for (int i = Wv::lane(); i < n; i += Wv::W) x[i] = z[i];
                     } else {
-                        for (int i = 0; i < n; ++i) {
-                            x[i] = stp * d[i] + t[i];
-                            if (nbd[i] == 1 || nbd[i] == 2) x[i] = dmax(x[i], l[i]);
-                            if (nbd[i] == 2 || nbd[i] == 3) x[i] = dmin(x[i], u[i]);
+                        for (int i = Wv::lane(); i < n; i += Wv::W) {
+                            double xi = stp * d[i] + t[i];
+                            if (nbd[i] == 1 || nbd[i] == 2) xi = dmax(xi, l[i]);
+                            if (nbd[i] == 2 || nbd[i] == 3) xi = dmin(xi, u[i]);
+                            x[i] = xi;
                         }
                     }
+                    Wv::sync();
                     fg(x, f, g);
+                    Wv::sync();
                     nfev += 1;
                     gd = 0.0;
                     for (int i = 0; i < n; ++i) gd += g[i] * d[i];
@@ -729,7 +792,9 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                 }
             }
             if (lsfail) {
-                for (int i = 0; i < n; ++i) { x[i] = t[i]; g[i] = r[i]; }
+                Wv::sync();
+                for (int i = Wv::lane(); i < n; i += Wv::W) { x[i] = t[i]; g[i] = r[i]; }
+                Wv::sync();
                 f = fold;
                 if (col == 0) {
                     R = {f, false, nfev, iter, 3};
@@ -759,7 +824,9 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
                 return R;
             }
         }
-        for (int i = 0; i < n; ++i) r[i] = g[i] - r[i];
+        Wv::sync();
+        for (int i = Wv::lane(); i < n; i += Wv::W) r[i] = g[i] - r[i];
+        Wv::sync();
         double rr = 0.0;
         for (int i = 0; i < n; ++i) rr += r[i] * r[i];
         double dr, ddum;
@@ -768,7 +835,8 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
             ddum = -gdold;
         } else {
             dr = (gd - gdold) * stp;
-            for (int i = 0; i < n; ++i) d[i] *= stp;
+            for (int i = Wv::lane(); i < n; i += Wv::W) d[i] *= stp;
+            Wv::sync();
             ddum = -gdold * stp;
         }
         if (dr <= epsmch * ddum) {
@@ -785,38 +853,79 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
             itail = itail % m + 1;
             head = head % m + 1;
         }
-        for (int i = 1; i <= n; ++i) { WS(i, itail) = d[i - 1]; WY(i, itail) = r[i - 1]; }
+        Wv::sync();
+        for (int i = 1 + Wv::lane(); i <= n; i += Wv::W) { WS(i, itail) = d[i - 1]; WY(i, itail) = r[i - 1]; }
         theta = rr / dr;
         if (iupdat > m) {
-            for (int j = 1; j <= col - 1; ++j) {
-                for (int q = 0; q < j; ++q) SS(1 + q, j) = SS(2 + q, j + 1);
-                for (int q = 0; q < col - j; ++q) SY(j + q, j) = SY(j + 1 + q, j + 1);
+            // SS moves one row up and one column left, SY likewise: simultaneous moves (read, barrier, write)
+            constexpr int NSH = ((M - 1) * M + Wv::W - 1) / Wv::W;
+            double tmp[NSH];
+            auto walk = [&](auto&& fn) {
+                int e = 0, slot = 0;
+                for (int j = 1; j <= col - 1; ++j) {
+                    for (int q = 0; q < j; ++q, ++e)
+                        if (e % Wv::W == Wv::lane()) fn(slot++, 0, 1 + q, j, 2 + q, j + 1);
+                    for (int q = 0; q < col - j; ++q, ++e)
+                        if (e % Wv::W == Wv::lane()) fn(slot++, 1, j + q, j, j + 1 + q, j + 1);
+                }
+            };
+            if constexpr (Wv::W == 1) {
+                (void)tmp;
+                walk([&](int, int which, int dr_, int dc_, int sr_, int sc_) {
+                    if (which == 0) SS(dr_, dc_) = SS(sr_, sc_);
+                    else SY(dr_, dc_) = SY(sr_, sc_);
+                });
+            } else {
+#pragma unroll
+                for (int i = 0; i < NSH; ++i) tmp[i] = 0.0;
+                walk([&](int slot, int which, int, int, int sr_, int sc_) {
+                    const double v = which == 0 ? SS(sr_, sc_) : SY(sr_, sc_);
+#pragma unroll
+                    for (int i = 0; i < NSH; ++i)
+                        if (i == slot) tmp[i] = v;
+                });
+                Wv::sync();
+                walk([&](int slot, int which, int dr_, int dc_, int, int) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NSH; ++i)
+                        if (i == slot) v = tmp[i];
+                    if (which == 0) SS(dr_, dc_) = v;
+                    else SY(dr_, dc_) = v;
+                });
             }
         }
+        Wv::sync();
         {
-            int pointr = head;
-            for (int j = 1; j <= col - 1; ++j) {
+            for (int j = 1 + Wv::lane(); j <= col - 1; j += Wv::W) {  // last row of SY, last column of SS
+                const int pointr = (head + j - 2) % m + 1;
                 double s1 = 0.0, s2 = 0.0;
                 for (int i = 1; i <= n; ++i) { s1 += d[i - 1] * WY(i, pointr); s2 += WS(i, pointr) * d[i - 1]; }
                 SY(col, j) = s1;
                 SS(j, col) = s2;
-                pointr = pointr % m + 1;
             }
-            if (stp == 1.0) SS(col, col) = dtd;
-            else SS(col, col) = stp * stp * dtd;
-            SY(col, col) = dr;
+            if (Wv::lane() == 0) {
+                if (stp == 1.0) SS(col, col) = dtd;
+                else SS(col, col) = stp * stp * dtd;
+                SY(col, col) = dr;
+            }
         }
+        Wv::sync();
         // -------------------------------------------------------------------- formt
-        for (int j = 1; j <= col; ++j) WT(1, j) = theta * SS(1, j);
-        for (int i = 2; i <= col; ++i) {
-            for (int j = i; j <= col; ++j) {
-                const int k1 = (i < j ? i : j) - 1;
+        for (int e = Wv::lane(); e < col * col; e += Wv::W) {  // one entry of the upper triangle per lane
+            const int i = e / col + 1, j = e % col + 1;
+            if (j < i) continue;
+            if (i == 1) {
+                WT(1, j) = theta * SS(1, j);
+            } else {
+                const int k1 = i - 1;  // min(i, j) - 1
                 double ddum2 = 0.0;
                 for (int k = 1; k <= k1; ++k) ddum2 += SY(i, k) * SY(j, k) / SY(k, k);
                 WT(i, j) = ddum2 + theta * SS(i, j);
             }
         }
-        if (lb::dpofa(W.wt, m, col) != 0) refresh();
+        Wv::sync();
+        if (lbp::dpofa<Wv>(W.wt, m, col, W.sacc) != 0) refresh();
     }
 #undef WS
 #undef WY

@@ -125,8 +125,10 @@ DSQ_HD void grid_fit_shrink2(const ShrinkArgs& A0, double cnst, double (&beta)[2
 }
 
 // beta[P] (out), inv_hessian[P*P] row-major (out); returns scipy's res.success
+// ih_entry (nullable): only inv_hessian[shrink_index][shrink_index] - all DeseqStats.lfc_shrink uses (ds.py:424-433)
 template <class Wv, int P>
-DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P], double* inv_hessian) {
+DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P], double* inv_hessian,
+                       double* ih_entry = nullptr) {
     constexpr int T = Tri<P>::N;
     double zero[P];
 #pragma unroll
@@ -152,7 +154,8 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
     if constexpr (P <= kShrinkDenseMax)
         res = lbfgsb_dense<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
     else
-        res = lbfgsb_nd<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+        // (the linear algebra between two evaluations spread over the wavefront's lanes: dsq_lbfgsb_par.h - same iterates)
+        res = lbfgsb_nd<P, decltype(fg)&, 10, Wv>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
 #pragma unroll
     for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
     if (!res.success && P == 2) {
@@ -191,8 +194,71 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
         const double s2 = A.sigma * A.sigma, b2 = bs * bs;
         hd[j] = (j == A.shrink_index) ? 2.0 * (s2 - b2) / ((s2 + b2) * (s2 + b2)) : 1.0 / (A.sigma0 * A.sigma0);
     }
-    if (inv_hessian != nullptr) {
+    if (inv_hessian != nullptr || ih_entry != nullptr) {
         // general inverse by Gauss-Jordan with partial pivoting on the full p x p matrix
+        if constexpr (Wv::W > 1) {
+            // One ROW per lane (lanes >= P idle along): the wave-redundant version below indexes its two p x p arrays with
+            // the run-time pivot row, which puts them into scratch memory - ~3000 scratch accesses per gene in every lane.
+            // Here a lane keeps its row of [H | I] in registers, rows are never moved: `pos` is the logical position of
+            // the row a lane holds, a pivot exchange swaps two positions.  Same operations on the same numbers.
+            const int ln = Wv::lane();
+            const int me = ln < P ? ln : P - 1;  // (idle lanes shadow the last row; they never win a pivot search)
+            double hr[P], ir[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) v = (i == me) ? M[tri(i > j ? i : j, i > j ? j : i)] : v;
+                hr[j] = v + hd[j];
+                ir[j] = (j == me) ? 1.0 : 0.0;
+            }
+            int pos = ln < P ? ln : 0x7fff;
+            static_for<0, P>([&](auto CC) {
+                constexpr int c = decltype(CC)::value;
+                // pivot: the first row at position >= c with the largest |H[., c]| (the scalar scan starts at position c and
+                // replaces on strictly greater: ties go to the smaller position)
+                const int src_c = Wv::maxi(pos == c ? ln : -1);
+                const double a_c = fabs(Wv::from_lane(hr[c], src_c));
+                const double mine = fabs(hr[c]);
+                // (NaN never wins a comparison: a NaN at position c keeps the pivot there, a NaN elsewhere is skipped)
+                const double av = (pos > c && pos < P && mine > a_c) ? mine : -1.0;
+                const double mx = Wv::max(av);
+                const int cand = (mx >= 0.0 && av == mx) ? pos : 0x7fff;
+                const int best = -Wv::maxi(-cand);  // smallest position among the maxima
+                const int pv = mx >= 0.0 ? best : c;
+                // exchange the positions c and pv
+                if (pos == c) pos = pv;
+                else if (pos == pv) pos = c;
+                const bool is_piv = pos == c;
+                // the pivot lane scales its row, every lane fetches it
+                const int src = Wv::maxi(is_piv ? ln : -1);
+                const double d = 1.0 / Wv::from_lane(hr[c], src);
+                double ph[P], pi[P];
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const double hk = hr[k] * d, ik = ir[k] * d;
+                    if (is_piv) { hr[k] = hk; ir[k] = ik; }
+                    ph[k] = Wv::from_lane(hk, src);
+                    pi[k] = Wv::from_lane(ik, src);
+                }
+                if (!is_piv) {
+                    const double fct = hr[c];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) { hr[k] -= fct * ph[k]; ir[k] -= fct * pi[k]; }
+                }
+            });
+            if (ln < P) {
+                if (inv_hessian != nullptr)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) inv_hessian[pos * P + j] = ir[j];
+                if (ih_entry != nullptr && pos == A.shrink_index) {
+                    double v = ir[0];
+#pragma unroll
+                    for (int j = 1; j < P; ++j) v = (j == A.shrink_index) ? ir[j] : v;
+                    *ih_entry = v;
+                }
+            }
+        } else {
         double Hm[P][P], Iv[P][P];
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -219,9 +285,13 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
                 for (int k = 0; k < P; ++k) { Hm[r][k] -= fct * Hm[c][k]; Iv[r][k] -= fct * Iv[c][k]; }
             }
         }
-        if (Wv::lane() == 0)
-            for (int i = 0; i < P; ++i)
-                for (int j = 0; j < P; ++j) inv_hessian[i * P + j] = Iv[i][j];
+        if (Wv::lane() == 0) {
+            if (inv_hessian != nullptr)
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j) inv_hessian[i * P + j] = Iv[i][j];
+            if (ih_entry != nullptr) *ih_entry = Iv[A.shrink_index][A.shrink_index];
+        }
+        }
     }
     return res.success ? 1 : 0;
 }
@@ -310,8 +380,8 @@ DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, ShrinkWorkWide<PMAX>& Wk
         for (int j = 0; j < PMAX; ++j)
             if (j < p) g[j] = gg[j] / cn;
     };
-    const LbfgsbResult res =
-        lbfgsb_nd<PMAX>(fg, p, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    const LbfgsbResult res = lbfgsb_nd<PMAX, decltype(fg)&, 10, Wv>(fg, p, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb,
+                                                                    1e-8 / 2.220446049250313e-16, 1e-8);
     Wv::sync();
     if (Wv::lane() == 0)
         for (int j = 0; j < p; ++j) beta[j] = Wk.x[j];

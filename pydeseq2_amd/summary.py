@@ -155,13 +155,17 @@ def lfc_shrink(pipe, res, coeff_idx, adapt=True, prior_no_shrink_scale=15.0):
     disp = np.where(nz, res.dispersions, 1.0)  # all-zero genes are fitted too (cheap) and masked below
     d_size = DeviceArray.from_host(ctx, 1.0 / disp)
     d_off = DeviceArray.from_host(ctx, np.log(res.size_factors))
-    d_beta, d_ih = DeviceArray(ctx, (G, P), np.float64), DeviceArray(ctx, (G, P * P), np.float64)
+    # only inv_hessian[coeff][coeff] is used (the shrunken lfcSE, ds.py:424-433): 8 bytes per gene come back, not 8 p^2
+    entry_only = P <= 12
+    d_beta = DeviceArray(ctx, (G, P), np.float64)
+    d_ih = DeviceArray(ctx, (G,) if entry_only else (G, P * P), np.float64)
     d_conv = DeviceArray(ctx, (G,), np.uint8)
-    ctx.call("dsq_dev_lfc_shrink", _vp(pipe.d_y.ptr), pipe.ldn, _vp(d_off.ptr), _vp(pipe.d_Xt.ptr), pipe.design.ldx,
+    ctx.call("dsq_dev_lfc_shrink2", _vp(pipe.d_y.ptr), pipe.ldn, _vp(d_off.ptr), _vp(pipe.d_Xt.ptr), pipe.design.ldx,
              N, G, P, _vp(d_size.ptr), C.c_double(prior_no_shrink_scale), C.c_double(prior_scale), int(coeff_idx),
-             _vp(d_beta.ptr), _vp(d_ih.ptr), _vp(d_conv.ptr))
-    beta, ih = d_beta.to_host(), d_ih.to_host().reshape(G, P, P)
+             _vp(d_beta.ptr), None if entry_only else _vp(d_ih.ptr), _vp(d_conv.ptr), _vp(d_ih.ptr) if entry_only else None)
+    beta = d_beta.to_host()
+    ihd = d_ih.to_host() if entry_only else d_ih.to_host().reshape(G, P, P)[:, coeff_idx, coeff_idx]
     lfc = np.where(nz, beta[:, coeff_idx], res.LFC[:, coeff_idx])
-    se = np.where(nz, np.sqrt(np.abs(ih[:, coeff_idx, coeff_idx])), res.lfcSE)
+    se = np.where(nz, np.sqrt(np.abs(ihd)), res.lfcSE)
     conv = np.where(nz, d_conv.to_host().astype(float), np.nan)
     return lfc, se, conv, prior_scale

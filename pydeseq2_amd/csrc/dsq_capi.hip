@@ -1433,6 +1433,7 @@ int dsq_dev_trend_fit(dsq_ctx* ctx, const double* d_disp, const double* d_means,
     double out5[5];
     DSQ_HIP(hipMemcpyAsync(out5, d_out, sizeof(out5), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (out5[2] < 0.0) return fail(ctx, DSQ_ERR_HIP, "trend fit: the workgroups' exchange timed out");
     h_coeffs2[0] = out5[0]; h_coeffs2[1] = out5[1];
     if (h_ok) *h_ok = (int)out5[2];
     if (h_n_outer) *h_n_outer = (int)out5[3];
@@ -1470,6 +1471,7 @@ int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_mean
         DSQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_small1, 0));
     }
     DSQ_HIP(hipStreamSynchronize(st));
+    if (h[2] < 0.0) return fail(ctx, DSQ_ERR_HIP, "trend fit: the workgroups' exchange timed out");
     h_coeffs2[0] = h[0]; h_coeffs2[1] = h[1];
     *h_ok = (int)h[2];
     if (h_n_outer) *h_n_outer = (int)h[3];

@@ -281,8 +281,9 @@ __device__ __forceinline__ int pick_digit(const unsigned int* h, int nbins, unsi
     return d;
 }
 
-template <class KeyFn>
-__device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, unsigned int& M_out) {
+// each(fn): calls fn(key) for every key this thread contributes (the same keys in every pass)
+template <class Each>
+__device__ void block_median_each(Each each, MedianShared& S, double& median, unsigned int& M_out) {
     const int shifts[6] = {53, 42, 31, 20, 9, 0};
     const int tid = threadIdx.x, NT = blockDim.x;
     for (int pass = 0; pass < 6; ++pass) {
@@ -292,9 +293,8 @@ __device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, 
         __syncthreads();
         const unsigned long long p0 = S.prefix[0], p1 = S.prefix[1];
         const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
-        for (int i = tid; i < n; i += NT) {
-            const unsigned long long k = key(i);
-            if (k == ~0ull) continue;
+        each([&](unsigned long long k) {
+            if (k == ~0ull) return;
             const unsigned int d = (unsigned int)(k >> shift) & (unsigned int)(nbins - 1);
             if (pass == 0) {
                 atomicAdd(&S.hist[0][d], 1u);
@@ -302,7 +302,7 @@ __device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, 
                 if ((k & himask) == p0) atomicAdd(&S.hist[0][d], 1u);
                 if ((k & himask) == p1) atomicAdd(&S.hist[1][d], 1u);
             }
-        }
+        });
         __syncthreads();
         if (pass == 0) {
             if (tid < 64) {  // total count and the two target ranks
@@ -336,6 +336,15 @@ __device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, 
     if (M == 0) { median = NAN; return; }
     const double v0 = key_f64(S.prefix[0]), v1 = key_f64(S.prefix[1]);
     median = ((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0;
+}
+
+template <class KeyFn>
+__device__ void block_median(KeyFn key, int n, MedianShared& S, double& median, unsigned int& M_out) {
+    block_median_each(
+        [&](auto fn) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) fn(key(i));
+        },
+        S, median, M_out);
 }
 
 // per-sample median of the log-ratio keys -> size factor (preprocessing.py:96-100)
@@ -672,12 +681,231 @@ __global__ __launch_bounds__(256) void k_sf_compact(const double* __restrict__ l
     if (use) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = g;
 }
 
+// ---- the usual case - at most kSfRegGenes = 32 768 usable genes: ONE kernel, one workgroup per sample, the
+// sample's log ratios in REGISTERS, and a selection that suits them.
+// The key-matrix path below is a bitwise radix select: it writes N x Gu keys, reads them six times (r03: 4.4 x the bytes
+// of the counts), and - log ratios of one sample are a tight cluster, so their leading 11 or 22 bits are all the same -
+// its first passes send every LDS histogram increment of a workgroup to the same two or three words.  Here a thread
+// gathers its <= 32 counts once and the median is narrowed in VALUE space: a 2048-bin histogram over [min, max] of the
+// current candidates spreads the cluster over the bins whatever its location; the bin(s) holding the two middle ranks
+// become the new candidate set; at <= 1024 candidates they are ranked against each other exactly.  Binning is monotone
+// in the value and membership is decided by the same expression in every pass, so the result is the exact order
+// statistic (ties included); usually one histogram level is enough.  More usable genes than the registers hold: this
+// kernel leaves at once and the two kernels below (which leave at once in the usual case) do the work.
+constexpr int kSfRegGenes = 32768;  // 1024 threads x 32 genes each
+constexpr int kSfCand = 1024;
+
+struct SfRowShared {
+    unsigned int hist[2048];
+    double cand[kSfCand];
+    double dred[16][2];
+    unsigned int ured[16][2];
+    unsigned int wtot[16];  // (sized for 1024 threads)
+    unsigned int bin[2], pre[2], ncand;
+    double a[2];
+};
+
+// min / max of (lo, hi) and sums of (c0, c1) over the workgroup's threads; every thread gets the results
+__device__ __forceinline__ void sf_block_reduce(SfRowShared& S, double& lo, double& hi, unsigned int& c0,
+                                                unsigned int& c1) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = dmin(lo, __shfl_xor(lo, o, 64));
+        hi = dmax(hi, __shfl_xor(hi, o, 64));
+        c0 += __shfl_xor(c0, o, 64);
+        c1 += __shfl_xor(c1, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // (the arrays may still be read from the previous reduction)
+    if ((threadIdx.x & 63) == 0) { S.dred[w][0] = lo; S.dred[w][1] = hi; S.ured[w][0] = c0; S.ured[w][1] = c1; }
+    __syncthreads();
+    lo = S.dred[0][0]; hi = S.dred[0][1]; c0 = S.ured[0][0]; c1 = S.ured[0][1];
+    for (int q = 1; q < (int)(blockDim.x >> 6); ++q) {
+        lo = dmin(lo, S.dred[q][0]); hi = dmax(hi, S.dred[q][1]);
+        c0 += S.ured[q][0]; c1 += S.ured[q][1];
+    }
+}
+
+template <class SrcT, int NT>
+__global__ __launch_bounds__(NT) void k_sf_row(const SrcT* __restrict__ counts, int N, int G,
+                                                 const double* __restrict__ logmeans, const int* __restrict__ idx,
+                                                 const int* __restrict__ count, double* __restrict__ sf,
+                                                 int zeros_low) {
+    __shared__ SfRowShared S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = blockIdx.x, Gu = *count;
+    constexpr int kSfRegKeys = kSfRegGenes / NT;
+    if (Gu > kSfRegGenes) return;
+    // this thread's log ratios: NaN = not part of the median (a zero count in the training data: see k_ratio_keys_c),
+    // -inf = a zero count of a NEW sample (counts at the low end, as numpy's median has it)
+    double v[kSfRegKeys];
+    double lo = INFINITY, hi = -INFINITY;
+    unsigned int n_fin = 0, n_low = 0;
+#pragma unroll
+    for (int k = 0; k < kSfRegKeys; ++k) v[k] = NAN;
+    // (every loop over a thread's slots stops at the sample's last occupied slot - a uniform branch: the slots are sized
+    // for 32 768 usable genes, a sample of the benchmark has 15 000, one of a gene shard 2 000)
+    const int kmax = (Gu + NT - 1) / NT;
+    {
+        // straight-line gathers, eight genes at a time: gene index -> count and log mean -> table logarithm are three
+        // dependent memory round trips, and with a branch per gene they ran one gene after the other (2 x 15 HBM
+        // latencies per thread: 316 us for 1000 samples where the bytes need 60)
+#pragma unroll
+        for (int k0 = 0; k0 < kSfRegKeys; k0 += 8) {
+            if (k0 >= kmax) continue;
+            __builtin_amdgcn_sched_barrier(0);
+            int g[8];
+            double c[8], lm[8], tl[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int j = tid + (k0 + kk) * NT;
+                g[kk] = idx[j < Gu ? j : Gu - 1];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                c[kk] = (double)counts[(size_t)n * G + g[kk]];
+                lm[kk] = logmeans[g[kk]];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) tl[kk] = kLogInt[c[kk] < 256.0 ? (c[kk] > 0.0 ? (int)c[kk] : 1) : 255];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bool in = tid + (k0 + kk) * NT < Gu, pos = c[kk] > 0.0;
+                const double x = (c[kk] < 256.0 ? tl[kk] : flog(pos ? c[kk] : 1.0)) - lm[kk];
+                const bool fin = in && pos, low = in && !pos && zeros_low != 0;
+                v[k0 + kk] = fin ? x : (low ? -INFINITY : NAN);
+                lo = fin ? dmin(lo, x) : lo;
+                hi = fin ? dmax(hi, x) : hi;
+                n_fin += fin ? 1u : 0u;
+                n_low += low ? 1u : 0u;
+            }
+        }
+    }
+    sf_block_reduce(S, lo, hi, n_fin, n_low);
+    const unsigned int M = n_fin + n_low;
+    if (M == 0) {
+        if (tid == 0) sf[n] = NAN;
+        return;
+    }
+    const unsigned int r0 = (M - 1) / 2, r1 = M / 2;
+    if (r1 < n_low) {  // both middle ranks are zero counts
+        if (tid == 0) sf[n] = 0.0;  // exp(-inf)
+        return;
+    }
+    // ranks among the finite values (r0 may still be a zero count: then only r1 is selected)
+    const bool low0 = r0 < n_low;
+    unsigned int q0 = (low0 ? r1 : r0) - n_low, q1 = r1 - n_low;
+    unsigned int cnt = n_fin;
+    double a0 = NAN, a1 = NAN;
+    for (int level = 0; level < 64; ++level) {
+        if (lo == hi) { a0 = lo; a1 = lo; break; }
+        if (cnt <= kSfCand) {
+            // rank the candidates against each other
+            if (tid == 0) S.ncand = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSfRegKeys; ++k) {
+                if (k >= kmax) continue;
+                if (v[k] >= lo && v[k] <= hi) S.cand[atomicAdd(&S.ncand, 1u)] = v[k];
+            }
+            __syncthreads();
+            const unsigned int m = S.ncand;
+            for (int i = tid; i < (int)m; i += NT) {
+                const double c = S.cand[i];
+                unsigned int less = 0, eq = 0;
+                for (unsigned int j = 0; j < m; ++j) {
+                    const double cj = S.cand[j];
+                    less += cj < c;
+                    eq += cj == c;
+                }
+                if (less <= q0 && q0 < less + eq) S.a[0] = c;
+                if (less <= q1 && q1 < less + eq) S.a[1] = c;
+            }
+            __syncthreads();
+            a0 = S.a[0]; a1 = S.a[1];
+            break;
+        }
+        // histogram of the candidates over [lo, hi]
+        for (int i = tid; i < 2048; i += NT) S.hist[i] = 0;
+        __syncthreads();
+        const double scale = 2048.0 / (hi - lo);
+        auto bin_of = [&](double x) {
+            const int bb = (int)((x - lo) * scale);
+            return bb > 2047 ? 2047 : bb;
+        };
+#pragma unroll
+        for (int k = 0; k < kSfRegKeys; ++k) {
+            if (k >= kmax) continue;
+            if (v[k] >= lo && v[k] <= hi) atomicAdd(&S.hist[bin_of(v[k])], 1u);
+        }
+        __syncthreads();
+        // the bins of the two ranks: exclusive prefix over the 2048 bins, 2048 / NT consecutive bins per thread
+        {
+            constexpr int PER = 2048 / NT;
+            unsigned int h[PER], all = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { h[q] = S.hist[PER * tid + q]; all += h[q]; }
+            unsigned int incl = all;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) S.wtot[w] = incl;
+            __syncthreads();
+            unsigned int base = 0;
+            for (int q = 0; q < w; ++q) base += S.wtot[q];
+            unsigned int excl = base + incl - all;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    const unsigned int t = which ? q1 : q0;
+                    if (excl <= t && t < excl + h[q]) { S.bin[which] = PER * tid + q; S.pre[which] = excl; }
+                }
+                excl += h[q];
+            }
+            __syncthreads();
+        }
+        const int b0 = (int)S.bin[0], b1 = (int)S.bin[1];
+        const unsigned int pre0 = S.pre[0];
+        // the new candidates: bin b0 (both ranks in it), or - the ranks are neighbours - the LAST value of bin b0 and the
+        // FIRST of bin b1
+        double nlo = INFINITY, nhi = -INFINITY, lo1 = INFINITY, hi0 = -INFINITY;
+        unsigned int c_new = 0, dummy = 0;
+#pragma unroll
+        for (int k = 0; k < kSfRegKeys; ++k) {
+            if (k >= kmax) continue;
+            if (v[k] >= lo && v[k] <= hi) {
+                const int bb = bin_of(v[k]);
+                if (bb == b0) { nlo = dmin(nlo, v[k]); nhi = dmax(nhi, v[k]); hi0 = dmax(hi0, v[k]); c_new += 1; }
+                if (bb == b1) lo1 = dmin(lo1, v[k]);
+            }
+        }
+        if (b0 != b1) {
+            sf_block_reduce(S, lo1, hi0, c_new, dummy);
+            a0 = hi0; a1 = lo1;
+            break;
+        }
+        sf_block_reduce(S, nlo, nhi, c_new, dummy);
+        lo = nlo; hi = nhi; cnt = c_new;
+        q0 -= pre0; q1 -= pre0;
+    }
+    if (tid == 0) {
+        const double v0 = low0 ? -INFINITY : a0;
+        const double med = (r0 == r1) ? v0 : (v0 + a1) / 2.0;
+        sf[n] = exp(med);
+    }
+}
+
 template <class SrcT>
 __global__ __launch_bounds__(256) void k_ratio_keys_c(const SrcT* __restrict__ counts, int N, int G,
                                                       const double* __restrict__ logmeans,
                                                       const int* __restrict__ idx, const int* __restrict__ count,
-                                                      unsigned long long* __restrict__ keys, int zeros_low) {
+                                                      unsigned long long* __restrict__ keys, int zeros_low,
+                                                      int after_sf_row) {
     const int n = blockIdx.y, Gu = *count;
+    if (after_sf_row && Gu <= kSfRegGenes) return;  // k_sf_row's case
     // a zero count: never among the usable genes of the training data in "ratio" mode; left out of the sample's
     // median in "poscounts" mode (dds.py:668-671); for NEW samples transformed with the training log means
     // (zeros_low) it is log(0) - logmean = -inf and counts at the low end of the median, as numpy does
@@ -694,6 +922,7 @@ __global__ __launch_bounds__(1024) void k_row_median_c(const unsigned long long*
                                                        const int* __restrict__ count, double* __restrict__ sf) {
     __shared__ MedianShared S;
     const int n = blockIdx.x, Gu = *count;
+    if (Gu <= kSfRegGenes) return;  // k_sf_row has written this sample's size factor
     const unsigned long long* row = keys + (size_t)n * Gu;
     double med;
     unsigned int M;
@@ -714,13 +943,23 @@ hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_
     hipError_t e0 = hipMemsetAsync(count, 0, sizeof(int), st);
     if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(k_sf_compact, dim3((G + 255) / 256), dim3(256), 0, st, logmeans, gene_mask, G, idx, count);
-    const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
+    if (count_type == 1)
+        hipLaunchKernelGGL((k_sf_row<int64_t, 1024>), dim3(N), dim3(1024), 0, st, (const int64_t*)counts_sm, N, G,
+                           logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
+    else
+        hipLaunchKernelGGL((k_sf_row<int32_t, 1024>), dim3(N), dim3(1024), 0, st, (const int32_t*)counts_sm, N, G,
+                           logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
+    if (G <= kSfRegGenes) return hipGetLastError();  // (the number of usable genes is known on the device only)
+    // (few, grid-striding workgroups: in the usual case they all leave at once, and a launch of N x 235 empty workgroups
+    // costs more than k_sf_row)
+    int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
+    if (gx > 4096 / N + 1) gx = 4096 / N + 1;
     if (count_type == 1)
         hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
-                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low);
+                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low, 1);
     else
         hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
-                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low);
+                           logmeans, (const int*)idx, (const int*)count, keys, zeros_low, 1);
     hipLaunchKernelGGL(k_row_median_c, dim3(N), dim3(1024), 0, st, (const unsigned long long*)keys, N,
                        (const int*)count, sf);
     return hipGetLastError();
@@ -1504,94 +1743,232 @@ hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const doubl
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ trend fit (one workgroup)
-// Wave 0 runs the L-BFGS-B state machine (dsq_lbfgsb.h) on an LDS workspace; every loss/gradient
-// evaluation, the initial mask and the outlier filter are data passes over the G genes that all
-// kTrendWaves waves share: the leader posts a command in LDS, the workgroup meets at barrier A,
-// everybody reduces its stripe, barrier B, the leader combines the per-wave partials in a fixed
-// order (deterministic).  Helper waves spin on the same two barriers until the leader posts 0.
-constexpr int kTrendWaves = 16;
+// ------------------------------------------------------------------ trend fit
+// The fit is a CHAIN of dependent data passes - one per L-BFGS-B evaluation (about 20 per gamma-GLM fit), one per
+// outlier filter - over two doubles per gene: its duration is (number of passes) x (latency of a pass), nearly
+// independent of the number of genes (r03: 0.39 ms at 7 500 genes, 0.47 ms at 60 000).  Everything here serves that
+// latency:
+//   - the genes live in REGISTERS: kTrendGridBlocks x 64 kTrendWaves threads hold kTrendRegGenes genes each (clipped
+//     dispersion, 1 / mean, keep bit), loaded once by the first pass; a pass reads no memory (genes beyond that
+//     capacity - more than 65 536 - go through the arrays, as before);
+//   - one cross-lane butterfly per reduction level for the six sums of a pass (loss, two gradient sums and their three
+//     NaN-free counts, carried as doubles): lanes -> wave, the waves of a workgroup (through LDS), the workgroups;
+//   - EVERY workgroup's wave 0 runs the same deterministic optimiser on the same totals (bit-identical: fixed butterfly
+//     order), so nothing is broadcast, and the workgroups exchange their partial sums through SELF-VALIDATING words:
+//     every 64-bit word carries 32 bits of payload and the pass number.  A reader polls the words of all workgroups
+//     until every tag is the current pass: one store and one (polled) load per pass and workgroup - no arrival counter,
+//     no fence, no second round trip for the data (the arrival-counter barrier this replaces cost three dependent
+//     memory round trips per pass).  Words are double-buffered by pass parity: a workgroup can be at most one pass
+//     ahead of the slowest reader (it needs that reader's words of pass p to leave pass p).
+// Launched cooperatively (all workgroups resident); a bounded poll sets a flag instead of hanging the GPU.
+constexpr int kTrendWaves = 8;
+#ifndef DSQ_TREND_GRID_BLOCKS
+#define DSQ_TREND_GRID_BLOCKS 32
+#endif
+constexpr int kTrendGridBlocks = DSQ_TREND_GRID_BLOCKS;  // <= 64: one lane of the leader wave per workgroup
+constexpr int kTrendRegGenes = 4;
+constexpr int kTrendWords = 12;  // six doubles, two tagged words each
+
+struct TrendGridMem {  // device global memory, zeroed before every launch (pass numbers start at 1)
+    unsigned int timeout;
+    unsigned int pad[31];
+    unsigned long long word[2][64][16];  // [pass parity][workgroup][word]
+};
 
 struct TrendShared {
     TrendWork W;
-    double a0, a1;
-    int cmd;  // 1 eval, 2 filter, 3 init mask, 0 done
-    double part[kTrendWaves][3];
-    int ipart[kTrendWaves][3];
+    double a0, a1;  // mailbox: leader wave -> helper waves of this workgroup
+    int cmd;        // 1 eval, 2 filter, 3 load + initial mask, 0 done
+    double part[kTrendWaves][6];
 };
 
-struct BlockTrendOps {
+// loss / gradient terms of one gene (trend_eval_partial's arithmetic, dsq_trend.h)
+__device__ __forceinline__ void trend_eval_one(double cov, double t, double a0, double a1, TrendPartial& P) {
+    const double mu = a0 + a1 * cov;
+    const double rmu = frcp(mu);
+    const double tm = t * rmu;
+    const double v = tm + flog(mu);
+    if (v == v) { P.s.add(v); P.cf += 1; }
+    const double r = tm - 1.0;
+    const double v0 = r * rmu, v1 = (r * cov) * rmu;
+    if (v0 == v0) { P.g0.add(v0); P.c0 += 1; }
+    if (v1 == v1) { P.g1.add(v1); P.c1 += 1; }
+}
+
+struct GridTrendOps {
     TrendData D;
-    TrendShared* S;
+    TrendGridMem* Gm;
+    TrendShared* S;  // LDS of this workgroup
+    unsigned int seq = 0;
+    // this thread's genes (i = tid + k * NT)
+    double cov_e[kTrendRegGenes], cov_f[kTrendRegGenes], tg[kTrendRegGenes];
+    unsigned int kbits = 0;
+#ifdef DSQ_TREND_PHASES
+    long long t_last = 0, c_opt = 0, c_pass = 0;
+    int n_eval = 0;
+#endif
+
+    // every thread of every workgroup, once per pass: this thread's share -> wave sums -> LDS
     __device__ void work(int cmd, double a0, double a1) {
-        const int w = threadIdx.x >> 6, tid = threadIdx.x, NT = 64 * kTrendWaves;
+        const int w = threadIdx.x >> 6;
+        const int tid = blockIdx.x * (64 * kTrendWaves) + threadIdx.x, NT = gridDim.x * 64 * kTrendWaves;
+        double v[6];
         if (cmd == 1) {
             TrendPartial P;
-            trend_eval_partial(D, tid, NT, a0, a1, P);
-            const double s = DeviceWave::sum_comp(P.s), g0 = DeviceWave::sum_comp(P.g0),
-                         g1 = DeviceWave::sum_comp(P.g1);
-            const int cf = DeviceWave::sumi(P.cf), c0 = DeviceWave::sumi(P.c0), c1 = DeviceWave::sumi(P.c1);
-            if ((tid & 63) == 0) {
-                S->part[w][0] = s; S->part[w][1] = g0; S->part[w][2] = g1;
-                S->ipart[w][0] = cf; S->ipart[w][1] = c0; S->ipart[w][2] = c1;
-            }
+#pragma unroll
+            for (int k = 0; k < kTrendRegGenes; ++k)
+                if (kbits & (1u << k)) trend_eval_one(cov_e[k], tg[k], a0, a1, P);
+            trend_eval_partial(D, tid + kTrendRegGenes * NT, NT, a0, a1, P);
+            v[0] = P.s.value(); v[1] = P.g0.value(); v[2] = P.g1.value();
+            v[3] = (double)P.cf; v[4] = (double)P.c0; v[5] = (double)P.c1;
         } else {
-            const int k = DeviceWave::sumi(cmd == 3 ? trend_init_keep(D, tid, NT) : trend_filter(D, tid, NT, a0, a1));
-            if ((tid & 63) == 0) S->ipart[w][0] = k;
+            int kept = 0;
+            if (cmd == 3) {
+#pragma unroll
+                for (int k = 0; k < kTrendRegGenes; ++k) {
+                    const int i = tid + k * NT;
+                    cov_e[k] = 0.0; cov_f[k] = 0.0; tg[k] = 0.0;
+                    if (i < D.n) {
+                        const double m = D.means[i], d = D.disp[i];
+                        const double c = D.raw ? 0.0 : 1.0 / m;
+                        const bool bad = (c != c) || (c == INFINITY) || (c == -INFINITY);  // dds.py:1225-1231
+                        cov_e[k] = D.raw ? m : frcp(m);
+                        cov_f[k] = c;
+                        tg[k] = D.raw ? d : dmin(dmax(d, D.min_disp), D.max_disp);
+                        if (!bad) { kbits |= 1u << k; kept += 1; }
+                    }
+                }
+                kept += trend_init_keep(D, tid + kTrendRegGenes * NT, NT);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kTrendRegGenes; ++k)
+                    if (kbits & (1u << k)) {
+                        const double ratio = tg[k] / (a0 + a1 * cov_f[k]);
+                        if (ratio < 1e-4 || ratio >= 15.0) kbits &= ~(1u << k);  // dds.py:1254-1264
+                        else kept += 1;
+                    }
+                kept += trend_filter(D, tid + kTrendRegGenes * NT, NT, a0, a1);
+            }
+            v[0] = (double)kept; v[1] = 0.0; v[2] = 0.0; v[3] = 0.0; v[4] = 0.0; v[5] = 0.0;
+        }
+        DeviceWave::sum_n<6>(v);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) S->part[w][q] = v[q];
         }
     }
-    __device__ void post(int cmd, double a0, double a1) {  // leader only
-        if ((threadIdx.x & 63) == 0) { S->cmd = cmd; S->a0 = a0; S->a1 = a1; }
-        __syncthreads();  // A
+
+    // leader wave: the workgroup's sums -> its words of this pass; poll everybody's; combine.  tot[] is identical in
+    // every lane of every workgroup's leader wave.
+    __device__ void exchange(double (&tot)[6]) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) tot[q] = (lane < kTrendWaves) ? S->part[lane][q] : 0.0;
+        DeviceWave::sum_n<6>(tot);
+        if (gridDim.x == 1) return;
+        seq += 1;
+        unsigned long long(*words)[16] = Gm->word[seq & 1];
+        if (lane < kTrendWords) {
+            double mine = tot[0];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) mine = (lane >> 1) == q ? tot[q] : mine;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+            const unsigned long long half = (lane & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+            __hip_atomic_store(&words[blockIdx.x][lane], (half << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool on = lane < (int)gridDim.x;
+        unsigned long long wd[kTrendWords];
+        unsigned int spins = 0;
+        for (;;) {
+            bool ok = true;
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < kTrendWords; ++j)
+                    wd[j] = __hip_atomic_load(&words[lane][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < kTrendWords; ++j) ok = ok && ((unsigned int)wd[j] == seq);
+            }
+            if (__all(ok)) break;
+            if (++spins > 20000000u) {
+                __hip_atomic_store(&Gm->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const unsigned long long bits = (wd[2 * q] >> 32) | (wd[2 * q + 1] & 0xffffffff00000000ull);
+            tot[q] = on ? __longlong_as_double((long long)bits) : 0.0;
+        }
+        DeviceWave::sum_n<6>(tot);
+    }
+
+    __device__ void pass(int cmd, double a0, double a1, double (&tot)[6]) {  // wave 0 of every workgroup
+        if ((threadIdx.x & 63) == 0) { S->a0 = a0; S->a1 = a1; S->cmd = cmd; }
+        __syncthreads();  // A: the mailbox is visible to the helper waves
         work(cmd, a0, a1);
-        __syncthreads();  // B
+        __syncthreads();  // B: the waves' sums are in LDS
+        exchange(tot);
     }
     __device__ int init_keep() {
-        post(3, 0.0, 0.0);
-        int k = 0;
-        for (int w = 0; w < kTrendWaves; ++w) k += S->ipart[w][0];
-        return k;
+        double tot[6];
+        pass(3, 0.0, 0.0, tot);
+        return (int)tot[0];
     }
     __device__ void eval(double a0, double a1, double& f, double* g) {
-        post(1, a0, a1);
-        KSum s, g0, g1;
-        int cf = 0, c0 = 0, c1 = 0;
-        for (int w = 0; w < kTrendWaves; ++w) {
-            s.add(S->part[w][0]); g0.add(S->part[w][1]); g1.add(S->part[w][2]);
-            cf += S->ipart[w][0]; c0 += S->ipart[w][1]; c1 += S->ipart[w][2];
-        }
-        f = s.value() / (double)cf;
-        g[0] = -(g0.value() / (double)c0);
-        g[1] = -(g1.value() / (double)c1);
+#ifdef DSQ_TREND_PHASES
+        const long long t0 = clock64();
+        if (t_last) c_opt += t0 - t_last;
+#endif
+        double tot[6];
+        pass(1, a0, a1, tot);
+        f = fdiv(tot[0], tot[3]);
+        g[0] = -fdiv(tot[1], tot[4]);
+        g[1] = -fdiv(tot[2], tot[5]);
+#ifdef DSQ_TREND_PHASES
+        t_last = clock64();
+        c_pass += t_last - t0;
+        n_eval += 1;
+#endif
     }
     __device__ int filter(double a0, double a1) {
-        post(2, a0, a1);
-        int k = 0;
-        for (int w = 0; w < kTrendWaves; ++w) k += S->ipart[w][0];
-        return k;
+        double tot[6];
+        pass(2, a0, a1, tot);
+        return (int)tot[0];
     }
 };
 
 __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __restrict__ disp,
                                                                 const double* __restrict__ means, int n,
                                                                 double min_disp, double max_disp,
-                                                                uint8_t* __restrict__ keep,
+                                                                uint8_t* __restrict__ keep, TrendGridMem* Gm,
                                                                 double* __restrict__ out5, int single) {
     __shared__ TrendShared S;
-    BlockTrendOps ops;
+    GridTrendOps ops;
     ops.D = TrendData{disp, means, keep, n, min_disp, max_disp, single};
+    ops.Gm = Gm;
     ops.S = &S;
-    if ((threadIdx.x >> 6) == 0) {
+    if ((threadIdx.x >> 6) == 0) {  // the leader wave of every workgroup runs the optimiser
         const TrendOut o = trend_fit_core(ops, S.W, single != 0);
         if (threadIdx.x == 0) {
-            out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
-            out5[4] = (double)o.n_kept;
+            if (blockIdx.x == 0) {
+                const bool timed_out =
+                    gridDim.x > 1 && __hip_atomic_load(&Gm->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                out5[0] = o.a0; out5[1] = o.a1; out5[2] = timed_out ? -1.0 : (double)o.ok;
+                out5[3] = (double)o.n_outer; out5[4] = (double)o.n_kept;
+#ifdef DSQ_TREND_PHASES
+                printf("trend phases: evals %d  optimiser %lld  pass %lld cycles | build_B %lld cauchy %lld subsm %lld "
+                       "ls-setup %lld fg %lld after-ls+update %lld\n", ops.n_eval, ops.c_opt, ops.c_pass, g_lbd_phase[0],
+                       g_lbd_phase[1], g_lbd_phase[2], g_lbd_phase[3], g_lbd_phase[4], g_lbd_phase[5]);
+                for (int q = 0; q < 8; ++q) g_lbd_phase[q] = 0;
+#endif
+            }
             S.cmd = 0;
         }
-        __syncthreads();  // A (release the helpers)
+        __syncthreads();  // release this workgroup's helper waves
     } else {
         for (;;) {
-            __syncthreads();  // A
+            __syncthreads();  // A: wait for the leader's next command
             const int cmd = S.cmd;
             if (cmd == 0) break;
             ops.work(cmd, S.a0, S.a1);
@@ -1600,175 +1977,31 @@ __global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit(const double* __
     }
 }
 
-// ---- multi-workgroup variant (cooperative launch) for large gene sets: the data passes are spread
-// over kTrendGridBlocks workgroups.  EVERY workgroup's wave 0 runs the same deterministic optimiser
-// on the same combined sums (bit-identical: one slot per workgroup, combined in a fixed order), so a
-// pass needs no parameter broadcast and only ONE grid-wide barrier: partials -> slot -> barrier ->
-// every leader combines all slots.  Slots are double-buffered by pass parity (a workgroup can run at
-// most one pass ahead of the slowest reader).
-#ifndef DSQ_TREND_GRID_BLOCKS
-#define DSQ_TREND_GRID_BLOCKS 32
-#endif
-constexpr int kTrendGridBlocks = DSQ_TREND_GRID_BLOCKS;
-
-struct TrendGridMem {  // device global memory (zeroed before every launch)
-    double a0, a1;
-    int cmd;
-    unsigned int arrive;  // monotonic arrival counter of the grid barrier
-    unsigned int timeout; // set if a spin ever exceeds its bound (never observed; avoids a hung GPU)
-    int pad;
-    double part[2][64][3];  // [pass parity][workgroup] (kTrendGridBlocks <= 64)
-    int ipart[2][64][3];
-};
-
-__device__ __forceinline__ void trend_grid_barrier(TrendGridMem* Gm, unsigned int& target) {
-    grid_barrier(&Gm->arrive, &Gm->timeout, target);
-}
-
-struct TrendBlockScratch {
-    double part[kTrendWaves][3];
-    int ipart[kTrendWaves][3];
-    double a0, a1;  // mailbox of this workgroup: its leader wave -> its helper waves
-    int cmd;
-};
-
-struct GridTrendOps {
-    TrendData D;
-    TrendGridMem* Gm;
-    TrendBlockScratch* B;  // LDS of this workgroup
-    unsigned int target;
-    __device__ void wr(double* p, double v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ void wri(int* p, int v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ double rd(const double* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ int rdi(const int* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    int phase = 0;
-    // every thread of every workgroup calls work() once per pass: wave partials -> LDS -> one slot
-    // per workgroup in global memory (agent-scope atomics on both sides: the per-XCD L2s are not
-    // coherent for plain accesses) -> the one grid-wide barrier of the pass
-    __device__ void work(int cmd, double a0, double a1) {
-        const int w = threadIdx.x >> 6;
-        const int tid = blockIdx.x * (64 * kTrendWaves) + threadIdx.x, NT = gridDim.x * 64 * kTrendWaves;
-        if (cmd == 1) {
-            TrendPartial P;
-            trend_eval_partial(D, tid, NT, a0, a1, P);
-            const double s = DeviceWave::sum_comp(P.s), g0 = DeviceWave::sum_comp(P.g0),
-                         g1 = DeviceWave::sum_comp(P.g1);
-            const int cf = DeviceWave::sumi(P.cf), c0 = DeviceWave::sumi(P.c0), c1 = DeviceWave::sumi(P.c1);
-            if ((threadIdx.x & 63) == 0) {
-                B->part[w][0] = s; B->part[w][1] = g0; B->part[w][2] = g1;
-                B->ipart[w][0] = cf; B->ipart[w][1] = c0; B->ipart[w][2] = c1;
-            }
-        } else {
-            const int k = DeviceWave::sumi(cmd == 3 ? trend_init_keep(D, tid, NT) : trend_filter(D, tid, NT, a0, a1));
-            if ((threadIdx.x & 63) == 0) { B->ipart[w][0] = k; B->ipart[w][1] = 0; B->ipart[w][2] = 0;
-                                           B->part[w][0] = 0.0; B->part[w][1] = 0.0; B->part[w][2] = 0.0; }
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            KSum s;
-            int c = 0;
-            for (int q = 0; q < kTrendWaves; ++q) { s.add(B->part[q][threadIdx.x]); c += B->ipart[q][threadIdx.x]; }
-            wr(&Gm->part[phase][blockIdx.x][threadIdx.x], s.value());
-            wri(&Gm->ipart[phase][blockIdx.x][threadIdx.x], c);
-        }
-        trend_grid_barrier(Gm, target);
-        phase ^= 1;
-    }
-    __device__ void post(int cmd, double a0, double a1) {  // wave 0 of every workgroup
-        if ((threadIdx.x & 63) == 0) { B->a0 = a0; B->a1 = a1; B->cmd = cmd; }
-        __syncthreads();  // mailbox visible to this workgroup's helper waves
-        work(cmd, a0, a1);
-    }
-    // leader wave: lane b fetches workgroup b's slot of the pass just completed, butterfly-combine
-    // (fixed order => every workgroup's leader gets the bit-identical totals)
-    __device__ void combine(double& s, double& g0, double& g1, int& cf, int& c0, int& c1) {
-        const int b = threadIdx.x & 63;
-        const bool on = b < (int)gridDim.x;
-        const int ph = phase ^ 1;
-        KSum ks, k0, k1;
-        ks.s = on ? rd(&Gm->part[ph][b][0]) : 0.0;
-        k0.s = on ? rd(&Gm->part[ph][b][1]) : 0.0;
-        k1.s = on ? rd(&Gm->part[ph][b][2]) : 0.0;
-        s = DeviceWave::sum_comp(ks); g0 = DeviceWave::sum_comp(k0); g1 = DeviceWave::sum_comp(k1);
-        cf = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][0]) : 0);
-        c0 = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][1]) : 0);
-        c1 = DeviceWave::sumi(on ? rdi(&Gm->ipart[ph][b][2]) : 0);
-    }
-    __device__ int init_keep() {
-        post(3, 0.0, 0.0);
-        double s, g0, g1; int cf, c0, c1;
-        combine(s, g0, g1, cf, c0, c1);
-        return cf;
-    }
-    __device__ void eval(double a0, double a1, double& f, double* g) {
-        post(1, a0, a1);
-        double s, g0, g1; int cf, c0, c1;
-        combine(s, g0, g1, cf, c0, c1);
-        f = s / (double)cf;
-        g[0] = -(g0 / (double)c0);
-        g[1] = -(g1 / (double)c1);
-    }
-    __device__ int filter(double a0, double a1) {
-        post(2, a0, a1);
-        double s, g0, g1; int cf, c0, c1;
-        combine(s, g0, g1, cf, c0, c1);
-        return cf;
-    }
-};
-
-__global__ __launch_bounds__(64 * kTrendWaves) void k_trend_fit_grid(const double* disp, const double* means, int n,
-                                                                     double min_disp, double max_disp,
-                                                                     uint8_t* keep, TrendGridMem* Gm,
-                                                                     double* out5) {
-    __shared__ TrendWork W;
-    __shared__ TrendBlockScratch Bs;
-    GridTrendOps ops;
-    ops.D = TrendData{disp, means, keep, n, min_disp, max_disp};
-    ops.Gm = Gm;
-    ops.B = &Bs;
-    ops.target = gridDim.x;
-    if ((threadIdx.x >> 6) == 0) {  // the leader wave of every workgroup runs the optimiser
-        const TrendOut o = trend_fit_core(ops, W);
-        if (threadIdx.x == 0) {
-            if (blockIdx.x == 0) {
-                out5[0] = o.a0; out5[1] = o.a1; out5[2] = (double)o.ok; out5[3] = (double)o.n_outer;
-                out5[4] = (double)o.n_kept;
-            }
-            Bs.cmd = 0;
-        }
-        __syncthreads();  // release this workgroup's helper waves
-    } else {
-        for (;;) {
-            __syncthreads();  // wait for the leader's next command
-            const int cmd = Bs.cmd;
-            if (cmd == 0) break;
-            ops.work(cmd, Bs.a0, Bs.a1);
-        }
-    }
-}
-
 size_t trend_grid_mem_bytes() { return sizeof(TrendGridMem); }
 
+// out5: {a0, a1, ok (1 converged, 0 not, -1 the workgroups' exchange timed out), gamma-GLM fits, genes in the last fit}
 hipError_t launch_trend_fit(hipStream_t st, const double* disp, const double* means, int n, double min_disp,
                             double max_disp, uint8_t* keep, double* out5, void* grid_mem, int force_grid) {
-    if (grid_mem != nullptr && force_grid >= 0 && (force_grid > 0 || n >= 2048)) {
-        TrendGridMem* gm = (TrendGridMem*)grid_mem;
-        hipError_t e0 = hipMemsetAsync(gm, 0, 64, st);  // cmd / arrival counter / timeout flag
+    TrendGridMem* gm = (TrendGridMem*)grid_mem;
+    int single = 0;
+    if (gm != nullptr && force_grid >= 0 && (force_grid > 0 || n >= 3072)) {  // (measured crossover of one workgroup against the grid: ~3000 genes)
+        hipError_t e0 = hipMemsetAsync(gm, 0, sizeof(TrendGridMem), st);
         if (e0 != hipSuccess) return e0;
-        void* args[] = {(void*)&disp, (void*)&means, (void*)&n, (void*)&min_disp, (void*)&max_disp, (void*)&keep,
-                        (void*)&gm, (void*)&out5};
-        return hipLaunchCooperativeKernel((const void*)k_trend_fit_grid, dim3(kTrendGridBlocks),
-                                          dim3(64 * kTrendWaves), args, 0, st);
+        void* args[] = {(void*)&disp, (void*)&means, (void*)&n,    (void*)&min_disp, (void*)&max_disp,
+                        (void*)&keep, (void*)&gm,    (void*)&out5, (void*)&single};
+        return hipLaunchCooperativeKernel((const void*)k_trend_fit, dim3(kTrendGridBlocks), dim3(64 * kTrendWaves), args,
+                                          0, st);
     }
-    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, disp, means, n, min_disp, max_disp,
-                       keep, out5, 0);
+    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, disp, means, n, min_disp, max_disp, keep,
+                       (TrendGridMem*)nullptr, out5, 0);
     return hipGetLastError();
 }
 
 // Inference.dispersion_trend_gamma_glm (inference.py:284-308): ONE gamma-GLM fit of targets ~ a0 + a1 * cov
 hipError_t launch_trend_glm(hipStream_t st, const double* targets, const double* cov, int n, uint8_t* keep,
                             double* out5) {
-    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, targets, cov, n, 0.0, 0.0, keep, out5, 1);
+    hipLaunchKernelGGL(k_trend_fit, dim3(1), dim3(64 * kTrendWaves), 0, st, targets, cov, n, 0.0, 0.0, keep,
+                       (TrendGridMem*)nullptr, out5, 1);
     return hipGetLastError();
 }
 
@@ -1878,10 +2111,10 @@ hipError_t launch_sf_keys_compact(hipStream_t st, const void* counts_sm, int cou
     const int gx = (G + 255) / 256 > 256 ? 256 : (G + 255) / 256;
     if (count_type == 1)
         hipLaunchKernelGGL((k_ratio_keys_c<int64_t>), dim3(gx, N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
-                           logmeans, idx_work, idx_work + G, keys, 0);
+                           logmeans, idx_work, idx_work + G, keys, 0, 0);
     else
         hipLaunchKernelGGL((k_ratio_keys_c<int32_t>), dim3(gx, N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
-                           logmeans, idx_work, idx_work + G, keys, 0);
+                           logmeans, idx_work, idx_work + G, keys, 0, 0);
     return hipGetLastError();
 }
 hipError_t launch_sf_count(hipStream_t st, const unsigned long long* keys, int N, int G, unsigned int* counts) {

@@ -14,6 +14,20 @@
 
 namespace dsq {
 
+#if defined(DSQ_TREND_PHASES) && defined(__HIPCC__)
+__device__ long long g_lbd_phase[8];
+#endif
+#if defined(DSQ_TREND_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define LBD_PH(k)                                                        \
+    {                                                                    \
+        const long long now_ = clock64();                                \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_lbd_phase[k] += now_ - lbd_t_; \
+        lbd_t_ = now_;                                                   \
+    }
+#else
+#define LBD_PH(k)
+#endif
+
 template <int NMAX, int M = 10>
 struct LbfgsbDenseWork {
     double S[M][NMAX], Y[M][NMAX];  // circular pair storage
@@ -65,8 +79,13 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                 Bs[i] = v;
             }
             for (int i = 0; i < n; ++i) { sBs += W.S[p][i] * Bs[i]; ys += W.Y[p][i] * W.S[p][i]; }
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) B[i][j] += W.Y[p][i] * W.Y[p][j] / ys - Bs[i] * Bs[j] / sBs;
+            // (two reciprocals per replayed pair, not 2 n^2 divisions: the replay is the optimiser's critical path
+            // between two evaluations - up to ten pairs per iteration; fdiv: <= 1 ulp, a fifth of an IEEE division)
+            const double rys = fdiv(1.0, ys), rsBs = fdiv(1.0, sBs);
+            for (int i = 0; i < n; ++i) {
+                const double yi = W.Y[p][i] * rys, bi = Bs[i] * rsBs;
+                for (int j = 0; j < n; ++j) B[i][j] += yi * W.Y[p][j] - bi * Bs[j];
+            }
         }
     };
 
@@ -75,8 +94,13 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
     double sbgnrm = projgr();
     if (sbgnrm <= pgtol) { R = {f, true, nfev, 0, 0}; return R; }
 
+#if defined(DSQ_TREND_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+    long long lbd_t_ = clock64();
+#endif
     for (;;) {
+        LBD_PH(5)
         build_B();
+        LBD_PH(0)
         // ------------------------------------------------------------ generalized Cauchy point
         for (int i = 0; i < n; ++i) z[i] = x[i];
         double tb[NMAX];
@@ -99,8 +123,8 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                 d[i] = 0.0;
             } else {
                 d[i] = neggi;
-                if (nbd[i] != 0 && nbd[i] <= 2 && neggi < 0.0) { tb[i] = tl / (-neggi); nbreak += 1; }
-                else if (nbd[i] >= 2 && neggi > 0.0) { tb[i] = tu / neggi; nbreak += 1; }
+                if (nbd[i] != 0 && nbd[i] <= 2 && neggi < 0.0) { tb[i] = fdiv(tl, -neggi); nbreak += 1; }
+                else if (nbd[i] >= 2 && neggi > 0.0) { tb[i] = fdiv(tu, neggi); nbreak += 1; }
                 else { nfreec += 1; if (fabs(neggi) > 0.0) bnded = false; }
             }
         }
@@ -118,7 +142,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
             };
             double f2 = quad(d, d);
             const double f2_org = f2;
-            double dtm = -f1 / f2, tsum = 0.0, tj = 0.0;
+            double dtm = fdiv(-f1, f2), tsum = 0.0, tj = 0.0;
             bool used[NMAX];
             for (int i = 0; i < n; ++i) used[i] = false;
             int nleft = nbreak;
@@ -147,9 +171,9 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                 f1 += quad(d, zc);
                 f2 = quad(d, d);
                 f2 = dmax(epsmch * f2_org, f2);
-                if (nleft > 0) { dtm = -f1 / f2; }
+                if (nleft > 0) { dtm = fdiv(-f1, f2); }
                 else if (bnded) { f1 = 0.0; f2 = 0.0; dtm = 0.0; }
-                else { dtm = -f1 / f2; }
+                else { dtm = fdiv(-f1, f2); }
             }
             if (!all_fixed) {
                 if (dtm <= 0.0) dtm = 0.0;
@@ -158,6 +182,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                     if (!used[i]) z[i] = x[i] + tsum * d[i];
             }
         }
+        LBD_PH(1)
         // ------------------------------------------------------------ subspace minimisation
         int nfree = 0, idx[NMAX];
         for (int i = 0; i < n; ++i)
@@ -175,7 +200,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
             for (int a = 0; a < nfree; ++a) {
                 const double piv = A[a][a];
                 for (int b = a + 1; b < nfree; ++b) {
-                    const double m_ = A[b][a] / piv;
+                    const double m_ = fdiv(A[b][a], piv);
                     for (int c = a; c < nfree; ++c) A[b][c] -= m_ * A[a][c];
                     rr_[b] -= m_ * rr_[a];
                 }
@@ -183,7 +208,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
             for (int a = nfree - 1; a >= 0; --a) {
                 double v = rr_[a];
                 for (int b = a + 1; b < nfree; ++b) v -= A[a][b] * ds[b];
-                ds[a] = v / A[a][a];
+                ds[a] = fdiv(v, A[a][a]);
             }
             int iword = 0;
             for (int i = 0; i < n; ++i) xp[i] = z[i];
@@ -212,10 +237,10 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                         if (nbd[k] != 0) {
                             if (dk < 0.0 && nbd[k] <= 2) {
                                 const double t2 = l[k] - z[k];
-                                if (t2 >= 0.0) temp1 = 0.0; else if (dk * alpha < t2) temp1 = t2 / dk;
+                                if (t2 >= 0.0) temp1 = 0.0; else if (dk * alpha < t2) temp1 = fdiv(t2, dk);
                             } else if (dk > 0.0 && nbd[k] >= 2) {
                                 const double t2 = u[k] - z[k];
-                                if (t2 <= 0.0) temp1 = 0.0; else if (dk * alpha > t2) temp1 = t2 / dk;
+                                if (t2 <= 0.0) temp1 = 0.0; else if (dk * alpha > t2) temp1 = fdiv(t2, dk);
                             }
                             if (temp1 < alpha) { alpha = temp1; ibd = a; }
                         }
@@ -230,11 +255,11 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                 }
             }
         }
+        LBD_PH(2)
         // ------------------------------------------------------------ line search
         for (int i = 0; i < n; ++i) d[i] = z[i] - x[i];
         dtd = 0.0;
         for (int i = 0; i < n; ++i) dtd += d[i] * d[i];
-        const double dnorm = sqrt(dtd);
         double stpmx = 1e10;
         if (cnstnd) {
             if (iter == 0) stpmx = 1.0;
@@ -244,15 +269,15 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                     if (nbd[i] != 0) {
                         if (a1 < 0.0 && nbd[i] <= 2) {
                             const double a2 = l[i] - x[i];
-                            if (a2 >= 0.0) stpmx = 0.0; else if (a1 * stpmx < a2) stpmx = a2 / a1;
+                            if (a2 >= 0.0) stpmx = 0.0; else if (a1 * stpmx < a2) stpmx = fdiv(a2, a1);
                         } else if (a1 > 0.0 && nbd[i] >= 2) {
                             const double a2 = u[i] - x[i];
-                            if (a2 <= 0.0) stpmx = 0.0; else if (a1 * stpmx > a2) stpmx = a2 / a1;
+                            if (a2 <= 0.0) stpmx = 0.0; else if (a1 * stpmx > a2) stpmx = fdiv(a2, a1);
                         }
                     }
                 }
         }
-        stp = (iter == 0 && !boxed) ? dmin(1.0 / dnorm, stpmx) : 1.0;
+        stp = (iter == 0 && !boxed) ? dmin(1.0 / sqrt(dtd), stpmx) : 1.0;
         for (int i = 0; i < n; ++i) { t[i] = x[i]; r[i] = g[i]; }
         fold = f;
         int ifun = 0;
@@ -274,7 +299,9 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                         if (nbd[i] == 1 || nbd[i] == 2) x[i] = dmax(x[i], l[i]);
                         if (nbd[i] == 2 || nbd[i] == 3) x[i] = dmin(x[i], u[i]);
                     }
+                LBD_PH(3)
                 fg(x, f, g);
+                LBD_PH(4)
                 nfev += 1;
                 gd = 0.0;
                 for (int i = 0; i < n; ++i) gd += g[i] * d[i];
@@ -306,7 +333,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
         if (col < M) { slot = (head + col) % M; col += 1; }
         else { slot = head; head = (head + 1) % M; }
         for (int i = 0; i < n; ++i) { W.S[slot][i] = d[i]; W.Y[slot][i] = r[i]; }
-        theta = rr / dr;
+        theta = fdiv(rr, dr);
     }
 }
 

@@ -197,6 +197,20 @@ DSQ_HD double frcp_g(double x) {
 #endif
 }
 
+// a / b to <= 1 ulp without the IEEE division's ~30 dependent instructions (v_rcp_f64 + Newton + one residual
+// correction): for scalar code whose latency matters (the optimisers between two evaluations), where b is a normal
+// non-zero number in every regular case; b = 0 or inf give what the division gives (through frcp_g).  Host: a / b.
+DSQ_HD double fdiv(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = frcp_g(b);
+    const double q = a * r;
+    const double q2 = fma(fma(-b, q, a), r, q);
+    return (q2 != q2) ? q : q2;
+#else
+    return a / b;
+#endif
+}
+
 namespace detail {
 constexpr double kLn2Hi = 6.93147180369123816490e-01, kLn2Lo = 1.90821492927058770002e-10;
 constexpr double kLg1 = 6.666666666666735130e-01, kLg2 = 3.999999999940941908e-01,

@@ -17,8 +17,6 @@ namespace dsq {
 
 struct TrendWork {
     LbfgsbDenseWork<2> lb;
-    double x[2], l[2], u[2];
-    int nbd[2];
 };
 
 struct TrendOut {
@@ -97,12 +95,15 @@ DSQ_HD TrendOut trend_fit_core(Ops& ops, TrendWork& W, bool single = false) {
     int kept = ops.init_keep();
     auto fg = [&](const double* c, double& f, double* g) { ops.eval(c[0], c[1], f, g); };
     double old0 = 0.1, old1 = 0.1, a0 = 1.0, a1 = 1.0;
+    // x0 = (1, 1), lower bound 1e-12 on both coefficients (default_inference.py:219-225).  Local constants, not workspace
+    // fields: inlined into the optimiser, the bound-type tests of its scalar code fold away (it runs on one wavefront
+    // between two data passes - its latency is the kernel's)
+    const double lo[2] = {1e-12, 1e-12}, up[2] = {0.0, 0.0};
+    const int nbd[2] = {1, 1};
     if (single) {  // DefaultInference.dispersion_trend_gamma_glm (default_inference.py:200-230): one fit
-        W.x[0] = 1.0; W.x[1] = 1.0;
-        W.l[0] = 1e-12; W.l[1] = 1e-12; W.u[0] = 0.0; W.u[1] = 0.0;
-        W.nbd[0] = 1; W.nbd[1] = 1;
-        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, W.x, W.l, W.u, W.nbd, W.lb);
-        out.a0 = W.x[0]; out.a1 = W.x[1]; out.ok = res.success ? 1 : 0; out.n_outer = 1; out.n_kept = kept;
+        double x[2] = {1.0, 1.0};
+        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, x, lo, up, nbd, W.lb);
+        out.a0 = x[0]; out.a1 = x[1]; out.ok = res.success ? 1 : 0; out.n_outer = 1; out.n_kept = kept;
         return out;
     }
     for (;;) {
@@ -110,11 +111,9 @@ DSQ_HD TrendOut trend_fit_core(Ops& ops, TrendWork& W, bool single = false) {
         const double l0 = log(fabs(a0 / old0)), l1 = log(fabs(a1 / old1));
         if (!(l0 * l0 + l1 * l1 >= 1e-6)) break;
         old0 = a0; old1 = a1;
-        W.x[0] = 1.0; W.x[1] = 1.0;
-        W.l[0] = 1e-12; W.l[1] = 1e-12; W.u[0] = 0.0; W.u[1] = 0.0;
-        W.nbd[0] = 1; W.nbd[1] = 1;
-        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, W.x, W.l, W.u, W.nbd, W.lb);
-        a0 = W.x[0]; a1 = W.x[1];
+        double x[2] = {1.0, 1.0};
+        const LbfgsbResult res = lbfgsb_dense<2>(fg, 2, x, lo, up, nbd, W.lb);
+        a0 = x[0]; a1 = x[1];
         out.n_outer += 1;
         out.n_kept = kept;
         if (!res.success || a0 <= 1e-10 || a1 <= 1e-10) {

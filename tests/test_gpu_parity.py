@@ -633,6 +633,26 @@ def test_distributed_pipeline_two_ranks_threads(sf_mode):
         assert_close(r.pvalue, res_full.pvalue[sl], 1e-6, 1e-300, "p")
 
 
+@pytest.mark.parametrize("G,N,zero_frac,count_dtype", [(3000, 7, 0.0, np.int64), (32768, 5, 0.0, np.int32),
+                                                     (32769, 5, 0.0, np.int64), (50000, 6, 0.0, np.int32),
+                                                     (50000, 9, 0.5, np.int64)])
+def test_size_factors_register_and_key_matrix_paths(G, N, zero_frac, count_dtype):
+    """Median of ratios (preprocessing.py:59-102): up to 32 768 usable genes a sample's keys stay in the registers of
+    its workgroup (k_sf_row), above that the key matrix is written and read by the radix passes - both against numpy's
+    medians, at the boundary, with ties (small counts) and with genes that contain zeros (left out)."""
+    import pydeseq2_amd
+
+    rng = np.random.default_rng(G + N)
+    counts = rng.poisson(rng.gamma(2.0, 20.0, G)[None, :] * rng.uniform(0.5, 2.0, N)[:, None]).astype(np.int64) + 1
+    zero_genes = rng.random(G) < zero_frac
+    counts[rng.integers(0, N, G)[zero_genes], np.nonzero(zero_genes)[0]] = 0
+    X = np.column_stack([np.ones(N), np.arange(N) % 2]).astype(np.float64)
+    pipe = pydeseq2_amd.DeseqPipeline(counts.astype(count_dtype), X, device=0)
+    res = pipe.deseq2(stop_after_size_factors=True)
+    sf_o = orc.size_factors_ratio(counts)[0]
+    assert_close(res.size_factors, sf_o, 1e-13, 0, "size factors")
+
+
 @pytest.mark.parametrize("n", [5000, 40000, 300001])
 def test_prior_mad_kernel_vs_numpy(n):
     """dsq_dev_prior_mad (one workgroup below 32768 genes, multi-workgroup radix passes above — the

@@ -1475,7 +1475,6 @@ int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_mean
     h_coeffs2[0] = h[0]; h_coeffs2[1] = h[1];
     *h_ok = (int)h[2];
     if (h_n_outer) *h_n_outer = (int)h[3];
-    if (*h_ok && h[9] < 0.0) return fail(ctx, DSQ_ERR_HIP, "prior MAD: grid barrier timed out");
     *h_squared_logres = h[8];
     return DSQ_OK;
 }
@@ -1489,7 +1488,6 @@ int dsq_dev_prior_mad(dsq_ctx* ctx, const double* d_gw_raw, const double* d_fitt
     double out2[2];
     DSQ_HIP(hipMemcpyAsync(out2, d_out, sizeof(out2), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (out2[1] < 0.0) return fail(ctx, DSQ_ERR_HIP, "prior MAD: grid barrier timed out");
     *h_squared_logres = out2[0];
     return DSQ_OK;
 }

@@ -359,45 +359,182 @@ __global__ __launch_bounds__(1024) void k_row_median(const unsigned long long* _
     if (threadIdx.x == 0) sf[n] = (M == 0) ? NAN : exp(med);
 }
 
-// dispersion prior (dds.py:866-884, utils.py:1210-1227): MAD^2 of log(genewise) - log(fitted) over
-// the genes with genewise >= 100 * min_disp, one workgroup.  out[0] = squared_logres.
-__global__ __launch_bounds__(1024) void k_prior_mad(const double* __restrict__ gw_raw,
-                                                    const double* __restrict__ fitted, int n, double min_disp,
-                                                    double max_disp, double* __restrict__ res,
-                                                    double* __restrict__ out) {
-    __shared__ MedianShared S;
-    // residuals once (NaN marks genes below the 100*min_disp threshold), then two radix selects
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const double g = dmin(dmax(gw_raw[i], min_disp), max_disp);
-        res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
+// ---- workgroup-wide exact median by narrowing in VALUE space -------------------------------------
+// The bitwise radix select above resolves the keys' bits from the top.  The values it is used on here - a sample's
+// log ratios, the genes' log residuals - are tight clusters: their leading 11 or 22 bits are all the same, so the first
+// passes narrow nothing and send every LDS histogram increment of the workgroup to the same two or three words.  This
+// select bins by VALUE: a 2048-bin histogram over [min, max] of the current candidates spreads a cluster over the bins
+// wherever it lies; the bin(s) that hold the two middle ranks are the new candidates; at <= 1024 candidates they are
+// ranked against each other.  Binning is monotone in the value and membership is decided by the same expression in every
+// pass, so the result is the exact order statistic, ties included.  Usually: one pass for min / max / count, one for the
+// histogram, one to collect the candidates.
+// each(fn): calls fn(x) for every value of this thread (the same values every time); NaN = not part of the median,
+// -inf allowed (counts at the low end), otherwise finite.  All threads of the workgroup must call it.
+constexpr int kSelCand = 1024;
+
+struct ValueSelectShared {
+    unsigned int hist[2048];
+    double cand[kSelCand];
+    double dred[16][2];
+    unsigned int ured[16][2];
+    unsigned int wtot[16];
+    unsigned int bin[2], pre[2], ncand;
+    double a[2];
+};
+
+// min / max of (lo, hi) and sums of (c0, c1) over the workgroup's threads; every thread gets the results
+__device__ __forceinline__ void vs_block_reduce(ValueSelectShared& S, double& lo, double& hi, unsigned int& c0,
+                                                unsigned int& c1) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = dmin(lo, __shfl_xor(lo, o, 64));
+        hi = dmax(hi, __shfl_xor(hi, o, 64));
+        c0 += __shfl_xor(c0, o, 64);
+        c1 += __shfl_xor(c1, o, 64);
     }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // (the arrays may still be read from the previous reduction)
+    if ((threadIdx.x & 63) == 0) { S.dred[w][0] = lo; S.dred[w][1] = hi; S.ured[w][0] = c0; S.ured[w][1] = c1; }
     __syncthreads();
-    double center, mad;
-    unsigned int M;
-    block_median([&](int i) { const double r = res[i]; return (r == r) ? f64_key(r) : ~0ull; }, n, S, center, M);
-    __syncthreads();
-    block_median([&](int i) { const double r = res[i]; return (r == r) ? f64_key(fabs(r - center)) : ~0ull; },
-                 n, S, mad, M);
-    if (threadIdx.x == 0) {
-        const double m = mad / 0.67448975019608171;  // norm.ppf(0.75)
-        out[0] = m * m;
-        out[1] = (double)M;
+    lo = S.dred[0][0]; hi = S.dred[0][1]; c0 = S.ured[0][0]; c1 = S.ured[0][1];
+    for (int q = 1; q < (int)(blockDim.x >> 6); ++q) {
+        lo = dmin(lo, S.dred[q][0]); hi = dmax(hi, S.dred[q][1]);
+        c0 += S.ured[q][0]; c1 += S.ured[q][1];
     }
 }
 
-// ---- the same two medians for LARGE gene sets (the gathered vectors of the multi-GPU layout: world x G
-// genes): one workgroup reading hundreds of thousands of keys 12 times is bandwidth-starved, so the
-// radix passes become wide kernels (LDS-privatised histograms flushed to a global one) alternating with
-// a 2-wave pick kernel; state lives in global memory.  Same digits, same tie handling as block_median.
-struct MedGlobal {
-    unsigned int hist[2][2048];
-    unsigned long long prefix[2];
-    unsigned int rank[2];
-    unsigned int M;
-    unsigned int pad;
-    double result;
-};
+template <int NT, class Each>
+__device__ void block_median_values(Each each, ValueSelectShared& S, double& median, unsigned int& M_out) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double lo = INFINITY, hi = -INFINITY;
+    unsigned int n_fin = 0, n_low = 0;
+    each([&](double x) {
+        if (x != x) return;
+        if (x == -INFINITY) { n_low += 1; return; }
+        lo = dmin(lo, x); hi = dmax(hi, x);
+        n_fin += 1;
+    });
+    vs_block_reduce(S, lo, hi, n_fin, n_low);
+    const unsigned int M = n_fin + n_low;
+    M_out = M;
+    if (M == 0) { median = NAN; return; }
+    const unsigned int r0 = (M - 1) / 2, r1 = M / 2;
+    if (r1 < n_low) { median = -INFINITY; return; }
+    // ranks among the finite values (r0 may still be a -inf: then only r1 is selected)
+    const bool low0 = r0 < n_low;
+    unsigned int q0 = (low0 ? r1 : r0) - n_low, q1 = r1 - n_low;
+    unsigned int cnt = n_fin;
+    double a0 = NAN, a1 = NAN;
+    for (int level = 0; level < 64; ++level) {
+        if (lo == hi) { a0 = lo; a1 = lo; break; }
+        const double scale = 2048.0 / (hi - lo);
+        auto bin_of = [&](double x) {
+            const int bb = (int)((x - lo) * scale);
+            return bb > 2047 ? 2047 : bb;
+        };
+        const bool direct = cnt <= (unsigned int)kSelCand;  // every value in [lo, hi] is a candidate
+        int b0 = 0, b1 = 2047;
+        if (!direct) {
+            for (int i = tid; i < 2048; i += NT) S.hist[i] = 0;
+            __syncthreads();
+            each([&](double x) {
+                if (x >= lo && x <= hi) atomicAdd(&S.hist[bin_of(x)], 1u);
+            });
+            __syncthreads();
+            // the bins of the two ranks: exclusive prefix over the 2048 bins, 2048 / NT consecutive bins per thread
+            {
+                constexpr int PER = 2048 / NT;
+                unsigned int h[PER], all = 0;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) { h[q] = S.hist[PER * tid + q]; all += h[q]; }
+                unsigned int incl = all;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                if (lane == 63) S.wtot[w] = incl;
+                __syncthreads();
+                unsigned int base = 0;
+                for (int q = 0; q < w; ++q) base += S.wtot[q];
+                unsigned int excl = base + incl - all;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        const unsigned int t = which ? q1 : q0;
+                        if (excl <= t && t < excl + h[q]) { S.bin[which] = PER * tid + q; S.pre[which] = excl; }
+                    }
+                    excl += h[q];
+                }
+                __syncthreads();
+            }
+            b0 = (int)S.bin[0]; b1 = (int)S.bin[1];
+            const unsigned int pre0 = S.pre[0];
+            const unsigned int c0 = S.hist[b0], csel = c0 + (b1 != b0 ? S.hist[b1] : 0u);
+            q0 -= pre0; q1 -= pre0;
+            if (csel > (unsigned int)kSelCand) {
+                // still too many: the ranks are neighbours, so either both lie in bin b0 - the next level's range - or
+                // they are the LAST value of bin b0 and the FIRST of bin b1
+                double nlo = INFINITY, nhi = -INFINITY, lo1 = INFINITY;
+                unsigned int d0 = 0, d1 = 0;
+                each([&](double x) {
+                    if (x >= lo && x <= hi) {
+                        const int bb = bin_of(x);
+                        if (bb == b0) { nlo = dmin(nlo, x); nhi = dmax(nhi, x); }
+                        if (bb == b1) lo1 = dmin(lo1, x);
+                    }
+                });
+                if (b0 != b1) {
+                    vs_block_reduce(S, lo1, nhi, d0, d1);
+                    a0 = nhi; a1 = lo1;
+                    break;
+                }
+                vs_block_reduce(S, nlo, nhi, d0, d1);
+                lo = nlo; hi = nhi; cnt = c0;
+                continue;
+            }
+        }
+        // rank the candidates against each other
+        if (tid == 0) { S.ncand = 0; S.a[0] = NAN; S.a[1] = NAN; }
+        __syncthreads();
+        each([&](double x) {
+            if (x >= lo && x <= hi) {
+                bool take = direct;
+                if (!direct) {
+                    const int bb = bin_of(x);
+                    take = bb == b0 || bb == b1;
+                }
+                if (take) S.cand[atomicAdd(&S.ncand, 1u)] = x;
+            }
+        });
+        __syncthreads();
+        const unsigned int m = S.ncand;
+        for (int i = tid; i < (int)m; i += NT) {
+            const double c = S.cand[i];
+            unsigned int less = 0, eq = 0;
+            for (unsigned int j = 0; j < m; ++j) {
+                const double cj = S.cand[j];
+                less += cj < c;
+                eq += cj == c;
+            }
+            if (less <= q0 && q0 < less + eq) S.a[0] = c;
+            if (less <= q1 && q1 < less + eq) S.a[1] = c;
+        }
+        __syncthreads();
+        a0 = S.a[0]; a1 = S.a[1];
+        break;
+    }
+    const double v0 = low0 ? -INFINITY : a0;
+    median = (r0 == r1) ? v0 : (v0 + a1) / 2.0;
+    __syncthreads();  // (S may be reused by the caller's next select)
+}
 
+// dispersion prior (dds.py:866-884, utils.py:1210-1227): MAD^2 of log(genewise) - log(fitted) over the genes with
+// genewise >= 100 * min_disp.  The residuals come from a wide kernel (two logarithms per gene: one workgroup's ALUs
+// would need longer for them than for everything else), the two medians - of the residuals, then of their absolute
+// deviations from the first - from one workgroup that reads them from the L2 (three passes each, usually).
+// out[0] = squared_logres, out[1] = number of genes that entered.
 __global__ void k_prior_res(const double* __restrict__ gw_raw, const double* __restrict__ fitted, int n,
                             double min_disp, double max_disp, double* __restrict__ res) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,256 +543,42 @@ __global__ void k_prior_res(const double* __restrict__ gw_raw, const double* __r
     res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
 }
 
-__global__ void k_med_zero(MedGlobal* S) {
-    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&S->hist[0][0])[i] = 0;
-    if (threadIdx.x == 0) { S->prefix[0] = 0; S->prefix[1] = 0; S->rank[0] = 0; S->rank[1] = 0; S->M = 0; }
-}
-
-// ABS: keys of |res - center| (center = result of the previous median), else keys of res; NaN skipped
-template <bool ABS>
-__global__ __launch_bounds__(1024) void k_med_hist(const double* __restrict__ res, int n,
-                                                   const MedGlobal* __restrict__ prev, int pass, MedGlobal* S) {
-    __shared__ unsigned int h[2][2048];
-    const int shifts[6] = {53, 42, 31, 20, 9, 0};
-    const int shift = shifts[pass];
-    const int nbins = pass == 5 ? 512 : 2048;
-    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const unsigned long long p0 = S->prefix[0], p1 = S->prefix[1];
-    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
-    const double center = ABS ? prev->result : 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double r = res[i];
-        if (r != r) continue;
-        const unsigned long long k = f64_key(ABS ? fabs(r - center) : r);
-        const unsigned int d = (unsigned int)(k >> shift) & (unsigned int)(nbins - 1);
-        if (pass == 0) {
-            atomicAdd(&h[0][d], 1u);
-        } else {
-            if ((k & himask) == p0) atomicAdd(&h[0][d], 1u);
-            if ((k & himask) == p1) atomicAdd(&h[1][d], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * 2048; i += blockDim.x) {
-        const unsigned int c = (&h[0][0])[i];
-        if (c) atomicAdd(&(&S->hist[0][0])[i], c);
-    }
-}
-
-__global__ __launch_bounds__(128) void k_med_pick(MedGlobal* S, int pass) {
-    const int shifts[6] = {53, 42, 31, 20, 9, 0};
-    const int shift = shifts[pass];
-    const int nbins = pass == 5 ? 512 : 2048;
+__global__ __launch_bounds__(1024) void k_prior_mad(const double* __restrict__ res, int n, double* __restrict__ out) {
+    __shared__ ValueSelectShared S;
     const int tid = threadIdx.x;
-    if (pass == 0) {
-        if (tid < 64) {
-            unsigned int c = 0;
-            for (int k = tid; k < 2048; k += 64) c += S->hist[0][k];
+    double center, mad;
+    unsigned int M, M2;
+    // (eight loads in flight per thread: the values are independent, a one-value loop body waits for each of them -
+    // at 60 000 genes a pass is 59 L2 round trips per thread then, and the passes are nothing else)
+    auto walk = [&](auto&& f) {
+        int i = tid;
+        for (; i + 7 * 1024 < n; i += 8 * 1024) {
+            double x[8];
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
-            if (tid == 0) { S->M = c; S->rank[0] = c ? (c - 1) / 2 : 0; S->rank[1] = c / 2; }
-        }
-        __syncthreads();
-    }
-    const int w = tid >> 6;
-    unsigned int r = S->rank[w];
-    const int d = pick_digit(S->hist[pass == 0 ? 0 : w], nbins, r);
-    __syncthreads();
-    if ((tid & 63) == 0) {
-        S->rank[w] = r;
-        S->prefix[w] |= ((unsigned long long)d << shift);
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * 2048; i += blockDim.x) (&S->hist[0][0])[i] = 0;  // ready for the next pass
-    if (pass == 5 && tid == 0) {
-        const unsigned int M = S->M;
-        const double v0 = key_f64(S->prefix[0]), v1 = key_f64(S->prefix[1]);
-        S->result = (M == 0) ? NAN : (((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0);
-    }
-}
-
-__global__ void k_prior_finish(const MedGlobal* S1, const MedGlobal* S2, double* out) {
-    const double m = S2->result / 0.67448975019608171;  // norm.ppf(0.75)
-    out[0] = m * m;
-    out[1] = (double)S1->M;
-}
-
-constexpr int kPriorWideMin = 32768;  // below this one workgroup is faster (launch latency)
-
-// Grid-wide barrier on one monotonic counter (MI355X_MICROARCH.md "barrier-counter", ~3 us at 32
-// workgroups vs ~45 us measured for cooperative_groups::grid.sync()): agent-scope release before
-// the arrival, relaxed polling with s_sleep, agent-scope acquire after; all words exchanged across
-// workgroups are agent-scope atomics on both sides.  Launches are cooperative so all workgroups are
-// resident; a bounded spin sets *timeout instead of hanging the GPU (never observed).
-__device__ __forceinline__ void grid_barrier(unsigned int* arrive, unsigned int* timeout, unsigned int& target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned int spins = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > 200000000u) {
-                __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    target += gridDim.x;
-}
-
-// ---- the wide medians as ONE cooperative launch: the 12 radix passes are separated by grid barriers
-// instead of kernel boundaries (28 launches of a few microseconds each were mostly launch gaps).  Per
-// pass: LDS-privatised digit histograms -> agent-scope atomics into a global histogram -> barrier ->
-// EVERY workgroup picks the digit from the same global histogram (identical state everywhere, no
-// broadcast, one barrier per pass).  Three global histograms rotate: pass p fills buffer p % 3 while
-// buffer (p + 1) % 3 — last read before barrier p - 1 — is cleared for the next pass.
-struct PriorGridMem {
-    unsigned int arrive, timeout, pad[14];
-    unsigned int hist[3][2 * 2048];
-};
-
-__global__ __launch_bounds__(1024) void k_prior_mad_grid(const double* __restrict__ gw_raw,
-                                                         const double* __restrict__ fitted, int n, double min_disp,
-                                                         double max_disp, double* __restrict__ res, PriorGridMem* Gm,
-                                                         double* __restrict__ out) {
-    __shared__ MedianShared S;
-    const int shifts[6] = {53, 42, 31, 20, 9, 0};
-    const int tid = threadIdx.x;
-    const int gtid = blockIdx.x * 1024 + tid, gstride = gridDim.x * 1024;
-    unsigned int target = gridDim.x;
-    // residuals of the elements this thread re-reads in every pass (thread-private: no barrier needed)
-    for (int i = gtid; i < n; i += gstride) {
-        const double g = dmin(dmax(gw_raw[i], min_disp), max_disp);
-        res[i] = (g >= 100.0 * min_disp) ? log(g) - log(fitted[i]) : NAN;
-    }
-    double center = 0.0, med = 0.0;
-    unsigned int M1 = 0;
-    int gp = 0;
-    for (int which = 0; which < 2; ++which) {
-        for (int pass = 0; pass < 6; ++pass, ++gp) {
-            const int shift = shifts[pass];
-            const int nbins = pass == 5 ? 512 : 2048;
-            unsigned int* gh = Gm->hist[gp % 3];
-            for (int i = tid; i < 2 * 2048; i += 1024) (&S.hist[0][0])[i] = 0;
-            __syncthreads();
-            const unsigned long long p0 = pass ? S.prefix[0] : 0ull, p1 = pass ? S.prefix[1] : 0ull;
-            const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shifts[pass - 1]));
-            for (int i = gtid; i < n; i += gstride) {
-                const double r = res[i];
-                if (r != r) continue;
-                const unsigned long long kk = f64_key(which ? fabs(r - center) : r);
-                const unsigned int d = (unsigned int)(kk >> shift) & (unsigned int)(nbins - 1);
-                if (pass == 0) {
-                    atomicAdd(&S.hist[0][d], 1u);
-                } else {
-                    if ((kk & himask) == p0) atomicAdd(&S.hist[0][d], 1u);
-                    if ((kk & himask) == p1) atomicAdd(&S.hist[1][d], 1u);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < 2 * 2048; i += 1024) {
-                const unsigned int c = (&S.hist[0][0])[i];
-                if (c) __hip_atomic_fetch_add(&gh[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (gp >= 2) {
-                unsigned int* nxt = Gm->hist[(gp + 1) % 3];
-                for (int i = gtid; i < 2 * 2048; i += gstride)
-                    __hip_atomic_store(&nxt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            grid_barrier(&Gm->arrive, &Gm->timeout, target);
-            for (int i = tid; i < 2 * 2048; i += 1024)
-                (&S.hist[0][0])[i] = __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (pass == 0) {
-                if (tid < 64) {  // total count and the two target ranks
-                    unsigned int c = 0;
-                    for (int k = tid; k < 2048; k += 64) c += S.hist[0][k];
+            for (int q = 0; q < 8; ++q) x[q] = res[i + q * 1024];
 #pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
-                    if (tid == 0) {
-                        S.M = c;
-                        S.rank[0] = c ? (c - 1) / 2 : 0;
-                        S.rank[1] = c / 2;
-                        S.prefix[0] = 0ull;
-                        S.prefix[1] = 0ull;
-                    }
-                }
-                __syncthreads();
-            }
-            const int w = tid >> 6;
-            if (w < 2) {
-                unsigned int r = S.rank[w];
-                const int d = pick_digit(S.hist[pass == 0 ? 0 : w], nbins, r);
-                if ((tid & 63) == 0) {
-                    S.rank[w] = r;
-                    S.prefix[w] |= ((unsigned long long)d << shift);
-                }
-            }
-            __syncthreads();
+            for (int q = 0; q < 8; ++q) f(x[q]);
         }
-        const unsigned int M = S.M;
-        const double v0 = key_f64(S.prefix[0]), v1 = key_f64(S.prefix[1]);
-        med = (M == 0) ? NAN : (((M - 1) / 2 == M / 2) ? v0 : (v0 + v1) / 2.0);
-        if (which == 0) { center = med; M1 = M; }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        const bool timed_out = __hip_atomic_load(&Gm->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        const double m = med / 0.67448975019608171;  // norm.ppf(0.75)
-        out[0] = timed_out ? NAN : m * m;
-        out[1] = timed_out ? -1.0 : (double)M1;
+        for (; i < n; i += 1024) f(res[i]);
+    };
+    block_median_values<1024>([&](auto fn) { walk(fn); }, S, center, M);
+    block_median_values<1024>([&](auto fn) { walk([&](double r) { fn(fabs(r - center)); }); }, S, mad, M2);
+    if (tid == 0) {
+        const double m = mad / 0.67448975019608171;  // norm.ppf(0.75)
+        out[0] = m * m;
+        out[1] = (double)M;
     }
 }
 
-// res_scratch: n doubles (+ 2 * sizeof(MedGlobal) bytes when n >= kPriorWideMin: see prior_mad_work_doubles)
-size_t prior_mad_work_doubles(int n) {
-    const size_t state = 2 * sizeof(MedGlobal) > sizeof(PriorGridMem) ? 2 * sizeof(MedGlobal) : sizeof(PriorGridMem);
-    return (size_t)n + (n >= kPriorWideMin ? (state + 7) / 8 + 8 : 0);
-}
+// res_scratch: n doubles
+size_t prior_mad_work_doubles(int n) { return (size_t)n + 8; }
 
 hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
                             double max_disp, double* res_scratch, double* out2) {
-    if (n < kPriorWideMin) {
-        hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, gw_raw, fitted, n, min_disp, max_disp,
-                           res_scratch, out2);
-        return hipGetLastError();
-    }
-    static const bool no_grid = getenv("DSQ_PRIOR_MULTI_LAUNCH") != nullptr;
-    if (!no_grid) {  // one cooperative launch (<= 1 workgroup per CU, so all are resident)
-        PriorGridMem* gm = (PriorGridMem*)(res_scratch + (((size_t)n + 7) & ~(size_t)7));
-        hipError_t e0 = hipMemsetAsync(gm, 0, sizeof(PriorGridMem), st);
-        if (e0 != hipSuccess) return e0;
-        const int gblocks = (n + 1023) / 1024 > 256 ? 256 : (n + 1023) / 1024;
-        void* args[] = {(void*)&gw_raw, (void*)&fitted, (void*)&n,  (void*)&min_disp,
-                        (void*)&max_disp, (void*)&res_scratch, (void*)&gm, (void*)&out2};
-        if (hipLaunchCooperativeKernel((const void*)k_prior_mad_grid, dim3(gblocks), dim3(1024), args, 0, st) ==
-            hipSuccess)
-            return hipSuccess;
-        (void)hipGetLastError();  // not launchable cooperatively here: the multi-launch passes below
-    }
-    MedGlobal* S1 = (MedGlobal*)(res_scratch + (((size_t)n + 7) & ~(size_t)7));
-    MedGlobal* S2 = S1 + 1;
-    const int blocks = (n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024;
-    hipLaunchKernelGGL(k_prior_res, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, fitted, n, min_disp, max_disp,
-                       res_scratch);
-    hipLaunchKernelGGL(k_med_zero, dim3(1), dim3(1024), 0, st, S1);
-    hipLaunchKernelGGL(k_med_zero, dim3(1), dim3(1024), 0, st, S2);
-    for (int pass = 0; pass < 6; ++pass) {
-        hipLaunchKernelGGL(k_med_hist<false>, dim3(blocks), dim3(1024), 0, st, (const double*)res_scratch, n,
-                           (const MedGlobal*)S1, pass, S1);
-        hipLaunchKernelGGL(k_med_pick, dim3(1), dim3(128), 0, st, S1, pass);
-    }
-    for (int pass = 0; pass < 6; ++pass) {
-        hipLaunchKernelGGL(k_med_hist<true>, dim3(blocks), dim3(1024), 0, st, (const double*)res_scratch, n,
-                           (const MedGlobal*)S1, pass, S2);
-        hipLaunchKernelGGL(k_med_pick, dim3(1), dim3(128), 0, st, S2, pass);
-    }
-    hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(1), 0, st, (const MedGlobal*)S1, (const MedGlobal*)S2, out2);
+    if (n > 0)
+        hipLaunchKernelGGL(k_prior_res, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, fitted, n, min_disp, max_disp,
+                           res_scratch);
+    hipLaunchKernelGGL(k_prior_mad, dim3(1), dim3(1024), 0, st, (const double*)res_scratch, n, out2);
     return hipGetLastError();
 }
 
@@ -693,54 +616,20 @@ __global__ __launch_bounds__(256) void k_sf_compact(const double* __restrict__ l
 // statistic (ties included); usually one histogram level is enough.  More usable genes than the registers hold: this
 // kernel leaves at once and the two kernels below (which leave at once in the usual case) do the work.
 constexpr int kSfRegGenes = 32768;  // 1024 threads x 32 genes each
-constexpr int kSfCand = 1024;
-
-struct SfRowShared {
-    unsigned int hist[2048];
-    double cand[kSfCand];
-    double dred[16][2];
-    unsigned int ured[16][2];
-    unsigned int wtot[16];  // (sized for 1024 threads)
-    unsigned int bin[2], pre[2], ncand;
-    double a[2];
-};
-
-// min / max of (lo, hi) and sums of (c0, c1) over the workgroup's threads; every thread gets the results
-__device__ __forceinline__ void sf_block_reduce(SfRowShared& S, double& lo, double& hi, unsigned int& c0,
-                                                unsigned int& c1) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        lo = dmin(lo, __shfl_xor(lo, o, 64));
-        hi = dmax(hi, __shfl_xor(hi, o, 64));
-        c0 += __shfl_xor(c0, o, 64);
-        c1 += __shfl_xor(c1, o, 64);
-    }
-    const int w = threadIdx.x >> 6;
-    __syncthreads();  // (the arrays may still be read from the previous reduction)
-    if ((threadIdx.x & 63) == 0) { S.dred[w][0] = lo; S.dred[w][1] = hi; S.ured[w][0] = c0; S.ured[w][1] = c1; }
-    __syncthreads();
-    lo = S.dred[0][0]; hi = S.dred[0][1]; c0 = S.ured[0][0]; c1 = S.ured[0][1];
-    for (int q = 1; q < (int)(blockDim.x >> 6); ++q) {
-        lo = dmin(lo, S.dred[q][0]); hi = dmax(hi, S.dred[q][1]);
-        c0 += S.ured[q][0]; c1 += S.ured[q][1];
-    }
-}
 
 template <class SrcT, int NT>
 __global__ __launch_bounds__(NT) void k_sf_row(const SrcT* __restrict__ counts, int N, int G,
                                                  const double* __restrict__ logmeans, const int* __restrict__ idx,
                                                  const int* __restrict__ count, double* __restrict__ sf,
                                                  int zeros_low) {
-    __shared__ SfRowShared S;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ ValueSelectShared S;
+    const int tid = threadIdx.x;
     const int n = blockIdx.x, Gu = *count;
     constexpr int kSfRegKeys = kSfRegGenes / NT;
     if (Gu > kSfRegGenes) return;
     // this thread's log ratios: NaN = not part of the median (a zero count in the training data: see k_ratio_keys_c),
     // -inf = a zero count of a NEW sample (counts at the low end, as numpy's median has it)
     double v[kSfRegKeys];
-    double lo = INFINITY, hi = -INFINITY;
-    unsigned int n_fin = 0, n_low = 0;
 #pragma unroll
     for (int k = 0; k < kSfRegKeys; ++k) v[k] = NAN;
     // (every loop over a thread's slots stops at the sample's last occupied slot - a uniform branch: the slots are sized
@@ -774,128 +663,19 @@ __global__ __launch_bounds__(NT) void k_sf_row(const SrcT* __restrict__ counts, 
                 const double x = (c[kk] < 256.0 ? tl[kk] : flog(pos ? c[kk] : 1.0)) - lm[kk];
                 const bool fin = in && pos, low = in && !pos && zeros_low != 0;
                 v[k0 + kk] = fin ? x : (low ? -INFINITY : NAN);
-                lo = fin ? dmin(lo, x) : lo;
-                hi = fin ? dmax(hi, x) : hi;
-                n_fin += fin ? 1u : 0u;
-                n_low += low ? 1u : 0u;
             }
         }
     }
-    sf_block_reduce(S, lo, hi, n_fin, n_low);
-    const unsigned int M = n_fin + n_low;
-    if (M == 0) {
-        if (tid == 0) sf[n] = NAN;
-        return;
-    }
-    const unsigned int r0 = (M - 1) / 2, r1 = M / 2;
-    if (r1 < n_low) {  // both middle ranks are zero counts
-        if (tid == 0) sf[n] = 0.0;  // exp(-inf)
-        return;
-    }
-    // ranks among the finite values (r0 may still be a zero count: then only r1 is selected)
-    const bool low0 = r0 < n_low;
-    unsigned int q0 = (low0 ? r1 : r0) - n_low, q1 = r1 - n_low;
-    unsigned int cnt = n_fin;
-    double a0 = NAN, a1 = NAN;
-    for (int level = 0; level < 64; ++level) {
-        if (lo == hi) { a0 = lo; a1 = lo; break; }
-        if (cnt <= kSfCand) {
-            // rank the candidates against each other
-            if (tid == 0) S.ncand = 0;
-            __syncthreads();
+    double med;
+    unsigned int M;
+    block_median_values<NT>(
+        [&](auto fn) {
 #pragma unroll
-            for (int k = 0; k < kSfRegKeys; ++k) {
-                if (k >= kmax) continue;
-                if (v[k] >= lo && v[k] <= hi) S.cand[atomicAdd(&S.ncand, 1u)] = v[k];
-            }
-            __syncthreads();
-            const unsigned int m = S.ncand;
-            for (int i = tid; i < (int)m; i += NT) {
-                const double c = S.cand[i];
-                unsigned int less = 0, eq = 0;
-                for (unsigned int j = 0; j < m; ++j) {
-                    const double cj = S.cand[j];
-                    less += cj < c;
-                    eq += cj == c;
-                }
-                if (less <= q0 && q0 < less + eq) S.a[0] = c;
-                if (less <= q1 && q1 < less + eq) S.a[1] = c;
-            }
-            __syncthreads();
-            a0 = S.a[0]; a1 = S.a[1];
-            break;
-        }
-        // histogram of the candidates over [lo, hi]
-        for (int i = tid; i < 2048; i += NT) S.hist[i] = 0;
-        __syncthreads();
-        const double scale = 2048.0 / (hi - lo);
-        auto bin_of = [&](double x) {
-            const int bb = (int)((x - lo) * scale);
-            return bb > 2047 ? 2047 : bb;
-        };
-#pragma unroll
-        for (int k = 0; k < kSfRegKeys; ++k) {
-            if (k >= kmax) continue;
-            if (v[k] >= lo && v[k] <= hi) atomicAdd(&S.hist[bin_of(v[k])], 1u);
-        }
-        __syncthreads();
-        // the bins of the two ranks: exclusive prefix over the 2048 bins, 2048 / NT consecutive bins per thread
-        {
-            constexpr int PER = 2048 / NT;
-            unsigned int h[PER], all = 0;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) { h[q] = S.hist[PER * tid + q]; all += h[q]; }
-            unsigned int incl = all;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned int t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) S.wtot[w] = incl;
-            __syncthreads();
-            unsigned int base = 0;
-            for (int q = 0; q < w; ++q) base += S.wtot[q];
-            unsigned int excl = base + incl - all;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-#pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    const unsigned int t = which ? q1 : q0;
-                    if (excl <= t && t < excl + h[q]) { S.bin[which] = PER * tid + q; S.pre[which] = excl; }
-                }
-                excl += h[q];
-            }
-            __syncthreads();
-        }
-        const int b0 = (int)S.bin[0], b1 = (int)S.bin[1];
-        const unsigned int pre0 = S.pre[0];
-        // the new candidates: bin b0 (both ranks in it), or - the ranks are neighbours - the LAST value of bin b0 and the
-        // FIRST of bin b1
-        double nlo = INFINITY, nhi = -INFINITY, lo1 = INFINITY, hi0 = -INFINITY;
-        unsigned int c_new = 0, dummy = 0;
-#pragma unroll
-        for (int k = 0; k < kSfRegKeys; ++k) {
-            if (k >= kmax) continue;
-            if (v[k] >= lo && v[k] <= hi) {
-                const int bb = bin_of(v[k]);
-                if (bb == b0) { nlo = dmin(nlo, v[k]); nhi = dmax(nhi, v[k]); hi0 = dmax(hi0, v[k]); c_new += 1; }
-                if (bb == b1) lo1 = dmin(lo1, v[k]);
-            }
-        }
-        if (b0 != b1) {
-            sf_block_reduce(S, lo1, hi0, c_new, dummy);
-            a0 = hi0; a1 = lo1;
-            break;
-        }
-        sf_block_reduce(S, nlo, nhi, c_new, dummy);
-        lo = nlo; hi = nhi; cnt = c_new;
-        q0 -= pre0; q1 -= pre0;
-    }
-    if (tid == 0) {
-        const double v0 = low0 ? -INFINITY : a0;
-        const double med = (r0 == r1) ? v0 : (v0 + a1) / 2.0;
-        sf[n] = exp(med);
-    }
+            for (int k = 0; k < kSfRegKeys; ++k)
+                if (k < kmax) fn(v[k]);
+        },
+        S, med, M);
+    if (tid == 0) sf[n] = (M == 0) ? NAN : exp(med);
 }
 
 template <class SrcT>

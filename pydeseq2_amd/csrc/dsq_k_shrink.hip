@@ -20,7 +20,11 @@ __global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1
                                                    int shrink_index, double* __restrict__ beta,
                                                    double* __restrict__ invh, uint8_t* __restrict__ conv,
                                                    double* __restrict__ ih_entry) {
+#ifdef DSQ_SHRINK_COMPACT  // A/B build: the compact-form optimiser for every p > 4
     __shared__ ShrinkWork<P> work[kWavesPerBlock];
+#else
+    __shared__ ShrinkWork<P, shrink_on_wave8(P)> work[kWavesPerBlock];
+#endif
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
     if (g >= G) return;

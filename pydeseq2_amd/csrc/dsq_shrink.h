@@ -15,6 +15,7 @@
 #include "dsq_alpha.h"  // linspace_at
 #include "dsq_lbfgsb.h"
 #include "dsq_lbfgsb_dense.h"
+#include "dsq_lbfgsb_wave.h"
 #include "dsq_linalg.h"
 #include "dsq_wave.h"
 
@@ -38,12 +39,23 @@ struct ShrinkLb { typedef LbfgsbWork<P> type; };
 template <int P>
 struct ShrinkLb<P, true> { typedef LbfgsbDenseWork<P> type; };
 
-template <int P>
+template <int P, bool WAVE8 = false>
 struct ShrinkWork {  // wave-private LDS on the device
     typename ShrinkLb<P>::type lb;
     double x[P], l[P], u[P];
     int nbd[P];
 };
+// 5 ... 8 coefficients on the device: the 8 x 8 inverse quasi-Newton matrix in the wavefront's registers
+// (dsq_lbfgsb_wave.h); the host instantiation (tests/hostsim) keeps the compact form
+template <int P>
+struct ShrinkWork<P, true> {
+    LbfgsbWaveWork lb;
+};
+constexpr bool shrink_on_wave8(int p) { return p > kShrinkDenseMax && p <= 8; }
+template <class T>
+struct IsWave8Work { static constexpr bool value = false; };
+template <int P>
+struct IsWave8Work<ShrinkWork<P, true>> { static constexpr bool value = true; };
 
 // prior - nll (unscaled) and, if g != nullptr, its gradient.
 // With d = eta + offset - log(size) and e = exp(-|d|) (one exponential per sample):
@@ -126,8 +138,8 @@ DSQ_HD void grid_fit_shrink2(const ShrinkArgs& A0, double cnst, double (&beta)[2
 
 // beta[P] (out), inv_hessian[P*P] row-major (out); returns scipy's res.success
 // ih_entry (nullable): only inv_hessian[shrink_index][shrink_index] - all DeseqStats.lfc_shrink uses (ds.py:424-433)
-template <class Wv, int P>
-DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P], double* inv_hessian,
+template <class Wv, int P, class Work>
+DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double* inv_hessian,
                        double* ih_entry = nullptr) {
     constexpr int T = Tri<P>::N;
     double zero[P];
@@ -136,10 +148,12 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
     const double f0 = shrink_fn<Wv, P>(A, zero, nullptr);
     const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
     const double cn = (f0 != f0) ? f0 : cnst;
+    if constexpr (!IsWave8Work<Work>::value) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-        Wk.x[j] = (j & 1) ? -0.1 : 0.1;
-        Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+        for (int j = 0; j < P; ++j) {
+            Wk.x[j] = (j & 1) ? -0.1 : 0.1;
+            Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+        }
     }
     auto fg = [&](const double* xb, double& f, double* g) {
         double b[P], gg[P];
@@ -151,13 +165,22 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, ShrinkWork<P>& Wk, double (&beta)[P]
     };
     // scipy: factr = ftol / eps, pgtol = gtol
     LbfgsbResult res;
-    if constexpr (P <= kShrinkDenseMax)
-        res = lbfgsb_dense<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
-    else
-        // (the linear algebra between two evaluations spread over the wavefront's lanes: dsq_lbfgsb_par.h - same iterates)
-        res = lbfgsb_nd<P, decltype(fg)&, 10, Wv>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    if constexpr (IsWave8Work<Work>::value) {
+        if (Wv::lane() < P) Wk.lb.x[Wv::lane()] = (Wv::lane() & 1) ? -0.1 : 0.1;
+        res = lbfgsb_wave8<P>(fg, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
 #pragma unroll
-    for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
+        for (int j = 0; j < P; ++j) beta[j] = Wk.lb.x[j];
+    } else {
+        if constexpr (P <= kShrinkDenseMax)
+            res = lbfgsb_dense<P>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+        else
+            // (the linear algebra between two evaluations spread over the wavefront's lanes: dsq_lbfgsb_par.h - same
+            // iterates)
+            res = lbfgsb_nd<P, decltype(fg)&, 10, Wv>(fg, P, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb,
+                                                      1e-8 / 2.220446049250313e-16, 1e-8);
+#pragma unroll
+        for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
+    }
     if (!res.success && P == 2) {
         if constexpr (P == 2) grid_fit_shrink2<Wv>(A, cn, beta);
     }

@@ -340,7 +340,7 @@ def bfgs_cases(ut):
 
 # end-to-end cases at the benchmark SHAPES (BASELINE configs[2..4]: N = 1000 / 500 / 5000): gene count, samples, design
 # kind and seed of pydeseq2_amd.synth.synth_counts - the counts regenerate from these, only outputs are committed
-E2E_CASES = {"c3": (8000, 1000, "2level", 2), "c4": (4000, 500, "3factor", 3), "c5": (1000, 5000, "mixed", 4)}
+E2E_CASES = {"c3": (8000, 1000, "2level", 2), "c4": (4000, 500, "3factor", 3), "c5": (4000, 5000, "mixed", 4)}
 E2E_FIELDS = ("size_factors", "normed_means", "non_zero", "mom_dispersions", "genewise_dispersions",
               "genewise_converged", "trend_coeffs", "fitted_dispersions", "squared_logres", "prior_disp_var",
               "MAP_dispersions", "MAP_converged", "outlier_genes", "dispersions", "LFC", "LFC_converged", "replaced",

@@ -297,7 +297,7 @@ def test_r_iterative_size_factors():
 @pytest.mark.parametrize("name", ["c3", "c4", "c5"])
 def test_oracle_end_to_end_is_the_unmodified_reference_at_benchmark_shapes(name):
     """kat_e2e_*.npz hold the outputs of the reference's own kernels (DefaultInference) end to end at the benchmark
-    shapes (8000 x 1000 p=2, 4000 x 500 p=8, 1000 x 5000 p=8 with continuous covariates).  The oracle's per-gene
+    shapes (8000 x 1000 p=2, 4000 x 500 p=8, 4000 x 5000 p=8 with categorical and continuous covariates).  The oracle's per-gene
     routines repeat the reference's operation sequence (same scipy / numpy / LAPACK calls on the same operands), so on
     the machine that generated the files every output is BIT-IDENTICAL.  Another CPU's BLAS kernels may round a dot
     product differently; a last-bit change of mu_hat moves the stopping point of ~0.1 % of the L-BFGS-B runs

@@ -227,6 +227,19 @@ def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs):
                "full_launch_ms": round(full_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                "achieved_GBps": round(alg / (full_ms * 1e-3) / 1e9, 2),
                "frac": round(alg / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    try:  # apeGLM MAP LFC of the last coefficient, all genes (DeseqStats.lfc_shrink; not part of ms_per_step)
+        from pydeseq2_amd.summary import lfc_shrink
+
+        res = pipe.deseq2()
+        lfc_shrink(pipe, res, X.shape[1] - 1)
+        ctx.sync()
+        t0 = time.perf_counter()
+        shr = lfc_shrink(pipe, res, X.shape[1] - 1)
+        ctx.sync()
+        out["lfc_shrink"] = {"ms": round((time.perf_counter() - t0) * 1e3, 3),
+                             "converged_fraction": round(float(np.nanmean(shr[2])), 6)}
+    except Exception as e:  # noqa: BLE001
+        out["lfc_shrink_error"] = repr(e)
     if parity_genes:
         try:
             with warnings.catch_warnings():

@@ -467,6 +467,11 @@ def main():
             tj = json.load(open(traffic_file))
             roofline["traffic"] = tj.get("k_alpha_hbm_bytes_per_launch")
             roofline["traffic_source"] = tj.get("source")
+            if roofline["traffic"] and tj.get("genes_per_launch") and tj["genes_per_launch"] != genes_full:
+                # counters collected on a launch of another size (c5: one GPU's shard): per-gene bytes, rescaled
+                roofline["traffic"] = int(roofline["traffic"] * genes_full / tj["genes_per_launch"])
+                roofline["traffic_source"] += f" - rescaled from a launch of {tj['genes_per_launch']} genes"
+
             if roofline["traffic"]:
                 roofline["traffic_ratio"] = round(roofline["traffic"] / alg_bytes, 3)
         except Exception:

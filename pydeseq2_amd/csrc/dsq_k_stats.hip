@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_sf_compact(const double* __restrict__ l
 // kernel leaves at once and the two kernels below (which leave at once in the usual case) do the work.
 constexpr int kSfRegGenes = 32768;  // 1024 threads x 32 genes each
 
-template <class SrcT, int NT>
+template <class SrcT, int NT, int kSfRegKeys>
 __global__ __launch_bounds__(NT) void k_sf_row(const SrcT* __restrict__ counts, int N, int G,
                                                  const double* __restrict__ logmeans, const int* __restrict__ idx,
                                                  const int* __restrict__ count, double* __restrict__ sf,
@@ -625,8 +625,7 @@ __global__ __launch_bounds__(NT) void k_sf_row(const SrcT* __restrict__ counts, 
     __shared__ ValueSelectShared S;
     const int tid = threadIdx.x;
     const int n = blockIdx.x, Gu = *count;
-    constexpr int kSfRegKeys = kSfRegGenes / NT;
-    if (Gu > kSfRegGenes) return;
+    if (Gu > NT * kSfRegKeys) return;
     // this thread's log ratios: NaN = not part of the median (a zero count in the training data: see k_ratio_keys_c),
     // -inf = a zero count of a NEW sample (counts at the low end, as numpy's median has it)
     double v[kSfRegKeys];
@@ -723,11 +722,22 @@ hipError_t launch_size_factors(hipStream_t st, const void* counts_sm, int count_
     hipError_t e0 = hipMemsetAsync(count, 0, sizeof(int), st);
     if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(k_sf_compact, dim3((G + 255) / 256), dim3(256), 0, st, logmeans, gene_mask, G, idx, count);
+    // (samples with few usable genes - a gene shard, a small panel - in 256-thread workgroups, four of them per compute
+    // unit: the per-sample passes are latency, not work, and a 5000-sample shard has 20 samples per compute unit)
+    if (G <= 256 * 32) {
+        if (count_type == 1)
+            hipLaunchKernelGGL((k_sf_row<int64_t, 256, 32>), dim3(N), dim3(256), 0, st, (const int64_t*)counts_sm, N, G,
+                               logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
+        else
+            hipLaunchKernelGGL((k_sf_row<int32_t, 256, 32>), dim3(N), dim3(256), 0, st, (const int32_t*)counts_sm, N, G,
+                               logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
+        return hipGetLastError();
+    }
     if (count_type == 1)
-        hipLaunchKernelGGL((k_sf_row<int64_t, 1024>), dim3(N), dim3(1024), 0, st, (const int64_t*)counts_sm, N, G,
+        hipLaunchKernelGGL((k_sf_row<int64_t, 1024, 32>), dim3(N), dim3(1024), 0, st, (const int64_t*)counts_sm, N, G,
                            logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
     else
-        hipLaunchKernelGGL((k_sf_row<int32_t, 1024>), dim3(N), dim3(1024), 0, st, (const int32_t*)counts_sm, N, G,
+        hipLaunchKernelGGL((k_sf_row<int32_t, 1024, 32>), dim3(N), dim3(1024), 0, st, (const int32_t*)counts_sm, N, G,
                            logmeans, (const int*)idx, (const int*)count, sf, zeros_low);
     if (G <= kSfRegGenes) return hipGetLastError();  // (the number of usable genes is known on the device only)
     // (few, grid-striding workgroups: in the usual case they all leave at once, and a launch of N x 235 empty workgroups

@@ -35,7 +35,10 @@ def main():
     # the dispersion stage: the row kernel (four genes per wavefront) + the continuation of its parked fits where the
     # design takes them, else the full-size k_alpha launches (largest grid)
     rows = [k for k in fetch if k.startswith("dsq::k_alpha_rows<") or k.startswith("dsq::k_alpha_rows_c<")]
-    if rows:
+    mix = [k for k in fetch if k.startswith("dsq::k_alpha_mix<")]
+    if mix:  # categorical + continuous designs: k_alpha_mix (main launch and the continuation of its parked fits)
+        parts = [max(mix, key=lambda k: fetch[k])]
+    elif rows:
         cont = [k for k in fetch if k.startswith("dsq::k_alpha_wg<")][:1]
         if not cont:  # the many-cell row kernel's parked fits are continued by k_alpha (largest launch of it)
             ka = [k for k in fetch if k.startswith("dsq::k_alpha<")]
@@ -53,6 +56,7 @@ def main():
                   "FETCH_SIZE x2 correction of MI355X_MICROARCH.md - calibrated there for 16-byte-per-lane streaming "
                   "reads; the row kernel reads 4 bytes per lane, so the absolute is uncalibrated)",
         "fetch_kib": f_kib, "write_kib": w_kib, "kernels": parts,
+        "genes_per_launch": json.loads(bench)["config"].get("genes_per_gpu"),
     }
     json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{cfg}.json"), "w"), indent=1)
     print(path, traffic)

@@ -276,7 +276,8 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
             DSQ_HIP(hipMalloc(&ctx->d_resume, need + need / 4));
             ctx->resume_cap = need + need / 4;
         }
-        ex2.eval_cap = dsq::kAlphaEvalCap;
+        static const int cap_env = getenv("DSQ_ALPHA_EVAL_CAP") ? atoi(getenv("DSQ_ALPHA_EVAL_CAP")) : 0;  // A/B switch
+        ex2.eval_cap = cap_env > 0 ? cap_env : dsq::kAlphaEvalCap;
         ex2.resume_state = ctx->d_resume;
         ex2.resume_list = (int32_t*)((char*)ctx->d_resume + ((dsq::alpha_resume_bytes(G) + 255) & ~(size_t)255));
         ex2.resume_count = d_cnt + 2;

@@ -31,6 +31,7 @@ __device__ long long g_lbd_phase[8];
 template <int NMAX, int M = 10>
 struct LbfgsbDenseWork {
     double S[M][NMAX], Y[M][NMAX];  // circular pair storage
+    double RHO[M];                  // 1 / y^T s of a pair (the inverse update of the interior iterations)
 };
 
 // FG: void(const double* x, double& f, double* g)
@@ -97,8 +98,65 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
 #if defined(DSQ_TREND_PHASES) && defined(__HIP_DEVICE_COMPILE__)
     long long lbd_t_ = clock64();
 #endif
+    bool unbounded = true;
+    for (int i = 0; i < n; ++i)
+        if (nbd[i] != 0) unbounded = false;
     for (;;) {
         LBD_PH(5)
+        // ------------------------------------------------------------ interior iteration
+        // When no bound takes part - the problem has none, or (two variables with lower bounds: the trend's case) no
+        // variable sits on its bound against the gradient, the minimiser of the model along -g comes before the first
+        // breakpoint, and the subspace minimiser lies strictly inside - the generalized Cauchy point fixes nothing and the
+        // subspace minimisation over all variables returns x - B^-1 g whatever the Cauchy point was.  H = B^-1 is the
+        // same pairs replayed through the inverse BFGS update on I / theta: no division per pair, no factorisation, no
+        // elimination - a third of the dependent operations of the code below, which is the latency of the trend kernel
+        // between two data passes.  Same iterate up to rounding; any doubt sends the iteration through the general code.
+        bool interior = false;
+        if (unbounded || (NMAX == 2 && n == 2 && nbd[0] == 1 && nbd[1] == 1)) {
+            double H[NMAX][NMAX];
+            const double ith = fdiv(1.0, theta);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) H[i][j] = (i == j) ? ith : 0.0;
+            for (int q = 0; q < col; ++q) {
+                const int p = (head + q) % M;
+                const double rho = W.RHO[p];
+                double Hy[NMAX], yHy = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double v = 0.0;
+                    for (int j = 0; j < n; ++j) v += H[i][j] * W.Y[p][j];
+                    Hy[i] = v;
+                }
+                for (int i = 0; i < n; ++i) yHy += W.Y[p][i] * Hy[i];
+                const double c = rho * (rho * yHy + 1.0);
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j)
+                        H[i][j] += c * (W.S[p][i] * W.S[p][j]) - rho * (W.S[p][i] * Hy[j] + Hy[i] * W.S[p][j]);
+            }
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                double v = 0.0;
+                for (int j = 0; j < n; ++j) v += H[i][j] * g[j];
+                z[i] = x[i] - v;
+            }
+            if (!unbounded) {  // n == 2, lower bounds
+                double t_min = INFINITY;
+                for (int i = 0; i < 2; ++i) {
+                    const double tl = x[i] - l[i];
+                    if (tl <= 0.0 && g[i] >= 0.0) ok = false;            // on its bound, pushed outwards: stays fixed
+                    if (g[i] > 0.0) t_min = dmin(t_min, fdiv(tl, g[i]));  // breakpoint of the projected path
+                    if (!(z[i] > l[i])) ok = false;                       // the projection would act
+                }
+                // minimiser of the model along -g: g'g / g'Bg with B = H^-1 (2 x 2: adjugate / determinant)
+                const double det = H[0][0] * H[1][1] - H[0][1] * H[1][0];
+                const double gBg = fdiv(H[1][1] * g[0] * g[0] - (H[0][1] + H[1][0]) * g[0] * g[1] + H[0][0] * g[1] * g[1], det);
+                const double dtm = fdiv(g[0] * g[0] + g[1] * g[1], gBg);
+                if (!(det > 0.0) || !(gBg > 0.0) || !(dtm < t_min)) ok = false;
+            }
+            for (int i = 0; i < n; ++i)
+                if (!(z[i] == z[i])) ok = false;
+            interior = ok;
+        }
+        if (!interior) {
         build_B();
         LBD_PH(0)
         // ------------------------------------------------------------ generalized Cauchy point
@@ -255,6 +313,7 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
                 }
             }
         }
+        }  // (!interior)
         LBD_PH(2)
         // ------------------------------------------------------------ line search
         for (int i = 0; i < n; ++i) d[i] = z[i] - x[i];
@@ -332,7 +391,9 @@ DSQ_HD LbfgsbResult lbfgsb_dense(FG&& fg, int n, double* x, const double* l, con
         int slot;
         if (col < M) { slot = (head + col) % M; col += 1; }
         else { slot = head; head = (head + 1) % M; }
-        for (int i = 0; i < n; ++i) { W.S[slot][i] = d[i]; W.Y[slot][i] = r[i]; }
+        double ys = 0.0;
+        for (int i = 0; i < n; ++i) { W.S[slot][i] = d[i]; W.Y[slot][i] = r[i]; ys += r[i] * d[i]; }
+        W.RHO[slot] = fdiv(1.0, ys);
         theta = fdiv(rr, dr);
     }
 }

@@ -1,5 +1,6 @@
-// dsq_lbfgsb_wave.h — UNCONSTRAINED L-BFGS-B for 5 ... 8 variables with the quasi-Newton matrix in the registers of a
-// wavefront: lane (i, j) = (lane >> 3, lane & 7) owns entry (i, j) of the 8 x 8 inverse matrix H_k.
+// dsq_lbfgsb_wave.h — UNCONSTRAINED L-BFGS-B for 5 ... 12 variables with the quasi-Newton matrix in the registers of a
+// wavefront: up to 8 variables lane (i, j) = (lane >> 3, lane & 7) owns entry (i, j) of an 8 x 8 inverse matrix H_k; from 9
+// to 16 lane (i, jg) = (lane >> 2, lane & 3) owns the four entries (i, 4 jg ... 4 jg + 3) of a 16 x 16 one.
 //
 // Why.  The apeGLM objective (utils.py:990-1207, minimize(..., method="L-BFGS-B") without bounds) is cheap - one pass
 // over the samples per evaluation - and scipy's optimiser between two evaluations is not: in its compact representation
@@ -23,10 +24,12 @@
 
 namespace dsq {
 
-struct LbfgsbWaveWork {  // wave-private LDS (1.7 KB; the compact form's workspace is 11.6 KB at p = 8)
-    double S[10][8], Y[10][8], RHO[10];
-    double x[8], g[8], t[8], r[8], z[8], d[8];
+template <int R>
+struct LbfgsbWaveWorkT {  // wave-private LDS (R = 8: 1.7 KB; the compact form's workspace is 11.6 KB at p = 8)
+    double S[10][R], Y[10][R], RHO[10];
+    double x[R], g[R], t[R], r[R], z[R], d[R];
 };
+typedef LbfgsbWaveWorkT<8> LbfgsbWaveWork;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 namespace wv8 {
@@ -46,21 +49,41 @@ __device__ __forceinline__ double colsum(double v) {
     return v;
 }
 }  // namespace wv8
+namespace wv16 {
+// lane = 4 i + jg: the four lanes of a quad hold row i
+__device__ __forceinline__ double rowsum(double v) {  // over the quad
+    v += detail::dpp_d<detail::kXor1>(v);
+    v += detail::dpp_d<detail::kXor2>(v);
+    return v;
+}
+// over the 16 lanes that share lane & 3 (a column group): + 8, + 4 inside a 16-lane row, then xor 16, xor 32
+__device__ __forceinline__ double colsum(double v) {
+    double a, c;
+    v += detail::dpp_d<detail::kRor8>(v);
+    v += detail::dpp_d<detail::kRor4>(v);
+    detail::swap_d<false>(v, a, c); v = a + c;
+    detail::swap_d<true>(v, a, c); v = a + c;
+    return v;
+}
+}  // namespace wv16
 #endif
 
 // x0 in W.x[0 .. P-1]; result in W.x.  FG: void(const double* x, double& f, double* g) (all lanes call it; g[0 .. P-1])
-template <int P, class FG>
-DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7, double pgtol = 1e-5, int maxls = 20,
-                                     int maxiter = 15000, int maxfun = 15000) {
-    static_assert(P >= 1 && P <= 8, "one lane per entry of an 8 x 8 matrix");
-    LbfgsbResult R;
+template <int P, int R, class FG>
+DSQ_HD LbfgsbResult lbfgsb_wave(FG&& fg, LbfgsbWaveWorkT<R>& W, double factr = 1e7, double pgtol = 1e-5, int maxls = 20,
+                                int maxiter = 15000, int maxfun = 15000) {
+    static_assert((R == 8 || R == 16) && P >= 1 && P <= R, "an 8 x 8 matrix with one entry per lane, or 16 x 16 with four");
+    LbfgsbResult R_;
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int M = 10;
-    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    constexpr int E = R == 8 ? 1 : 4;  // entries per lane
+    const int lane = threadIdx.x & 63;
+    const int i = R == 8 ? lane >> 3 : lane >> 2;          // row of this lane's entries
+    const int j0 = R == 8 ? (lane & 7) : 4 * (lane & 3);   // first column of this lane's entries
     const double epsmch = kEps, tol = factr * epsmch;
     int col = 0, head = 0, iter = 0, nfev = 0;
     double theta = 1.0, f = 0.0, fold = 0.0, gd = 0.0, gdold = 0.0, stp = 0.0;
-    if (lane < 8) {
+    if (lane < R) {
         if (lane >= P) W.x[lane] = 0.0;
         W.g[lane] = 0.0; W.t[lane] = 0.0; W.r[lane] = 0.0; W.z[lane] = 0.0; W.d[lane] = 0.0;
     }
@@ -77,34 +100,50 @@ DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7,
         for (int k = 0; k < P; ++k) s += a[k] * b[k];
         return s;
     };
+    auto rowsum = [&](double v) { if constexpr (R == 8) return wv8::rowsum(v); else return wv16::rowsum(v); };
+    auto colsum = [&](double v) { if constexpr (R == 8) return wv8::colsum(v); else return wv16::colsum(v); };
     fg(W.x, f, W.g);
     DeviceWave::sync();
     nfev = 1;
     double sbgnrm = projgr();
-    if (sbgnrm <= pgtol) { R = {f, true, nfev, 0, 0}; return R; }
+    if (sbgnrm <= pgtol) { R_ = {f, true, nfev, 0, 0}; return R_; }
 
     for (;;) {
         // ------------------------------------------------------------ H_k: the pairs replayed on I / theta
-        double h = (i == j) ? fdiv(1.0, theta) : 0.0;
+        double h[E];
+        {
+            const double ith = fdiv(1.0, theta);
+#pragma unroll
+            for (int c = 0; c < E; ++c) h[c] = (i == j0 + c) ? ith : 0.0;
+        }
         for (int q = 0; q < col; ++q) {
             const int p = (head + q) % M;
-            const double si = W.S[p][i], sj = W.S[p][j], yi = W.Y[p][i], yj = W.Y[p][j], rho = W.RHO[p];
-            const double hy_i = wv8::rowsum(h * yj);  // (H y)_i
-            const double hy_j = wv8::colsum(h * yi);  // (H y)_j: H is symmetric
-            const double yhy = wv8::colsum(yi * hy_i);
-            h += rho * ((rho * yhy + 1.0) * (si * sj) - (si * hy_j + hy_i * sj));
+            const double si = W.S[p][i], yi = W.Y[p][i], rho = W.RHO[p];
+            double sj[E], yj[E], hy_j[E], t = 0.0;
+#pragma unroll
+            for (int c = 0; c < E; ++c) { sj[c] = W.S[p][j0 + c]; yj[c] = W.Y[p][j0 + c]; t += h[c] * yj[c]; }
+            const double hy_i = rowsum(t);  // (H y)_i
+#pragma unroll
+            for (int c = 0; c < E; ++c) hy_j[c] = colsum(h[c] * yi);  // (H y)_j: H is symmetric
+            const double yhy = colsum(yi * hy_i);
+            const double cc = rho * yhy + 1.0;
+#pragma unroll
+            for (int c = 0; c < E; ++c) h[c] += rho * (cc * (si * sj[c]) - (si * hy_j[c] + hy_i * sj[c]));
         }
         // ------------------------------------------------------------ z = x - H g (Cauchy point + subspace minimisation)
         {
-            const double hg_i = wv8::rowsum(h * W.g[j]);
-            if (j == 0) { W.d[i] = -hg_i; W.z[i] = W.x[i] - hg_i; }
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < E; ++c) t += h[c] * W.g[j0 + c];
+            const double hg_i = rowsum(t);
+            if (j0 == 0) { W.d[i] = -hg_i; W.z[i] = W.x[i] - hg_i; }
         }
         DeviceWave::sync();
         // ------------------------------------------------------------ line search (dsq_lbfgsb_dense.h, nbd = 0)
         const double dtd = dot(W.d, W.d);
         const double stpmx = 1e10;
         stp = (iter == 0) ? dmin(1.0 / sqrt(dtd), stpmx) : 1.0;
-        if (lane < 8) { W.t[lane] = W.x[lane]; W.r[lane] = W.g[lane]; }
+        if (lane < R) { W.t[lane] = W.x[lane]; W.r[lane] = W.g[lane]; }
         DeviceWave::sync();
         fold = f;
         int ifun = 0;
@@ -118,7 +157,7 @@ DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7,
             while (!lsfail) {
                 ifun += 1;
                 if (ifun - 1 >= maxls) { lsfail = true; break; }
-                if (lane < 8) W.x[lane] = (stp == 1.0) ? W.z[lane] : stp * W.d[lane] + W.t[lane];
+                if (lane < R) W.x[lane] = (stp == 1.0) ? W.z[lane] : stp * W.d[lane] + W.t[lane];
                 DeviceWave::sync();
                 fg(W.x, f, W.g);
                 DeviceWave::sync();
@@ -128,22 +167,22 @@ DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7,
             }
         }
         if (lsfail) {
-            if (lane < 8) { W.x[lane] = W.t[lane]; W.g[lane] = W.r[lane]; }
+            if (lane < R) { W.x[lane] = W.t[lane]; W.g[lane] = W.r[lane]; }
             DeviceWave::sync();
             f = fold;
-            if (col == 0) { R = {f, false, nfev, iter, 3}; return R; }
+            if (col == 0) { R_ = {f, false, nfev, iter, 3}; return R_; }
             col = 0; head = 0; theta = 1.0;
             continue;
         }
         iter += 1;
         sbgnrm = projgr();
-        if (iter >= maxiter || nfev > maxfun) { R = {f, false, nfev, iter, 4}; return R; }
-        if (sbgnrm <= pgtol) { R = {f, true, nfev, iter, 1}; return R; }
+        if (iter >= maxiter || nfev > maxfun) { R_ = {f, false, nfev, iter, 4}; return R_; }
+        if (sbgnrm <= pgtol) { R_ = {f, true, nfev, iter, 1}; return R_; }
         {
             const double ddum = dmax(fabs(fold), dmax(fabs(f), 1.0));
-            if ((fold - f) <= tol * ddum) { R = {f, true, nfev, iter, 2}; return R; }
+            if ((fold - f) <= tol * ddum) { R_ = {f, true, nfev, iter, 2}; return R_; }
         }
-        if (lane < 8) W.r[lane] = W.g[lane] - W.r[lane];
+        if (lane < R) W.r[lane] = W.g[lane] - W.r[lane];
         DeviceWave::sync();
         const double rr = dot(W.r, W.r);
         double dr, ddum;
@@ -153,7 +192,7 @@ DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7,
         int slot;
         if (col < M) { slot = (head + col) % M; col += 1; }
         else { slot = head; head = (head + 1) % M; }
-        if (lane < 8) {
+        if (lane < R) {
             W.S[slot][lane] = (stp == 1.0) ? W.d[lane] : W.d[lane] * stp;
             W.Y[slot][lane] = W.r[lane];
         }
@@ -163,9 +202,14 @@ DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7,
     }
 #else
     (void)fg; (void)W; (void)factr; (void)pgtol; (void)maxls; (void)maxiter; (void)maxfun;
-    R = {0.0, false, 0, 0, 3};
-    return R;
+    R_ = {0.0, false, 0, 0, 3};
+    return R_;
 #endif
+}
+
+template <int P, class FG>
+DSQ_HD LbfgsbResult lbfgsb_wave8(FG&& fg, LbfgsbWaveWork& W, double factr = 1e7, double pgtol = 1e-5) {
+    return lbfgsb_wave<P, 8>(fg, W, factr, pgtol);
 }
 
 }  // namespace dsq

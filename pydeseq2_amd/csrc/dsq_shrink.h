@@ -45,13 +45,15 @@ struct ShrinkWork {  // wave-private LDS on the device
     double x[P], l[P], u[P];
     int nbd[P];
 };
-// 5 ... 8 coefficients on the device: the 8 x 8 inverse quasi-Newton matrix in the wavefront's registers
-// (dsq_lbfgsb_wave.h); the host instantiation (tests/hostsim) keeps the compact form
+// 5 ... 12 coefficients on the device: the inverse quasi-Newton matrix in the wavefront's registers (dsq_lbfgsb_wave.h:
+// 8 x 8 with one entry per lane up to 8 coefficients, 16 x 16 with four per lane beyond); the host instantiation
+// (tests/hostsim) keeps the compact form
+constexpr int shrink_wave_rank(int p) { return p <= 8 ? 8 : 16; }
 template <int P>
 struct ShrinkWork<P, true> {
-    LbfgsbWaveWork lb;
+    LbfgsbWaveWorkT<shrink_wave_rank(P)> lb;
 };
-constexpr bool shrink_on_wave8(int p) { return p > kShrinkDenseMax && p <= 8; }
+constexpr bool shrink_on_wave8(int p) { return p > kShrinkDenseMax && p <= 12; }
 template <class T>
 struct IsWave8Work { static constexpr bool value = false; };
 template <int P>
@@ -167,7 +169,7 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double*
     LbfgsbResult res;
     if constexpr (IsWave8Work<Work>::value) {
         if (Wv::lane() < P) Wk.lb.x[Wv::lane()] = (Wv::lane() & 1) ? -0.1 : 0.1;
-        res = lbfgsb_wave8<P>(fg, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+        res = lbfgsb_wave<P, shrink_wave_rank(P)>(fg, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
 #pragma unroll
         for (int j = 0; j < P; ++j) beta[j] = Wk.lb.x[j];
     } else {

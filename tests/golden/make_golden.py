@@ -404,6 +404,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "bfgs":
         bfgs_cases(ut)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shrink_mid":  # round 4: apeGLM shrinkage at the widths 5-7 and 9-12
+        shrink_mid_cases(ut)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "shrink_wide":  # round 3: apeGLM shrinkage for designs of 13 ... 32 columns
         shrink_wide_cases(ut)
         return
@@ -511,6 +514,25 @@ def shrink_wide_cases(ut):
             sh[f"{case}{tag}_scale"] = np.array(ps)
         sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
     np.savez(os.path.join(HERE, "kat_shrink_wide.npz"), **sh)
+
+
+def shrink_mid_cases(ut):
+    """utils.nbinomGLM (the unmodified reference) on the KAT inputs of the design widths between the three of kat_shrink.npz:
+    p = 5, 6, 7 (the wavefront-resident optimiser, dsq_lbfgsb_wave.h, with padding rows) and p = 9 ... 12 -> kat_shrink_mid.npz"""
+    sh = {}
+    for case, sidx in (("p5", 1), ("p6", 4), ("p7", 2), ("p9", 1), ("p10", 6), ("p11", 3), ("p12", 1)):
+        k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
+        counts, X, sf = k["counts"], k["X"], k["sf"]
+        size = 1.0 / np.clip(k["map_alpha"], 1e-8, max(10, counts.shape[0]))
+        G = min(counts.shape[1], 24)
+        for tag, ps in (("a", 1.0), ("b", 0.3)):
+            r = [ut.nbinomGLM(X, counts[:, i], size[i], np.log(sf), 15, ps, "L-BFGS-B", sidx) for i in range(G)]
+            sh[f"{case}{tag}_beta"] = np.stack([x[0] for x in r])
+            sh[f"{case}{tag}_invh"] = np.stack([x[1] for x in r])
+            sh[f"{case}{tag}_conv"] = np.array([x[2] for x in r], dtype=bool)
+            sh[f"{case}{tag}_scale"] = np.array(ps)
+        sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
+    np.savez(os.path.join(HERE, "kat_shrink_mid.npz"), **sh)
 
 
 def rest_of_main(ut):

@@ -95,6 +95,29 @@ def test_lfc_shrink_inference_vs_reference_kats(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["p5", "p6", "p7", "p9", "p10", "p11", "p12"])
+def test_lfc_shrink_inference_vs_reference_kats_at_the_widths_between(case):
+    """5 ... 12 design columns - the optimiser's inverse matrix in the wavefront's registers (dsq_lbfgsb_wave.h: one lane per
+    entry of an 8 x 8 matrix up to 8 columns, four entries per lane of a 16 x 16 one from 9) - against outputs of the
+    unmodified utils.nbinomGLM (kat_shrink_mid.npz), convergence flags included."""
+    import os
+
+    from pydeseq2_amd import HipInference
+    from tests.helpers import load_kat
+
+    inf = HipInference(device=0)
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_mid.npz"))
+    kk = load_kat(case)
+    G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
+    for tag in "ab":
+        b, ih, cv = inf.lfc_shrink_nbinom_glm(kk["X"], kk["counts"][:, :G], k[f"{case}_size"], np.log(kk["sf"]), 15,
+                                              float(k[f"{case}{tag}_scale"]), "L-BFGS-B", sidx)
+        assert (cv == k[f"{case}{tag}_conv"]).all()
+        np.testing.assert_allclose(b, k[f"{case}{tag}_beta"], rtol=1e-5, atol=1e-8)
+        scale = np.abs(k[f"{case}{tag}_invh"]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
+
+
 @pytest.mark.parametrize("case", ["p16", "p24"])
 def test_lfc_shrink_wide_designs_vs_reference_kats(case):
     """13 ... 32 design columns (k_shrink_wide: run-time p) against outputs of the unmodified utils.nbinomGLM."""

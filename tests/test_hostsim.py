@@ -357,6 +357,23 @@ def test_apeglm_shrinkage_templates_match_reference(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-8
 
 
+@pytest.mark.parametrize("case", ["p5", "p6", "p7", "p9", "p10", "p11", "p12"])
+def test_apeglm_shrinkage_templates_match_reference_at_the_widths_between(case):
+    """The same at the design widths between the three above (kat_shrink_mid.npz): the host instantiation runs scipy's
+    compact-form L-BFGS-B at these widths; the device runs the wavefront-resident inverse form (dsq_lbfgsb_wave.h), which
+    tests/test_gpu_summary.py holds to the same file."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_mid.npz"))
+    kk = load_kat(case)
+    G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
+    for tag in "ab":
+        b, ih, cv = hs.shrink(kk["counts"][:, :G], kk["X"], k[f"{case}_size"], np.log(kk["sf"]), 15.0,
+                              float(k[f"{case}{tag}_scale"]), sidx)
+        assert (cv == k[f"{case}{tag}_conv"]).all()
+        np.testing.assert_allclose(b, k[f"{case}{tag}_beta"], rtol=1e-6, atol=1e-9)
+        scale = np.abs(k[f"{case}{tag}_invh"]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-8
+
+
 @pytest.mark.parametrize("case", ["p16", "p24"])
 def test_apeglm_shrinkage_wide_designs_match_reference(case):
     """Designs of 13 ... 32 columns (shrink_gene_wide: run-time p, Hessian row by row, inverse in the LDS workspace) against

@@ -1196,18 +1196,12 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     const bool lean = redo != nullptr && robust_disp_lean_eligible(min_cell, max_cell, whole, N);
     if (lean) {
         hipError_t e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) {
-            fprintf(stderr, "[launch_robust_disp] hipMemsetAsync(%p): %s\n", (void*)redo, hipGetErrorString(e));
-            return e;
-        }
+        if (e != hipSuccess) return e;
         constexpr int WPB = 4;
         hipLaunchKernelGGL((k_robust_disp_lean<WPB>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, ldn, sf,
                            cell_offsets, cell_index, n_cells, whole, N, G, robust_disp, redo, redo + 1);
         e = hipGetLastError();
-        if (e != hipSuccess) {
-            fprintf(stderr, "[launch_robust_disp] k_robust_disp_lean launch: %s (G %d N %d)\n", hipGetErrorString(e), G, N);
-            return e;
-        }
+        if (e != hipSuccess) return e;
     }
     const int32_t* list = lean ? redo + 1 : nullptr;
     const int32_t* n_dev = lean ? redo : nullptr;
@@ -1219,10 +1213,7 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
     const bool big = biggest >= kTrimBucketMin;
-    if (per_wave > 160 * 1024) {
-        fprintf(stderr, "[launch_robust_disp] %zu bytes of LDS per wavefront (cell of %d samples)\n", per_wave, biggest);
-        return hipErrorInvalidValue;
-    }
+    if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // (a cell of > 13 000 samples that the lean kernel did not take)
 #define DSQ_RD_LAUNCH(WPB) \
     do { if (big) DSQ_RD_LAUNCH_(WPB, true); else DSQ_RD_LAUNCH_(WPB, false); } while (0)
 #define DSQ_RD_LAUNCH_(WPB, BIG)                                                                             \
@@ -1241,13 +1232,7 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     else DSQ_RD_LAUNCH(1);
 #undef DSQ_RD_LAUNCH
 #undef DSQ_RD_LAUNCH_
-    {
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess)
-            fprintf(stderr, "[launch_robust_disp] buffered kernel launch: %s (G %d, %zu B of LDS per wavefront, lean %d)\n",
-                    hipGetErrorString(e), G, per_wave, (int)lean);
-        return e;
-    }
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ outlier replacement

@@ -49,7 +49,11 @@ __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ 
                                                     double sigma0, double sigma, int shrink_index,
                                                     double* __restrict__ beta, double* __restrict__ invh,
                                                     uint8_t* __restrict__ conv) {
+#ifdef DSQ_SHRINK_COMPACT
     __shared__ ShrinkWorkWide<PMAX> work;
+#else
+    __shared__ ShrinkWorkWide<PMAX, true> work;
+#endif
     const int g = blockIdx.x;
     if (g >= G) return;
     ShrinkArgs A;

@@ -1,6 +1,7 @@
 // dsq_lbfgsb_wave.h — UNCONSTRAINED L-BFGS-B for 5 ... 12 variables with the quasi-Newton matrix in the registers of a
 // wavefront: up to 8 variables lane (i, j) = (lane >> 3, lane & 7) owns entry (i, j) of an 8 x 8 inverse matrix H_k; from 9
-// to 16 lane (i, jg) = (lane >> 2, lane & 3) owns the four entries (i, 4 jg ... 4 jg + 3) of a 16 x 16 one.
+// to 16 lane (i, jg) = (lane >> 2, lane & 3) owns the four entries (i, 4 jg ... 4 jg + 3) of a 16 x 16 one; from 17 to 32
+// lane (i, jg) = (lane >> 1, lane & 1) owns sixteen entries of a row of a 32 x 32 one.
 //
 // Why.  The apeGLM objective (utils.py:990-1207, minimize(..., method="L-BFGS-B") without bounds) is cheap - one pass
 // over the samples per evaluation - and scipy's optimiser between two evaluations is not: in its compact representation
@@ -66,20 +67,36 @@ __device__ __forceinline__ double colsum(double v) {
     return v;
 }
 }  // namespace wv16
+namespace wv32 {
+// lane = 2 i + jg: two lanes hold row i
+__device__ __forceinline__ double rowsum(double v) { return v + detail::dpp_d<detail::kXor1>(v); }
+// over the 32 lanes that share lane & 1: + 8, + 4 inside a 16-lane row (in that order: the second relies on the period
+// the first leaves), xor 2, then xor 16, xor 32
+__device__ __forceinline__ double colsum(double v) {
+    double a, c;
+    v += detail::dpp_d<detail::kRor8>(v);
+    v += detail::dpp_d<detail::kRor4>(v);
+    v += detail::dpp_d<detail::kXor2>(v);
+    detail::swap_d<false>(v, a, c); v = a + c;
+    detail::swap_d<true>(v, a, c); v = a + c;
+    return v;
+}
+}  // namespace wv32
 #endif
 
 // x0 in W.x[0 .. P-1]; result in W.x.  FG: void(const double* x, double& f, double* g) (all lanes call it; g[0 .. P-1])
 template <int P, int R, class FG>
 DSQ_HD LbfgsbResult lbfgsb_wave(FG&& fg, LbfgsbWaveWorkT<R>& W, double factr = 1e7, double pgtol = 1e-5, int maxls = 20,
                                 int maxiter = 15000, int maxfun = 15000) {
-    static_assert((R == 8 || R == 16) && P >= 1 && P <= R, "an 8 x 8 matrix with one entry per lane, or 16 x 16 with four");
+    static_assert((R == 8 || R == 16 || R == 32) && P >= 1 && P <= R,
+                  "an 8 x 8 matrix with one entry per lane, 16 x 16 with four, 32 x 32 with sixteen");
     LbfgsbResult R_;
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int M = 10;
-    constexpr int E = R == 8 ? 1 : 4;  // entries per lane
+    constexpr int E = R * R / 64;  // entries per lane: 1, 4, 16
     const int lane = threadIdx.x & 63;
-    const int i = R == 8 ? lane >> 3 : lane >> 2;          // row of this lane's entries
-    const int j0 = R == 8 ? (lane & 7) : 4 * (lane & 3);   // first column of this lane's entries
+    const int i = R == 8 ? lane >> 3 : (R == 16 ? lane >> 2 : lane >> 1);                   // row of this lane's entries
+    const int j0 = R == 8 ? (lane & 7) : (R == 16 ? 4 * (lane & 3) : 16 * (lane & 1));      // their first column
     const double epsmch = kEps, tol = factr * epsmch;
     int col = 0, head = 0, iter = 0, nfev = 0;
     double theta = 1.0, f = 0.0, fold = 0.0, gd = 0.0, gdold = 0.0, stp = 0.0;
@@ -100,8 +117,16 @@ DSQ_HD LbfgsbResult lbfgsb_wave(FG&& fg, LbfgsbWaveWorkT<R>& W, double factr = 1
         for (int k = 0; k < P; ++k) s += a[k] * b[k];
         return s;
     };
-    auto rowsum = [&](double v) { if constexpr (R == 8) return wv8::rowsum(v); else return wv16::rowsum(v); };
-    auto colsum = [&](double v) { if constexpr (R == 8) return wv8::colsum(v); else return wv16::colsum(v); };
+    auto rowsum = [&](double v) {
+        if constexpr (R == 8) return wv8::rowsum(v);
+        else if constexpr (R == 16) return wv16::rowsum(v);
+        else return wv32::rowsum(v);
+    };
+    auto colsum = [&](double v) {
+        if constexpr (R == 8) return wv8::colsum(v);
+        else if constexpr (R == 16) return wv16::colsum(v);
+        else return wv32::colsum(v);
+    };
     fg(W.x, f, W.g);
     DeviceWave::sync();
     nfev = 1;

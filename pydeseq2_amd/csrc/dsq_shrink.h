@@ -327,13 +327,24 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double*
 // one row per pass over the samples (p passes: the p (p + 1) / 2 accumulators of the narrow path would not fit the
 // register file), and the inverse runs on two p x p matrices in the wave's LDS workspace, column-parallel.  One gene per
 // wavefront; not tuned - what matters here is that wide designs run at all.
-template <int PMAX>
+template <int PMAX, bool WAVE = false>
 struct ShrinkWorkWide {  // wave-private LDS on the device
     LbfgsbWork<PMAX> lb;
     double x[PMAX], l[PMAX], u[PMAX];
     int nbd[PMAX];
     double Hm[PMAX * PMAX], Iv[PMAX * PMAX];
 };
+// the device build: the optimiser's inverse matrix in the wavefront's registers (dsq_lbfgsb_wave.h: 16 x 16 with four
+// entries per lane, 32 x 32 with sixteen); x lives in its workspace
+template <int PMAX>
+struct ShrinkWorkWide<PMAX, true> {
+    LbfgsbWaveWorkT<PMAX> lb;
+    double Hm[PMAX * PMAX], Iv[PMAX * PMAX];
+};
+template <class T>
+struct IsWaveWideWork { static constexpr bool value = false; };
+template <int PMAX>
+struct IsWaveWideWork<ShrinkWorkWide<PMAX, true>> { static constexpr bool value = true; };
 
 template <class Wv, int PMAX>
 DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, double* g) {
@@ -386,16 +397,22 @@ DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, doubl
 }
 
 // beta[p] (out), inv_hessian[p*p] row-major (out, nullable); returns scipy's res.success
-template <class Wv, int PMAX>
-DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, ShrinkWorkWide<PMAX>& Wk, double* beta, double* inv_hessian) {
-    for (int j = 0; j < p; ++j) Wk.x[j] = 0.0;
+template <class Wv, int PMAX, class Work>
+DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, Work& Wk, double* beta, double* inv_hessian) {
+    constexpr bool kWave = IsWaveWideWork<Work>::value;
+    double* const xw = [&]() { if constexpr (kWave) return Wk.lb.x; else return Wk.x; }();
+    for (int j = 0; j < p; ++j) xw[j] = 0.0;
     Wv::sync();
-    const double f0 = shrink_fn_wide<Wv, PMAX>(A, p, Wk.x, nullptr);
+    const double f0 = shrink_fn_wide<Wv, PMAX>(A, p, xw, nullptr);
     const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
     const double cn = (f0 != f0) ? f0 : cnst;
-    for (int j = 0; j < p; ++j) {
-        Wk.x[j] = (j & 1) ? -0.1 : 0.1;
-        Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+    for (int j = 0; j < PMAX; ++j) {
+        if constexpr (kWave) {
+            xw[j] = j < p ? ((j & 1) ? -0.1 : 0.1) : 0.0;  // (columns beyond p: zero coefficients, zero gradient)
+        } else if (j < p) {
+            xw[j] = (j & 1) ? -0.1 : 0.1;
+            Wk.l[j] = 0.0; Wk.u[j] = 0.0; Wk.nbd[j] = 0;  // unbounded
+        }
     }
     Wv::sync();
     auto fg = [&](const double* xb, double& f, double* g) {
@@ -405,18 +422,22 @@ DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, ShrinkWorkWide<PMAX>& Wk
         for (int j = 0; j < PMAX; ++j)
             if (j < p) g[j] = gg[j] / cn;
     };
-    const LbfgsbResult res = lbfgsb_nd<PMAX, decltype(fg)&, 10, Wv>(fg, p, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb,
-                                                                    1e-8 / 2.220446049250313e-16, 1e-8);
+    LbfgsbResult res;
+    if constexpr (kWave)
+        res = lbfgsb_wave<PMAX, PMAX>(fg, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
+    else
+        res = lbfgsb_nd<PMAX, decltype(fg)&, 10, Wv>(fg, p, Wk.x, Wk.l, Wk.u, Wk.nbd, Wk.lb, 1e-8 / 2.220446049250313e-16,
+                                                     1e-8);
     Wv::sync();
     if (Wv::lane() == 0)
-        for (int j = 0; j < p; ++j) beta[j] = Wk.x[j];
+        for (int j = 0; j < p; ++j) beta[j] = xw[j];
     if (inv_hessian == nullptr) return res.success ? 1 : 0;
     // Hessian (cnst = 1), one row per pass:  X^T diag(frac) X + h  with the reference's broadcasting quirk (h_j is added
     // to every row of column j, utils.py:1099-1110; see shrink_gene)
     double b[PMAX];
 #pragma unroll
-    for (int j = 0; j < PMAX; ++j) b[j] = j < p ? Wk.x[j] : 0.0;
-    const double bs = Wk.x[A.shrink_index];
+    for (int j = 0; j < PMAX; ++j) b[j] = j < p ? xw[j] : 0.0;
+    const double bs = xw[A.shrink_index];
     const double s2 = A.sigma * A.sigma, b2 = bs * bs;
     for (int i = 0; i < p; ++i) {
         double r[PMAX];

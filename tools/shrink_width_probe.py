@@ -19,7 +19,7 @@ def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     rng = np.random.default_rng(5)
-    for p in (5, 8, 10, 12):
+    for p in ([int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else (5, 8, 10, 12)):
         i = np.arange(N)
         a, b = i % 2, (i // 2) % 4
         cols = [np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)]

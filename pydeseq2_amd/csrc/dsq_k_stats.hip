@@ -369,7 +369,8 @@ __global__ __launch_bounds__(1024) void k_row_median(const unsigned long long* _
 // pass, so the result is the exact order statistic, ties included.  Usually: one pass for min / max / count, one for the
 // histogram, one to collect the candidates.
 // each(fn): calls fn(x) for every value of this thread (the same values every time); NaN = not part of the median,
-// -inf allowed (counts at the low end), otherwise finite.  All threads of the workgroup must call it.
+// -inf / +inf count at the low / high end (numpy's median: an infinite middle value gives an infinite median, opposite
+// infinities NaN) and never enter a histogram.  All threads of the workgroup must call it.
 constexpr int kSelCand = 1024;
 
 struct ValueSelectShared {
@@ -407,19 +408,25 @@ template <int NT, class Each>
 __device__ void block_median_values(Each each, ValueSelectShared& S, double& median, unsigned int& M_out) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double lo = INFINITY, hi = -INFINITY;
-    unsigned int n_fin = 0, n_low = 0;
+    unsigned int n_fin = 0, n_low = 0, n_high = 0, none = 0;
     each([&](double x) {
         if (x != x) return;
         if (x == -INFINITY) { n_low += 1; return; }
+        if (x == INFINITY) { n_high += 1; return; }
         lo = dmin(lo, x); hi = dmax(hi, x);
         n_fin += 1;
     });
     vs_block_reduce(S, lo, hi, n_fin, n_low);
-    const unsigned int M = n_fin + n_low;
+    {
+        double d0 = 0.0, d1 = 0.0;
+        vs_block_reduce(S, d0, d1, n_high, none);
+    }
+    const unsigned int M = n_fin + n_low + n_high;
     M_out = M;
     if (M == 0) { median = NAN; return; }
     const unsigned int r0 = (M - 1) / 2, r1 = M / 2;
     if (r1 < n_low) { median = -INFINITY; return; }
+    if (r1 >= n_low + n_fin) { median = (r0 < n_low) ? NAN : INFINITY; return; }  // (-inf + inf) / 2 = NaN, as numpy
     // ranks among the finite values (r0 may still be a -inf: then only r1 is selected)
     const bool low0 = r0 < n_low;
     unsigned int q0 = (low0 ? r1 : r0) - n_low, q1 = r1 - n_low;

@@ -1380,7 +1380,8 @@ int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size
     static const int n_threads = [] {
         const char* e = getenv("DSQ_UPLOAD_THREADS");
         int t = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        return t < 1 ? 1 : (t > 16 ? 16 : t);
+        const int cap = e ? 128 : 16;
+        return t < 1 ? 1 : (t > cap ? cap : t);
     }();
     int bad = 0;
     size_t off = 0;

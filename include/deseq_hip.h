@@ -465,11 +465,15 @@ int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, in
  * default_inference.py:232-264 -> utils.nbinomGLM, utils.py:990-1142).  size = 1/dispersion [G],
  * offset = log(size factors) [N]; outputs beta [G][P], inv_hessian [G][P][P] (the reference's matrix,
  * incl. its broadcast prior curvature), converged [G] (L-BFGS-B success; for P == 2 a failed gene has
- * already been re-fitted by the reference's grid search). */
+ * already been re-fitted by the reference's grid search).
+ * optimizer (utils.py:990-1121 hands the name to scipy.optimize.minimize): 0 "L-BFGS-B" (what ds.py:407 passes; every
+ * design width up to 32), 1 "BFGS" (gtol = 1e-8), 2 "Newton-CG" (with the reference's Hessian; scipy's default xtol - the
+ * ftol / gtol options are unknown to that method) - the latter two for designs of at most DSQ_BFGS_MAX_P = 12 columns;
+ * `converged` is the chosen optimiser's res.success. */
 int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                                   const double* design, const double* size, const double* offset, int N, int G,
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
-                                  double* beta_out, double* inv_hessian_out, uint8_t* converged);
+                                  double* beta_out, double* inv_hessian_out, uint8_t* converged, int optimizer);
 int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
@@ -481,6 +485,11 @@ int dsq_dev_lfc_shrink2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double*
                         int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                         double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                         uint8_t* d_converged, double* d_ih_entry);
+/* ... with the optimiser as dsq_inf_lfc_shrink_nbinom_glm takes it (0 "L-BFGS-B", 1 "BFGS", 2 "Newton-CG": utils.py:1112-1121) */
+int dsq_dev_lfc_shrink3(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                        uint8_t* d_converged, double* d_ih_entry, int optimizer);
 /* Adjusted p-values of DeseqStats.summary() (ds.py:486-542).
  * prepare: sorts the p-values once, derives the 50 baseMean cut-offs (np.quantile of base_mean at
  *   theta = linspace(mean(base_mean == 0), 0.95 or 1, 50)), assigns every gene the number of cut-offs it

@@ -1125,8 +1125,11 @@ def grid_fit_shrink_beta(counts, offset, X, size, prior_no_shrink_scale, prior_s
     return np.array([fx[i], fy[j]])
 
 
-def nbinom_glm_gene(X, counts, size, offset, prior_no_shrink_scale, prior_scale, shrink_index=1):
-    """utils.nbinomGLM (utils.py:990-1142) with optimizer='L-BFGS-B': (beta, inv_hessian, converged).
+def nbinom_glm_gene(X, counts, size, offset, prior_no_shrink_scale, prior_scale, shrink_index=1,
+                    optimizer="L-BFGS-B"):
+    """utils.nbinomGLM (utils.py:990-1142): (beta, inv_hessian, converged).  ``optimizer``: 'L-BFGS-B' (what ds.py:407
+    passes), 'BFGS' or 'Newton-CG' - handed to scipy.optimize.minimize with the Hessian only for 'Newton-CG'
+    (utils.py:1112-1121; the ftol / gtol options are unknown to some of the methods: scipy warns and ignores them).
 
     Kept as in the reference: the Hessian adds ``np.diag(h)`` where ``h`` is already a diagonal matrix,
     i.e. the VECTOR of prior curvatures is broadcast onto every row (utils.py:1099-1110)."""
@@ -1157,7 +1160,12 @@ def nbinom_glm_gene(X, counts, size, offset, prior_no_shrink_scale, prior_scale,
         h = np.diag(no_shrink_mask * h11 + shrink_mask * h22)
         return 1 / c * ((X.T * frac) @ X + np.diag(h))
 
-    res = minimize(f, beta_init, jac=df, method="L-BFGS-B", options={"ftol": 1e-8, "gtol": 1e-8})
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize(f, beta_init, jac=df, hess=(lambda b: ddf(b, cnst)) if optimizer == "Newton-CG" else None,
+                       method=optimizer, options={"ftol": 1e-8, "gtol": 1e-8})
     beta, converged = res.x, res.success
     if not converged and p == 2:
         beta = grid_fit_shrink_beta(counts, offset, X, size, prior_no_shrink_scale, prior_scale, cnst)

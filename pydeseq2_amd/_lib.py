@@ -116,11 +116,13 @@ def load():
     proto("dsq_dev_logmeans_poscounts", _vp, _vp, c_int, c_int, c_int, _vp, _vp)
     proto("dsq_dev_vst", _vp, _vp, c_int, c_int, c_int, _vp, c_int, c_double, c_double, _vp)
     proto("dsq_inf_lfc_shrink_nbinom_glm", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double,
-          c_double, c_int, _vp, _vp, _vp)
+          c_double, c_int, _vp, _vp, _vp, c_int)
     proto("dsq_dev_lfc_shrink", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
           c_int, _vp, _vp, _vp)
     proto("dsq_dev_lfc_shrink2", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
           c_int, _vp, _vp, _vp, _vp)
+    proto("dsq_dev_lfc_shrink3", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
+          c_int, _vp, _vp, _vp, _vp, c_int)
     proto("dsq_dev_padj_prepare", _vp, _vp, _vp, c_int, c_double, _vp, _vp, _vp, _vp, C.POINTER(c_int))
     proto("dsq_dev_padj_finish", _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp)
     proto("dsq_d2d", _vp, _vp, _vp, c_size_t)
@@ -203,7 +205,7 @@ EXPORTS = [
     "dsq_dev_gather_rows_i32", "dsq_comm_unique_id", "dsq_comm_init", "dsq_comm_destroy",
     "dsq_comm_allreduce_sum", "dsq_comm_allgather", "dsq_dev_sf_keys", "dsq_dev_sf_count", "dsq_dev_sf_init",
     "dsq_dev_sf_hist", "dsq_dev_sf_pick", "dsq_dev_sf_finish", "dsq_dev_trend_eval", "dsq_dev_trend_prior", "dsq_dev_select_dispersions",
-    "dsq_dev_scatter_rows_f64", "dsq_d2d", "dsq_dev_mom_lin_mu", "dsq_dev_sf_keys_compact", "dsq_prior_mad_work_doubles", "dsq_size_factors_work_doubles", "dsq_dev_mom_raw", "dsq_dev_nll_const", "dsq_dev_nll_scaled", "dsq_dev_logmeans_poscounts", "dsq_dev_vst", "dsq_inf_lfc_shrink_nbinom_glm", "dsq_dev_lfc_shrink", "dsq_dev_lfc_shrink2", "dsq_dev_padj_prepare", "dsq_dev_padj_finish", "dsq_host_alloc", "dsq_host_free", "dsq_d2h_async", "dsq_h2d_async",
+    "dsq_dev_scatter_rows_f64", "dsq_d2d", "dsq_dev_mom_lin_mu", "dsq_dev_sf_keys_compact", "dsq_prior_mad_work_doubles", "dsq_size_factors_work_doubles", "dsq_dev_mom_raw", "dsq_dev_nll_const", "dsq_dev_nll_scaled", "dsq_dev_logmeans_poscounts", "dsq_dev_vst", "dsq_inf_lfc_shrink_nbinom_glm", "dsq_dev_lfc_shrink", "dsq_dev_lfc_shrink2", "dsq_dev_lfc_shrink3", "dsq_dev_padj_prepare", "dsq_dev_padj_finish", "dsq_host_alloc", "dsq_host_free", "dsq_d2h_async", "dsq_h2d_async",
     "dsq_dev_size_factors_new", "dsq_dev_mom_lin_coef", "dsq_dev_alpha_mle2", "dsq_dev_robust_disp", "dsq_dev_robust_disp2", "dsq_dev_lfc_fit", "dsq_dev_lfc_fit2", "dsq_dev_irls_layers",
     "dsq_side_begin", "dsq_side_end", "dsq_side_wait", "dsq_side_abort", "dsq_set_deferred", "dsq_irls_order_hint", "dsq_set_alpha_hook", "dsq_dev_alpha_mle3", "dsq_dev_alpha_mle4", "dsq_mix_create", "dsq_mix_destroy", "dsq_mix_info", "dsq_mix_slots", "dsq_mix_takes_irls", "dsq_dev_replace_outliers2", "dsq_mix_launch_count", "dsq_alpha_rows_eligible", "dsq_alpha_needs_mu", "dsq_dev_cell_mu", "dsq_dev_alpha_row_split",
     "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",

@@ -1227,16 +1227,26 @@ int dsq_dev_gather_rows_f64(dsq_ctx* ctx, const double* d_src, int ld, const int
     return DSQ_OK;
 }
 
+int dsq_dev_lfc_shrink3(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
+                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
+                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
+                        uint8_t* d_converged, double* d_ih_entry, int optimizer) {
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
+    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
+    DSQ_CHECK_ARG(d_ih_entry == nullptr || P <= DSQ_BFGS_MAX_P, "d_ih_entry: designs of at most 12 columns (wider: d_inv_hessian)");
+    DSQ_CHECK_ARG(optimizer >= 0 && optimizer <= 2, "optimizer: 0 (L-BFGS-B), 1 (BFGS) or 2 (Newton-CG)");
+    DSQ_CHECK_ARG(optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer BFGS / Newton-CG: designs of at most 12 columns");
+    DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
+                               prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged, d_ih_entry, optimizer));
+    return DSQ_OK;
+}
+
 int dsq_dev_lfc_shrink2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
                         int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                         double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                         uint8_t* d_converged, double* d_ih_entry) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
-    DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
-    DSQ_CHECK_ARG(d_ih_entry == nullptr || P <= DSQ_BFGS_MAX_P, "d_ih_entry: designs of at most 12 columns (wider: d_inv_hessian)");
-    DSQ_HIP(dsq::launch_shrink(ctx->stream, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale,
-                               prior_scale, shrink_index, d_beta, d_inv_hessian, d_converged, d_ih_entry));
-    return DSQ_OK;
+    return dsq_dev_lfc_shrink3(ctx, d_y, ldn, d_offset, d_Xt, ldx, N, G, P, d_size, prior_no_shrink_scale, prior_scale,
+                               shrink_index, d_beta, d_inv_hessian, d_converged, d_ih_entry, 0);
 }
 
 int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
@@ -1716,7 +1726,7 @@ int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int coun
 int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                                   const double* design, const double* size, const double* offset, int N, int G,
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
-                                  double* beta_out, double* inv_hessian_out, uint8_t* converged) {
+                                  double* beta_out, double* inv_hessian_out, uint8_t* converged, int optimizer) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     if (G <= 0) return DSQ_OK;
@@ -1731,9 +1741,9 @@ int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_ty
     DSQ_HIP(b.alloc((size_t)G * P * sizeof(double)));
     DSQ_HIP(ih.alloc((size_t)G * P * P * sizeof(double)));
     DSQ_HIP(conv.alloc((size_t)G));
-    if ((rc = dsq_dev_lfc_shrink(ctx, y.as<int32_t>(), ldn, off.as<double>(), D.Xt.as<double>(), D.ldx, N, G, P,
-                                 sz.as<double>(), prior_no_shrink_scale, prior_scale, shrink_index, b.as<double>(),
-                                 ih.as<double>(), conv.as<uint8_t>())))
+    if ((rc = dsq_dev_lfc_shrink3(ctx, y.as<int32_t>(), ldn, off.as<double>(), D.Xt.as<double>(), D.ldx, N, G, P,
+                                  sz.as<double>(), prior_no_shrink_scale, prior_scale, shrink_index, b.as<double>(),
+                                  ih.as<double>(), conv.as<uint8_t>(), nullptr, optimizer)))
         return rc;
     DSQ_HIP(hipMemcpyAsync(beta_out, b.p, (size_t)G * P * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(inv_hessian_out, ih.p, (size_t)G * P * P * sizeof(double), hipMemcpyDeviceToHost,

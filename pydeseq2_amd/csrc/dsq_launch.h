@@ -286,7 +286,7 @@ hipError_t launch_gather_rows_f64(hipStream_t st, const double* src, int ld, con
 // ---- dsq_k_shrink.hip (apeGLM MAP LFC)
 hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx,
                          int N, int G, int P, const double* size, double sigma0, double sigma, int shrink_index,
-                         double* beta, double* invh, uint8_t* conv, double* ih_entry = nullptr);
+                         double* beta, double* invh, uint8_t* conv, double* ih_entry = nullptr, int optimizer = 0);
 // ---- dsq_k_summary.hip (adjusted p-values of DeseqStats.summary())
 size_t summary_sort_temp_bytes(int n);
 hipError_t launch_padj_prepare(hipStream_t st, const double* base_mean, const double* pvalue, int n, double alpha,

@@ -16,6 +16,7 @@
 #include "dsq_lbfgsb.h"
 #include "dsq_lbfgsb_dense.h"
 #include "dsq_lbfgsb_wave.h"
+#include "dsq_bfgs.h"
 #include "dsq_linalg.h"
 #include "dsq_wave.h"
 
@@ -45,6 +46,16 @@ struct ShrinkWork {  // wave-private LDS on the device
     double x[P], l[P], u[P];
     int nbd[P];
 };
+// optimizer = "BFGS" / "Newton-CG" (utils.py:1112-1121 hands the name to scipy.optimize.minimize): dsq_bfgs.h
+template <int P>
+struct ShrinkWorkAlt {
+    NewtonCgWork<P> opt;
+    double x[P];
+};
+template <class T>
+struct IsAltWork { static constexpr bool value = false; };
+template <int P>
+struct IsAltWork<ShrinkWorkAlt<P>> { static constexpr bool value = true; };
 // 5 ... 12 coefficients on the device: the inverse quasi-Newton matrix in the wavefront's registers (dsq_lbfgsb_wave.h:
 // 8 x 8 with one entry per lane up to 8 coefficients, 16 x 16 with four per lane beyond); the host instantiation
 // (tests/hostsim) keeps the compact form
@@ -140,9 +151,10 @@ DSQ_HD void grid_fit_shrink2(const ShrinkArgs& A0, double cnst, double (&beta)[2
 
 // beta[P] (out), inv_hessian[P*P] row-major (out); returns scipy's res.success
 // ih_entry (nullable): only inv_hessian[shrink_index][shrink_index] - all DeseqStats.lfc_shrink uses (ds.py:424-433)
+// optimizer: 0 "L-BFGS-B" (what ds.py:407 passes), 1 "BFGS", 2 "Newton-CG" - the latter two with a ShrinkWorkAlt workspace
 template <class Wv, int P, class Work>
 DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double* inv_hessian,
-                       double* ih_entry = nullptr) {
+                       double* ih_entry = nullptr, int optimizer = 0) {
     constexpr int T = Tri<P>::N;
     double zero[P];
 #pragma unroll
@@ -150,7 +162,10 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double*
     const double f0 = shrink_fn<Wv, P>(A, zero, nullptr);
     const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
     const double cn = (f0 != f0) ? f0 : cnst;
-    if constexpr (!IsWave8Work<Work>::value) {
+    if constexpr (IsAltWork<Work>::value) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) Wk.x[j] = (j & 1) ? -0.1 : 0.1;
+    } else if constexpr (!IsWave8Work<Work>::value) {
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             Wk.x[j] = (j & 1) ? -0.1 : 0.1;
@@ -165,9 +180,53 @@ DSQ_HD int shrink_gene(const ShrinkArgs& A, Work& Wk, double (&beta)[P], double*
 #pragma unroll
         for (int j = 0; j < P; ++j) g[j] = gg[j] / cn;
     };
+    // the reference's Hessian of the scaled objective at b: (X^T F X + h broadcast over the rows) / cnst (utils.py:1091-1110;
+    // the broadcasting quirk is described below) - what Newton-CG's conjugate gradients multiply with
+    auto hess = [&](const double* xb, double* Hm) {
+        double b[P], Mh[T];
+#pragma unroll
+        for (int j = 0; j < P; ++j) b[j] = xb[j];
+#pragma unroll
+        for (int k = 0; k < T; ++k) Mh[k] = 0.0;
+        for (int n = Wv::lane(); n < A.N; n += Wv::W) {
+            const double yv = (double)A.y[n];
+            double x[P];
+            double eta = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) { x[j] = A.Xt[j * A.ldx + n]; eta += x[j] * b[j]; }
+            const double e = exp(eta + A.offset[n]);
+            const double fr = (yv + A.size) * A.size * e / ((A.size + e) * (A.size + e));
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const double xw = x[i] * fr;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) Mh[tri(i, j)] += xw * x[j];
+            }
+        }
+        Wv::template sum_n<T>(Mh);
+        double bsh = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) bsh = (j == A.shrink_index) ? b[j] : bsh;
+        const double s2 = A.sigma * A.sigma, b2 = bsh * bsh;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const double hdj = (j == A.shrink_index) ? 2.0 * (s2 - b2) / ((s2 + b2) * (s2 + b2))
+                                                         : 1.0 / (A.sigma0 * A.sigma0);
+                Hm[i * P + j] = (Mh[tri(i > j ? i : j, i > j ? j : i)] + hdj) / cn;
+            }
+    };
     // scipy: factr = ftol / eps, pgtol = gtol
     LbfgsbResult res;
-    if constexpr (IsWave8Work<Work>::value) {
+    if constexpr (IsAltWork<Work>::value) {
+        // (the options the reference passes are {"ftol": 1e-8, "gtol": 1e-8}: BFGS knows gtol, Newton-CG neither)
+        const BfgsResult rb = optimizer == 1 ? bfgs_min<P>(fg, P, Wk.x, Wk.opt, 1e-8)
+                                             : newton_cg_min<P>(fg, hess, P, Wk.x, Wk.opt);
+        res.success = rb.success;
+#pragma unroll
+        for (int j = 0; j < P; ++j) beta[j] = Wk.x[j];
+    } else if constexpr (IsWave8Work<Work>::value) {
         if (Wv::lane() < P) Wk.lb.x[Wv::lane()] = (Wv::lane() & 1) ? -0.1 : 0.1;
         res = lbfgsb_wave<P, shrink_wave_rank(P)>(fg, Wk.lb, 1e-8 / 2.220446049250313e-16, 1e-8);
 #pragma unroll

@@ -18,6 +18,7 @@ from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context
 
 _vp, c_int, c_double = C.c_void_p, C.c_int, C.c_double
 _OPTIMIZER = {"L-BFGS-B": 0, "BFGS": 1}  # the `optimizer` argument of dsq_inf_irls / dsq_inf_alpha_mle
+_SHRINK_OPTIMIZER = {"L-BFGS-B": 0, "BFGS": 1, "Newton-CG": 2}  # ... of dsq_inf_lfc_shrink_nbinom_glm (utils.py:1028-1030)
 
 
 def _counts_arg(counts):
@@ -221,8 +222,8 @@ class HipInference:
                               optimizer, shrink_index):
         """See ``Inference.lfc_shrink_nbinom_glm`` (inference.py:306-362, default_inference.py:232-264).
         Returns (beta G x p, inv_hessian G x p x p, converged G)."""
-        if optimizer != "L-BFGS-B":
-            raise NotImplementedError("HipInference implements the L-BFGS-B apeGLM fit only")
+        if optimizer not in _SHRINK_OPTIMIZER:
+            raise ValueError(f"optimizer: one of {sorted(_SHRINK_OPTIMIZER)} (utils.py:1028-1030)")
         y, ct, lay = _counts_arg(counts)
         N, G = y.shape
         X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
@@ -232,5 +233,5 @@ class HipInference:
         self.ctx.call("dsq_inf_lfc_shrink_nbinom_glm", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data),
                       _vp(sz.ctypes.data), _vp(off.ctypes.data), N, G, P, c_double(prior_no_shrink_scale),
                       c_double(prior_scale), int(shrink_index), _vp(beta.ctypes.data), _vp(invh.ctypes.data),
-                      _vp(conv.ctypes.data))
+                      _vp(conv.ctypes.data), _SHRINK_OPTIMIZER[optimizer])
         return beta, invh, conv.astype(bool)

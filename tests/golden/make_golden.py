@@ -404,6 +404,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "bfgs":
         bfgs_cases(ut)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shrink_opt":  # round 4: apeGLM shrinkage with the two other optimisers
+        shrink_optimizer_cases(ut)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "shrink_mid":  # round 4: apeGLM shrinkage at the widths 5-7 and 9-12
         shrink_mid_cases(ut)
         return
@@ -533,6 +536,29 @@ def shrink_mid_cases(ut):
             sh[f"{case}{tag}_scale"] = np.array(ps)
         sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
     np.savez(os.path.join(HERE, "kat_shrink_mid.npz"), **sh)
+
+
+def shrink_optimizer_cases(ut):
+    """utils.nbinomGLM (the unmodified reference) with optimizer = "BFGS" and "Newton-CG" (utils.py:1028-1030, 1112-1121)
+    on the KAT inputs of p = 2, 4, 8, 12 -> kat_shrink_opt.npz"""
+    import warnings
+
+    sh = {}
+    for case, sidx in (("p2", 1), ("p4", 3), ("p8", 1), ("p12", 1)):
+        k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
+        counts, X, sf = k["counts"], k["X"], k["sf"]
+        size = 1.0 / np.clip(k["map_alpha"], 1e-8, max(10, counts.shape[0]))
+        G = min(counts.shape[1], 24)
+        for opt, tag in (("BFGS", "bfgs"), ("Newton-CG", "ncg")):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r = [ut.nbinomGLM(X, counts[:, i], size[i], np.log(sf), 15, 0.5, opt, sidx) for i in range(G)]
+            sh[f"{case}_{tag}_beta"] = np.stack([x[0] for x in r])
+            sh[f"{case}_{tag}_invh"] = np.stack([x[1] for x in r])
+            sh[f"{case}_{tag}_conv"] = np.array([x[2] for x in r], dtype=bool)
+        sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"], sh[f"{case}_scale"] = (np.array(sidx), size[:G], np.array(G),
+                                                                                        np.array(0.5))
+    np.savez(os.path.join(HERE, "kat_shrink_opt.npz"), **sh)
 
 
 def rest_of_main(ut):

@@ -343,7 +343,7 @@ def trimmed_sum(buf, nt):
     return float(f(_p(b, C.c_double), C.c_int(len(b)), C.c_int(int(nt))))
 
 
-def shrink(counts, X, size, offset, prior_no_shrink_scale, prior_scale, shrink_index):
+def shrink(counts, X, size, offset, prior_no_shrink_scale, prior_scale, shrink_index, optimizer="L-BFGS-B"):
     """apeGLM MAP fit (nbinomGLM) through the device templates: (beta G x p, inv_hessian G x p x p, converged)."""
     y = gene_major(counts)
     G, N = y.shape
@@ -355,7 +355,8 @@ def shrink(counts, X, size, offset, prior_no_shrink_scale, prior_scale, shrink_i
     rc = lib().hs_shrink(_p(y, C.c_int32), C.c_int(N), _p(off, C.c_double), _p(Xt, C.c_double), C.c_int(N),
                          C.c_int(N), C.c_int(G), C.c_int(P), _p(sz, C.c_double), C.c_double(prior_no_shrink_scale),
                          C.c_double(prior_scale), C.c_int(shrink_index), _p(beta, C.c_double),
-                         _p(invh, C.c_double), _p(conv, C.c_uint8))
+                         _p(invh, C.c_double), _p(conv, C.c_uint8),
+                         C.c_int({"L-BFGS-B": 0, "BFGS": 1, "Newton-CG": 2}[optimizer]))
     assert rc == 0
     return beta, invh, conv.astype(bool)
 

@@ -374,6 +374,26 @@ def test_apeglm_shrinkage_templates_match_reference_at_the_widths_between(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-8
 
 
+@pytest.mark.parametrize("case", ["p2", "p4", "p8", "p12"])
+@pytest.mark.parametrize("optimizer,tag", [("BFGS", "bfgs"), ("Newton-CG", "ncg")])
+def test_apeglm_shrinkage_other_optimizers_match_reference(case, optimizer, tag):
+    """utils.nbinomGLM(optimizer="BFGS" | "Newton-CG") of the unmodified reference (kat_shrink_opt.npz; ds.py never passes
+    them, the Inference interface allows them) against dsq_bfgs.h's restatements of scipy's two methods: convergence flags
+    equal - the files contain fits that scipy gives up on - Newton-CG to 1e-9 on every gene, BFGS to the resolution of
+    its own stopping rule (max |g| <= 1e-8 on a flat scaled objective: the first iterate that meets it depends on the
+    rounding of numpy's BLAS products in the inverse-Hessian update; <= 1e-6 absolute on the coefficients)."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_opt.npz"))
+    kk = load_kat(case)
+    G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
+    b, ih, cv = hs.shrink(kk["counts"][:, :G], kk["X"], k[f"{case}_size"], np.log(kk["sf"]), 15.0, float(k[f"{case}_scale"]),
+                          sidx, optimizer)
+    assert (cv == k[f"{case}_{tag}_conv"]).all()
+    rtol, atol = (1e-9, 1e-11) if optimizer == "Newton-CG" else (5e-4, 2e-6)
+    np.testing.assert_allclose(b, k[f"{case}_{tag}_beta"], rtol=rtol, atol=atol)
+    scale = np.abs(k[f"{case}_{tag}_invh"]).max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(ih - k[f"{case}_{tag}_invh"]) / scale) < (1e-8 if optimizer == "Newton-CG" else 2e-6)
+
+
 @pytest.mark.parametrize("case", ["p16", "p24"])
 def test_apeglm_shrinkage_wide_designs_match_reference(case):
     """Designs of 13 ... 32 columns (shrink_gene_wide: run-time p, Hessian row by row, inverse in the LDS workspace) against

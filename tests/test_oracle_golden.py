@@ -245,6 +245,20 @@ def test_nbinom_glm_matches_reference(case):
             assert cv == k[f"{case}{tag}_conv"][g]
 
 
+@pytest.mark.parametrize("optimizer,tag", [("BFGS", "bfgs"), ("Newton-CG", "ncg")])
+def test_nbinom_glm_other_optimizers_match_reference(optimizer, tag):
+    """The restated utils.nbinomGLM with optimizer = "BFGS" / "Newton-CG" against the unmodified reference (kat_shrink_opt.npz)."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_opt.npz"))
+    for case in ("p2", "p8"):
+        kk = load_kat(case)
+        sidx = int(k[f"{case}_sidx"])
+        for g in range(0, int(k[f"{case}_G"]), 4):
+            b, ih, cv = orc.nbinom_glm_gene(kk["X"], kk["counts"][:, g], k[f"{case}_size"][g], np.log(kk["sf"]), 15,
+                                            float(k[f"{case}_scale"]), sidx, optimizer)
+            np.testing.assert_allclose(b, k[f"{case}_{tag}_beta"][g], rtol=1e-10, atol=1e-12)
+            assert cv == k[f"{case}_{tag}_conv"][g]
+
+
 @pytest.mark.parametrize("adapt,fn", [(True, "r_test_lfc_shrink_res.csv"),
                                       (False, "r_test_lfc_shrink_no_apeAdapt_res.csv")])
 def test_r_lfc_shrink_single_factor(adapt, fn):

@@ -45,6 +45,7 @@ struct dsq_ctx {
     size_t lsf_cap = 0;
     void* stage[2] = {nullptr, nullptr};  // page-locked staging chunks of dsq_upload_counts_i32
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    void* d_stage16[2] = {nullptr, nullptr};  // device side of a chunk that travels as uint16
     const int32_t* d_irls_hint = nullptr;  // dsq_irls_order_hint: iteration counts of an earlier fit (one-shot)
     int irls_hint_genes = 0;
     void (*alpha_hook)(void*) = nullptr;  // dsq_set_alpha_hook (one-shot)
@@ -422,6 +423,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_sum) (void)hipFree(ctx->d_sum);
     for (int k = 0; k < 2; ++k) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+        if (ctx->d_stage16[k]) (void)hipFree(ctx->d_stage16[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     }
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -1378,6 +1380,46 @@ void narrow_chunk(const SrcT* src, int32_t* dst, size_t n, int n_threads, int* b
 }  // namespace
 }  // extern "C++"
 
+extern "C++" {
+namespace {
+// the same, to uint16 - for a chunk whose counts are all below 65 536 (the usual RNA-seq matrix): the PCIe link, which is
+// what bounds the upload (240 MB of int32 at ~25 GB/s of pinned-memory DMA: 10 of the 12 ms), carries a QUARTER of the
+// int64 matrix's bytes; the device widens the chunk into its place.  *big is set if some count does not fit (the chunk
+// is then narrowed to int32 as before); negative counts set *bad.
+template <class SrcT>
+void narrow_chunk_u16(const SrcT* src, uint16_t* dst, size_t n, int n_threads, int* bad, int* big) {
+    auto work = [=](size_t lo, size_t hi, int* flags) {
+        int b = 0, g = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const SrcT v = src[i];
+            b |= (v < 0);
+            g |= ((long long)v > 65535LL);
+            dst[i] = (uint16_t)v;
+        }
+        if (b) flags[0] = 1;
+        if (g) flags[1] = 1;
+    };
+    std::vector<int> flags((size_t)2 * (n_threads > 1 ? n_threads : 1), 0);
+    if (n_threads <= 1 || n < ((size_t)1 << 16)) {
+        work(0, n, flags.data());
+    } else {
+        std::vector<std::thread> th;
+        const size_t per = (n + n_threads - 1) / n_threads;
+        for (int t = 0; t < n_threads; ++t) {
+            const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+            if (lo >= hi) break;
+            th.emplace_back(work, lo, hi, &flags[(size_t)2 * t]);
+        }
+        for (auto& x : th) x.join();
+    }
+    for (size_t t = 0; t < flags.size(); t += 2) {
+        if (flags[t]) *bad = 1;
+        if (flags[t + 1]) *big = 1;
+    }
+}
+}  // namespace
+}  // extern "C++"
+
 int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size_t n_elems, int32_t* d_dst,
                           int* h_bad) {
     DSQ_CHECK_ARG(count_type == DSQ_I32 || count_type == DSQ_I64, "count_type");
@@ -1393,6 +1435,7 @@ int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size
         const int cap = e ? 128 : 16;
         return t < 1 ? 1 : (t > cap ? cap : t);
     }();
+    static const bool no_u16 = getenv("DSQ_UPLOAD_NO_U16") != nullptr;  // A/B switch
     int bad = 0;
     size_t off = 0;
     for (int c = 0; off < n_elems; ++c, off += kStageElems) {
@@ -1400,10 +1443,23 @@ int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size
         const int k = c & 1;
         if (c >= 2) DSQ_HIP(hipEventSynchronize(ctx->stage_ev[k]));  // the DMA out of this buffer has finished
         int32_t* st = (int32_t*)ctx->stage[k];
-        if (count_type == DSQ_I64) narrow_chunk((const int64_t*)counts + off, st, n, n_threads, &bad);
-        else narrow_chunk((const int32_t*)counts + off, st, n, n_threads, &bad);
-        DSQ_HIP(hipMemcpyAsync(d_dst + off, st, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        DSQ_HIP(hipEventRecord(ctx->stage_ev[k], ctx->stream));
+        int big = no_u16 ? 1 : 0;
+        if (!big) {  // optimistic: the chunk as uint16
+            if (count_type == DSQ_I64) narrow_chunk_u16((const int64_t*)counts + off, (uint16_t*)st, n, n_threads, &bad, &big);
+            else narrow_chunk_u16((const int32_t*)counts + off, (uint16_t*)st, n, n_threads, &bad, &big);
+        }
+        if (!big) {
+            if (!ctx->d_stage16[k]) DSQ_HIP(hipMalloc(&ctx->d_stage16[k], kStageElems * sizeof(uint16_t)));
+            // (stream order: the widening kernel of chunk c - 2 has read this device buffer before this copy starts)
+            DSQ_HIP(hipMemcpyAsync(ctx->d_stage16[k], st, n * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+            DSQ_HIP(hipEventRecord(ctx->stage_ev[k], ctx->stream));
+            DSQ_HIP(dsq::launch_widen_u16(ctx->stream, (const uint16_t*)ctx->d_stage16[k], d_dst + off, n));
+        } else {
+            if (count_type == DSQ_I64) narrow_chunk((const int64_t*)counts + off, st, n, n_threads, &bad);
+            else narrow_chunk((const int32_t*)counts + off, st, n, n_threads, &bad);
+            DSQ_HIP(hipMemcpyAsync(d_dst + off, st, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            DSQ_HIP(hipEventRecord(ctx->stage_ev[k], ctx->stream));
+        }
     }
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
     if (h_bad) *h_bad = bad;

@@ -113,6 +113,29 @@ __global__ __launch_bounds__(256) void k_repitch(const SrcT* __restrict__ src, i
     if (CHECK && isbad) atomicOr(bad, 1);
 }
 
+// upload chunks that travel as uint16 (dsq_upload_counts_i32): widened into their place in the int32 matrix
+__global__ __launch_bounds__(256) void k_widen_u16(const uint16_t* __restrict__ src, int32_t* __restrict__ dst, size_t n) {
+    const size_t n8 = n / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = ((const uint4*)src)[i];  // eight counts
+        int4 a, b;
+        a.x = (int)(v.x & 0xffffu); a.y = (int)(v.x >> 16); a.z = (int)(v.y & 0xffffu); a.w = (int)(v.y >> 16);
+        b.x = (int)(v.z & 0xffffu); b.y = (int)(v.z >> 16); b.z = (int)(v.w & 0xffffu); b.w = (int)(v.w >> 16);
+        ((int4*)dst)[2 * i] = a;
+        ((int4*)dst)[2 * i + 1] = b;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (int)src[i];
+}
+hipError_t launch_widen_u16(hipStream_t st, const uint16_t* src, int32_t* dst, size_t n) {
+    if (n == 0) return hipSuccess;
+    // (dst = matrix base + a multiple of the chunk size: 16-byte aligned whenever the matrix is)
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_widen_u16, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
                                    int G, int32_t* dst, int ldn, int* bad_flag) {
     if (N <= 0 || G <= 0) return hipSuccess;

@@ -237,6 +237,7 @@ bool alpha_is_wide(int P, int n_cells);
 bool alpha_needs_mu(int N, int P, int n_cells);  // the design takes the run-time-P (LDS) kernels of dsq_k_wide.hip
 
 // ---- dsq_k_stats.hip
+hipError_t launch_widen_u16(hipStream_t st, const uint16_t* src, int32_t* dst, size_t n);
 hipError_t launch_transpose_counts(hipStream_t st, const void* src, int count_type, int layout, int N,
                                    int G, int32_t* dst, int ldn, int* bad_flag);
 hipError_t launch_transpose_f64(hipStream_t st, const double* src, int layout, int N, int G,

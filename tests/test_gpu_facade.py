@@ -254,3 +254,29 @@ def test_more_than_65535_genes():
     assert same.mean() > 0.99
     # (atol: a dispersion at the lower bound 1e-8 is compared to 1e-12 absolute - the loss is flat there)
     np.testing.assert_allclose(res.genewise_dispersions[sl][keep][same], np.clip(a, 1e-8, 24.0)[same], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_upload_narrows_chunks_to_uint16_where_the_counts_fit(dtype, monkeypatch):
+    """dsq_upload_counts_i32: a chunk (8 Mi counts) whose values are all below 65 536 travels as uint16 and is widened on
+    the device, any other as int32 - the device matrix is the host matrix either way; a negative count is reported."""
+    import ctypes as C
+
+    from pydeseq2_amd._lib import Context, DeviceArray
+
+    ctx = Context(0)
+    rng = np.random.default_rng(11)
+    n = (8 << 20) * 2 + 12345  # two full chunks and a ragged one
+    host = rng.integers(0, 60000, n).astype(dtype)
+    host[(8 << 20) + 777] = 70000          # second chunk: int32
+    host[n - 3] = 65535                    # last chunk: still uint16
+    d = DeviceArray(ctx, (n,), np.int32)
+    bad = C.c_int(0)
+    ctx.call("dsq_upload_counts_i32", C.c_void_p(host.ctypes.data), 0 if dtype == np.int32 else 1, C.c_size_t(n),
+             C.c_void_p(d.ptr), C.byref(bad))
+    assert bad.value == 0
+    assert np.array_equal(d.to_host(), host.astype(np.int32))
+    host[5] = -1
+    ctx.call("dsq_upload_counts_i32", C.c_void_p(host.ctypes.data), 0 if dtype == np.int32 else 1, C.c_size_t(n),
+             C.c_void_p(d.ptr), C.byref(bad))
+    assert bad.value == 1

@@ -456,6 +456,10 @@ def main():
         "algorithmic_bytes_per_launch": int(alg_bytes), "full_launch_ms": round(full_ms, 4),
         "full_launches_timed": len(big),
         "full_launch_ms_genewise_only": round(float(np.mean(solo)), 4) if solo else None,
+        "frac_genewise_only": round(alg_bytes / (float(np.mean(solo)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if solo else None,
+        "overlap_note": "the genewise launches have the device to themselves; the MAP launches start while the "
+                        "robust-dispersion kernel of the side stream is still running (the shorter the trend fit, the longer "
+                        "that overlap) and are the longer for it - `achieved` / `frac` average over both, as rocprofv3 does",
         "avg_launch_ms_all": round(float(np.mean([ms for ms, _ in launches])), 4), "launches_timed": len(launches),
         "pipeline_algorithmic_GBps": round(G * 104.0 * N / (dt / args.steps) / 1e9, 2),
         "kernel_ms_per_step": stage_ms, "grid_fallback_genes_per_step": n_fallback,

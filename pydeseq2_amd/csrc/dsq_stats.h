@@ -150,7 +150,8 @@ DSQ_HD MomOut mom_lin_mu_gene(const int32_t* y, const double* sf, const double* 
 // NG genes per wavefront (device kernels k_mom4 / k_mom_lin_mu4): the size factors and the rows of pinvXt / Xt are
 // read once per sample and applied to NG count rows - the single-gene loops read 8 + 16 p bytes of shared vectors per
 // 4 bytes of counts and ran at 1 TB/s of HBM.  Per gene the same operations in the same per-lane order, and the
-// multi-value reduction is bit-identical to the single sums: same results as mom_lin_mu_gene.
+// multi-value reduction is bit-identical to the single sums: same results as mom_lin_mu_gene up to the last bit of the
+// normalised counts (the quotients y / sf are formed from one reciprocal per sample here, see below).
 template <class Wv, int P, int NG>
 DSQ_HD void mom_lin_mu_block(const int32_t* y0, int ldn, int n_valid, const double* sf, const double* Xt,
                              const double* pinvXt, int ldx, int N, double s_mean_inv, double min_disp,
@@ -163,14 +164,22 @@ DSQ_HD void mom_lin_mu_block(const int32_t* y0, int ldn, int n_valid, const doub
     for (int k = 0; k < NG; ++k) s[k] = 0.0;
 #pragma unroll
     for (int i = 0; i < NG * P; ++i) b[i] = 0.0;
+    // y / sf for NG genes and two passes: ONE division per sample (the reciprocal) and, per quotient, a product with one
+    // residual correction - the correctly rounded quotient but for rare double roundings (<= 1 ulp) - instead of 2 NG
+    // IEEE divisions of ~30 dependent instructions each, which made this HBM-sized kernel ALU-bound (0.235 ms for 240 MB)
+    auto quot = [](double yv, double sfn, double rs) {
+        const double q = yv * rs;
+        return fma(fma(-q, sfn, yv), rs, q);
+    };
     for (int n = Wv::lane(); n < N; n += Wv::W) {
         const double sfn = sf[n];
+        const double rs = 1.0 / sfn;
         double pv[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) pv[j] = pinvXt[j * ldx + n];
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const double v = (double)yr[k][n] / sfn;
+            const double v = quot((double)yr[k][n], sfn, rs);
             s[k] += v;
 #pragma unroll
             for (int j = 0; j < P; ++j) b[k * P + j] += pv[j] * v;
@@ -184,12 +193,13 @@ DSQ_HD void mom_lin_mu_block(const int32_t* y0, int ldn, int n_valid, const doub
     const double dof = (double)(N - P);
     for (int n = Wv::lane(); n < N; n += Wv::W) {
         const double sfn = sf[n];
+        const double rs = 1.0 / sfn;
         double xv[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) xv[j] = Xt[j * ldx + n];
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const double v = (double)yr[k][n] / sfn;
+            const double v = quot((double)yr[k][n], sfn, rs);
             const double d = v - mean[k];
             acc[k] += d * d;
             double yh = 0.0;
@@ -197,7 +207,7 @@ DSQ_HD void mom_lin_mu_block(const int32_t* y0, int ldn, int n_valid, const doub
             for (int j = 0; j < P; ++j) yh += xv[j] * b[k * P + j];
             if (mu0 != nullptr && k < n_valid) mu0[(size_t)k * ldn + n] = dmax(sfn * yh, min_mu);
             yh = dmax(yh, 1.0);
-            acc[NG + k] += ((v - yh) * (v - yh) - yh) / (dof * yh * yh);
+            acc[NG + k] += ((v - yh) * (v - yh) - yh) * frcp(dof * yh * yh);  // (yh >= 1: a normal positive number)
         }
     }
     Wv::template sum_n<2 * NG>(acc);

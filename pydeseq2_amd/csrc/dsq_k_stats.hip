@@ -1566,7 +1566,10 @@ hipError_t launch_trend_loss_grad(hipStream_t st, const double* cov, const doubl
 //     memory round trips per pass).  Words are double-buffered by pass parity: a workgroup can be at most one pass
 //     ahead of the slowest reader (it needs that reader's words of pass p to leave pass p).
 // Launched cooperatively (all workgroups resident); a bounded poll sets a flag instead of hanging the GPU.
-constexpr int kTrendWaves = 8;
+#ifndef DSQ_TREND_WAVES
+#define DSQ_TREND_WAVES 8
+#endif
+constexpr int kTrendWaves = DSQ_TREND_WAVES;
 #ifndef DSQ_TREND_GRID_BLOCKS
 #define DSQ_TREND_GRID_BLOCKS 32
 #endif

@@ -174,6 +174,16 @@ def parity_report(res, ref):
     }
     max_rel = {k: float(v[ok].max()) if ok.any() else 0.0 for k, v in errs.items()}
     max_noise = {k: float(v[noisy].max()) if noisy.any() else 0.0 for k, v in errs.items()}
+    # the RAW p-value error (north-star wording: "1e-5 on Wald p-values"), reported next to the asserted per-z^2 quantity so
+    # that the reader sees what the relaxation covers: how many genes exceed a raw 1e-5 and how far out in the tail they sit
+    p_raw = rel(res.pvalue, ref.pvalue, 1e-300)
+    absz = np.abs(np.nan_to_num(np.asarray(ref.stat, float)))
+    beyond = ok & (p_raw > 1e-5)
+    pv_raw = {"pvalue": float(f"{(p_raw[ok].max() if ok.any() else 0.0):.3e}"),
+              "n_genes_pvalue_beyond_1e-5": int(beyond.sum()),
+              "abs_z_range_of_those_genes": [round(float(absz[beyond].min()), 2), round(float(absz[beyond].max()), 2)]
+              if beyond.any() else None,
+              "max_abs_z": round(float(absz[ok].max()), 2) if ok.any() else 0.0}
     untouched = nz & ~res.refitted & ~ref.refitted
     both = untouched & (((res.genewise_converged == 0) & (ref.genewise_converged == 0))
                         | ((res.MAP_converged == 0) & (ref.MAP_converged == 0)))
@@ -183,6 +193,7 @@ def parity_report(res, ref):
             and float(np.max(np.abs(res.size_factors - ref.size_factors) / ref.size_factors)) < 1e-12
             and bool((res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()))
     return {"genes": int(G), "tolerance": PARITY_TOL, "max_rel": {k: float(f"{v:.3e}") for k, v in max_rel.items()},
+            "raw_pvalue": pv_raw,
             "n_noise_genes": int(noisy.sum()), "frac_noise": round(float(noisy.sum()) / G, 6),
             "max_rel_noise": {k: float(f"{v:.3e}") for k, v in max_noise.items()},
             "n_grid_on_both_sides": int(both.sum()),
@@ -190,11 +201,32 @@ def parity_report(res, ref):
             "ok": bool(good)}
 
 
-def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs):
+def timed_steps(pipe, ctx, steps):
+    """`steps` passes of the resident path, each timed twice: host wall clock around the call (it ends with the final
+    synchronisation) and HIP events on the engine's stream around the same call - a host stall shows up in the first only,
+    a device stall in both.  Returns (wall_ms list, gpu_ms list)."""
+    wall, gpu = [], []
+    for _ in range(steps):
+        ctx.sync()
+        ctx.timer_start()
+        t0 = time.perf_counter()
+        pipe.deseq2()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        gpu.append(float(ctx.timer_stop()))
+    return wall, gpu
+
+
+def _mmm(v):
+    v = np.asarray(v, float)
+    return {"min": round(float(v.min()), 3), "median": round(float(np.median(v)), 3), "max": round(float(v.max()), 3)}
+
+
+def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs, shrink=True):
     """One more configuration on the same device (extras of the default run, so that the driver's record carries every
-    BASELINE configuration, not only the headline one): ms per step of the resident path, the dispersion stage's launch
-    time and HBM-roofline fraction (HIP events, as for the main line) and an in-run parity object against the oracle on
-    a slice of the same matrix."""
+    BASELINE configuration, not only the headline one): ms per step of the resident path (MEDIAN of `steps` individually
+    timed passes after `warmup` untimed ones, with min / max and the per-pass GPU time from HIP events beside the wall
+    clock), the dispersion stage's launch time and HBM-roofline fraction (HIP events, as for the main line), the per-stage
+    wall times of one profiled pass, and an in-run parity object against the oracle on a slice of the same matrix."""
     import warnings
 
     import pydeseq2_amd
@@ -203,43 +235,55 @@ def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs):
 
     G_cfg, N, design = CONFIGS[name]
     G = genes or G_cfg
+    t_gen = time.perf_counter()
     if name == "c5":
         counts, X = synth_counts_block(G, N, design, SEEDS[name])
     else:
         counts, X = synth_fast(G, N, design, seed=SEEDS[name])
+    t_gen = time.perf_counter() - t_gen
     pipe = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx)
     for _ in range(warmup + 1):
         pipe.deseq2()
     pipe.kernel_log = {}
     ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.deseq2()
-    ctx.sync()
-    dt = (time.perf_counter() - t0) / steps
+    wall, gpu = timed_steps(pipe, ctx, steps)
+    loop_ms = (time.perf_counter() - t0) * 1e3 / steps
+    dt = float(np.median(wall)) * 1e-3
     big = [(ms, g) for ms, g in pipe.kernel_log.get("k_alpha", []) if g > 0.5 * G]
-    full_ms = float(np.mean([ms for ms, _ in big])) if big else None
+    full_ms = float(np.median([ms for ms, _ in big])) if big else None
     alg = G * (12.0 * N + 17.0)
     out = {"workload": f"{name}: {G} genes x {N} samples, design {design} (p={X.shape[1]})"
                        + (" - one of eight GPUs' share of BASELINE configs[4]" if (name == "c5" and G < G_cfg) else ""),
            "ms_per_step": round(dt * 1e3, 3), "genes_per_s": round(G / dt, 1),
+           "steps": steps, "warmup": warmup, "ms_per_step_wall": _mmm(wall), "ms_per_step_gpu_events": _mmm(gpu),
+           "ms_per_step_loop_mean": round(loop_ms, 3),
+           "timing_note": "ms_per_step = median wall time of the individually timed passes; gpu_events = HIP events on the "
+                          "engine's stream around the same passes (a host stall widens wall only)",
+           "generator_s": round(t_gen, 2),
            "dispersion_stage": None if full_ms is None else {
                "full_launch_ms": round(full_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                "achieved_GBps": round(alg / (full_ms * 1e-3) / 1e9, 2),
                "frac": round(alg / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
-    try:  # apeGLM MAP LFC of the last coefficient, all genes (DeseqStats.lfc_shrink; not part of ms_per_step)
-        from pydeseq2_amd.summary import lfc_shrink
-
-        res = pipe.deseq2()
-        lfc_shrink(pipe, res, X.shape[1] - 1)
-        ctx.sync()
-        t0 = time.perf_counter()
-        shr = lfc_shrink(pipe, res, X.shape[1] - 1)
-        ctx.sync()
-        out["lfc_shrink"] = {"ms": round((time.perf_counter() - t0) * 1e3, 3),
-                             "converged_fraction": round(float(np.nanmean(shr[2])), 6)}
+    try:
+        rp = pipe.deseq2(profile=True)
+        out["stage_wall_ms_profiled_step"] = {k: round(v * 1e3, 3) for k, v in rp.timings.items()}
     except Exception as e:  # noqa: BLE001
-        out["lfc_shrink_error"] = repr(e)
+        out["stage_wall_error"] = repr(e)
+    if shrink:
+        try:  # apeGLM MAP LFC of the last coefficient, all genes (DeseqStats.lfc_shrink; not part of ms_per_step)
+            from pydeseq2_amd.summary import lfc_shrink
+
+            res = pipe.deseq2()
+            lfc_shrink(pipe, res, X.shape[1] - 1)
+            ctx.sync()
+            t0 = time.perf_counter()
+            shr = lfc_shrink(pipe, res, X.shape[1] - 1)
+            ctx.sync()
+            out["lfc_shrink"] = {"ms": round((time.perf_counter() - t0) * 1e3, 3),
+                                 "converged_fraction": round(float(np.nanmean(shr[2])), 6)}
+        except Exception as e:  # noqa: BLE001
+            out["lfc_shrink_error"] = repr(e)
     if parity_genes:
         try:
             with warnings.catch_warnings():
@@ -253,6 +297,91 @@ def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs):
         except Exception as e:  # noqa: BLE001
             out["parity_error"] = repr(e)
     pipe.close()
+    return out
+
+
+def measure_plugin_path(counts, X, ctx, res, with_shrink=True):
+    """The DROP-IN path: the eight `Inference` methods as the reference's DeseqDataSet.deseq2() / DeseqStats call them
+    (dds.py:747-785, 901-911, 953-960, 1150-1157, 1240; ds.py:338-350, 400) - host numpy arrays in, host numpy arrays
+    out, every call handed FRESH copies of the count / mu matrices as `self.X[:, self.non_zero_idx]` makes them.  Timed
+    per call; `total_ms` = their sum in dds.py call order (the copies the reference itself makes are outside the timers).
+    Two passes: `first` (nothing cached) and `repeat` (the second deseq2() on the same data)."""
+    from pydeseq2_amd import HipInference
+
+    inf = HipInference(ctx=ctx)
+    nz = np.asarray(res.non_zero, bool)
+    nzi = np.nonzero(nz)[0]
+    N, G = counts.shape
+    sf = np.asarray(res.size_factors, float)
+    min_mu, min_disp, max_disp, beta_tol = 0.5, 1e-8, float(max(10.0, N)), 1e-8
+    linear = len({tuple(r) for r in np.asarray(X)}) == X.shape[1]  # dds.py:747-750
+    normed_layer = counts / sf[:, None]
+
+    def one_pass():
+        T = {}
+
+        def tm(name, fn):
+            t0 = time.perf_counter()
+            o = fn()
+            T[name] = T.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            return o
+
+        normed = normed_layer[:, nzi]  # dds.py:1149
+        rde = tm("fit_rough_dispersions", lambda: inf.fit_rough_dispersions(normed, X))
+        mde = tm("fit_moments_dispersions", lambda: inf.fit_moments_dispersions(normed, sf))
+        mom = np.clip(np.minimum(rde, mde), min_disp, max_disp)
+        if linear:
+            mu_hat = tm("lin_reg_mu", lambda: inf.lin_reg_mu(counts[:, nzi], sf, X, min_mu))
+        else:
+            mu_hat = tm("irls(mu_hat)", lambda: inf.irls(counts[:, nzi], sf, X, mom, min_mu, beta_tol)[1])
+        layer = np.full((N, G), np.nan)  # dds.py:770-771
+        layer[:, nz] = mu_hat
+        del mu_hat
+        y, m = counts[:, nzi], layer[:, nzi]
+        gw, _ = tm("alpha_mle(genewise)", lambda: inf.alpha_mle(y, X, m, mom, min_disp, max_disp))
+        gw = np.clip(gw, min_disp, max_disp)
+        # dds.py:1234-1262: the trend's outer loop (a GLM fit per pass, genes far off the curve dropped in between)
+        cov, tgt = 1.0 / normed.mean(0), gw.copy()
+        old_c, cf, n_trend = np.array([0.1, 0.1]), np.array([1.0, 1.0]), 0
+        while (cf > 1e-10).all() and (np.log(np.abs(cf / old_c)) ** 2).sum() >= 1e-6 and n_trend < 20:
+            old_c = cf
+            cf, pred, okc = tm("dispersion_trend_gamma_glm", lambda: inf.dispersion_trend_gamma_glm(cov, tgt))
+            n_trend += 1
+            if not okc or (cf <= 1e-10).any():
+                break
+            ratio = tgt / pred
+            keep = ~((ratio < 1e-4) | (ratio >= 15))
+            cov, tgt = cov[keep], tgt[keep]
+        T["trend_passes"] = n_trend
+        fitted = np.asarray(res.fitted_dispersions, float)[nz]
+        y, m = counts[:, nzi], layer[:, nzi]
+        mp, _ = tm("alpha_mle(MAP)", lambda: inf.alpha_mle(y, X, m, fitted, min_disp, max_disp,
+                                                          float(res.prior_disp_var), True, True))
+        disp = np.asarray(res.dispersions, float)[nz]
+        y = counts[:, nzi]
+        beta, mu, hat, _ = tm("irls(LFC)", lambda: inf.irls(y, sf, X, disp, min_mu, beta_tol))
+        mu_layer = np.full((N, G), np.nan)  # dds.py:972-974
+        mu_layer[:, nz] = mu
+        del mu, hat
+        contrast = np.zeros(X.shape[1])
+        contrast[-1] = 1.0
+        m = mu_layer[:, nzi]
+        tm("wald_test", lambda: inf.wald_test(X, disp, beta, m, np.diag(np.repeat(1e-6, X.shape[1])), contrast, 0.0))
+        T["total_ms"] = float(sum(v for k, v in T.items() if k != "trend_passes"))
+        if with_shrink:  # not part of deseq2() (ds.py:400); the eighth method, reported beside the total
+            y = counts[:, nzi]
+            tm("lfc_shrink_nbinom_glm", lambda: inf.lfc_shrink_nbinom_glm(X, y, 1.0 / disp, np.log(sf), 15.0, 1.0, "L-BFGS-B",
+                                                                          X.shape[1] - 1))
+        return {k: round(v, 3) for k, v in T.items()}
+
+    first = one_pass()
+    repeat = one_pass()
+    out = {"workload": f"{G} genes x {N} samples, p={X.shape[1]}: HipInference methods on host arrays in dds.py / ds.py call "
+                       "order, fresh host copies per call", "first": first, "repeat": repeat,
+           "total_ms": repeat["total_ms"], "total_ms_first": first["total_ms"]}
+    stats = getattr(inf, "cache_stats", None)
+    if stats is not None:
+        out["cache"] = stats()
     return out
 
 
@@ -408,6 +537,11 @@ def main():
                                     "note": "apeGLM MAP LFC of the last coefficient, all genes (not part of value)"}
         except Exception as e:  # noqa: BLE001
             extras["extras_error"] = repr(e)
+        if world == 1 and not os.environ.get("DSQ_BENCH_NO_PLUGIN"):
+            try:  # the drop-in path (HipInference under the reference's call sequence), host arrays in and out
+                extras["plugin_path"] = measure_plugin_path(counts, X, ctx, res_prof)
+            except Exception as e:  # noqa: BLE001
+                extras["plugin_path_error"] = repr(e)
     barrier()
 
     if rank != 0:
@@ -514,11 +648,15 @@ def main():
                 # the other BASELINE configurations on the same device (configs[1], [3] at full size, and one GPU's share
                 # of configs[4]): each with its step time, its dispersion-stage roofline fraction and an in-run parity check
                 oc = {}
-                for nm, gn, pg in (("c2", 0, 2000), ("c4", 0, 0), ("c5", 7500, 300)):
+                for nm, gn, pg, st, wu in (("c2", 0, 2000, 20, 5), ("c4", 0, 0, 20, 5), ("c5", 7500, 300, 20, 5),
+                                           ("c5", 0, 0, 8, 3)):
+                    key = nm if gn == 0 else f"{nm}_shard"
+                    if key == "c5" and os.environ.get("DSQ_BENCH_NO_C5_FULL"):
+                        continue
                     try:
-                        oc[nm if gn == 0 else f"{nm}_shard"] = measure_other_config(nm, gn, ctx, 5, 2, pg, n_jobs)
+                        oc[key] = measure_other_config(nm, gn, ctx, st, wu, pg, n_jobs)
                     except Exception as e:  # noqa: BLE001
-                        oc[nm] = {"error": repr(e)}
+                        oc[key] = {"error": repr(e)}
                 if "c4" in oc and "parity_c4" in extras:
                     oc["c4"]["parity"] = extras["parity_c4"]
                 extras["other_configs"] = oc

@@ -756,8 +756,10 @@ class _OracleInference:
     interface in ``DeseqDataSet``'s call order (dds.py:713-984, ds.py:303-360) — tests use it to run the
     engine's ``HipInference`` plug-in under the reference's orchestration."""
 
-    def __init__(self, n_jobs=1):
+    def __init__(self, n_jobs=1, irls_maxiter=250):
         self.n_jobs = n_jobs
+        self.irls_maxiter = irls_maxiter  # `maxiter` of Inference.irls (inference.py:46-119): tests lower it to push genes
+                                          # through the rescue of utils.py:374-413
 
     def fit_rough_dispersions(self, normed_counts, design_matrix):
         return rough_dispersions(normed_counts, design_matrix)
@@ -769,7 +771,8 @@ class _OracleInference:
         return lin_reg_mu(counts, size_factors, design_matrix, min_mu)
 
     def irls(self, counts, size_factors, design_matrix, disp, min_mu, beta_tol, **kw):
-        return irls(counts, size_factors, design_matrix, disp, min_mu, beta_tol, n_jobs=self.n_jobs)
+        return irls(counts, size_factors, design_matrix, disp, min_mu, beta_tol, maxiter=self.irls_maxiter,
+                    n_jobs=self.n_jobs)
 
     def alpha_mle(self, counts, design_matrix, mu, alpha_hat, min_disp, max_disp, prior_disp_var=None,
                   cr_reg=True, prior_reg=False, **kw):

@@ -417,6 +417,8 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_resume) (void)hipFree(ctx->d_resume);
     if (ctx->d_mix) (void)hipFree(ctx->d_mix);
+    if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
+    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
     if (ctx->d_trend_grid) (void)hipFree(ctx->d_trend_grid);
@@ -676,6 +678,7 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     dsq::IrlsExtras ex_local{};
     if (extras != nullptr) ex_local = *extras;
+    const dsq::MixDesign* const extras_in_mix = ex_local.mix;
     ex_local.optimizer = optimizer;
     DSQ_CHECK_ARG(optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
     extras = &ex_local;
@@ -727,6 +730,13 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
         n_fb = *h_cnt;
     }
     if (n_fb > 0) {  // stream-ordered ahead of the caller's next work: no second synchronisation
+        if (ex_local.cooks_ld != 0 && ex_local.cooks != nullptr && ex_local.flags != nullptr) {
+            // slot-ordered Cook's layer (mixed designs): the general rescue kernels write sample order - into scratch rows
+            // that launch_irls_rescue scatters through MixDesign::slot_of
+            DSQ_HIP(ensure_ws(ctx, (size_t)n_fb * ldn * sizeof(double)));
+            ex_local.cooks_tmp = (double*)ctx->d_ws;
+            ex_local.mix = extras_in_mix;
+        }
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
                                         d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras,
@@ -814,6 +824,7 @@ int dsq_dev_alpha_mle2(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int
 int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** out) {
     DSQ_CHECK_ARG(out != nullptr && design != nullptr, "null argument");
     *out = nullptr;
+    DSQ_HIP(hipSetDevice(ctx->device));  // (the descriptor's block must live on this context's GPU)
     if (P < 1 || P > dsq::kMixMaxP || N < 2 || N > 65535 || !dsq::alpha_mix_enabled()) return DSQ_OK;
     const bool force = getenv("DSQ_MIX_FORCE") != nullptr;  // tests: also designs whose padding exceeds the waste limit
     // columns by decreasing number of distinct values

@@ -317,6 +317,8 @@ __global__ __launch_bounds__(kBlock) void k_irls_rescue(const int32_t* __restric
     __shared__ IrlsRescueWork<P> work[kWavesPerBlock];
     LfcEpilogue E;
     epilogue_begin<P>(E, ex, g, ldn);
+    // slot-ordered Cook's layer (mixed designs): this kernel writes sample order - into the scratch row of list entry k
+    if (ex.cooks_ld != 0 && E.cooks_row != nullptr) E.cooks_row = ex.cooks_tmp + (size_t)k * ldn;
     double b[P];
     const IrlsOut o = irls_rescue_gene<DeviceWave, P>(A, work[threadIdx.x >> 6], b,
                                                       mu ? mu + (size_t)g * ldn : nullptr,
@@ -536,6 +538,20 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     return hipGetLastError();
 }
 
+// Cook's rows of rescued genes: sample-order scratch rows -> the slot-ordered layer of a mixed design (dsq_mix.h)
+__global__ __launch_bounds__(256) void k_cooks_rows_to_slots(const double* __restrict__ tmp, int ldn,
+                                                             const int32_t* __restrict__ fb_list, int n_fb,
+                                                             const int32_t* __restrict__ n_dev,
+                                                             const int32_t* __restrict__ slot_of, int N,
+                                                             double* __restrict__ cooks, int cooks_ld) {
+    if (n_dev != nullptr) n_fb = min(n_fb, *n_dev);
+    const int k = blockIdx.x;
+    if (k >= n_fb) return;
+    const double* src = tmp + (size_t)k * ldn;
+    double* dst = cooks + (size_t)fb_list[k] * cooks_ld;
+    for (int n = threadIdx.x; n < N; n += 256) dst[slot_of[n]] = src[n];
+}
+
 hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const double* sf,
                               const double* lsf, const double* Xt, const double* pinvXt, int ldx, int N, int P_,
                               int full_rank, const double* disp, double min_mu, double beta_tol,
@@ -547,13 +563,24 @@ hipError_t launch_irls_rescue(hipStream_t st, const int32_t* y, int ldn, const d
     if (extras != nullptr) ex = *extras;
     const bool wide = P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()));
     if (wide && n_dev != nullptr) return hipErrorInvalidValue;  // the LDS path takes its count from the host
-    if (wide)
-        return launch_wide_irls_rescue(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, P_, full_rank, disp, min_mu, beta_tol,
-                                       min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, &ex);
-    const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
-    DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
-                                          ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
-                                          maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, ex, n_dev))
+    const bool to_slots = ex.cooks_ld != 0 && ex.cooks != nullptr && ex.flags != nullptr;
+    if (to_slots && (ex.cooks_tmp == nullptr || ex.mix == nullptr)) return hipErrorInvalidValue;
+    // (ex.mix is a host pointer to the descriptor; its members are device pointers)
+    const int32_t* slot_of = to_slots ? ex.mix->slot_of : nullptr;
+    if (wide) {
+        hipError_t e = launch_wide_irls_rescue(st, y, ldn, sf, lsf, Xt, pinvXt, ldx, N, P_, full_rank, disp, min_mu,
+                                               beta_tol, min_beta, max_beta, maxiter, beta, mu, hat, conv, iters, fb_list,
+                                               n_fb, &ex);
+        if (e != hipSuccess) return e;
+    } else {
+        const dim3 grid(genes_to_blocks(n_fb)), block(kBlock);
+        DSQ_DISPATCH_P(P_, hipLaunchKernelGGL(k_irls_rescue<P>, grid, block, 0, st, y, ldn, sf, lsf, Xt, pinvXt,
+                                              ldx, N, full_rank, disp, min_mu, beta_tol, min_beta, max_beta,
+                                              maxiter, beta, mu, hat, conv, iters, fb_list, n_fb, ex, n_dev))
+    }
+    if (to_slots)
+        hipLaunchKernelGGL(k_cooks_rows_to_slots, dim3(n_fb), dim3(256), 0, st, ex.cooks_tmp, ldn, fb_list, n_fb, n_dev,
+                           slot_of, N, ex.cooks, ex.cooks_ld);
     return hipGetLastError();
 }
 

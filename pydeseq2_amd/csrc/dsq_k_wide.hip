@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64) void k_irls_rescue_wide(const int32_t* __restri
     DeviceWave::sync();
     LfcEpilogue E;
     wide_epilogue_begin(E, ex, g, ldn);
+    if (ex.cooks_ld != 0 && E.cooks_row != nullptr) E.cooks_row = ex.cooks_tmp + (size_t)k * ldn;  // (see k_irls_rescue)
     const IrlsOut o = irls_rescue_wide<DeviceWave>(A, W, Lb, xlu, nbd, mu ? mu + (size_t)g * ldn : nullptr,
                                                    hat ? hat + (size_t)g * ldn : nullptr, &E);
     for (int j = threadIdx.x & 63; j < P; j += 64) beta[(size_t)g * P + j] = W.v(0)[j];

@@ -185,6 +185,9 @@ struct IrlsExtras {
     double cutoff;
     double* cooks;               // [G][ldn] or null
     int cooks_ld;                // mixed designs: != 0: the layer is written in SLOT order with this pitch (>= mix->Ns)
+    double* cooks_tmp;           // rescue of diverged genes under cooks_ld != 0: [n_fb][ldn] scratch the general rescue kernels
+                                 // write their Cook's rows to in SAMPLE order (row k = k-th gene of the fallback list);
+                                 // launch_irls_rescue then scatters them into the slot-ordered layer
     uint8_t *any_all, *any_use, *any_use_nr, *few_above;  // [G]
     // fused Wald statistics: on when ridge != nullptr (device pointers)
     const double* ridge;         // [P*P]

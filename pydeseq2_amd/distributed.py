@@ -167,14 +167,18 @@ class TcpControl:
                 # A connection that is not one of this job's ranks (a rank of another job probing the port range reads
                 # the greeting, sees another base port and hangs up; a port scanner; a health probe) must not take the
                 # hub down: its handshake fails, the socket is closed, the hub keeps accepting until the deadline.
+                # The handshake is served inline, so it gets a SHORT deadline (a real rank answers the greeting within
+                # a round trip; a silent connection may not hold up the ranks waiting in the backlog), and the rank is
+                # only admitted once it has the hub's acknowledgement: a rank whose handshake was cut reconnects.
                 try:
-                    c.settimeout(min(5.0, max(left, 0.1)))
+                    c.settimeout(min(0.5, max(left, 0.1)))
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     # (the job's base port: two jobs with overlapping port ranges do not adopt each other's ranks)
                     c.sendall(self.MAGIC + int(port).to_bytes(4, "little"))
                     r = int.from_bytes(self._recvn(c, 4), "little")
                     if not (1 <= r < world) or r in peers:
                         raise ConnectionError(f"control plane: unexpected rank {r}")
+                    c.sendall(b"\x01")
                     c.settimeout(timeout)
                 except (OSError, ConnectionError):
                     c.close()
@@ -190,13 +194,14 @@ class TcpControl:
                         c = socket.create_connection((addr, pt), timeout=2)
                         c.settimeout(5)
                         if self._recvn(c, len(self.MAGIC) + 4) == self.MAGIC + int(port).to_bytes(4, "little"):
-                            c.settimeout(timeout)
                             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             c.sendall(int(rank).to_bytes(4, "little"))
-                            self.sock = c
-                            break
+                            if self._recvn(c, 1) == b"\x01":  # admitted (else: the hub dropped this handshake - retry)
+                                c.settimeout(timeout)
+                                self.sock = c
+                                break
                         c.close()
-                    except OSError:
+                    except (OSError, ConnectionError):
                         continue
                 if self.sock is None:
                     if time.time() - t0 > timeout:

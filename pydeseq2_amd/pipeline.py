@@ -146,7 +146,8 @@ class DeseqPipeline:
 
     def __init__(self, counts, design_matrix, *, ctx: Context | None = None, device: int = 0, min_mu=0.5,
                  min_disp=1e-8, max_disp=10.0, refit_cooks=True, min_replicates=7, beta_tol=1e-8,
-                 fit_type="parametric", keep_cooks=True, size_factors_fit_type="ratio", control_genes=None):
+                 fit_type="parametric", keep_cooks=True, size_factors_fit_type="ratio", control_genes=None,
+                 irls_maxiter=250):
         self.ctx = ctx if ctx is not None else Context(device)
         counts = np.asarray(counts)
         if counts.ndim != 2:
@@ -170,6 +171,7 @@ class DeseqPipeline:
         self.max_disp = float(max(max_disp, self.N))  # dds.py:312
         self.refit_cooks, self.min_replicates = bool(refit_cooks), int(min_replicates)
         self.beta_tol, self.fit_type = float(beta_tol), fit_type
+        self.irls_maxiter = int(irls_maxiter)  # `maxiter` of Inference.irls (inference.py:46-119; dds.py never changes it)
         self.keep_cooks = keep_cooks
         if size_factors_fit_type not in ("ratio", "poscounts", "iterative"):
             raise ValueError("size_factors_fit_type: 'ratio' (median of ratios), 'poscounts' or 'iterative'")
@@ -223,12 +225,14 @@ class DeseqPipeline:
             if mp.value:
                 self._mix, self._row_mode = mp.value, 3
                 ns = C.c_int()
-                ctx_.lib.dsq_mix_info(mp, C.byref(ns), None, None)
+                if ctx_.lib.dsq_mix_info(mp, C.byref(ns), None, None) != 0:
+                    raise RuntimeError("dsq_mix_info failed")
                 self._mix_slots = int(ns.value)
                 # the Cook's layer of such a design is written in slot order (coalesced rows, csrc/dsq_k_irls_mix.hip):
                 # whoever reads it - the outlier replacement on the device, layer() on the host - goes through this map
                 self._slot_of = np.empty(self.N, dtype=np.int32)
-                ctx_.lib.dsq_mix_slots(mp, _vp(self._slot_of.ctypes.data))
+                if ctx_.lib.dsq_mix_slots(mp, _vp(self._slot_of.ctypes.data)) != 0:
+                    raise RuntimeError("dsq_mix_slots failed")
         if self._row_mode:
             d_fl = DeviceArray(ctx_, (self.G,), np.int32)
             ctx_.call("dsq_dev_alpha_row_split", _vp(self.d_y.ptr), self.ldn, self.N, self.G, _vp(d_fl.ptr))
@@ -486,7 +490,7 @@ class DeseqPipeline:
             S["_irls_it"] = self._dvec(Gs, np.int32)
             self._k("irls_mu", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
-                    c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                    c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
                     _vp(d_b.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, None, _vp(d_c.ptr), _vp(S["_irls_it"].ptr),
                     self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
@@ -552,7 +556,7 @@ class DeseqPipeline:
             self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
         self._k("lfc_fit", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
-                c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), 250,
+                c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
                 _vp(S["beta"].ptr), _vp(d_mu.ptr) if d_mu else None, _vp(d_hat.ptr) if d_hat else None,
                 _vp(S["lconv"].ptr), None, self._cells_arg(), *ck,
                 _vp(ridge.ctypes.data), _vp(contrast.ctypes.data), c_double(lfc_null), alt,

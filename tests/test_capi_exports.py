@@ -49,6 +49,23 @@ def test_inference_interface_matches_reference():
         sig = inspect.signature(getattr(HipInference, name))
         assert list(sig.parameters)[1:] == params, name
     assert isinstance(HipInference.n_cpus, property)
+    # where the reference tree is present (the build container; not the GPU box): the table above IS the abstract class -
+    # every abstract method, its parameter names in order, and the defaults the reference declares
+    ref_file = "/root/reference/pydeseq2/inference.py"
+    if os.path.exists(ref_file):
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("_ref_inference_abc", ref_file)  # (numpy / pandas only)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ref = mod.Inference
+        assert sorted(ref.__abstractmethods__) == sorted(want)
+        for name in ref.__abstractmethods__:
+            rs, hs = inspect.signature(getattr(ref, name)), inspect.signature(getattr(HipInference, name))
+            assert list(rs.parameters) == list(hs.parameters), name
+            for k, rp in rs.parameters.items():
+                if rp.default is not inspect.Parameter.empty:
+                    assert hs.parameters[k].default == rp.default, (name, k)
 
 
 def test_fails_loudly_without_gpu():

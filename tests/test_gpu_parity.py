@@ -934,3 +934,61 @@ def test_mixed_design_irls_kernel_vs_reference_kats(inf, case, monkeypatch):
     assert (c0 == c1).all()
     assert_close(b1, b0, 1e-8, 1e-10, "beta, 17-bit gene")
     assert_close(H1, H0, 1e-8, 1e-12, "hat, 17-bit gene")
+
+
+def test_mixed_design_cooks_layer_of_rescued_genes():
+    """for mixed designs the Cook's layer is slot-ordered, and genes that leave the mixed IRLS kernel for the
+    general rescue kernel (utils.py:374-413) get their row written in sample order.  The rescued rows must land in their own
+    slot-ordered row (and nobody else's).  `irls_maxiter=5` (the `maxiter` of Inference.irls) pushes a quarter of the genes through the
+    rescue on both sides: layer('cooks') of EVERY gene against the oracle."""
+    import pydeseq2_amd
+
+    G = 96
+    counts, X = _mixed_case(8, 3, 1400, G, 4242, (2, 4))
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0, irls_maxiter=5)
+    assert pipe._row_mode == 3 and pipe._cooks_ld() > 0, "not on the slot-ordered mixed-design path"
+    res = pipe.deseq2()
+    ref = orc.deseq2(counts, X, n_jobs=_jobs(), inference=orc._OracleInference(_jobs(), irls_maxiter=5))
+    sweeps = orc.irls(counts, ref.size_factors, X, ref.dispersions, maxiter=250, return_iters=True, n_jobs=_jobs())[-1]
+    rescued = sweeps >= 4  # (>= 5 sweeps: rescued, utils.py:374; one sweep of margin for the looser tolerance)
+    assert (sweeps >= 5).sum() >= 10, "maxiter=5 did not push genes through the rescue: the test tests nothing"
+    ck = pipe.layer("cooks")
+    # rescued fits end where a loosely-toleranced L-BFGS-B stops (two implementations: 1e-6 on beta): 1e-4 on their rows;
+    # a misplaced row (the bug) is off by orders of magnitude
+    assert_close(ck[:, ~rescued], ref.cooks[:, ~rescued], 1e-6, 1e-12, "cooks layer, ordinary genes")
+    assert_close(ck[:, rescued], ref.cooks[:, rescued], 1e-4, 1e-10, "cooks layer, rescued genes (slot-ordered layer)")
+    assert_close(res.LFC, ref.LFC, 1e-4, 1e-6, "LFC incl. rescued genes")
+    assert (res.cooks_outlier == ref.cooks_outlier).all()
+
+
+def test_mixed_design_refit_with_rescued_genes():
+    """The same with a design whose rows repeat (a dose covariate with few distinct values next to a two-level factor):
+    cells of >= 7 replicates exist, so the outlier replacement READS the slot-ordered Cook's layer (dds.py:1301-1367) -
+    injected outliers in rescued and ordinary genes, replaced / refitted flags and the layer against the oracle."""
+    import pydeseq2_amd
+
+    rng = np.random.default_rng(99)
+    N, G = 960, 120
+    grp = (np.arange(N) % 2).astype(float)
+    dose = rng.permutation(np.arange(N) % 40).astype(float) / 10.0  # 40 distinct values -> "continuous" for the design analysis
+    X = np.column_stack([np.ones(N), grp, dose])
+    beta = np.vstack([rng.normal(5, 1, G), rng.normal(0, 0.3, G), rng.normal(0, 0.1, G)])
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * 2.0 ** (X @ beta)
+    size = 1 / (0.05 + 4 / mu.mean(0))
+    counts = rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu)).astype(np.int64)
+    for g in (5, 9, 50, 70):  # gross outliers: Cook's distance far beyond the cutoff
+        n = int(np.nonzero(grp == 0)[0][g % 7])
+        counts[n, g] = counts[:, g].max() * 400 + 10000
+    pipe = pydeseq2_amd.DeseqPipeline(counts, X, device=0, irls_maxiter=4)
+    if pipe._row_mode != 3 or pipe._cooks_ld() == 0:
+        pytest.skip("design not taken by the mixed-design IRLS kernel")
+    res = pipe.deseq2()
+    ref = orc.deseq2(counts, X, n_jobs=_jobs(), inference=orc._OracleInference(_jobs(), irls_maxiter=4))
+    assert ref.replaced.sum() >= 3, "the injected outliers were not replaced on the reference side"
+    assert (res.replaced == ref.replaced).all()
+    assert (res.refitted == ref.refitted).all()
+    assert_close(pipe.layer("cooks"), ref.cooks, 1e-4, 1e-10, "cooks layer")
+    assert_close(res.LFC, ref.LFC, 1e-4, 1e-6, "LFC")
+    assert_close(res.dispersions, ref.dispersions, 1e-4, 0, "dispersions")
+    assert (res.cooks_outlier == ref.cooks_outlier).all()

@@ -34,6 +34,7 @@
 extern "C" {
 #endif
 
+#define DSQ_ABI_VERSION 5   /* bumped whenever an exported signature changes; dsq_abi_version() returns the library's */
 #define DSQ_MAX_P 32        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path */
 #define DSQ_SHRINK_MAX_P 32 /* apeGLM shrinkage (dsq_*_lfc_shrink*): up to 12 columns in registers, 13 ... 32 run-time p */
 #define DSQ_BFGS_MAX_P 12   /* optimizer = "BFGS" of the dispersion fit / the IRLS rescue: register kernels only */
@@ -108,9 +109,30 @@ int dsq_d2h_2d(dsq_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t s
                size_t row_bytes, size_t rows);
 
 /* ================================================================== Inference-level API
- * Host pointers in, host pointers out; stateless between calls (safe for the re-entrant
+ * Host pointers in, host pointers out; results depend on the arguments only (safe for the re-entrant
  * use by DeseqDataSet._refit_without_outliers, dds.py:1392-1408).
- * design[N*P] is the row-major design matrix (obsm["design_matrix"].values).          */
+ * design[N*P] is the row-major design matrix (obsm["design_matrix"].values).
+ *
+ * The reference calls its plug-in 7-9 times per deseq2() with the same matrices, each time as a fresh host copy
+ * (dds.py:747-785, 901-911, 953-960, 1149-1157; ds.py:338-350).  Behind these entry points every N x G host matrix is
+ * identified by an exact 128-bit content digest (every element takes part; host pointers are never trusted, a matrix
+ * mutated in place is a different matrix) and its gene-major device copy stays resident per context; mu_hat / mu
+ * matrices an entry point returns stay resident under the digest of what went back to the host, so the call that hands
+ * them back (alpha_mle, wald_test) uploads nothing.  LRU over a byte budget (default: a quarter of the device memory;
+ * environment DSQ_PLUGIN_CACHE_MB, DSQ_PLUGIN_CACHE=0 switches the cache off, DSQ_HASH_THREADS the digest's host
+ * threads).  csrc/dsq_plugin_cache.h.                                                                          */
+int dsq_abi_version(void);   /* DSQ_ABI_VERSION of the loaded library */
+/* enabled / budget_bytes: < 0 leaves the setting as it is */
+int dsq_plugin_cache_config(dsq_ctx* ctx, int enabled, long long budget_bytes);
+int dsq_plugin_cache_clear(dsq_ctx* ctx);   /* frees every resident matrix and pooled buffer */
+/* out[0..n): hits, misses, adopted (resident outputs), evictions, bytes uploaded, bytes downloaded (N x G layers), host
+ * milliseconds spent in digests, resident bytes, pooled free bytes, resident matrices, hipMalloc calls, budget bytes */
+int dsq_plugin_cache_stats(dsq_ctx* ctx, double* out, int n);
+/* The digest itself (needs no context / GPU): elem_type 0 int32, 1 int64 (counts: digest of the VALUES, so both types of
+ * the same matrix agree), 2 double (bit patterns); layout as dsq_layout; out2 = the two 64-bit halves.  Independent of
+ * layout and thread count by construction. */
+int dsq_plugin_digest_host(const void* data, int elem_type, int layout, int N, int G, int n_threads,
+                           unsigned long long* out2);
 
 /* Inference.lin_reg_mu (inference.py:13-44; DefaultInference.lin_reg_mu
  * default_inference.py:58-81 -> utils.fit_lin_mu utils.py:682-715).
@@ -123,21 +145,33 @@ int dsq_inf_lin_reg_mu(dsq_ctx* ctx, const void* counts, int count_type, int cou
  * utils.py:273-438).  beta_out[G*P]; mu_out, hat_out: G x N gene-major; converged[G].
  * optimizer (utils.py:343, the rescue of diverged genes utils.py:389-399): 0 = "L-BFGS-B" (bounded; the default and the
  * only one dds.py / ds.py pass), 1 = "BFGS" (scipy's unbounded BFGS restated, csrc/dsq_bfgs.h; at most 12 columns). */
+int dsq_inf_irls2(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                  const double* size_factors, const double* design, const double* disp, int N,
+                  int G, int P, double min_mu, double beta_tol, double min_beta, double max_beta,
+                  int maxiter, double* beta_out, double* mu_out, double* hat_out,
+                  uint8_t* converged, int optimizer);
+/* (the signature of ABI versions < 5, without the trailing optimizer: L-BFGS-B) */
 int dsq_inf_irls(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                  const double* size_factors, const double* design, const double* disp, int N,
                  int G, int P, double min_mu, double beta_tol, double min_beta, double max_beta,
                  int maxiter, double* beta_out, double* mu_out, double* hat_out,
-                 uint8_t* converged, int optimizer);
+                 uint8_t* converged);
 
 /* Inference.alpha_mle (inference.py:121-178; default_inference.py:126-161 ->
  * utils.fit_alpha_mle utils.py:441-564, grid_search.grid_fit_alpha grid_search.py:54-142).
  * mu given in `mu_layout`; prior_disp_var ignored unless prior_reg; optimizer (utils.py:546-554): 0 = "L-BFGS-B",
  * 1 = "BFGS" (at most 12 design columns). */
+int dsq_inf_alpha_mle2(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                       const double* design, const double* mu, int mu_layout,
+                       const double* alpha_hat, int N, int G, int P, double min_disp,
+                       double max_disp, double prior_disp_var, int cr_reg, int prior_reg,
+                       double* alpha_out, uint8_t* converged, int optimizer);
+/* (the signature of ABI versions < 5, without the trailing optimizer: L-BFGS-B) */
 int dsq_inf_alpha_mle(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                       const double* design, const double* mu, int mu_layout,
                       const double* alpha_hat, int N, int G, int P, double min_disp,
                       double max_disp, double prior_disp_var, int cr_reg, int prior_reg,
-                      double* alpha_out, uint8_t* converged, int optimizer);
+                      double* alpha_out, uint8_t* converged);
 
 /* Inference.wald_test (inference.py:180-235; default_inference.py:163-198 ->
  * utils.wald_test utils.py:718-811).  lfc[G*P] natural log; ridge[P*P]; contrast[P];
@@ -155,6 +189,10 @@ int dsq_inf_fit_rough_dispersions(dsq_ctx* ctx, const double* normed, int layout
                                   const double* design, int N, int G, int P, double* alpha_out);
 int dsq_inf_fit_moments_dispersions(dsq_ctx* ctx, const double* normed, int layout,
                                     const double* size_factors, int N, int G, double* alpha_out);
+/* ... that also reports all_zero[G] (1: every normalised count of the gene is zero): the reference drops those columns
+ * before taking the moments (utils.py:878), i.e. the caller drops the same entries of alpha_out */
+int dsq_inf_fit_moments_dispersions2(dsq_ctx* ctx, const double* normed, int layout, const double* size_factors,
+                                     int N, int G, double* alpha_out, uint8_t* all_zero);
 
 /* Inference.dispersion_trend_gamma_glm (inference.py:284-308; default_inference.py:200-230): ONE gamma-GLM
  * fit targets ~ a0 + a1 * covariates (L-BFGS-B from (1, 1), lower bound 1e-12, scipy defaults; NaN entries
@@ -470,10 +508,15 @@ int dsq_dev_vst(dsq_ctx* ctx, const void* d_counts_sm, int count_type, int N, in
  * design width up to 32), 1 "BFGS" (gtol = 1e-8), 2 "Newton-CG" (with the reference's Hessian; scipy's default xtol - the
  * ftol / gtol options are unknown to that method) - the latter two for designs of at most DSQ_BFGS_MAX_P = 12 columns;
  * `converged` is the chosen optimiser's res.success. */
+int dsq_inf_lfc_shrink_nbinom_glm2(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
+                                   const double* design, const double* size, const double* offset, int N, int G,
+                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
+                                   double* beta_out, double* inv_hessian_out, uint8_t* converged, int optimizer);
+/* (the signature of ABI versions < 5, without the trailing optimizer: L-BFGS-B) */
 int dsq_inf_lfc_shrink_nbinom_glm(dsq_ctx* ctx, const void* counts, int count_type, int count_layout,
                                   const double* design, const double* size, const double* offset, int N, int G,
                                   int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
-                                  double* beta_out, double* inv_hessian_out, uint8_t* converged, int optimizer);
+                                  double* beta_out, double* inv_hessian_out, uint8_t* converged);
 int dsq_dev_lfc_shrink(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_offset, const double* d_Xt,
                        int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                        double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,

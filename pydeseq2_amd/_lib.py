@@ -73,14 +73,25 @@ def load():
     proto("dsq_d2h_2d", _vp, _vp, c_size_t, _vp, c_size_t, c_size_t, c_size_t)
     # Inference level
     proto("dsq_inf_lin_reg_mu", _vp, _vp, c_int, c_int, _vp, _vp, c_int, c_int, c_int, c_double, _vp)
-    proto("dsq_inf_irls", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double, c_double,
+    # (the ...2 entry points carry the trailing `optimizer`; the unsuffixed ones are the pre-ABI-5 signatures: L-BFGS-B)
+    proto("dsq_inf_irls2", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double, c_double,
           c_double, c_double, c_int, _vp, _vp, _vp, _vp, c_int)
-    proto("dsq_inf_alpha_mle", _vp, _vp, c_int, c_int, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_double,
+    proto("dsq_inf_irls", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double, c_double,
+          c_double, c_double, c_int, _vp, _vp, _vp, _vp)
+    proto("dsq_inf_alpha_mle2", _vp, _vp, c_int, c_int, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_double,
           c_double, c_double, c_int, c_int, _vp, _vp, c_int)
+    proto("dsq_inf_alpha_mle", _vp, _vp, c_int, c_int, _vp, _vp, c_int, _vp, c_int, c_int, c_int, c_double,
+          c_double, c_double, c_int, c_int, _vp, _vp)
+    proto("dsq_abi_version", res=c_int)
+    proto("dsq_plugin_cache_config", _vp, c_int, C.c_longlong)
+    proto("dsq_plugin_cache_clear", _vp)
+    proto("dsq_plugin_cache_stats", _vp, C.POINTER(c_double), c_int)
+    proto("dsq_plugin_digest_host", _vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(C.c_ulonglong))
     proto("dsq_inf_wald_test", _vp, _vp, _vp, _vp, _vp, c_int, _vp, _vp, c_double, c_int, c_int, c_int,
           c_int, _vp, _vp, _vp)
     proto("dsq_inf_fit_rough_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, c_int, _vp)
     proto("dsq_inf_fit_moments_dispersions", _vp, _vp, c_int, _vp, c_int, c_int, _vp)
+    proto("dsq_inf_fit_moments_dispersions2", _vp, _vp, c_int, _vp, c_int, c_int, _vp, _vp)
     proto("dsq_inf_dispersion_trend_gamma_glm", _vp, _vp, _vp, c_int, _vp, _vp, C.POINTER(c_int))
     proto("dsq_inf_grid_fit_alpha", _vp, _vp, c_int, c_int, _vp, _vp, c_int, c_int, c_int, c_int, c_double, c_double,
           _vp)
@@ -115,8 +126,10 @@ def load():
     proto("dsq_dev_nll_scaled", _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp, _vp, _vp)
     proto("dsq_dev_logmeans_poscounts", _vp, _vp, c_int, c_int, c_int, _vp, _vp)
     proto("dsq_dev_vst", _vp, _vp, c_int, c_int, c_int, _vp, c_int, c_double, c_double, _vp)
-    proto("dsq_inf_lfc_shrink_nbinom_glm", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double,
+    proto("dsq_inf_lfc_shrink_nbinom_glm2", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double,
           c_double, c_int, _vp, _vp, _vp, c_int)
+    proto("dsq_inf_lfc_shrink_nbinom_glm", _vp, _vp, c_int, c_int, _vp, _vp, _vp, c_int, c_int, c_int, c_double,
+          c_double, c_int, _vp, _vp, _vp)
     proto("dsq_dev_lfc_shrink", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
           c_int, _vp, _vp, _vp)
     proto("dsq_dev_lfc_shrink2", _vp, _vp, c_int, _vp, _vp, c_int, c_int, c_int, c_int, _vp, c_double, c_double,
@@ -209,6 +222,9 @@ EXPORTS = [
     "dsq_dev_size_factors_new", "dsq_dev_mom_lin_coef", "dsq_dev_alpha_mle2", "dsq_dev_robust_disp", "dsq_dev_robust_disp2", "dsq_dev_lfc_fit", "dsq_dev_lfc_fit2", "dsq_dev_irls_layers",
     "dsq_side_begin", "dsq_side_end", "dsq_side_wait", "dsq_side_abort", "dsq_set_deferred", "dsq_irls_order_hint", "dsq_set_alpha_hook", "dsq_dev_alpha_mle3", "dsq_dev_alpha_mle4", "dsq_mix_create", "dsq_mix_destroy", "dsq_mix_info", "dsq_mix_slots", "dsq_mix_takes_irls", "dsq_dev_replace_outliers2", "dsq_mix_launch_count", "dsq_alpha_rows_eligible", "dsq_alpha_needs_mu", "dsq_dev_cell_mu", "dsq_dev_alpha_row_split",
     "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",
+    "dsq_inf_irls2", "dsq_inf_alpha_mle2", "dsq_inf_lfc_shrink_nbinom_glm2", "dsq_inf_fit_moments_dispersions2",
+    "dsq_abi_version", "dsq_plugin_cache_config", "dsq_plugin_cache_clear", "dsq_plugin_cache_stats",
+    "dsq_plugin_digest_host",
 ]
 
 
@@ -354,5 +370,54 @@ class DeviceArray:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class _PinnedPool:
+    """Free list of page-locked host buffers of one pipeline (results may outlive the pipeline)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.free, self.closed = ctx, [], False
+
+    def take(self, nbytes):
+        best = None
+        for k, (cap, ptr) in enumerate(self.free):  # best fit; a small request must not eat the big slab
+            if nbytes <= cap <= 2 * nbytes + 65536 and (best is None or cap < self.free[best][0]):
+                best = k
+        if best is not None:
+            cap, ptr = self.free.pop(best)
+            return _PinnedSlab(self, cap, ptr)
+        p = _vp()
+        self.ctx.call("dsq_host_alloc", c_size_t(int(nbytes)), C.byref(p))
+        return _PinnedSlab(self, int(nbytes), p.value)
+
+    def release(self, cap, ptr):
+        if self.closed:
+            self.ctx.call("dsq_host_free", _vp(ptr))
+        else:
+            self.free.append((cap, ptr))
+
+    def close(self):
+        self.closed = True
+        while self.free:
+            _cap, ptr = self.free.pop()
+            self.ctx.call("dsq_host_free", _vp(ptr))
+
+
+class _PinnedSlab:
+    """Page-locked host buffer; numpy views keep it alive, the last one returns it to the pool."""
+
+    def __init__(self, pool, cap, ptr):
+        self._pool, self.cap, self.ptr = pool, cap, ptr
+
+    def view(self, offset, count, dtype):
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(self.ptr + offset)
+        buf._slab = self  # numpy array -> ctypes buffer -> slab
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    def __del__(self):
+        try:
+            self._pool.release(self.cap, self.ptr)
         except Exception:
             pass

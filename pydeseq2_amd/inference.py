@@ -14,7 +14,7 @@ from typing import Literal
 
 import numpy as np
 
-from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context
+from ._lib import ALT, GENE_MAJOR, I32, I64, SAMPLE_MAJOR, Context, _PinnedPool
 
 _vp, c_int, c_double = C.c_void_p, C.c_int, C.c_double
 _OPTIMIZER = {"L-BFGS-B": 0, "BFGS": 1}  # the `optimizer` argument of dsq_inf_irls / dsq_inf_alpha_mle
@@ -67,9 +67,45 @@ class HipInference:
         dds.py:324-333); ignored.
     """
 
-    def __init__(self, device: int = 0, n_cpus: int | None = None, ctx: Context | None = None):
+    def __init__(self, device: int = 0, n_cpus: int | None = None, ctx: Context | None = None,
+                 pinned_outputs: bool = True):
         self.ctx = ctx if ctx is not None else Context(device)
         self._n_cpus = n_cpus
+        # The N x G layers a method returns (mu_hat, mu, hat diagonals: 0.5 GB each at 60k x 1k) are written into
+        # page-locked buffers that go back to a free list when the caller drops the array (the reference copies them into
+        # its own layers and does): a fresh np.empty costs 40 ms of page faults per layer, five times its PCIe transfer.
+        self._pinned = _PinnedPool(self.ctx) if pinned_outputs else None
+
+    def _layer(self, G, N):
+        """Host buffer of a G x N output layer (returned to the caller as its N x G transpose view)."""
+        if self._pinned is None or G * N * 8 < (1 << 20):
+            return np.empty((G, N))
+        return self._pinned.take(G * N * 8).view(0, G * N, np.float64).reshape(G, N)
+
+    # ---- the device cache behind the entry points (include/deseq_hip.h, csrc/dsq_plugin_cache.h)
+    def cache_stats(self) -> dict:
+        """Counters of the content-addressed device cache of this context."""
+        v = (c_double * 12)()
+        self.ctx.call("dsq_plugin_cache_stats", v, 12)
+        keys = ("hits", "misses", "adopted_outputs", "evictions", "h2d_bytes", "d2h_bytes", "hash_ms", "resident_bytes",
+                "pooled_free_bytes", "resident_matrices", "device_mallocs", "budget_bytes")
+        return {k: (round(float(x), 3) if k == "hash_ms" else int(x)) for k, x in zip(keys, v)}
+
+    def cache_config(self, enabled: bool | None = None, budget_bytes: int | None = None):
+        """Switch the cache on / off or set its byte budget (None: unchanged)."""
+        self.ctx.call("dsq_plugin_cache_config", -1 if enabled is None else int(bool(enabled)),
+                      C.c_longlong(-1 if budget_bytes is None else int(budget_bytes)))
+
+    def cache_clear(self):
+        """Free every resident matrix and pooled device buffer of the plug-in entry points."""
+        self.ctx.call("dsq_plugin_cache_clear")
+
+    def __del__(self):
+        try:
+            if self._pinned is not None:
+                self._pinned.close()
+        except Exception:
+            pass
 
     @property
     def n_cpus(self):  # noqa: D102
@@ -86,7 +122,7 @@ class HipInference:
         N, G = y.shape
         X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
         sf = _vec(size_factors)
-        out = np.empty((G, N))
+        out = self._layer(G, N)
         self.ctx.call("dsq_inf_lin_reg_mu", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data),
                       _vp(X.ctypes.data), N, G, X.shape[1], c_double(min_mu), _vp(out.ctypes.data))
         return out.T
@@ -104,10 +140,10 @@ class HipInference:
         X = np.ascontiguousarray(np.asarray(design_matrix, dtype=np.float64))
         P = X.shape[1]
         sf, d = _vec(size_factors), _vec(disp)
-        beta, mu, H = np.empty((G, P)), np.empty((G, N)), np.empty((G, N))
+        beta, mu, H = np.empty((G, P)), self._layer(G, N), self._layer(G, N)
         conv = np.empty(G, dtype=np.uint8)
         # last argument: the rescue of diverged genes - bounded L-BFGS-B (0) or scipy's BFGS restated (1)
-        self.ctx.call("dsq_inf_irls", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
+        self.ctx.call("dsq_inf_irls2", _vp(y.ctypes.data), ct, lay, _vp(sf.ctypes.data), _vp(X.ctypes.data),
                       _vp(d.ctypes.data), N, G, P, c_double(min_mu), c_double(beta_tol), c_double(min_beta),
                       c_double(max_beta), int(maxiter), _vp(beta.ctypes.data), _vp(mu.ctypes.data),
                       _vp(H.ctypes.data), _vp(conv.ctypes.data), _OPTIMIZER[optimizer])
@@ -126,7 +162,7 @@ class HipInference:
         m, mlay = _matrix_arg(mu)
         ah = _vec(alpha_hat)
         out, conv = np.empty(G), np.empty(G, dtype=np.uint8)
-        self.ctx.call("dsq_inf_alpha_mle", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
+        self.ctx.call("dsq_inf_alpha_mle2", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data), _vp(m.ctypes.data),
                       mlay, _vp(ah.ctypes.data), N, G, X.shape[1], c_double(min_disp), c_double(max_disp),
                       c_double(prior_disp_var if prior_disp_var is not None else 1.0), int(bool(cr_reg)),
                       int(bool(prior_reg)), _vp(out.ctypes.data), _vp(conv.ctypes.data), _OPTIMIZER[optimizer])
@@ -163,15 +199,15 @@ class HipInference:
 
     def fit_moments_dispersions(self, normed_counts, size_factors):
         """See ``Inference.fit_moments_dispersions`` (inference.py:261-282)."""
-        v = np.asarray(normed_counts, dtype=np.float64)
-        v = v[:, ~(v == 0).all(axis=0)]  # utils.py:878
-        v, lay = _matrix_arg(v)
+        v, lay = _matrix_arg(normed_counts)
         N, G = v.shape
         sf = _vec(size_factors)
-        out = np.empty(G)
-        self.ctx.call("dsq_inf_fit_moments_dispersions", _vp(v.ctypes.data), lay, _vp(sf.ctypes.data), N, G,
-                      _vp(out.ctypes.data))
-        return out
+        out, zero = np.empty(G), np.empty(G, dtype=np.uint8)
+        self.ctx.call("dsq_inf_fit_moments_dispersions2", _vp(v.ctypes.data), lay, _vp(sf.ctypes.data), N, G,
+                      _vp(out.ctypes.data), _vp(zero.ctypes.data))
+        # utils.py:878 drops the all-zero genes before taking the moments (the flags come from the device: no host pass
+        # over the matrix); dds.py:1149 never passes one
+        return out[zero == 0] if zero.any() else out
 
     # ------------------------------------------------------------------ trend
     def dispersion_trend_gamma_glm(self, covariates, targets):
@@ -230,7 +266,7 @@ class HipInference:
         P = X.shape[1]
         sz, off = _vec(size), _vec(offset)
         beta, invh, conv = np.empty((G, P)), np.empty((G, P, P)), np.empty(G, dtype=np.uint8)
-        self.ctx.call("dsq_inf_lfc_shrink_nbinom_glm", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data),
+        self.ctx.call("dsq_inf_lfc_shrink_nbinom_glm2", _vp(y.ctypes.data), ct, lay, _vp(X.ctypes.data),
                       _vp(sz.ctypes.data), _vp(off.ctypes.data), N, G, P, c_double(prior_no_shrink_scale),
                       c_double(prior_scale), int(shrink_index), _vp(beta.ctypes.data), _vp(invh.ctypes.data),
                       _vp(conv.ctypes.data), _SHRINK_OPTIMIZER[optimizer])

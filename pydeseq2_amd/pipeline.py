@@ -25,7 +25,7 @@ from scipy.stats import f as f_dist
 
 from . import trend as _trend
 from ._design import DesignPack, pad16
-from ._lib import ALT, HOOK_FN, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells
+from ._lib import ALT, HOOK_FN, I32, I64, SAMPLE_MAJOR, Context, DeviceArray, DsqCells, _PinnedPool, _PinnedSlab  # noqa: F401
 
 import ctypes as C
 import functools
@@ -85,55 +85,6 @@ class _View:
 
     def __init__(self, ptr):
         self.ptr = ptr
-
-
-class _PinnedPool:
-    """Free list of page-locked host buffers of one pipeline (results may outlive the pipeline)."""
-
-    def __init__(self, ctx):
-        self.ctx, self.free, self.closed = ctx, [], False
-
-    def take(self, nbytes):
-        best = None
-        for k, (cap, ptr) in enumerate(self.free):  # best fit; a small request must not eat the big slab
-            if nbytes <= cap <= 2 * nbytes + 65536 and (best is None or cap < self.free[best][0]):
-                best = k
-        if best is not None:
-            cap, ptr = self.free.pop(best)
-            return _PinnedSlab(self, cap, ptr)
-        p = _vp()
-        self.ctx.call("dsq_host_alloc", C.c_size_t(int(nbytes)), C.byref(p))
-        return _PinnedSlab(self, int(nbytes), p.value)
-
-    def release(self, cap, ptr):
-        if self.closed:
-            self.ctx.call("dsq_host_free", _vp(ptr))
-        else:
-            self.free.append((cap, ptr))
-
-    def close(self):
-        self.closed = True
-        while self.free:
-            _cap, ptr = self.free.pop()
-            self.ctx.call("dsq_host_free", _vp(ptr))
-
-
-class _PinnedSlab:
-    """Page-locked host buffer; numpy views keep it alive, the last one returns it to the pool."""
-
-    def __init__(self, pool, cap, ptr):
-        self._pool, self.cap, self.ptr = pool, cap, ptr
-
-    def view(self, offset, count, dtype):
-        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(self.ptr + offset)
-        buf._slab = self  # numpy array -> ctypes buffer -> slab
-        return np.frombuffer(buf, dtype=dtype, count=count)
-
-    def __del__(self):
-        try:
-            self._pool.release(self.cap, self.ptr)
-        except Exception:
-            pass
 
 
 class DeseqPipeline:

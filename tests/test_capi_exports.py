@@ -88,3 +88,45 @@ def test_host_mean_trend_matches_oracle():
 
     gw = np.clip(load_kat("p2")["gw_alpha"], 1e-8, 40)
     assert trend.mean_trend(gw, 1e-8) == orc.mean_trend(gw, 1e-8)
+
+
+def test_plugin_cache_digest_is_layout_dtype_and_thread_independent():
+    """The content digest the Inference-level entry points identify a host matrix by (include/deseq_hip.h,
+    csrc/dsq_plugin_cache.h): the same for the C-order and the F-order copy of a matrix, for int32 and int64 counts, for
+    any number of hashing threads - and different after ANY single-element change."""
+    import ctypes as C
+
+    import numpy as np
+
+    from pydeseq2_amd import _lib
+
+    lib = _lib.load()
+
+    def dg(a, threads=4):
+        et = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float64): 2}[a.dtype]
+        lay = 0 if a.flags.c_contiguous else 1
+        assert a.flags.c_contiguous or a.flags.f_contiguous
+        out = (C.c_ulonglong * 2)()
+        assert lib.dsq_plugin_digest_host(a.ctypes.data, et, lay, a.shape[0], a.shape[1], threads, out) == 0
+        return (int(out[0]), int(out[1]))
+
+    rng = np.random.default_rng(5)
+    y = rng.poisson(30, (700, 900)).astype(np.int64)  # (above the single-thread threshold)
+    base = dg(y)
+    assert dg(np.asfortranarray(y)) == base
+    assert dg(y.astype(np.int32)) == base and dg(np.asfortranarray(y.astype(np.int32))) == base
+    assert dg(y, 1) == base and dg(y, 7) == base and dg(np.asfortranarray(y), 13) == base
+    for (n, g) in ((0, 0), (699, 899), (123, 456)):
+        z = y.copy()
+        z[n, g] += 1
+        assert dg(z) != base
+    z = y.copy()
+    z[3, 4], z[4, 3] = y[4, 3], y[3, 4]  # the same multiset of values at other positions
+    assert (z == y).all() or dg(z) != base
+    assert dg(y.T.copy()) != base  # (another shape)
+    m = rng.normal(size=(300, 1100)) + 5.0
+    bm = dg(m)
+    assert dg(np.asfortranarray(m)) == bm and dg(m, 1) == bm
+    m2 = m.copy()
+    m2[17, 1000] = np.nextafter(m2[17, 1000], np.inf)  # one ulp
+    assert dg(m2) != bm

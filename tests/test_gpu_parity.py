@@ -992,3 +992,71 @@ def test_mixed_design_refit_with_rescued_genes():
     assert_close(res.LFC, ref.LFC, 1e-4, 1e-6, "LFC")
     assert_close(res.dispersions, ref.dispersions, 1e-4, 0, "dispersions")
     assert (res.cooks_outlier == ref.cooks_outlier).all()
+
+
+def test_plugin_cache_hits_adoption_and_invalidation():
+    """The device cache behind HipInference (csrc/dsq_plugin_cache.h): a second call with a fresh host COPY of the same
+    matrices uploads nothing; the mu_hat lin_reg_mu returned is recognised when it comes back into alpha_mle; a matrix
+    mutated IN PLACE (same pointer, one element changed) is a different matrix - the result follows the new content; the
+    results with the cache on equal those with it off, bit for bit."""
+    from pydeseq2_amd import HipInference
+
+    k = load_kat("p2")
+    counts, X, sf = k["counts"].astype(np.int64), k["X"], k["sf"]
+    N, G = counts.shape
+    maxd = float(max(10.0, N))
+    inf = HipInference(device=0)
+    inf.cache_clear()
+    s0 = inf.cache_stats()
+    mu = inf.lin_reg_mu(counts, sf, X, 0.5)
+    s1 = inf.cache_stats()
+    assert s1["misses"] == s0["misses"] + 1 and s1["adopted_outputs"] == s0["adopted_outputs"] + 1
+    mu_copy = np.ascontiguousarray(np.array(mu))  # what `layers["_mu_hat"][:, idx]` hands back: a fresh C-order copy
+    a1, c1 = inf.alpha_mle(counts.copy(), X, mu_copy, k["mom"], 1e-8, maxd)
+    s2 = inf.cache_stats()
+    assert s2["misses"] == s1["misses"], "the count matrix or the returned mu_hat was uploaded again"
+    assert s2["h2d_bytes"] == s1["h2d_bytes"] and s2["hits"] == s1["hits"] + 2
+    assert_close(a1, k["gw_alpha"], 1e-6, 0, "genewise alpha through the cache")
+    # F-order copy, int32 counts: the same matrices
+    a1f, _ = inf.alpha_mle(np.asfortranarray(counts.astype(np.int32)), X, np.asfortranarray(mu_copy), k["mom"], 1e-8, maxd)
+    assert inf.cache_stats()["misses"] == s2["misses"] and (a1f == a1).all()
+    # in-place mutation: same buffer, one count of gene 3 changed -> that gene's fit changes, nobody else's
+    y = counts.copy()
+    a_y, _ = inf.alpha_mle(y, X, mu_copy, k["mom"], 1e-8, maxd)
+    n_hit = int(np.argmax(y[:, 3]))
+    y[n_hit, 3] = y[n_hit, 3] * 3 + 50
+    s3 = inf.cache_stats()
+    a_y2, _ = inf.alpha_mle(y, X, mu_copy, k["mom"], 1e-8, maxd)
+    s4 = inf.cache_stats()
+    assert s4["misses"] == s3["misses"] + 1, "a mutated count matrix was served from the cache"
+    assert a_y2[3] != a_y[3] and (np.delete(a_y2, 3) == np.delete(a_y, 3)).all()
+    # ... and one element of mu changed by one ulp
+    m2 = mu_copy.copy()
+    m2[5, 9] = np.nextafter(m2[5, 9], np.inf)
+    inf.alpha_mle(counts, X, m2, k["mom"], 1e-8, maxd)
+    assert inf.cache_stats()["misses"] == s4["misses"] + 1
+    # cache off: every call uploads; identical results
+    inf.cache_config(enabled=False)
+    s5 = inf.cache_stats()
+    b1, d1 = inf.alpha_mle(counts, X, mu_copy, k["mom"], 1e-8, maxd)
+    b2, d2 = inf.alpha_mle(counts, X, mu_copy, k["mom"], 1e-8, maxd)
+    s6 = inf.cache_stats()
+    assert s6["misses"] == s5["misses"] + 4 and s6["hits"] == s5["hits"]
+    assert (b1 == a1).all() and (b2 == a1).all() and (d1 == c1).all()
+    inf.cache_config(enabled=True)
+    # a budget smaller than one matrix: still correct (entries of the running call are kept until it ends)
+    inf.cache_config(budget_bytes=1024)
+    e1, _ = inf.alpha_mle(counts, X, mu_copy, k["mom"], 1e-8, maxd)
+    assert (e1 == a1).all()
+    inf.cache_config(budget_bytes=8 << 30)
+    # a non-positive mu is still refused (checked on the device, once per resident matrix)
+    bad = mu_copy.copy()
+    bad[0, 0] = 0.0
+    with pytest.raises(ValueError):
+        inf.alpha_mle(counts, X, bad, k["mom"], 1e-8, maxd)
+    # all-zero genes are dropped by fit_moments_dispersions as utils.py:878 does
+    normed = counts / sf[:, None]
+    normed[:, 4] = 0.0
+    mde = inf.fit_moments_dispersions(normed, sf)
+    assert len(mde) == G - 1
+    assert_close(mde, orc.moments_dispersions(normed, sf), 1e-10, 1e-14, "moments with a zero gene")

@@ -330,10 +330,11 @@ def measure_plugin_path(counts, X, ctx, res, with_shrink=True):
         rde = tm("fit_rough_dispersions", lambda: inf.fit_rough_dispersions(normed, X))
         mde = tm("fit_moments_dispersions", lambda: inf.fit_moments_dispersions(normed, sf))
         mom = np.clip(np.minimum(rde, mde), min_disp, max_disp)
+        y = counts[:, nzi]  # (the reference's own copy, `self.X[:, self.non_zero_idx]`: outside the timers, as all of them)
         if linear:
-            mu_hat = tm("lin_reg_mu", lambda: inf.lin_reg_mu(counts[:, nzi], sf, X, min_mu))
+            mu_hat = tm("lin_reg_mu", lambda: inf.lin_reg_mu(y, sf, X, min_mu))
         else:
-            mu_hat = tm("irls(mu_hat)", lambda: inf.irls(counts[:, nzi], sf, X, mom, min_mu, beta_tol)[1])
+            mu_hat = tm("irls(mu_hat)", lambda: inf.irls(y, sf, X, mom, min_mu, beta_tol)[1])
         layer = np.full((N, G), np.nan)  # dds.py:770-771
         layer[:, nz] = mu_hat
         del mu_hat

@@ -1,5 +1,7 @@
 """Summary tail on the device: adjusted p-values with independent filtering, through
 the C ABI, against the oracle restatement of DeseqStats.summary() and the R fixtures."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -15,12 +17,18 @@ def _same(a, b, rtol=1e-12):
     np.testing.assert_allclose(a[ok], b[ok], rtol=rtol, atol=0)
 
 
-@pytest.mark.parametrize("case", ["plain", "ties", "many_zero_means", "few_rejections", "all_nan_but_few"])
+@pytest.mark.parametrize("case", ["plain", "ties", "ties354", "ties456", "many_zero_means", "few_rejections",
+                                  "all_nan_but_few"])
 def test_adjusted_pvalues_vs_oracle(case):
     from pydeseq2_amd import summary as sm
     from pydeseq2_amd._lib import Context
 
-    rng = np.random.default_rng(hash(case) % 1000)
+    # (hash() of a str is salted per process: this test used it and drew another vector in every run; two of the seeds on
+    # which p-values tie exactly on the alpha boundary - where the oracle's BH then rounded differently from scipy's - are
+    # now cases of their own)
+    rng = np.random.default_rng(int(case[4:]) if case[4:].isdigit() else zlib.crc32(case.encode()) % 1000)
+    if case.startswith("ties"):
+        case = "ties"
     G = 5000
     bm = 10 ** rng.uniform(-1, 4, G)
     p = rng.uniform(0, 1, G) ** np.where(bm > 50, 6, 1.2)  # expressed genes carry the signal

@@ -213,6 +213,28 @@ def test_lowess_and_bh_match_reference():
     np.testing.assert_allclose(orc.bh_adjust(k["bh_in"]), k["bh_out"], rtol=1e-14)
 
 
+def test_bh_equals_scipy_bit_for_bit_on_ties():
+    """scipy.stats.false_discovery_control is what the reference calls (ds.py:486-542); it is installed here.  On
+    p-values that tie exactly on the alpha boundary one rounding decides a rejection, so the restatement must keep
+    scipy's operation order (`ps *= m / i`): bit-for-bit on tie-heavy vectors, and the rejection counts of the
+    independent-filtering passes on the vector that exposed it (seed 354: 208 rejections in pass 47, not 206)."""
+    from scipy.stats import false_discovery_control
+
+    for seed in (354, 456, 903, 1, 2):
+        rng = np.random.default_rng(seed)
+        G = 5000
+        bm = 10 ** rng.uniform(-1, 4, G)
+        p = rng.uniform(0, 1, G) ** np.where(bm > 50, 6, 1.2)
+        p[rng.random(G) < 0.03] = np.nan
+        p, bm = np.round(p, 3), np.round(bm, 0)
+        ok = ~np.isnan(p)
+        assert (orc.bh_adjust(p[ok]) == false_discovery_control(p[ok], method="bh")).all()
+        _, info = orc.independent_filtering(bm, p, 0.05)
+        for i in (16, 17, 47, 48, 49):
+            use = (bm >= info["cutoffs"][i]) & ok
+            assert info["num_rej"][i] == int((false_discovery_control(p[use], method="bh") < 0.05).sum())
+
+
 def test_r_single_factor_summary_padj():
     """DeseqStats.summary() columns incl. independent filtering against R (tests/test_pydeseq2.py:94-118)."""
     counts, X, names = _run_r_case("synthetic", ["condition"])

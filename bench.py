@@ -489,13 +489,33 @@ def main():
     # stream around every k_alpha launch, read after the synchronisation the launch ends with anyway.
     pipe.time_kernels = False
     pipe.kernel_log = {}
+
+    class _CountingComm:  # (collectives of the TIMED steps themselves, not only of the profiled one)
+        def __init__(self, inner):
+            self.inner, self.rank, self.world, self.n = inner, inner.rank, inner.world, 0
+
+        def allreduce_sum(self, darr):
+            self.n += 1
+            return self.inner.allreduce_sum(darr)
+
+        def allgather(self, dsend, drecv):
+            self.n += 1
+            return self.inner.allgather(dsend, drecv)
+
+    counting = _CountingComm(comm) if comm is not None else None
+    if counting is not None:
+        pipe.comm = counting
     barrier()
+    syncs0 = int(ctx.lib.dsq_host_sync_count())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = pipe.deseq2()
     ctx.sync()
     dt = control.max_float(time.perf_counter() - t0)
+    host_syncs_per_step = (int(ctx.lib.dsq_host_sync_count()) - syncs0 - 1) / max(args.steps, 1)
     barrier()
+    if counting is not None:
+        pipe.comm = comm
     klog_timed = pipe.kernel_log
     # one extra, untimed step with per-stage event timing (synchronises after every stage)
     coll_log = []
@@ -668,6 +688,12 @@ def main():
         print("[bench] PARITY CHECK FAILED - no speed-up is reported", file=sys.stderr)
 
     coll_ms = round(float(sum(ms for _, ms in coll_log)), 3) if comm is not None else None
+    rccl_nranks = None
+    if transport == "rccl":
+        try:
+            rccl_nranks = comm.info()[0]  # what ncclCommCount says, not what the launcher's environment says
+        except Exception as e:  # noqa: BLE001
+            rccl_nranks = repr(e)
     out = {
         "metric": "genes/sec end-to-end deseq2() (size factors->dispersion->IRLS->Wald)",
         "value": round(value, 1), "unit": "genes/s", "n_gpus": world, "steps": args.steps,
@@ -678,6 +704,8 @@ def main():
                                + f", design {design} (p={X.shape[1]}), NB counts (SURVEY 8d generator)",
                    "genes_per_gpu": G, "genes_total": G_total, "samples": N, "p": int(X.shape[1]),
                    "collectives": transport, "generator": generator,
+                   "sample_block_rows": (None if samp is None else int(samp.shape[0])),
+                   "rccl_nranks": rccl_nranks,
                    "device": info["name"] or f"{info['arch']} ({info['cu_count']} CUs)", "arch": info["arch"]},
         "first_call_ms": round(first_call_ms, 3), "cold_first_call_ms": round(cold_first_ms, 3),
         "first_call_note": "cold_first_call_ms: the very first deseq2() of the process on a fresh pipeline (code objects, "
@@ -689,7 +717,9 @@ def main():
         "h2d_note": f"host int64 {N} x {G} ({counts.nbytes / 1e6:.0f} MB per GPU) -> int32 in HBM through pinned "
                     "staging chunks + gene-major transposition; value_with_h2d = genes / (one upload + one step)",
         "collective_ms_per_step": coll_ms,
-        "collectives_per_step": len(coll_log) if comm is not None else None,
+        "collectives_per_step": (counting.n / max(args.steps, 1)) if counting is not None else None,
+        "collectives_profiled_step": len(coll_log) if comm is not None else None,
+        "host_syncs_per_step": round(host_syncs_per_step, 2),
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,

@@ -574,6 +574,15 @@ int dsq_comm_init(dsq_ctx* ctx, const char* uid128, int rank, int world);
 int dsq_comm_destroy(dsq_ctx* ctx);
 int dsq_comm_allreduce_sum(dsq_ctx* ctx, void* d_buf, size_t count, int dtype /*0 u32, 1 f64*/);
 int dsq_comm_allgather(dsq_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* nranks / rank as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank) */
+int dsq_comm_info(dsq_ctx* ctx, int* nranks, int* rank);
+/* number of host-side waits (hipStreamSynchronize / hipEventSynchronize) this library has made in this process */
+unsigned long long dsq_host_sync_count(void);
+/* Gene-sharded trend exchange: d_send[0..len) = d_a[0..n) then NaN, d_send[len..2 len) = d_b[0..n) then NaN (one
+ * all-gather carries both per-gene vectors); d_recv [world][2][len] -> d_a_all, d_b_all [world * len]. */
+int dsq_dev_pack2(dsq_ctx* ctx, const double* d_a, const double* d_b, int n, int len, double* d_send);
+int dsq_dev_unzip2(dsq_ctx* ctx, const double* d_recv, int world, int len, double* d_a_all, double* d_b_all);
+
 /* size factors pass by pass: keys -> per-sample counts -> (all-reduce) -> init -> 8 x
  * [hist -> (all-reduce) -> pick] -> finish.  d_keys: N*G u64, d_prefix: 2*N u64, d_rank: 2*N u32,
  * d_hist: 2*N*256 u32. */

@@ -86,6 +86,10 @@ def load():
     proto("dsq_plugin_cache_config", _vp, c_int, C.c_longlong)
     proto("dsq_plugin_cache_clear", _vp)
     proto("dsq_plugin_cache_stats", _vp, C.POINTER(c_double), c_int)
+    proto("dsq_comm_info", _vp, C.POINTER(c_int), C.POINTER(c_int))
+    proto("dsq_host_sync_count", res=C.c_ulonglong)
+    proto("dsq_dev_pack2", _vp, _vp, _vp, c_int, c_int, _vp)
+    proto("dsq_dev_unzip2", _vp, _vp, c_int, c_int, _vp, _vp)
     proto("dsq_plugin_digest_host", _vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(C.c_ulonglong))
     proto("dsq_inf_wald_test", _vp, _vp, _vp, _vp, _vp, c_int, _vp, _vp, c_double, c_int, c_int, c_int,
           c_int, _vp, _vp, _vp)
@@ -224,7 +228,7 @@ EXPORTS = [
     "dsq_upload_counts_i32", "dsq_inf_dispersion_trend_gamma_glm", "dsq_inf_grid_fit_alpha", "dsq_inf_grid_fit_beta",
     "dsq_inf_irls2", "dsq_inf_alpha_mle2", "dsq_inf_lfc_shrink_nbinom_glm2", "dsq_inf_fit_moments_dispersions2",
     "dsq_abi_version", "dsq_plugin_cache_config", "dsq_plugin_cache_clear", "dsq_plugin_cache_stats",
-    "dsq_plugin_digest_host",
+    "dsq_plugin_digest_host", "dsq_comm_info", "dsq_host_sync_count", "dsq_dev_pack2", "dsq_dev_unzip2",
 ]
 
 

@@ -14,6 +14,13 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
+
+// every host-side wait of this library is counted (dsq_host_sync_count: bench.py reports host synchronisations per step)
+static std::atomic<unsigned long long> g_dsq_host_syncs{0};
+#define hipStreamSynchronize(s) (++g_dsq_host_syncs, (hipStreamSynchronize)(s))
+#define hipEventSynchronize(e) (++g_dsq_host_syncs, (hipEventSynchronize)(e))
+
 #include "../../include/deseq_hip.h"
 #include "dsq_launch.h"
 #include "dsq_plugin_cache.h"
@@ -2175,6 +2182,8 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -2190,6 +2199,8 @@ bool load_rccl(std::string& err) {
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather) {
         err = "librccl.so lacks the expected nccl* symbols";
         return false;
@@ -2247,6 +2258,30 @@ int dsq_comm_allreduce_sum(dsq_ctx* ctx, void* d_buf, size_t count, int dtype) {
 int dsq_comm_allgather(dsq_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank) {
     DSQ_CHECK_ARG(ctx->comm != nullptr, "dsq_comm_init has not been called");
     DSQ_NCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, 0 /*ncclInt8*/, ctx->comm, ctx->stream));
+    return DSQ_OK;
+}
+
+// what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank): bench.py prints it in the result line
+int dsq_comm_info(dsq_ctx* ctx, int* nranks, int* rank) {
+    DSQ_CHECK_ARG(ctx->comm != nullptr, "dsq_comm_init has not been called");
+    DSQ_CHECK_ARG(g_rccl.CommCount != nullptr && g_rccl.CommUserRank != nullptr, "librccl.so lacks ncclCommCount");
+    if (nranks) DSQ_NCCL(g_rccl.CommCount(ctx->comm, nranks));
+    if (rank) DSQ_NCCL(g_rccl.CommUserRank(ctx->comm, rank));
+    return DSQ_OK;
+}
+
+unsigned long long dsq_host_sync_count(void) { return g_dsq_host_syncs.load(); }
+
+// gene-sharded trend exchange (pydeseq2_amd/distributed.py): both per-gene vectors of a rank in ONE send buffer, NaN-padded
+// to `len` genes each; after the all-gather the [world][2][len] block is split into the two [world * len] vectors the
+// trend / prior kernels read
+int dsq_dev_pack2(dsq_ctx* ctx, const double* d_a, const double* d_b, int n, int len, double* d_send) {
+    DSQ_CHECK_ARG(n >= 0 && n <= len, "n out of range");
+    DSQ_HIP(dsq::launch_pack2(ctx->stream, d_a, d_b, n, len, d_send));
+    return DSQ_OK;
+}
+int dsq_dev_unzip2(dsq_ctx* ctx, const double* d_recv, int world, int len, double* d_a_all, double* d_b_all) {
+    DSQ_HIP(dsq::launch_unzip2(ctx->stream, d_recv, world, len, d_a_all, d_b_all));
     return DSQ_OK;
 }
 

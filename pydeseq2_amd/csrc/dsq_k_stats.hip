@@ -1960,4 +1960,31 @@ hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out) 
     return hipGetLastError();
 }
 
+// Gene-sharded trend exchange: ONE all-gather carries both per-gene vectors of a rank.
+// pack:  send[0..len) = a[0..n) then NaN, send[len..2 len) = b[0..n) then NaN   (NaN = "no gene": the trend / prior kernels skip them)
+// unzip: recv [world][2][len] -> a_all [world * len], b_all [world * len]
+__global__ void k_pack2(const double* __restrict__ a, const double* __restrict__ b, int n, int len, double* __restrict__ send) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * len) return;
+    const int k = i < len ? i : i - len;
+    send[i] = k < n ? (i < len ? a[k] : b[k]) : __longlong_as_double(0x7ff8000000000000LL);
+}
+__global__ void k_unzip2(const double* __restrict__ recv, int world, int len, double* __restrict__ a_all, double* __restrict__ b_all) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= world * len) return;
+    const int r = i / len, k = i - r * len;
+    a_all[i] = recv[(size_t)r * 2 * len + k];
+    b_all[i] = recv[(size_t)r * 2 * len + len + k];
+}
+hipError_t launch_pack2(hipStream_t st, const double* a, const double* b, int n, int len, double* send) {
+    if (len <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack2, dim3((2 * len + 255) / 256), dim3(256), 0, st, a, b, n, len, send);
+    return hipGetLastError();
+}
+hipError_t launch_unzip2(hipStream_t st, const double* recv, int world, int len, double* a_all, double* b_all) {
+    if (world * len <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unzip2, dim3((world * len + 255) / 256), dim3(256), 0, st, recv, world, len, a_all, b_all);
+    return hipGetLastError();
+}
+
 }  // namespace dsq

@@ -347,6 +347,8 @@ hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, co
 hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
                             double max_disp, double* res_scratch, double* out2);
 hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out);
+hipError_t launch_pack2(hipStream_t st, const double* a, const double* b, int n, int len, double* send);
+hipError_t launch_unzip2(hipStream_t st, const double* recv, int world, int len, double* a_all, double* b_all);
 // normed counts (double, gene-major) based rough / moments for the Inference-level API
 hipError_t launch_rough_from_normed(hipStream_t st, const double* normed, int ldn, const double* Xt,
                                     const double* pinvXt, int ldx, int N, int G, int P, double* out);

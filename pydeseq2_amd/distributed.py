@@ -69,6 +69,25 @@ def trend_inputs_padded(gw_nz, nm_nz, G):
     return gw, nm
 
 
+def trend_gather_protocol(ops, allgather):
+    """Trend / prior inputs of ALL ranks with ONE collective: a rank packs its two per-gene vectors (raw genewise
+    dispersions, normalised means), each NaN-padded to the largest shard, into one send buffer [2 * Gpad]; the all-gather
+    gives [world][2][Gpad], which `ops.unzip` splits into the two [world * Gpad] vectors the trend and prior kernels
+    read.  `ops`: pack() -> send buffer, unzip(recv) -> (gw_all, nm_all)."""
+    return ops.unzip(allgather(ops.pack()))
+
+
+def pack_trend_inputs(gw_nz, nm_nz, G):
+    """numpy form of the packing (CPU tests, host-side callers): concatenated trend_inputs_padded vectors."""
+    return np.concatenate(trend_inputs_padded(gw_nz, nm_nz, G))
+
+
+def unzip_trend_inputs(recv, world, G):
+    """numpy form of the split: recv [world * 2 * G] -> (gw_all, nm_all), each [world * G] in rank order."""
+    v = np.asarray(recv).reshape(world, 2, G)
+    return v[:, 0, :].reshape(-1).copy(), v[:, 1, :].reshape(-1).copy()
+
+
 # ------------------------------------------------------------------ RCCL binding
 class _CStdoutToStderr:
     """librccl prints a version banner on C stdout at communicator creation; route it to stderr so
@@ -119,6 +138,12 @@ class RcclComm:
     def allgather(self, dsend: DeviceArray, drecv: DeviceArray):
         self.ctx.call("dsq_comm_allgather", _vp(dsend.ptr), _vp(drecv.ptr), C.c_size_t(dsend.nbytes))
         return drecv
+
+    def info(self):
+        """(nranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(0), C.c_int(0)
+        self.ctx.call("dsq_comm_info", C.byref(n), C.byref(r))
+        return int(n.value), int(r.value)
 
     def close(self):
         self.ctx.call("dsq_comm_destroy")
@@ -479,25 +504,52 @@ class DistDeseqPipeline(DeseqPipeline):
         return self._sf_finish(d_sf)
 
     def _gather_trend_inputs(self, Gn):
-        """All-gather (raw genewise dispersion, normalised mean) of every rank on the device: two
-        [world][Gpad] vectors (Gpad = largest shard), NaN beyond a rank's non-zero genes (the trend and
-        prior kernels skip NaNs)."""
+        """(raw genewise dispersion, normalised mean) of every rank on the device with ONE all-gather
+        (trend_gather_protocol): two [world * Gpad] vectors (Gpad = largest shard), NaN beyond a rank's non-zero genes
+        (the trend and prior kernels skip NaNs)."""
         d_gw, d_nm = self._last_gw_dev
-        G, W = self.Gpad, self.comm.world
-        out = []
-        for d_src in (d_gw, d_nm):
-            d_send = self._pooled((G,), np.float64)
-            if Gn < G:
-                self.ctx.memset(d_send.ptr, 0xFF, 8 * G)  # all-ones bit pattern: a quiet NaN
-            self.ctx.call("dsq_d2d", _vp(d_send.ptr), _vp(d_src.ptr), C.c_size_t(8 * Gn))
-            d_all = self._pooled((G * W,), np.float64)
-            self.comm.allgather(d_send, d_all)
-            out.append(d_all)
-        self._gathered = tuple(out)
+        G, W, pipe = self.Gpad, self.comm.world, self
+
+        class _Ops:
+            def pack(self):
+                d_send = pipe._pooled((2 * G,), np.float64)
+                pipe.ctx.call("dsq_dev_pack2", _vp(d_gw.ptr), _vp(d_nm.ptr), int(Gn), G, _vp(d_send.ptr))
+                return d_send
+
+            def unzip(self, d_recv):
+                d_a, d_b = pipe._pooled((G * W,), np.float64), pipe._pooled((G * W,), np.float64)
+                pipe.ctx.call("dsq_dev_unzip2", _vp(d_recv.ptr), W, G, _vp(d_a.ptr), _vp(d_b.ptr))
+                return d_a, d_b
+
+        def gather(d_send):
+            return self.comm.allgather(d_send, self._pooled((2 * G * W,), np.float64))
+
+        self._gathered = trend_gather_protocol(_Ops(), gather)
         return self._gathered
 
-    def _fit_trend(self, Gn):
+    def _trend_prior_fused(self, Gn, d_fit):
+        """The single-GPU step's fused call (trend fit, fitted values, MAD prior: one host synchronisation) on the
+        gathered vectors of all ranks; this rank's own fitted values (d_fit) follow from the coefficients without
+        another wait.  A step of the sharded pipeline thus has the same host synchronisations as the single-GPU one and
+        three collectives (two for the size factors under the sample-block protocol, one here)."""
         d_gw_all, d_nm_all = self._gather_trend_inputs(Gn)
+        n_all = self.Gpad * self.comm.world
+        c2, ok, n_outer, sq = (C.c_double * 2)(), C.c_int(0), C.c_int(0), C.c_double()
+        d_keep = self._dvec(n_all, np.uint8)
+        d_fit_all = self._dvec(n_all)
+        d_work = self._dvec(self.ctx.lib.dsq_prior_mad_work_doubles(int(n_all)))
+        self.ctx.call("dsq_dev_trend_prior", _vp(d_gw_all.ptr), _vp(d_nm_all.ptr), int(n_all), C.c_double(self.min_disp),
+                      C.c_double(self.max_disp), _vp(d_keep.ptr), _vp(d_fit_all.ptr), _vp(d_work.ptr), c2, C.byref(ok),
+                      C.byref(n_outer), C.byref(sq))
+        if not ok.value:
+            return None, None  # (the gathered vectors stay for _mean_trend / _prior)
+        self._gathered = None
+        d_nm = self._last_gw_dev[1]
+        self.ctx.call("dsq_dev_trend_eval", _vp(d_nm.ptr), int(Gn), C.c_double(c2[0]), C.c_double(c2[1]), _vp(d_fit.ptr))
+        return np.array([c2[0], c2[1]]), float(sq.value)
+
+    def _fit_trend(self, Gn):
+        d_gw_all, d_nm_all = self._gathered if self._gathered is not None else self._gather_trend_inputs(Gn)
         return self._run_trend_kernel(d_gw_all, d_nm_all, self.Gpad * self.comm.world)
 
     def _mean_trend(self, Gn):

@@ -193,6 +193,7 @@ class DeseqPipeline:
         self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
         self._robust_early = bool(os.environ.get("DSQ_ROBUST_EARLY"))  # (measurement switch: fork before the genewise fit)
         self._robust_late = bool(os.environ.get("DSQ_ROBUST_LATE"))    # (measurement switch: fork after the genewise stage)
+        self._map_waits_side = os.environ.get("DSQ_MAP_WAIT", "1") != "0"  # the MAP launch waits for the side stream
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -753,10 +754,9 @@ class DeseqPipeline:
         coeffs = None
         fused_sq = None
         if self.fit_type == "parametric":
-            cls = type(self)
-            if (cls._fit_trend is DeseqPipeline._fit_trend and cls._prior is DeseqPipeline._prior
-                    and not (stop_after_trend or self.time_kernels)):
-                # trend fit, fitted values and prior in one call (one synchronisation instead of two and a launch gap)
+            if not (stop_after_trend or self.time_kernels):
+                # trend fit, fitted values and prior in one call (one synchronisation instead of two and a launch gap);
+                # the gene-sharded pipeline runs the same call on the all-gathered vectors (distributed.py)
                 coeffs, fused_sq = self._trend_prior_fused(Gn, S["fit"])
             else:
                 coeffs = self._fit_trend(Gn)
@@ -802,6 +802,12 @@ class DeseqPipeline:
         t3 = tick(); T["trend_prior"] = t3 - t2
 
         # ---- MAP dispersions + dispersion outliers (dds.py:886-935)
+        if self.overlap and self._map_waits_side and self._side_pending:
+            # the robust-dispersion kernel of the side stream is (0.9 ms at c3) a little longer than the latency-bound tail
+            # it runs under; a MAP launch that starts beside its last 0.15-0.25 ms shares every compute unit with it for
+            # its whole life (persistent workgroups) and pays more than the wait costs (A/B: DSQ_MAP_WAIT=0)
+            ctx.call("dsq_side_wait")
+            self._side_pending = False
         self._stage_map(d_ynz, d_mu_hat, Gn, d_sf, r.prior_disp_var, r.squared_logres, S)
         t4 = tick(); T["MAP"] = t4 - t3
 
@@ -812,7 +818,7 @@ class DeseqPipeline:
         wald_args = (ridge, contrast, float(np.log(2) * lfc_null), ALT[alt_hypothesis])
         cld = self._cooks_ld()
         d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
-        if self.overlap:
+        if self.overlap and self._side_pending:
             ctx.call("dsq_side_wait")
             self._side_pending = False
         d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks))

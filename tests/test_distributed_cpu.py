@@ -55,10 +55,24 @@ def _worker(rank, world, port, q):
     sf = D.median_select_protocol(NumpySfOps(mine, lm), allreduce)
     # trend inputs: gather padded vectors
     G = len(shard) + 3
-    gw, nm = D.trend_inputs_padded(np.full(len(shard), 0.1 * (rank + 1)), np.arange(len(shard)) + 1.0, G)
-    out = [torch.zeros(2 * G, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(out, torch.from_numpy(np.concatenate([gw, nm])))
-    allv = torch.stack(out).numpy().reshape(world, 2, G)
+    n_gathers = [0]
+
+    def allgather_f64(x):
+        n_gathers[0] += 1
+        out = [torch.zeros(len(x), dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)))
+        return torch.cat(out).numpy()
+
+    class NumpyTrendOps:  # what DistDeseqPipeline._gather_trend_inputs does with dsq_dev_pack2 / dsq_dev_unzip2
+        def pack(self):
+            return D.pack_trend_inputs(np.full(len(shard), 0.1 * (rank + 1)), np.arange(len(shard)) + 1.0, G)
+
+        def unzip(self, recv):
+            return D.unzip_trend_inputs(recv, world, G)
+
+    gw_all, nm_all = D.trend_gather_protocol(NumpyTrendOps(), allgather_f64)
+    assert n_gathers[0] == 1  # ONE collective for both per-gene vectors
+    allv = np.stack([gw_all.reshape(world, G), nm_all.reshape(world, G)], axis=1)  # [world][2][G]
     # the two-collective protocol: all-gather of log means, medians of the rank's own samples, all-gather of medians
     class NumpySampleOps:
         def local_logmeans(self):

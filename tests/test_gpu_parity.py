@@ -619,9 +619,9 @@ def test_distributed_pipeline_two_ranks_threads(sf_mode):
     [t.join(600) for t in ts]
     assert not errs, errs
     # collectives per step + 1 at construction: radix protocol 1 + 8 all-reduces, sample-shard protocol 2 all-gathers;
-    # trend inputs 2 all-gathers in both
+    # trend inputs ONE all-gather in both (both per-gene vectors packed into one send buffer): 3 per step
     if sf_mode != "iterative":
-        assert n_collectives[0] == (1 + 2 + 2 if sf_mode == "ratio-sample-shard" else 1 + 9 + 2), n_collectives
+        assert n_collectives[0] == (1 + 2 + 1 if sf_mode == "ratio-sample-shard" else 1 + 9 + 1), n_collectives
     for rank in range(W):
         sl = slice(cuts[rank], cuts[rank + 1])
         r = out[rank]
@@ -764,8 +764,35 @@ def test_bench_two_ranks_strong_scaling_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["genes_total"] == 3000
     assert d["config"]["genes_per_gpu"] == 1500 and "host-staged" in d["config"]["collectives"]
-    assert d["collectives_per_step"] >= 3 and d["collective_ms_per_step"] > 0
+    assert d["collectives_per_step"] == 3 and d["collective_ms_per_step"] > 0
     assert d["parity"]["ok"], d["parity"]
+
+
+@pytest.mark.parametrize("config,genes,per_rank,block", [("c3", 0, 7500, 125), ("c5", 6000, 750, 625)])
+def test_bench_eight_ranks_on_one_gpu(config, genes, per_rank, block):
+    """The driver's `--gpus 8` launch shape on a one-GPU box: eight ranks of bench.py share device 0 over the host-staged
+    transport - strong scaling of BASELINE configs[2] (60 000 x 1000: 7 500 genes and a block of 125 samples per rank)
+    and of a slice of configs[4] (5000 samples: blocks of 625; the tiled generator builds only the rank's blocks) -
+    three collectives per step and the single-GPU step's host synchronisations."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSQ_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", config, "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"] + (["--genes", str(genes)] if genes else [])
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["genes_per_gpu"] == per_rank and d["config"]["genes_total"] == 8 * per_rank
+    assert d["config"]["sample_block_rows"] == block
+    assert d["collectives_per_step"] == 3, d["collectives_per_step"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -725,6 +725,9 @@ def main():
         "parity": parity,
         "stage_wall_ms_profiled_step": {k: round(v * 1e3, 3) for k, v in res_prof.timings.items()},
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if (cpu and parity_ok) else None,
+        "speedup_note": "value / cpu_baseline.value: GPU resident rate over the oracle ('port') on this box's host cores; the "
+                        "oracle is bit-identical to the unmodified reference and runs at 0.77-1.18 x its speed on the same "
+                        "cores (cpu_baseline.reference_slice, profiles/cpu_reference_slice.json, regenerated in round 5)",
     }
     out.update(extras)
     print(json.dumps(out))

@@ -347,6 +347,16 @@ int dsq_mix_info(const dsq_mix* mix, int* n_slots, int* n_cells, int* n_continuo
 int dsq_mix_slots(const dsq_mix* mix, int32_t* h_slot_of);
 /* 1 when dsq_dev_lfc_fit2 runs such a design on k_irls_mix (and may therefore be given a slot-ordered Cook's layer), else
  * 0: the library's own routing rule */
+/* Slot-ordered copies for the mixed-design kernels (round 5): the counts of a gene-major matrix as uint16 [G][Ns]
+ * (Ns from dsq_mix_info; 0xFFFF in padding slots; counts >= 65 534 saturate and set d_big[g]) and the IRLS route's mu_hat
+ * sf * exp(X beta) (dds.py:757-771, UNclamped) as fp64 [G][Ns] (0 in padding slots).  dsq_mix_bind hands them to the NEXT
+ * dispersion fit (dsq_dev_alpha_mle*) or IRLS fit (dsq_dev_lfc_fit*, dsq_dev_irls) of the context - one-shot; a fit of a
+ * mixed design that finds nothing bound builds its own copies per call. */
+int dsq_mix_bind(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const double* d_mu_slots);
+int dsq_dev_mix_counts_to_slots(dsq_ctx* ctx, const int32_t* d_y, int ldn, int G, const dsq_mix* mix, uint16_t* d_ys,
+                                uint8_t* d_big);
+int dsq_dev_mix_mu_slots(dsq_ctx* ctx, const dsq_mix* mix, const double* d_beta, const double* d_sf, int G,
+                         double* d_mu_slots);
 int dsq_mix_takes_irls(const dsq_mix* mix, int full_rank);
 /* diagnostics: launches of the mixed-design dispersion kernel by this process so far */
 int dsq_mix_launch_count(void);

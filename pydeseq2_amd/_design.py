@@ -4,6 +4,9 @@ from __future__ import annotations
 import numpy as np
 
 
+MAX_DESIGN_COLUMNS = 32  # DSQ_MAX_P of include/deseq_hip.h
+
+
 def pad16(n: int) -> int:
     return (int(n) + 15) & ~15
 
@@ -28,6 +31,11 @@ class DesignPack:
             raise ValueError("NaNs are not allowed in the design.")
         self.X = X
         self.N, self.P = X.shape
+        if self.P > MAX_DESIGN_COLUMNS:
+            # documented limit: the reference's per-gene solvers take any width (utils.py:345-371, numpy / scipy
+            # on a p x p system); here the p x p workspaces of the widest kernel family live in a wavefront's LDS segment
+            raise ValueError(f"The design matrix has {self.P} columns; the device kernels take at most "
+                             f"{MAX_DESIGN_COLUMNS} (DSQ_MAX_P).  Merge or drop design variables.")
         self.ldx = pad16(self.N)
         self.full_rank = bool(np.linalg.matrix_rank(X) == self.P)
         self.Xt = np.zeros((self.P, self.ldx))

@@ -64,8 +64,11 @@ struct dsq_ctx {
     size_t ws_cap = 0;
     void* d_resume = nullptr;     // parked optimiser states + gene list of the two-phase dispersion launch (grow-only)
     size_t resume_cap = 0;
-    void* d_mix = nullptr;        // wave-private mu_hat rows of the mixed-design dispersion kernel (grow-only)
+    void* d_mix = nullptr;        // slot-ordered copies (counts, mu_hat) of a mixed-design call whose caller bound none (grow-only)
     size_t mix_cap = 0;
+    const uint16_t* bind_ys = nullptr;  // dsq_mix_bind (one-shot: the next dispersion / IRLS fit consumes it)
+    const uint8_t* bind_big = nullptr;
+    const double* bind_mu = nullptr;
     void* d_mixw = nullptr;       // slot-ordered per-sample vectors of the mixed-design IRLS kernel (grow-only)
     size_t mixw_cap = 0;
     int32_t* d_redo = nullptr;    // genes the buffer-less robust-dispersion kernel hands back (side stream; grow-only)
@@ -205,6 +208,10 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     // optimizer: 0 = "L-BFGS-B" (the reference's default and the only one dds.py / ds.py use), 1 = "BFGS" (utils.py:546-554)
     if (G <= 0) return DSQ_OK;
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
+    struct Unbind {  // dsq_mix_bind is one-shot: whatever this call does with it, the next one starts unbound
+        dsq_ctx* c;
+        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; }
+    } unbind{ctx};
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes, [3] gene queue of the continuation launch
     int32_t* d_cnt = ctx->d_counter + 4;
@@ -228,19 +235,42 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         ex2.mid_hook = ctx->alpha_hook != nullptr ? fire_alpha_hook : nullptr;
         ex2.mid_arg = ctx;
         if (ex2.mix != nullptr && ex2.rows != nullptr && ex2.n_rows > 0) {
-            // wave-private mu_hat rows of the mixed-design kernel (persistent launch: a fixed number of wavefronts)
-            const size_t need_d = dsq::alpha_mix_scratch_doubles(*ex2.mix, ex2.n_rows);
-            if (need_d == 0) {
+            if (!dsq::alpha_mix_fits(*ex2.mix)) {
                 ex2.mix = nullptr;  // rows too long for that kernel: the general one takes every gene
             } else {
-                if (need_d * sizeof(double) > ctx->mix_cap) {
+                // the kernel streams the counts and mu_hat from slot-ordered copies: the caller's (dsq_mix_bind), or built
+                // here (plug-in entry points; mu_hat from the caller's matrix or from the IRLS coefficients)
+                const size_t Ns = (size_t)ex2.mix->Ns;
+                const uint16_t* ys = ctx->bind_ys;
+                const double* mus = ctx->bind_mu;
+                size_t need = 256;
+                if (mus == nullptr) need += (size_t)G * Ns * sizeof(double);
+                if (ys == nullptr) need += (size_t)G * Ns * sizeof(uint16_t) + (size_t)G + 256;
+                if ((mus == nullptr || ys == nullptr) && need > ctx->mix_cap) {
                     if (ctx->d_mix) (void)hipFree(ctx->d_mix);
                     ctx->d_mix = nullptr; ctx->mix_cap = 0;
-                    DSQ_HIP(hipMalloc(&ctx->d_mix, need_d * sizeof(double)));
-                    ctx->mix_cap = need_d * sizeof(double);
+                    DSQ_HIP(hipMalloc(&ctx->d_mix, need));
+                    ctx->mix_cap = need;
                 }
-                ex2.mix_scratch = (double*)ctx->d_mix;
-                ex2.mix_scratch_doubles = ctx->mix_cap / sizeof(double);
+                char* w = (char*)ctx->d_mix;
+                if (mus == nullptr) {
+                    double* t = (double*)w;
+                    w += (size_t)G * Ns * sizeof(double);
+                    if (d_mu != nullptr)
+                        DSQ_HIP(dsq::launch_mix_f64_to_slots(ctx->stream, d_mu, ldn, *ex2.mix, G, t));
+                    else if (ex2.mix_beta != nullptr && ex2.sf != nullptr)
+                        DSQ_HIP(dsq::launch_mix_mu_slots(ctx->stream, ex2.mix_beta, ex2.sf, *ex2.mix, G, t));
+                    else
+                        return fail(ctx, DSQ_ERR_ARG, "mixed-design dispersion fit: no mu_hat (matrix, bound slots or beta)");
+                    mus = t;
+                }
+                if (ys == nullptr) {
+                    uint16_t* t = (uint16_t*)w;
+                    DSQ_HIP(dsq::launch_mix_counts_to_slots(ctx->stream, d_y, ldn, *ex2.mix, G, t, (uint8_t*)(t + (size_t)G * Ns)));
+                    ys = t;
+                }
+                ex2.mix_ys = ys;
+                ex2.mix_mu = mus;
             }
         }
         if (ex2.mix == nullptr && d_mu == nullptr && ex2.mix_beta != nullptr)
@@ -624,6 +654,10 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     // optimizer of the rescue of diverged genes (utils.py:343, 389-399): 0 = bounded L-BFGS-B (default), 1 = BFGS
     if (G <= 0) return DSQ_OK;
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
+    struct Unbind {  // (see run_alpha)
+        dsq_ctx* c;
+        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; }
+    } unbind{ctx};
     dsq::IrlsExtras ex_local{};
     if (extras != nullptr) ex_local = *extras;
     const dsq::MixDesign* const extras_in_mix = ex_local.mix;
@@ -661,6 +695,23 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
         ex_local.mix_work = ctx->d_mixw;
         ex_local.mix_work_bytes = ctx->mixw_cap;
         ex_local.mix_queue = ctx->d_counter + 1;
+        // the counts in slot order: the caller's copy (dsq_mix_bind) or one built here
+        ex_local.mix_ys = ctx->bind_ys;
+        ex_local.mix_big = ctx->bind_big;
+        if (ex_local.mix_ys == nullptr || ex_local.mix_big == nullptr) {
+            const size_t Ns = (size_t)ex_local.mix->Ns;
+            const size_t need_s = (size_t)G * Ns * sizeof(uint16_t) + (size_t)G + 256;
+            if (need_s > ctx->mix_cap) {
+                if (ctx->d_mix) (void)hipFree(ctx->d_mix);
+                ctx->d_mix = nullptr; ctx->mix_cap = 0;
+                DSQ_HIP(hipMalloc(&ctx->d_mix, need_s));
+                ctx->mix_cap = need_s;
+            }
+            uint16_t* t = (uint16_t*)ctx->d_mix;
+            DSQ_HIP(dsq::launch_mix_counts_to_slots(ctx->stream, d_y, ldn, *ex_local.mix, G, t, (uint8_t*)(t + (size_t)G * Ns)));
+            ex_local.mix_ys = t;
+            ex_local.mix_big = (const uint8_t*)(t + (size_t)G * Ns);
+        }
     } else {
         ex_local.mix = nullptr;
     }
@@ -837,7 +888,7 @@ int dsq_mix_create(dsq_ctx* ctx, const double* design, int N, int P, dsq_mix** o
             if (cont[(size_t)j]) M.zcol[q++] = j;
         }
     }
-    if (dsq::alpha_mix_scratch_doubles(M, 4) == 0) return DSQ_OK;  // rows too long for the kernel's LDS staging
+    if (!dsq::alpha_mix_fits(M)) return DSQ_OK;  // rows too long for the kernel's LDS staging
     std::vector<int32_t> perm((size_t)Ns, -1), slot_of((size_t)N, 0);
     std::vector<uint8_t> trip_cell((size_t)(Ns / 64), (uint8_t)(C - 1));
     std::vector<double> Zs((size_t)Q * Ns, 0.0), Xc((size_t)C * P, 0.0), Ginv;
@@ -938,6 +989,28 @@ int dsq_mix_slots(const dsq_mix* mix, int32_t* h_slot_of) {
     return hipMemcpy(h_slot_of, mix->d.slot_of, (size_t)mix->d.N * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess
                ? DSQ_OK
                : DSQ_ERR_HIP;
+}
+
+// Slot-ordered copies for the mixed-design kernels (dsq_mix.h): written once per count matrix / per fit by the caller and
+// handed to the NEXT dispersion or IRLS fit of this context (one-shot; any of the three may be NULL - the fit then builds
+// what it lacks itself, per call).
+int dsq_mix_bind(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const double* d_mu_slots) {
+    ctx->bind_ys = d_ys;
+    ctx->bind_big = d_big;
+    ctx->bind_mu = d_mu_slots;
+    return DSQ_OK;
+}
+int dsq_dev_mix_counts_to_slots(dsq_ctx* ctx, const int32_t* d_y, int ldn, int G, const dsq_mix* mix, uint16_t* d_ys,
+                                uint8_t* d_big) {
+    DSQ_CHECK_ARG(mix != nullptr && d_y != nullptr && d_ys != nullptr && d_big != nullptr, "null argument");
+    DSQ_HIP(dsq::launch_mix_counts_to_slots(ctx->stream, d_y, ldn, mix->d, G, d_ys, d_big));
+    return DSQ_OK;
+}
+int dsq_dev_mix_mu_slots(dsq_ctx* ctx, const dsq_mix* mix, const double* d_beta, const double* d_sf, int G,
+                         double* d_mu_slots) {
+    DSQ_CHECK_ARG(mix != nullptr && d_beta != nullptr && d_sf != nullptr && d_mu_slots != nullptr, "null argument");
+    DSQ_HIP(dsq::launch_mix_mu_slots(ctx->stream, d_beta, d_sf, mix->d, G, d_mu_slots));
+    return DSQ_OK;
 }
 
 int dsq_mix_takes_irls(const dsq_mix* mix, int full_rank) {

@@ -304,11 +304,10 @@ bool no_two_phase();
 // ---- mixed designs: one translation unit per number of continuous covariates (dsq_k_alpha_mix.hip)
 #define DSQ_MIX_DECL(Q_)                                                                                               \
     void alpha_mix_grid_q##Q_(int Ns, int P, int n_list, int* blocks, int* nw);                                        \
-    hipError_t launch_alpha_mix_q##Q_(hipStream_t, const int32_t*, int, const MixDesign&, const int32_t*, int,         \
-                                      const int32_t*, int32_t*, const double*, const double*, const double*,           \
-                                      const double*, double, double, double, int, double*, uint8_t*, int32_t*,         \
-                                      int32_t*, int32_t*, double*, int, int, int, void*, int32_t*, int32_t*, double*,  \
-                                      size_t);
+    hipError_t launch_alpha_mix_q##Q_(hipStream_t, const uint16_t*, const double*, const MixDesign&, const int32_t*, int, \
+                                      const int32_t*, int32_t*, const double*, double, double, double, int, double*,   \
+                                      uint8_t*, int32_t*, int32_t*, int32_t*, double*, int, int, int, void*, int32_t*,  \
+                                      int32_t*);
 DSQ_MIX_DECL(1)
 DSQ_MIX_DECL(2)
 DSQ_MIX_DECL(3)
@@ -322,27 +321,24 @@ bool alpha_mix_enabled() {
     return !off;
 }
 
-size_t alpha_mix_scratch_doubles(const MixDesign& D, int n_list) {
+bool alpha_mix_fits(const MixDesign& D) {
     int blocks = 0, nw = 0;
-    if (D.Q == 1) alpha_mix_grid_q1(D.Ns, D.P, n_list, &blocks, &nw);
-    else if (D.Q == 2) alpha_mix_grid_q2(D.Ns, D.P, n_list, &blocks, &nw);
-    else if (D.Q == 3) alpha_mix_grid_q3(D.Ns, D.P, n_list, &blocks, &nw);
-    return blocks > 0 ? (size_t)blocks * nw * D.Ns + (size_t)D.Ns : 0;  // the rows + the slot-ordered size factors
+    if (D.Q == 1) alpha_mix_grid_q1(D.Ns, D.P, 1, &blocks, &nw);
+    else if (D.Q == 2) alpha_mix_grid_q2(D.Ns, D.P, 1, &blocks, &nw);
+    else if (D.Q == 3) alpha_mix_grid_q3(D.Ns, D.P, 1, &blocks, &nw);
+    return blocks > 0;
 }
 
-hipError_t launch_alpha_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const int32_t* list,
-                            int n_list, const int32_t* n_dev, int32_t* queue, const double* beta, const double* mu,
-                            const double* sf, const double* alpha_hat, double min_disp, double max_disp,
-                            double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev,
+hipError_t launch_alpha_mix(hipStream_t st, const uint16_t* ys, const double* mu_s, const MixDesign& D, const int32_t* list,
+                            int n_list, const int32_t* n_dev, int32_t* queue, const double* alpha_hat, double min_disp,
+                            double max_disp, double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev,
                             int32_t* grid_count, int32_t* grid_list, double* nll_const, int const_mode, int eval_cap,
-                            int resume, void* park_state, int32_t* park_count, int32_t* park_list, double* mu_scratch,
-                            size_t scratch_doubles) {
+                            int resume, void* park_state, int32_t* park_count, int32_t* park_list) {
     g_mix_launches.fetch_add(1, std::memory_order_relaxed);
 #define DSQ_MIX_CALL(Q_)                                                                                              \
-    return launch_alpha_mix_q##Q_(st, y, ldn, D, list, n_list, n_dev, queue, beta, mu, sf, alpha_hat, min_disp,        \
-                                  max_disp, prior_var, prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const, \
-                                  const_mode, eval_cap, resume, park_state, park_count, park_list, mu_scratch,         \
-                                  scratch_doubles)
+    return launch_alpha_mix_q##Q_(st, ys, mu_s, D, list, n_list, n_dev, queue, alpha_hat, min_disp, max_disp, prior_var, \
+                                  prior_reg, alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode, eval_cap, \
+                                  resume, park_state, park_count, park_list)
     switch (D.Q) {
         case 1: DSQ_MIX_CALL(1);
         case 2: DSQ_MIX_CALL(2);
@@ -385,27 +381,24 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                           alpha_rows_eligible(N, P_, ex.cells.C, ex.coef != nullptr, cr_reg);
     const bool rows_lds = have_lists && !rows_reg && cr_reg != 0 && (ex.coef != nullptr || ex.cell_mu != nullptr) &&
                           alpha_rowsc_tail(N, P_, ex.cells.C) > 0;
-    // mixed designs (dsq_k_alpha_mix.hip): the genes of ex.rows, mu_hat from the IRLS coefficients or from the matrix
-    const bool rows_mix = have_lists && ex.mix != nullptr && cr_reg != 0 && ex.mix_scratch != nullptr &&
-                          (ex.mix_beta != nullptr || mu != nullptr) && alpha_mix_enabled();
+    // mixed designs (dsq_k_alpha_mix.hip): the genes of ex.rows, counts and mu_hat streamed from their slot-ordered copies
+    const bool rows_mix = have_lists && ex.mix != nullptr && cr_reg != 0 && ex.mix_ys != nullptr && ex.mix_mu != nullptr &&
+                          alpha_mix_enabled();
     if (rows_mix) {
         const bool park = ex.resume_state != nullptr && ex.resume_count != nullptr && ex.resume_list != nullptr &&
                           nll_const != nullptr && ex.eval_cap > 0 && !no_two_phase();
-        const double* mu_m = ex.mix_beta != nullptr ? nullptr : mu;
-        hipError_t e = launch_alpha_mix(st, y, ldn, *ex.mix, ex.rows, ex.n_rows, nullptr, queue, ex.mix_beta, mu_m, ex.sf,
-                                        alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv, nfev,
-                                        grid_count, grid_list, nll_const, const_mode, park ? ex.eval_cap : 0, 0,
-                                        ex.resume_state, ex.resume_count, ex.resume_list, ex.mix_scratch,
-                                        ex.mix_scratch_doubles);
+        hipError_t e = launch_alpha_mix(st, ex.mix_ys, ex.mix_mu, *ex.mix, ex.rows, ex.n_rows, nullptr, queue, alpha_hat,
+                                        min_disp, max_disp, prior_var, prior_reg, alpha, conv, nfev, grid_count, grid_list,
+                                        nll_const, const_mode, park ? ex.eval_cap : 0, 0, ex.resume_state, ex.resume_count,
+                                        ex.resume_list);
         if (e != hipSuccess) return e;
         if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
         if (park) {
             // continuation of the parked fits: the same kernel, one gene per wavefront again, launched for a capacity
             // (the count is on the device); queue + 2: its own gene counter (run_alpha zeroes both)
-            e = launch_alpha_mix(st, y, ldn, *ex.mix, ex.resume_list, ex.n_rows, ex.resume_count, queue + 2,
-                                 ex.mix_beta, mu_m, ex.sf, alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha,
-                                 conv, nfev, grid_count, grid_list, nll_const, const_mode, 0, 1, ex.resume_state,
-                                 ex.resume_count, ex.resume_list, ex.mix_scratch, ex.mix_scratch_doubles);
+            e = launch_alpha_mix(st, ex.mix_ys, ex.mix_mu, *ex.mix, ex.resume_list, ex.n_rows, ex.resume_count, queue + 2,
+                                 alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv, nfev, grid_count,
+                                 grid_list, nll_const, const_mode, 0, 1, ex.resume_state, ex.resume_count, ex.resume_list);
             if (e != hipSuccess) return e;
         }
         if (ex.n_waves <= 0) return hipSuccess;

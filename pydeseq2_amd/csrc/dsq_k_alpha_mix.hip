@@ -8,10 +8,11 @@
 //     wave-uniform, X^T W X and X^T dW X come from 2 (1 + Q + Q (Q + 1) / 2) = 20 register accumulators per lane that are
 //     folded into the matrices when the cell changes (one multi-value butterfly per cell and evaluation; lane e owns
 //     matrix entry e);
-//   * the gene's counts are gathered into LDS once (uint16, 2 B per slot), mu_hat is rebuilt from the IRLS coefficients
-//     (dds.py:757-771: the UNclamped sf * exp(X beta)) into a wave-private global scratch row that stays in L2 / MALL:
-//     the N x G mu_hat matrix is neither written by the IRLS kernel nor read here (the plug-in entry point, which is
-//     handed mu as a matrix, gathers its row instead);
+//   * the gene's counts and its mu_hat row come from SLOT-ORDERED copies (round 5: ys [G][Ns] uint16 written once per count
+//     matrix, mu_s [G][Ns] fp64 written once per fit by k_mix_mu_slots from the IRLS coefficients - dds.py:757-771: the
+//     UNclamped sf * exp(X beta) - or by k_mix_f64_to_slots from the plug-in caller's matrix): staging is a contiguous
+//     copy of 2 B per slot into LDS plus one streaming pass over the mu_hat row for the NLL constant, no gather through
+//     the slot permutation, no exponential; every evaluation streams the mu_hat row again (L2 / MALL);
 //   * gamma-function terms from per-gene tail counts (dsq_k_alpha_rows.hip): no lgamma / digamma per sample;
 //   * two trips per loop iteration, the next iteration's loads issued ahead of the arithmetic (software pipelining);
 //   * fits that outlast the evaluation cap are parked and continued by a second launch of this kernel (resume != 0),
@@ -49,7 +50,6 @@ extern __device__ unsigned long long g_mix_phase[12];
 
 struct MixWaveLds {  // wave-private LDS record (followed by the gene's counts, uint16 [Ns])
     Lbfgsb1d m;
-    double cellv[kMixMaxCells];                      // x_c . beta of the categorical part, per cell
     double ent[2 * (kMixMaxP * (kMixMaxP + 1) / 2)]; // matrix entries on their way from the owning lane to all lanes
     unsigned int hist[kMixTail];
     uint16_t tail[kMixTail];
@@ -63,13 +63,13 @@ DSQ_HD size_t mix_shared_bytes(int Ns, int P) {
 
 template <int P, int Q>
 __global__ __launch_bounds__(256, 2) void k_alpha_mix(
-    const int32_t* __restrict__ y, int ldn, const MixDesign D, unsigned cont_mask, const int32_t* __restrict__ list,
-    int n_list, const int32_t* __restrict__ n_dev, int32_t* __restrict__ queue, const double* __restrict__ beta,
-    const double* __restrict__ mu, const double* __restrict__ sf, const double* __restrict__ alpha_hat, double min_disp,
-    double max_disp, double prior_var, int prior_reg, double* __restrict__ alpha_out, uint8_t* __restrict__ conv,
-    int32_t* __restrict__ nfev, int32_t* __restrict__ grid_count, int32_t* __restrict__ grid_list,
-    double* __restrict__ nll_const, int const_mode, int eval_cap, int resume, Lbfgsb1d* __restrict__ park_state,
-    int32_t* __restrict__ park_count, int32_t* __restrict__ park_list, double* __restrict__ mu_scratch) {
+    const uint16_t* __restrict__ ys, const double* __restrict__ mu_s, const MixDesign D, unsigned cont_mask,
+    const int32_t* __restrict__ list, int n_list, const int32_t* __restrict__ n_dev, int32_t* __restrict__ queue,
+    const double* __restrict__ alpha_hat, double min_disp, double max_disp, double prior_var, int prior_reg,
+    double* __restrict__ alpha_out, uint8_t* __restrict__ conv, int32_t* __restrict__ nfev,
+    int32_t* __restrict__ grid_count, int32_t* __restrict__ grid_list, double* __restrict__ nll_const, int const_mode,
+    int eval_cap, int resume, Lbfgsb1d* __restrict__ park_state, int32_t* __restrict__ park_count,
+    int32_t* __restrict__ park_list) {
     constexpr int T = Tri<P>::N;
     constexpr int NS = 2 * (1 + Q);       // per-cell sums: w, w z_q | dw, dw z_q
     constexpr int QQ = Q * (Q + 1) / 2;   // continuous x continuous block
@@ -77,13 +77,12 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
     static_assert(Q >= 1 && Q <= kMixMaxQ && P >= Q && P <= kMixMaxP, "design shape");
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int Ns = D.Ns, ntrips = Ns >> 6, C = D.C;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double* const xc_s = dyn;                                       // [C][P] (continuous columns 0)
     uint8_t* const tc_s = (uint8_t*)(xc_s + kMixMaxCells * P);      // [ntrips]
     char* const wbase = (char*)dyn + mix_shared_bytes(Ns, P) + mix_wave_bytes(Ns) * (size_t)w;
     MixWaveLds* const L = (MixWaveLds*)wbase;
     uint16_t* const y16 = (uint16_t*)(wbase + sizeof(MixWaveLds));
-    double* const mus = mu_scratch + (size_t)(blockIdx.x * nw + w) * Ns;
     if (n_dev != nullptr) n_list = min(n_list, *n_dev);  // launched for a capacity, the count is on the device
 
     log_tab_fill();
@@ -134,50 +133,26 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
         // ------------------------------------------------------------------------------------------ stage the gene
         MIX_PH(2);
         for (int i = lane; i < kMixTail; i += 64) L->hist[i] = 0u;
-        double bz[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) bz[q] = 0.0;
-        if (beta != nullptr) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q) bz[q] = beta[(size_t)g * P + D.zcol[q]];
-            if (lane < kMixMaxCells) {
-                double e = 0.0;
-                if (lane < C) {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) e += xc_s[lane * P + j] * beta[(size_t)g * P + j];
-                }
-                L->cellv[lane] = e;
-            }
-        }
         DeviceWave::sync();
-        const int32_t* const yg = y + (size_t)g * ldn;
-        const double* const mg = mu != nullptr ? mu + (size_t)g * ldn : nullptr;
+        const uint16_t* const yg = ys + (size_t)g * Ns;
+        const double* const mus = mu_s + (size_t)g * Ns;  // mu_hat in slot order, 0 in padding slots
         const bool want_cst = !(const_mode == DSQ_CONST_LOAD || resume != 0);
         KSum cs;
         int maxc = 0, nbig = 0;
-        constexpr int CH = kMixU;  // gathered loads per lane in flight (Ns is a multiple of 64 * kMixU)
+        constexpr int CH = 4;  // contiguous loads per lane in flight (Ns is a multiple of 256)
         for (int base = 0; base < Ns; base += 64 * CH) {
-            int pp[CH], v4[CH];
-            double zq[CH][Q], sfv[CH], mv[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) pp[c] = D.perm[base + 64 * c + lane];
+            int v4[CH];
+            double mv[CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int s = base + 64 * c + lane;
-                const int pc = pp[c] >= 0 ? pp[c] : 0;
-                v4[c] = yg[pc];
-                if (beta != nullptr) {
-                    sfv[c] = sf[pc];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) zq[c][q] = D.Zs[(size_t)q * Ns + s];
-                } else {
-                    mv[c] = mg[pc];
-                }
+                v4[c] = yg[s];
+                mv[c] = want_cst ? mus[s] : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int s = base + 64 * c + lane;
-                const bool valid = pp[c] >= 0;
+                const bool valid = v4[c] != 0xFFFF;  // (padding slot of the slot-ordered copy)
                 const int v = valid ? v4[c] : 0;
                 y16[s] = (uint16_t)v;
                 maxc = v > maxc ? v : maxc;
@@ -190,17 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                            ((zM - 0.5) * flog(zM) - zM + stirling_tail(frcp(zM))));
                 }
                 nbig += __popcll(bm);
-                double m;
-                if (beta != nullptr) {
-                    double eta = L->cellv[tc_s[s >> 6]];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) eta += zq[c][q] * bz[q];
-                    m = valid ? sfv[c] * exp(eta) : 0.0;  // UNclamped (utils.py:435-437)
-                } else {
-                    m = valid ? mv[c] : 0.0;
-                }
-                mus[s] = m;
-                if (want_cst && valid) cs.add(-((double)v * flog_t(m)));
+                if (want_cst && valid) cs.add(-((double)v * flog_t(mv[c])));
             }
         }
         MIX_PH(3);
@@ -462,17 +427,17 @@ void DSQ_MIX_CAT(alpha_mix_grid_q, DSQ_MIX_Q)(int Ns, int P, int n_list, int* bl
 }
 
 hipError_t DSQ_MIX_CAT(launch_alpha_mix_q, DSQ_MIX_Q)(
-    hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const int32_t* list, int n_list, const int32_t* n_dev,
-    int32_t* queue, const double* beta, const double* mu, const double* sf, const double* alpha_hat, double min_disp,
-    double max_disp, double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev, int32_t* grid_count,
-    int32_t* grid_list, double* nll_const, int const_mode, int eval_cap, int resume, void* park_state,
-    int32_t* park_count, int32_t* park_list, double* mu_scratch, size_t scratch_doubles) {
+    hipStream_t st, const uint16_t* ys, const double* mu_s, const MixDesign& D, const int32_t* list, int n_list,
+    const int32_t* n_dev, int32_t* queue, const double* alpha_hat, double min_disp, double max_disp, double prior_var,
+    int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev, int32_t* grid_count, int32_t* grid_list,
+    double* nll_const, int const_mode, int eval_cap, int resume, void* park_state, int32_t* park_count,
+    int32_t* park_list) {
     constexpr int Q = DSQ_MIX_Q;
     if (n_list <= 0) return hipSuccess;
-    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || (beta == nullptr) == (mu == nullptr)) return hipErrorInvalidValue;
+    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || ys == nullptr || mu_s == nullptr) return hipErrorInvalidValue;
     int blocks = 0, nw = 0;
     DSQ_MIX_CAT(alpha_mix_grid_q, DSQ_MIX_Q)(D.Ns, D.P, n_list, &blocks, &nw);
-    if (blocks == 0 || (size_t)blocks * nw * D.Ns > scratch_doubles) return hipErrorInvalidValue;
+    if (blocks == 0) return hipErrorInvalidValue;
     const size_t smem = mix_shared_bytes(D.Ns, D.P) + mix_wave_bytes(D.Ns) * nw + 64;
     unsigned cont_mask = 0;
     for (int q = 0; q < Q; ++q) cont_mask |= 1u << D.zcol[q];
@@ -491,10 +456,10 @@ hipError_t DSQ_MIX_CAT(launch_alpha_mix_q, DSQ_MIX_Q)(
                 fprintf(stderr, "[k_alpha_mix<%d,%d>] smem %zu blocks %d x %d waves, n_list %d, occupancy %d blocks/CU\n", \
                         PP, Q, smem, blocks, nw, n_list, nb);                                                           \
             }                                                                                                           \
-            hipLaunchKernelGGL((k_alpha_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, y, ldn, D, cont_mask, list,  \
-                               n_list, n_dev, queue, beta, mu, sf, alpha_hat, min_disp, max_disp, prior_var, prior_reg, \
-                               alpha, conv, nfev, grid_count, grid_list, nll_const, const_mode, eval_cap, resume,       \
-                               (Lbfgsb1d*)park_state, park_count, park_list, mu_scratch);                               \
+            hipLaunchKernelGGL((k_alpha_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, ys, mu_s, D, cont_mask, list, \
+                               n_list, n_dev, queue, alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv,  \
+                               nfev, grid_count, grid_list, nll_const, const_mode, eval_cap, resume,                    \
+                               (Lbfgsb1d*)park_state, park_count, park_list);                                           \
         }                                                                                                               \
     } while (0)
     switch (D.P) {

@@ -424,9 +424,10 @@ bool irls_takes_rows(int N, int P_, int n_cells) {
 #define DSQ_MIXI_DECL(Q_)                                                                                             \
     bool irls_mix_fits_q##Q_(int Ns, int P);                                                                          \
     void irls_mix_grid_q##Q_(int Ns, int P, int G, int* blocks, int* nw);                                             \
-    hipError_t launch_irls_mix_q##Q_(hipStream_t, const int32_t*, int, const MixDesign&, const double*, int, int32_t*, \
-                                     const double*, double, double, double, int, double*, double*, double*, uint8_t*, \
-                                     int32_t*, int32_t*, int32_t*, const IrlsExtras&, void*, size_t);
+    hipError_t launch_irls_mix_q##Q_(hipStream_t, const int32_t*, int, const uint16_t*, const uint8_t*, const MixDesign&, \
+                                     const double*, int, int32_t*, const double*, double, double, double, int, double*, \
+                                     double*, double*, uint8_t*, int32_t*, int32_t*, int32_t*, const IrlsExtras&, void*, \
+                                     size_t);
 DSQ_MIXI_DECL(1)
 DSQ_MIXI_DECL(2)
 DSQ_MIXI_DECL(3)
@@ -458,11 +459,11 @@ static hipError_t launch_irls_mix(hipStream_t st, const int32_t* y, int ldn, con
                                   int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work,
                                   size_t work_bytes) {
     switch (D.Q) {
-        case 1: return launch_irls_mix_q1(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+        case 1: return launch_irls_mix_q1(st, y, ldn, ex.mix_ys, ex.mix_big, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
                                           hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
-        case 2: return launch_irls_mix_q2(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+        case 2: return launch_irls_mix_q2(st, y, ldn, ex.mix_ys, ex.mix_big, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
                                           hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
-        case 3: return launch_irls_mix_q3(st, y, ldn, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
+        case 3: return launch_irls_mix_q3(st, y, ldn, ex.mix_ys, ex.mix_big, D, sf, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu,
                                           hat, conv, iters, fb_count, fb_list, ex, work, work_bytes);
         default: return hipErrorInvalidValue;
     }
@@ -479,7 +480,8 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
     IrlsExtras ex{};
     if (extras != nullptr) ex = *extras;
     // mixed designs (dsq_k_irls_mix.hip): one gene per wavefront in slot order; the same outputs and fallback list
-    if (ex.mix != nullptr && ex.mix_work != nullptr && ex.mix_queue != nullptr && irls_takes_mix(ex.mix, full_rank))
+    if (ex.mix != nullptr && ex.mix_work != nullptr && ex.mix_queue != nullptr && ex.mix_ys != nullptr &&
+        ex.mix_big != nullptr && irls_takes_mix(ex.mix, full_rank))
         return launch_irls_mix(st, y, ldn, *ex.mix, sf, G, ex.mix_queue, disp, min_mu, beta_tol, max_beta, maxiter, beta,
                                mu, hat, conv, iters, fb_count, fb_list, ex, ex.mix_work, ex.mix_work_bytes);
     if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (ex.cells.C == 0 || wide_with_cells()))) {

@@ -7,8 +7,9 @@
 //   * per sample and sweep 1 + Q + Q (Q + 1) / 2 + 1 + Q = 14 accumulations at Q = 3 (X^T W X and X^T W z from per-cell
 //     sums, cell x covariate sums and a small covariate block) instead of 36 + 8, no design loads: the linear predictor
 //     is eta_c + z . beta_z with eta_c looked up per loop iteration;
-//   * counts staged once per gene in LDS (uint16), log size factors and covariates streamed from L2 with the next
-//     iteration's loads issued ahead of the arithmetic;
+//   * counts staged once per gene in LDS (uint16) from their slot-ordered copy (round 5: a contiguous row, no gather
+//     through the slot permutation; a gene with a count beyond 16 bits - flagged in `big` - gathers from its int32 row),
+//     log size factors and covariates streamed from L2 with the next iteration's loads issued ahead of the arithmetic;
 //   * start values from per-cell sums of log(y / sf + 0.1) and (X^T X)^-1 (the reference's QR solve, utils.py:349-353,
 //     is the same least-squares solution);
 //   * the mu-independent part of the deviance from per-gene tail counts (no lgamma per sample);
@@ -60,7 +61,8 @@ __global__ void k_mix_prep(const double* __restrict__ sf, const uint8_t* __restr
 
 template <int P, int Q>
 __global__ __launch_bounds__(256, 2) void k_irls_mix(
-    const int32_t* __restrict__ y, int ldn, const MixDesign D, unsigned cont_mask, const double* __restrict__ sfs,
+    const int32_t* __restrict__ y, int ldn, const uint16_t* __restrict__ ys, const uint8_t* __restrict__ ys_big,
+    const MixDesign D, unsigned cont_mask, const double* __restrict__ sfs,
     const double* __restrict__ lsfs, const uint8_t* __restrict__ flags_s, int G, int32_t* __restrict__ queue,
     const double* __restrict__ disp, double min_mu, double beta_tol, double max_beta, int maxiter,
     double* __restrict__ beta_out, double* __restrict__ mu_out, double* __restrict__ hat_out,
@@ -130,7 +132,15 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
         const double dsp = DeviceWave::uniform(disp[g]);
         const double a = DeviceWave::uniform(1.0 / dsp);
         const int32_t* const yg = y + (size_t)g * ldn;
-        bool big_gene = false;  // a count beyond the 16-bit staging: the sweeps gather this gene's counts from its row
+        const uint16_t* const ysg = ys + (size_t)g * Ns;
+        // a count beyond the 16-bit staging: staging, sweeps and epilogue gather this gene's counts from its int32 row
+#if defined(DSQ_IRLS_MIX_GATHER)  // developer A/B: staging through the permutation gather, as before round 5
+        bool big_gene = false;
+        constexpr bool kGatherAlways = true;
+#else
+        const bool big_gene = __builtin_amdgcn_readfirstlane((int)ys_big[g]) != 0;
+        constexpr bool kGatherAlways = false;
+#endif
         // ---------------------------------------------------------------- stage the counts; start values; deviance constant
         for (int i = lane; i < kMixTail; i += 64) L->hist[i] = 0u;
         DeviceWave::sync();
@@ -148,19 +158,8 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                 rv += xc_s[c * P + rj] * S;
                 sly = 0.0;
             };
-            for (int base = 0; base < Ns; base += 64 * U) {
-                int pp[U], v2[U];
-                double sv[U], zq[U][Q];
-#pragma unroll
-                for (int c = 0; c < U; ++c) pp[c] = D.perm[base + 64 * c + lane];
-#pragma unroll
-                for (int c = 0; c < U; ++c) {
-                    const int s = base + 64 * c + lane;
-                    v2[c] = yg[pp[c] >= 0 ? pp[c] : 0];
-                    sv[c] = sfs[s];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) zq[c][q] = D.Zs[(size_t)q * Ns + s];
-                }
+            // one loop iteration = U trips of one design cell: valid[c] / v[c] the slot's count, sv its size factor, zq its covariates
+            auto body = [&](int base, const bool (&vl)[U], const int (&v2)[U], const double (&sv)[U], const double (&zq)[U][Q]) {
                 const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[base >> 6]);
                 if (cell != cur) {
                     fold0(cur);
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 #pragma unroll
                 for (int c = 0; c < U; ++c) {
                     const int s = base + 64 * c + lane;
-                    const bool valid = pp[c] >= 0;
+                    const bool valid = vl[c];
                     const int v = valid ? v2[c] : 0;
                     y16[s] = (uint16_t)(valid ? v : kMixPad);
                     maxc = v > maxc ? v : maxc;
@@ -189,12 +188,63 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 #pragma unroll
                     for (int q = 0; q < Q; ++q) zl[q] = fma(zq[c][q], ly, zl[q]);
                 }
+            };
+            if (kGatherAlways || big_gene) {  // (wave-uniform, rare: a count beyond 16 bits) the int32 row through the permutation
+                for (int base = 0; base < Ns; base += 64 * U) {
+                    int pp[U], v2[U];
+                    bool vl[U];
+                    double sv[U], zq[U][Q];
+#pragma unroll
+                    for (int c = 0; c < U; ++c) pp[c] = D.perm[base + 64 * c + lane];
+#pragma unroll
+                    for (int c = 0; c < U; ++c) {
+                        const int s = base + 64 * c + lane;
+                        v2[c] = yg[pp[c] >= 0 ? pp[c] : 0];
+                        vl[c] = pp[c] >= 0;
+                        sv[c] = sfs[s];
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) zq[c][q] = D.Zs[(size_t)q * Ns + s];
+                    }
+                    body(base, vl, v2, sv, zq);
+                }
+            } else {
+                // the slot-ordered uint16 row: contiguous, the next iteration's loads issued ahead of this one's arithmetic
+                int vn[U];
+                double sn[U], zn0[U][Q];
+                auto issue0 = [&](int base) {
+#pragma unroll
+                    for (int c = 0; c < U; ++c) {
+                        const int s = base + 64 * c + lane;
+                        vn[c] = ysg[s];
+                        sn[c] = sfs[s];
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) zn0[c][q] = D.Zs[(size_t)q * Ns + s];
+                    }
+                };
+                issue0(0);
+                for (int base = 0; base < Ns; base += 64 * U) {
+                    int v2[U];
+                    bool vl[U];
+                    double sv[U], zq[U][Q];
+#pragma unroll
+                    for (int c = 0; c < U; ++c) {
+                        v2[c] = vn[c];
+                        vl[c] = vn[c] != kMixPad;
+                        sv[c] = sn[c];
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) zq[c][q] = zn0[c][q];
+                    }
+                    issue0(base + 64 * U < Ns ? base + 64 * U : base);  // (the last iteration re-reads its own slots: no branch)
+                    body(base, vl, v2, sv, zq);
+                }
             }
             fold0(cur);
             DeviceWave::template sum_n<Q>(zl);
             if (rj_cont) rv = pick3(rj_q, zl[0], zl[q1], zl[q2]);
             maxc = DeviceWave::maxi(maxc);
+#if defined(DSQ_IRLS_MIX_GATHER)
             big_gene = maxc >= kMixPad;
+#endif
             if (lane < P) L->ent[lane] = rv;
             DeviceWave::sync();
 #pragma unroll
@@ -592,13 +642,15 @@ void DSQ_MIX_CAT(irls_mix_grid_q, DSQ_MIX_Q)(int Ns, int P, int G, int* blocks, 
 
 // work (irls_mix_work_bytes): slot-ordered size factors, their logs, Cook's flags
 hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
-    hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G, int32_t* queue,
+    hipStream_t st, const int32_t* y, int ldn, const uint16_t* ys, const uint8_t* ys_big, const MixDesign& D,
+    const double* sf, int G, int32_t* queue,
     const double* disp, double min_mu, double beta_tol, double max_beta, int maxiter, double* beta, double* mu,
     double* hat, uint8_t* conv, int32_t* iters, int32_t* fb_count, int32_t* fb_list, const IrlsExtras& ex, void* work,
     size_t work_bytes) {
     constexpr int Q = DSQ_MIX_Q;
     if (G <= 0) return hipSuccess;
-    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || D.Ginv == nullptr || work == nullptr) return hipErrorInvalidValue;
+    if (D.Q != Q || D.P < Q || D.P > kMixMaxP || D.Ginv == nullptr || work == nullptr || ys == nullptr || ys_big == nullptr)
+        return hipErrorInvalidValue;
     if (ex.cooks_ld != 0 && ex.cooks_ld < D.Ns) return hipErrorInvalidValue;
     int blocks = 0, nw = 0;
     DSQ_MIX_CAT(irls_mix_grid_q, DSQ_MIX_Q)(D.Ns, D.P, G, &blocks, &nw);
@@ -629,9 +681,9 @@ hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
                 fprintf(stderr, "[k_irls_mix<%d,%d>] smem %zu blocks %d x %d waves, G %d, occupancy %d blocks/CU\n", PP, \
                         Q, smem, blocks, nw, G, nb);                                                                    \
             }                                                                                                           \
-            hipLaunchKernelGGL((k_irls_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, y, ldn, D, cont_mask, sfs,   \
-                               lsfs, flags_s, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, mu, hat, conv, \
-                               iters, fb_count, fb_list, ex);                                                           \
+            hipLaunchKernelGGL((k_irls_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, y, ldn, ys, ys_big, D,      \
+                               cont_mask, sfs, lsfs, flags_s, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, \
+                               mu, hat, conv, iters, fb_count, fb_list, ex);                                            \
         }                                                                                                               \
     } while (0)
     switch (D.P) {

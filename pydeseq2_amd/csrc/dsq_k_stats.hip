@@ -1960,6 +1960,87 @@ hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out) 
     return hipGetLastError();
 }
 
+// ---- mixed designs (dsq_mix.h): slot-ordered copies of per-gene rows, so that the kernels of that family stream contiguous
+// rows instead of gathering every sample through the slot permutation (a 64-lane trip of the gather touched 16-32 cache
+// lines; 24.6 % of k_alpha_mix's cycles were staging)
+constexpr int kMixSlotPad = 0xFFFF;  // padding slot; 0xFFFE: "a count of at least 65 534" (the gene is flagged big)
+// counts [G][ldn] int32 (sample order) -> ys [G][Ns] uint16 (slot order), big[g] = 1 when a count does not fit
+__global__ __launch_bounds__(256) void k_mix_counts_to_slots(const int32_t* __restrict__ y, int ldn,
+                                                             const int32_t* __restrict__ perm, int Ns, int G,
+                                                             uint16_t* __restrict__ ys, uint8_t* __restrict__ big) {
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    const int32_t* row = y + (size_t)g * ldn;
+    uint16_t* dst = ys + (size_t)g * Ns;
+    int any_big = 0;
+    for (int s = threadIdx.x; s < Ns; s += 256) {
+        const int p = perm[s];
+        int v = kMixSlotPad;
+        if (p >= 0) {
+            v = row[p];
+            if (v >= 0xFFFE) { v = 0xFFFE; any_big = 1; }
+        }
+        dst[s] = (uint16_t)v;
+    }
+    any_big = __syncthreads_or(any_big);
+    if (threadIdx.x == 0 && big != nullptr) big[g] = (uint8_t)(any_big ? 1 : 0);
+}
+// fp64 rows [G][ldn] (sample order) -> [G][Ns] (slot order), 0 in padding slots
+__global__ __launch_bounds__(256) void k_mix_f64_to_slots(const double* __restrict__ m, int ldn,
+                                                          const int32_t* __restrict__ perm, int Ns, int G,
+                                                          double* __restrict__ ms) {
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    const double* row = m + (size_t)g * ldn;
+    double* dst = ms + (size_t)g * Ns;
+    for (int s = threadIdx.x; s < Ns; s += 256) {
+        const int p = perm[s];
+        dst[s] = p >= 0 ? row[p] : 0.0;
+    }
+}
+// mu_hat of the IRLS route in slot order: mu[g][s] = sf * exp(x_c . beta + z . beta_z), UNclamped (dds.py:757-771,
+// utils.py:435-437), 0 in padding slots.  One workgroup per gene; written once, read by both dispersion fits (the kernels
+// used to rebuild it - an exponential per sample - in every launch and every continuation launch).
+__global__ __launch_bounds__(256) void k_mix_mu_slots(const double* __restrict__ beta, const double* __restrict__ sf,
+                                                      const MixDesign D, int G, double* __restrict__ mu) {
+    __shared__ double cellv[kMixMaxCells];
+    __shared__ double bz[kMixMaxQ];
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    const double* b = beta + (size_t)g * D.P;
+    if (threadIdx.x < kMixMaxCells) {
+        double e = 0.0;
+        if ((int)threadIdx.x < D.C)
+            for (int j = 0; j < D.P; ++j) e += D.Xc[threadIdx.x * D.P + j] * b[j];
+        cellv[threadIdx.x] = e;
+    }
+    if ((int)threadIdx.x < D.Q) bz[threadIdx.x] = b[D.zcol[threadIdx.x]];
+    __syncthreads();
+    double* dst = mu + (size_t)g * D.Ns;
+    for (int s = threadIdx.x; s < D.Ns; s += 256) {
+        const int p = D.perm[s];
+        double eta = cellv[D.trip_cell[s >> 6]];
+        for (int q = 0; q < D.Q; ++q) eta += D.Zs[(size_t)q * D.Ns + s] * bz[q];
+        dst[s] = p >= 0 ? sf[p] * exp(eta) : 0.0;
+    }
+}
+hipError_t launch_mix_counts_to_slots(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, int G, uint16_t* ys,
+                                      uint8_t* big) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mix_counts_to_slots, dim3(G), dim3(256), 0, st, y, ldn, D.perm, D.Ns, G, ys, big);
+    return hipGetLastError();
+}
+hipError_t launch_mix_f64_to_slots(hipStream_t st, const double* m, int ldn, const MixDesign& D, int G, double* ms) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mix_f64_to_slots, dim3(G), dim3(256), 0, st, m, ldn, D.perm, D.Ns, G, ms);
+    return hipGetLastError();
+}
+hipError_t launch_mix_mu_slots(hipStream_t st, const double* beta, const double* sf, const MixDesign& D, int G, double* mu) {
+    if (G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mix_mu_slots, dim3(G), dim3(256), 0, st, beta, sf, D, G, mu);
+    return hipGetLastError();
+}
+
 // Gene-sharded trend exchange: ONE all-gather carries both per-gene vectors of a rank.
 // pack:  send[0..len) = a[0..n) then NaN, send[len..2 len) = b[0..n) then NaN   (NaN = "no gene": the trend / prior kernels skip them)
 // unzip: recv [world][2][len] -> a_all [world * len], b_all [world * len]

@@ -104,13 +104,14 @@ struct AlphaExtras {
     // tail (continuation of the parked fits, second passes) is about to be (dsq_set_alpha_hook); may be null
     void (*mid_hook)(void*);
     void* mid_arg;
-    // Mixed designs (dsq_mix.h, dsq_k_alpha_mix.hip): the genes of `rows` run k_alpha_mix.  mu_hat comes from the IRLS
-    // coefficients mix_beta [G][P] (sf * exp(X beta), unclamped: dds.py:757-771) or, when mix_beta is null, from `mu`.
-    // mix_scratch: [mix_scratch_doubles] wave-private mu_hat rows (alpha_mix_scratch_doubles).
+    // Mixed designs (dsq_mix.h, dsq_k_alpha_mix.hip): the genes of `rows` run k_alpha_mix.
+    // mix_ys [G][Ns] uint16: the counts in slot order (launch_mix_counts_to_slots); mix_mu [G][Ns]: mu_hat in slot order
+    // (launch_mix_mu_slots from the IRLS coefficients, or launch_mix_f64_to_slots from a caller's matrix) - the kernel
+    // streams both rows; mix_beta stays for the rows of the grid-search genes (launch_mu_from_beta).
     const MixDesign* mix;
     const double* mix_beta;
-    double* mix_scratch;
-    size_t mix_scratch_doubles;
+    const uint16_t* mix_ys;
+    const double* mix_mu;
 };
 constexpr int kAlphaEvalCap = 8;
 size_t alpha_resume_bytes(int G);
@@ -140,15 +141,13 @@ hipError_t launch_mu_from_cells(hipStream_t st, const double* cell_mu, int C, co
 // ---- dsq_k_alpha_mix.hip (one translation unit per number of continuous covariates): mixed designs, dsq_mix.h
 bool alpha_mix_enabled();
 int alpha_mix_launches();  // launches of k_alpha_mix by this process so far (tests: did the design take that route?)
-// doubles of wave-private scratch a launch for n_list genes needs (0: such rows do not fit the kernel)
-size_t alpha_mix_scratch_doubles(const MixDesign& D, int n_list);
-hipError_t launch_alpha_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const int32_t* list,
-                            int n_list, const int32_t* n_dev, int32_t* queue, const double* beta, const double* mu,
-                            const double* sf, const double* alpha_hat, double min_disp, double max_disp,
-                            double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev,
+bool alpha_mix_fits(const MixDesign& D);  // rows of D.Ns slots fit the kernel's LDS
+// ys [G][Ns] uint16 / mu_s [G][Ns] fp64: the genes' counts and mu_hat in slot order (launch_mix_counts_to_slots, ...)
+hipError_t launch_alpha_mix(hipStream_t st, const uint16_t* ys, const double* mu_s, const MixDesign& D, const int32_t* list,
+                            int n_list, const int32_t* n_dev, int32_t* queue, const double* alpha_hat, double min_disp,
+                            double max_disp, double prior_var, int prior_reg, double* alpha, uint8_t* conv, int32_t* nfev,
                             int32_t* grid_count, int32_t* grid_list, double* nll_const, int const_mode, int eval_cap,
-                            int resume, void* park_state, int32_t* park_count, int32_t* park_list, double* mu_scratch,
-                            size_t scratch_doubles);
+                            int resume, void* park_state, int32_t* park_count, int32_t* park_list);
 // rows of mu_hat = sf * exp(X beta) (unclamped) for a gene list (grid-search pass when no N x G mu_hat exists)
 hipError_t launch_mu_from_beta(hipStream_t st, const double* beta, const double* sf, const double* Xt, int ldx, int N,
                                int P, const int32_t* list, int n_list, double* dst, int ldn, int32_t* idx_out,
@@ -205,6 +204,8 @@ struct IrlsExtras {
     void* mix_work;
     size_t mix_work_bytes;
     int32_t* mix_queue;
+    const uint16_t* mix_ys;      // [G][Ns] counts in slot order (launch_mix_counts_to_slots) and, per gene, whether a count
+    const uint8_t* mix_big;      // did not fit its 16 bits (such a gene gathers its counts from the int32 row)
 };
 bool irls_takes_mix(const MixDesign* mix, int full_rank);
 // device scratch of a mixed-design fit of G genes that writes n_layers N x G layers (Cook's distances, mu, hat diagonal)
@@ -347,6 +348,12 @@ hipError_t launch_sf_finish(hipStream_t st, const unsigned long long* prefix, co
 hipError_t launch_prior_mad(hipStream_t st, const double* gw_raw, const double* fitted, int n, double min_disp,
                             double max_disp, double* res_scratch, double* out2);
 hipError_t launch_log_vec(hipStream_t st, const double* in, int n, double* out);
+// mixed designs: slot-ordered copies (dsq_mix.h): counts as uint16 [G][Ns] (0xFFFF padding, 0xFFFE saturated + big[g]),
+// fp64 rows [G][Ns] (0 padding), the IRLS route's mu_hat from its coefficients
+hipError_t launch_mix_counts_to_slots(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, int G, uint16_t* ys,
+                                      uint8_t* big);
+hipError_t launch_mix_f64_to_slots(hipStream_t st, const double* m, int ldn, const MixDesign& D, int G, double* ms);
+hipError_t launch_mix_mu_slots(hipStream_t st, const double* beta, const double* sf, const MixDesign& D, int G, double* mu);
 hipError_t launch_pack2(hipStream_t st, const double* a, const double* b, int n, int len, double* send);
 hipError_t launch_unzip2(hipStream_t st, const double* recv, int world, int len, double* a_all, double* b_all);
 // normed counts (double, gene-major) based rough / moments for the Inference-level API

@@ -169,7 +169,7 @@ class DeseqPipeline:
             self._row_mode = 0
         # 3: MIXED design - categorical columns with few distinct rows + up to three continuous covariates (dsq_mix_create,
         # csrc/dsq_mix.h: the analysis and the eligibility rule live in the library).  IRLS mu_hat route only.
-        self._mix, self._mix_slots, self._slot_of = None, 0, None
+        self._mix, self._mix_slots, self._slot_of, self._mix_ys_cache = None, 0, None, None
         if self._row_mode == 0 and not D.linear_mu and not os.environ.get("DSQ_NO_ALPHA_MIX"):
             mp = _vp()
             ctx_.call("dsq_mix_create", _vp(D.X.ctypes.data), self.N, self.P, C.byref(mp))
@@ -193,7 +193,11 @@ class DeseqPipeline:
         self.overlap = not os.environ.get("DSQ_NO_OVERLAP")  # robust dispersions on a side stream under the trend fit
         self._robust_early = bool(os.environ.get("DSQ_ROBUST_EARLY"))  # (measurement switch: fork before the genewise fit)
         self._robust_late = bool(os.environ.get("DSQ_ROBUST_LATE"))    # (measurement switch: fork after the genewise stage)
-        self._map_waits_side = os.environ.get("DSQ_MAP_WAIT", "1") != "0"  # the MAP launch waits for the side stream
+        # the MAP launch waits for the side stream (robust dispersions) where that kernel is about as long as the tail it hides
+        # under (row kernels: c2 / c3 5.92 -> 5.80 ms); the mixed-design family's lean kernel runs 2-3 ms past that tail at
+        # 5000 samples, where sharing the compute units costs less than idling (c5: 51.7 vs 52.9 ms).  DSQ_MAP_WAIT=0 / 1.
+        mw = os.environ.get("DSQ_MAP_WAIT")
+        self._map_waits_side = (self._row_mode != 3) if mw is None else (mw != "0")
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -407,7 +411,35 @@ class DeseqPipeline:
             c = self._row_lists = (non_zero.copy(), d_rows, len(rows), d_waves, len(waves))
         return (c[1], c[2], c[3], c[4]) if c[2] > 0 else None
 
-    def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None, pre_alpha=None):
+    def _mix_slots_for(self, d_y, Gs, persistent_key=None):
+        """Slot-ordered uint16 copy of a gene-major count matrix + per-gene "a count beyond 16 bits" flags for the
+        mixed-design kernels (dsq_dev_mix_counts_to_slots).  The copy of the pipeline's own matrix depends on the counts
+        only: it is built once (per non-zero mask) and kept; a sub-problem's (the refit's replaced counts) is pooled."""
+        if self._mix is None:
+            return None
+        if persistent_key is not None:
+            c = self._mix_ys_cache
+            if c is not None and np.array_equal(c[0], persistent_key):
+                return c[1], c[2]
+            if c is not None:
+                c[1].free(); c[2].free()
+            d_ys = DeviceArray(self.ctx, (max(Gs, 1) * self._mix_slots,), np.uint16)
+            d_big = DeviceArray(self.ctx, (max(Gs, 1),), np.uint8)
+        else:
+            d_ys = self._pooled((max(Gs, 1) * self._mix_slots,), np.uint16)
+            d_big = self._pooled((max(Gs, 1),), np.uint8)
+        self.ctx.call("dsq_dev_mix_counts_to_slots", _vp(d_y.ptr), self.ldn, Gs, _vp(self._mix), _vp(d_ys.ptr),
+                      _vp(d_big.ptr))
+        if persistent_key is not None:
+            self._mix_ys_cache = (np.array(persistent_key, copy=True), d_ys, d_big)
+        return d_ys, d_big
+
+    def _mix_bind(self, slots, d_mu_slots=None):
+        """Hand the slot-ordered copies to the next fit of the context (one-shot, csrc: dsq_mix_bind)."""
+        if slots is not None:
+            self.ctx.call("dsq_mix_bind", _vp(slots[0].ptr), _vp(slots[1].ptr), _vp(d_mu_slots.ptr) if d_mu_slots else None)
+
+    def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None, pre_alpha=None, mix_slots=None):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
         unclipped), gconv]; returns the description of mu_hat the MAP fit needs: the device matrix, or - for
         the designs with the linear-model mu_hat (dds.py:747-756) - only the per-gene OLS coefficients from
@@ -415,6 +447,7 @@ class DeseqPipeline:
         D = self.design
         mh = type("MuHat", (), {})()
         mh.d_mu, mh.d_coef, mh.d_cell_mu, mh.d_beta, mh.row_lists = None, None, None, None, row_lists
+        mh.mix_slots, mh.d_mu_slots = mix_slots, None
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
@@ -440,6 +473,7 @@ class DeseqPipeline:
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
             # the iteration counts of this fit order the genes of the LFC fit (dsq_irls_order_hint)
             S["_irls_it"] = self._dvec(Gs, np.int32)
+            self._mix_bind(mix_slots)
             self._k("irls_mu", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
@@ -449,6 +483,12 @@ class DeseqPipeline:
                     None, None, c_double(0.0), 0, None, None, None, _vp(self._mix) if self._mix else None, 0)
             if from_beta:
                 mh.d_beta = d_b
+                if mix_slots is not None:
+                    # mu_hat = sf * exp(X beta) in slot order, written ONCE here and streamed by both dispersion fits (they
+                    # used to rebuild it - one exponential per sample - in every launch and continuation launch)
+                    mh.d_mu_slots = self._pooled((max(Gs, 1) * self._mix_slots,), np.float64)
+                    self.ctx.call("dsq_dev_mix_mu_slots", _vp(self._mix), _vp(d_b.ptr), _vp(d_sf.ptr), Gs,
+                                  _vp(mh.d_mu_slots.ptr))
             if per_cell:
                 mh.d_cell_mu = self._dvec(Gs * int(D.n_design_cells))
                 self.ctx.call("dsq_dev_cell_mu", _vp(d_b.ptr), self._cells_arg(), Gs, self.P, _vp(mh.d_cell_mu.ptr))
@@ -467,6 +507,8 @@ class DeseqPipeline:
         mix = self._mix if (self._row_mode == 3 and getattr(mh, "row_lists", None) is not None) else None
         # (d_rows, n_rows, d_waves, n_waves) or None; the mixed-design kernel also takes its rows from a mu_hat matrix
         rows = getattr(mh, "row_lists", None) if (mh.d_mu is None or mix) else None
+        if mix and rows:
+            self._mix_bind(getattr(mh, "mix_slots", None), getattr(mh, "d_mu_slots", None))
         self._k(name, Gs, "dsq_dev_alpha_mle4", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
                 _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
                 c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
@@ -487,7 +529,7 @@ class DeseqPipeline:
                       c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
                       _vp(S["disp"].ptr), _vp(S["outl"].ptr))
 
-    def _stage_lfc(self, d_y, Gs, d_sf, S, wald, cooks=None):
+    def _stage_lfc(self, d_y, Gs, d_sf, S, wald, cooks=None, mix_slots=None):
         """IRLS LFC fit (dds.py:937-984) with S[disp] -> S[beta, lconv] and, fused into its epilogue, the Wald
         statistics S[p, stat, se] (ds.py:303-360; wald = (ridge, contrast, lfc_null, alt)) and - cooks =
         (robust dispersions, cutoff, cooks layer) - the per-sample half of the Cook's stage (dds.py:986-1040,
@@ -506,6 +548,7 @@ class DeseqPipeline:
                  [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
         if S.get("_irls_it") is not None:
             self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
+        self._mix_bind(mix_slots)
         self._k("lfc_fit", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
@@ -686,6 +729,8 @@ class DeseqPipeline:
             ctx.call("dsq_dev_gather_rows_i32", _vp(self.d_y.ptr), self.ldn, _vp(d_idx.ptr), Gn, N,
                      _vp(d_ynz.ptr))
         S = self._dev_slab(Gn)
+        # mixed designs: the counts in slot order (built once per non-zero mask, outside the steady-state step)
+        mix_slots = self._mix_slots_for(d_ynz, Gn, persistent_key=non_zero) if (self._mix and Gn > 0) else None
 
         # ---- genewise dispersions (dds.py:713-797)
         # the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
@@ -727,7 +772,7 @@ class DeseqPipeline:
             ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook, C.c_void_p), None)
         try:
             d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero),
-                                            pre_alpha=launch_robust if early else None)
+                                            pre_alpha=launch_robust if early else None, mix_slots=mix_slots)
         finally:
             if mid:
                 ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
@@ -821,7 +866,7 @@ class DeseqPipeline:
         if self.overlap and self._side_pending:
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks))
+        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks), mix_slots=mix_slots)
         want_refit = self.refit_cooks and D.replaceable.sum() > 0
         # Everything in S is final now except the rows the refit will replace: the block copy of the result vectors
         # starts here, on the side stream, and runs underneath the refit's kernels; the host patches the (few)
@@ -872,12 +917,13 @@ class DeseqPipeline:
                 deferred = not (profile or self.time_kernels or self.collect_nfev)
                 if deferred:
                     ctx.call("dsq_set_deferred", 1)
+                sub_slots = self._mix_slots_for(d_ysub, Gr) if self._mix else None  # (the replaced counts' own copy)
                 try:
-                    s_mu = self._stage_genewise(d_ysub, Gr, d_sf, S2)
+                    s_mu = self._stage_genewise(d_ysub, Gr, d_sf, S2, mix_slots=sub_slots)
                     ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gr, c_double(a0), c_double(a1),
                              _vp(S2["fit"].ptr))
                     self._stage_map(d_ysub, s_mu, Gr, d_sf, r.prior_disp_var, r.squared_logres, S2)
-                    self._stage_lfc(d_ysub, Gr, d_sf, S2, wald_args)
+                    self._stage_lfc(d_ysub, Gr, d_sf, S2, wald_args, mix_slots=sub_slots)
                 finally:
                     if deferred:
                         ctx.call("dsq_set_deferred", 0)
@@ -1016,6 +1062,9 @@ class DeseqPipeline:
         for _cap, ptr in self._pool_free + self._pool_used:
             self.ctx.free(ptr)
         self._pool_free, self._pool_used = [], []
+        if getattr(self, "_mix_ys_cache", None) is not None:
+            self._mix_ys_cache[1].free(); self._mix_ys_cache[2].free()
+            self._mix_ys_cache = None
         if getattr(self, "_mix", None):
             self.ctx.lib.dsq_mix_destroy(_vp(self._mix))
             self._mix = None

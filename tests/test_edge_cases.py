@@ -99,6 +99,14 @@ def test_gpu_invalid_inputs_raise():
     Xn[0, 1] = np.nan
     with pytest.raises(ValueError):
         pydeseq2_amd.DeseqPipeline(counts, Xn, device=0)
+    big = counts.astype(np.int64)
+    big[1, 2] = 2**31  # documented limit: counts live as int32 on the device (the reference holds int64, dds.py:245-249)
+    with pytest.raises(ValueError, match="below 2\\^31"):
+        pydeseq2_amd.DeseqPipeline(big, X, device=0)
+    from pydeseq2_amd import HipInference
+
+    with pytest.raises(Exception, match="2\\^31"):
+        HipInference(device=0).lin_reg_mu(big, np.ones(len(big)), X, 0.5)
     with pytest.raises(ValueError):  # N == p: no replicates (utils.py:839-844)
         pydeseq2_amd.deseq2(counts[:2], X[:2] + np.array([[0, 0], [0, 1.0]]) * 0 + np.eye(2), device=0)
 

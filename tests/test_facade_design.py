@@ -132,3 +132,15 @@ def test_contrast_validation():
         DeseqStats(dds, contrast=None)
     with pytest.raises(AttributeError):
         DeseqStats(SimpleNamespace(_res=None), contrast=["condition", "B", "A"])
+
+
+def test_documented_limits_are_refused_with_a_clear_error():
+    """DESIGN.md 7 (limits the reference does not have): more than 32 design columns (utils.py:345-371 takes any width) is
+    refused when the design is packed - before any GPU work - with a message that names the limit."""
+    from pydeseq2_amd._design import MAX_DESIGN_COLUMNS, DesignPack
+
+    rng = np.random.default_rng(0)
+    X = np.column_stack([np.ones(200)] + [rng.normal(size=200) for _ in range(MAX_DESIGN_COLUMNS)])
+    with pytest.raises(ValueError, match="at most 32"):
+        DesignPack(X)
+    assert DesignPack(X[:, :MAX_DESIGN_COLUMNS]).P == MAX_DESIGN_COLUMNS

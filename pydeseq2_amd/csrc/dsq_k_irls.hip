@@ -414,6 +414,12 @@ static size_t row_lds_bytes(int C, int P, int N) {
     return (size_t)C * (P * (P + 1) / 2 + 2 * P) * sizeof(double) + (size_t)npad * 20 + (size_t)kMaxCells * 4;
 }
 
+// batches below this many genes leave the sixteen-lane kernel to the one-gene-per-wavefront kernels (DSQ_IRLS_ROW_MIN_G)
+static int irls_row_min_genes() {  // (read per launch: tests pin both kernels to the reference KATs in one process)
+    const char* e = getenv("DSQ_IRLS_ROW_MIN_G");
+    return e ? atoi(e) : 1024;
+}
+
 bool irls_takes_rows(int N, int P_, int n_cells) {
     if (P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (n_cells == 0 || wide_with_cells()))) return false;
     return n_cells > kSmallCells && P_ >= kRowMinP && P_ >= row_min_p() && row_wave_enabled() &&
@@ -511,8 +517,10 @@ hipError_t launch_irls(hipStream_t st, const int32_t* y, int ldn, const double* 
                                        max_beta, maxiter, beta, mu, hat, conv, iters, fb_count, fb_list, ex, stage);
             }
         })
-    } else if (irls_takes_rows(N, P_, ex.cells.C)) {
-        // wide categorical designs: sixteen lanes per gene (k_irls_row)
+    } else if (irls_takes_rows(N, P_, ex.cells.C) && G >= irls_row_min_genes()) {
+        // wide categorical designs: sixteen lanes per gene (k_irls_row) - a throughput kernel: a row walks its gene's samples
+        // sixteen at a time, so a single fit takes ~4x as long as on a whole wavefront; small batches (the outlier refit's
+        // few dozen genes: 175 + 199 us of c4's 7.1 ms step) take the one-gene-per-wavefront cell kernel below
         const dim3 grid_r((G + kRowGenes - 1) / kRowGenes);
         DSQ_DISPATCH_P(P_, {
             if constexpr (P >= kRowMinP)

@@ -27,6 +27,14 @@
 #error "compile with -DDSQ_MIX_Q=1, 2 or 3"
 #endif
 
+// the exponential of the sweeps (one per sample and sweep): -DDSQ_MIX_FEXP selects the table-driven fexp_t (dsq_math.h,
+// <= 1 ulp, ~22 instructions + one LDS read) instead of the library's
+#if defined(DSQ_MIX_FEXP)
+#define DSQ_MIX_EXP(x) fexp_t(x)
+#else
+#define DSQ_MIX_EXP(x) exp(x)
+#endif
+
 namespace dsq {
 
 constexpr int kMixPad = 0xFFFF;  // count stored for a padding slot (real counts are <= 65534: dsq_dev_alpha_row_split)
@@ -83,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
     uint16_t* const y16 = (uint16_t*)(wbase + sizeof(MixIrlsLds));
 
     log_tab_fill();
+#if defined(DSQ_MIX_FEXP)
+    exp_tab_fill();
+#endif
     for (int i = threadIdx.x; i < C * P; i += blockDim.x) xc_s[i] = D.Xc[i];
     for (int i = threadIdx.x; i < P * P; i += blockDim.x) gi_s[i] = D.Ginv[i];
     for (int i = threadIdx.x; i < ntrips; i += blockDim.x) tc_s[i] = D.trip_cell[i];
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 #pragma unroll
                     for (int q = 0; q < Q; ++q) t = fma(z[u][q], bz[q], t);
                     eta0[u] = t;
-                    e[u] = exp(t + lsf[u]);  // mu = sf exp(eta) = exp(eta + log sf)
+                    e[u] = DSQ_MIX_EXP(t + lsf[u]);  // mu = sf exp(eta) = exp(eta + log sf)
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                     double z[Q], t = etac;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) { z[q] = D.Zs[(size_t)q * Ns + s]; t = fma(z[q], bz[q], t); }
-                    const double mu_raw = exp(t + lsfs[s]);
+                    const double mu_raw = DSQ_MIX_EXP(t + lsfs[s]);
                     if (valid && mu_row != nullptr) mu_row[n] = mu_raw;
                     double wv = 0.0;
                     if (have_w) {

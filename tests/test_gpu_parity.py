@@ -4,6 +4,8 @@ synthetic inputs, and the reference's R fixtures.  Tolerance for floating point 
 north-star's 1e-5 relative (LFC, dispersions, Wald p-values); genes on which either optimiser's
 line search fails at rounding-noise level (reference falls back to a quantised grid search) are
 counted and bounded separately."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,6 +76,18 @@ def test_inference_vs_reference_kats(inf, case):
     assert_close(inf.fit_rough_dispersions(k["normed"], k["X"]), k["rough"], 1e-9, 1e-13, "rough")
     assert_close(inf.fit_moments_dispersions(k["normed"], k["sf"]), k["moments"], 1e-10, 1e-14, "moments")
     assert_close(inf.lin_reg_mu(k["counts"], k["sf"], k["X"], 0.5), k["lin_mu"], 1e-10, 0, "lin_mu")
+    if 5 <= P <= 12:
+        # batches of < 1024 genes (these KATs; the outlier refit) leave the sixteen-lane IRLS kernel to the one-gene-per-
+        # wavefront kernels: pin the sixteen-lane kernel to the same reference outputs as well
+        os.environ["DSQ_IRLS_ROW_MIN_G"] = "0"
+        try:
+            b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], k["mom"], 0.5, 1e-8)
+        finally:
+            del os.environ["DSQ_IRLS_ROW_MIN_G"]
+        assert (conv == k["irls_conv"]).all()
+        assert_close(b, k["irls_beta"], 1e-8, 1e-10, "irls beta (sixteen-lane kernel)")
+        assert_close(mu, k["irls_mu"], 1e-8, 1e-10, "irls mu (sixteen-lane kernel)")
+        assert_close(H, k["irls_H"], 1e-8, 1e-12, "irls H (sixteen-lane kernel)")
     b, mu, H, conv = inf.irls(k["counts"], k["sf"], k["X"], k["mom"], 0.5, 1e-8)
     # p16 holds one low-count gene whose IRLS diverges; the success flag of its L-BFGS-B rescue is decided at
     # rounding-noise level (tests/test_hostsim.py::test_wide_path_vs_reference_kats), its beta agrees

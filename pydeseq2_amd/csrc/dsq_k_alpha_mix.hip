@@ -57,11 +57,22 @@ struct MixWaveLds {  // wave-private LDS record (followed by the gene's counts, 
 static_assert(sizeof(MixWaveLds) % 8 == 0, "the counts follow the record");
 
 DSQ_HD size_t mix_wave_bytes(int Ns) { return (sizeof(MixWaveLds) + (size_t)Ns * 2 + 15) & ~(size_t)15; }
+// the one-gene-per-workgroup continuation (WG): two (double-buffered) sets of per-wavefront partial sums - the matrix
+// entries of X^T W X and X^T dW X, the loss and the gradient sum - and the gene index of the workgroup
+constexpr int kMixRedStride = 2 * (kMixMaxP * (kMixMaxP + 1) / 2) + 8;
+constexpr int kMixRedWaves = 4;
+constexpr size_t kMixRedBytes = (size_t)2 * kMixRedWaves * kMixRedStride * 8 + 16;
 DSQ_HD size_t mix_shared_bytes(int Ns, int P) {
-    return (size_t)kMixMaxCells * P * 8 + (size_t)(((Ns >> 6) + 15) & ~15);
+    return (size_t)kMixMaxCells * P * 8 + (size_t)(((Ns >> 6) + 15) & ~15) + kMixRedBytes;
 }
 
-template <int P, int Q>
+// WG = false: one gene per wavefront (the full-size launch).  WG = true: one gene per WORKGROUP - the continuation of the
+// parked fits (the 1 % of the genes whose line search takes up to 34 evaluations): with a wavefront per gene that launch was
+// as long as its slowest fit, 26 more evaluations of ~55 us each at 5000 samples = 1.4-1.7 ms for 75 genes, longer than the
+// full-size launch before it (profiles/r05_timeline_c5_shard.txt).  The wavefronts of a workgroup take every nw-th loop
+// iteration of the same gene (an iteration lies inside one design cell), reduce their partial sums through LDS in a fixed
+// order and all step their own copy of the optimiser with the same totals (as k_alpha_wg does for the row kernel).
+template <int P, int Q, bool WG = false>
 __global__ __launch_bounds__(256, 2) void k_alpha_mix(
     const uint16_t* __restrict__ ys, const double* __restrict__ mu_s, const MixDesign D, unsigned cont_mask,
     const int32_t* __restrict__ list, int n_list, const int32_t* __restrict__ n_dev, int32_t* __restrict__ queue,
@@ -78,8 +89,12 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int Ns = D.Ns, ntrips = Ns >> 6, C = D.C;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wq = WG ? w : 0, nq = WG ? (int)(blockDim.x >> 6) : 1;  // this wavefront's share of a gene's loop iterations
     double* const xc_s = dyn;                                       // [C][P] (continuous columns 0)
     uint8_t* const tc_s = (uint8_t*)(xc_s + kMixMaxCells * P);      // [ntrips]
+    double* const red_s = (double*)((char*)dyn + mix_shared_bytes(Ns, P) - kMixRedBytes);
+    int* const gene_s = (int*)(red_s + 2 * kMixRedWaves * kMixRedStride);
+    int red_parity = 0;
     char* const wbase = (char*)dyn + mix_shared_bytes(Ns, P) + mix_wave_bytes(Ns) * (size_t)w;
     MixWaveLds* const L = (MixWaveLds*)wbase;
     uint16_t* const y16 = (uint16_t*)(wbase + sizeof(MixWaveLds));
@@ -126,8 +141,15 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
     for (;;) {
         MIX_PH(0);
         int k = 0;
-        if (lane == 0) k = atomicAdd(queue, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
+        if constexpr (WG) {  // one gene for the whole workgroup
+            if (threadIdx.x == 0) *gene_s = atomicAdd(queue, 1);
+            __syncthreads();
+            k = *gene_s;
+            __syncthreads();
+        } else {
+            if (lane == 0) k = atomicAdd(queue, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+        }
         if (k >= n_list) break;
         const int g = list != nullptr ? list[k] : k;
         // ------------------------------------------------------------------------------------------ stage the gene
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
             const double lal = DeviceWave::uniform(flog_t(alpha));  // log of the ROUNDED alpha (see alpha_eval_body)
             KSum accf;
             double accg = 0.0;
-            for (int i = lane; i < n_tail; i += 64) {  // gamma-function terms from the tail counts
+            for (int i = lane + 64 * wq; i < n_tail; i += 64 * nq) {  // gamma-function terms from the tail counts
                 const double t = a + (double)i;
                 const double ti = (double)L->tail[i];
                 accf.add(-(ti * flog_t(t)));
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
             if (nbig > 0) {  // counts beyond the table (high-count genes): Stirling, sample by sample
                 double lgM, psiM;
                 stirling_big((double)kMixTail + a, lgM, psiM);
-                for (int s = lane; s < Ns; s += 64) {
+                for (int s = lane + 64 * wq; s < Ns; s += 64 * nq) {
                     const int yi = y16[s];
                     if (yi >= kMixTail) {
                         double lgz, psiz;
@@ -250,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
 #pragma unroll
                 for (int i = 0; i < NS; ++i) sc[i] = 0.0;
             };
-            int cur = __builtin_amdgcn_readfirstlane((int)tc_s[0]);
+            const int t_first = U * wq < ntrips ? U * wq : 0;  // (a wavefront without an iteration: the loop below is empty)
+            int cur = __builtin_amdgcn_readfirstlane((int)tc_s[t_first]);
             KSum af[U];
             double ag[U];
 #pragma unroll
@@ -272,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
                 }
             };
             MIX_PH(5);
-            issue(0);
-            for (int t0 = 0; t0 < ntrips; t0 += U) {
+            issue(t_first);
+            for (int t0 = U * wq; t0 < ntrips; t0 += U * nq) {
                 int yi[U];
                 double m[U], z[U][Q], r1[U], L1[U];
 #pragma unroll
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
 #pragma unroll
                     for (int q = 0; q < Q; ++q) z[u][q] = zn[u][q];
                 }
-                issue(t0 + U < ntrips ? t0 + U : t0);  // (the last iteration re-reads its own slots: no branch)
+                issue(t0 + U * nq < ntrips ? t0 + U * nq : t0);  // (the last iteration re-reads its own slots: no branch)
                 const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[t0]);
                 if (cell != cur) {
                     fold(cur);
@@ -342,8 +365,26 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) { accf.merge(af[u].s, af[u].c); accg += ag[u]; }
-            const double sumf = DeviceWave::sum_comp(accf);
+            double sumf = DeviceWave::sum_comp(accf);
             accg = DeviceWave::sum(accg);
+            if constexpr (WG) {
+                // partial sums of the workgroup's wavefronts -> totals, summed in wavefront order by everybody (so that
+                // every wavefront steps its optimiser copy with the same numbers); double-buffered: one barrier per evaluation
+                double* const red = red_s + (size_t)red_parity * kMixRedWaves * kMixRedStride;
+                double* const mine = red + w * kMixRedStride;
+                if (lane < T) { mine[lane] = Me; mine[T + lane] = dMe; }
+                if (lane == 0) { mine[2 * T] = sumf; mine[2 * T + 1] = accg; }
+                __syncthreads();
+                double m2 = 0.0, d2 = 0.0, f2 = 0.0, g2 = 0.0;
+                for (int q = 0; q < nq; ++q) {
+                    const double* r = red + q * kMixRedStride;
+                    if (lane < T) { m2 += r[lane]; d2 += r[T + lane]; }
+                    f2 += r[2 * T];
+                    g2 += r[2 * T + 1];
+                }
+                Me = m2; dMe = d2; sumf = f2; accg = g2;
+                red_parity ^= 1;
+            }
             double f = sumf + cst;
             double gr = alpha * (-(a * a * accg));
             if (lane < T) { L->ent[lane] = Me; L->ent[T + lane] = dMe; }
@@ -374,7 +415,9 @@ __global__ __launch_bounds__(256, 2) void k_alpha_mix(
         }
         MIX_PH(9);
         // ------------------------------------------------------------------------------------------ result / parking
-        if (!L->m.done) {  // out of this launch's evaluation budget: the continuation launch resumes the gene
+        if (WG && w != 0) {
+            // (the workgroup's other wavefronts hold the same result)
+        } else if (!L->m.done) {  // out of this launch's evaluation budget: the continuation launch resumes the gene
             constexpr int kDw = (int)(sizeof(Lbfgsb1d) / 4);
             uint32_t* dst = (uint32_t*)(park_state + g);
             const uint32_t* src = (const uint32_t*)&L->m;
@@ -442,24 +485,39 @@ hipError_t DSQ_MIX_CAT(launch_alpha_mix_q, DSQ_MIX_Q)(
     unsigned cont_mask = 0;
     for (int q = 0; q < Q; ++q) cont_mask |= 1u << D.zcol[q];
     if (nll_const == nullptr) const_mode = DSQ_CONST_COMPUTE;
+    // the continuation of the parked fits: one gene per workgroup (DSQ_MIX_WG_CONT=0: a wavefront per gene, as the main launch)
+    static const bool wg_cont = !(getenv("DSQ_MIX_WG_CONT") && atoi(getenv("DSQ_MIX_WG_CONT")) == 0);
+    const bool wg = resume != 0 && wg_cont && nw > 1;
+    if (wg) {  // a workgroup per listed gene (the list's length is a capacity: the count is on the device)
+        const int n_cu = current_device_cus();
+        int per_cu = (int)((156 * 1024) / smem);
+        if (per_cu * nw > 8) per_cu = 8 / nw;
+        if (per_cu < 1) per_cu = 1;
+        blocks = n_list < per_cu * n_cu ? n_list : per_cu * n_cu;
+    }
+#define DSQ_MIX_LAUNCH_K(PP, WG_)                                                                                       \
+    do {                                                                                                                \
+        if (smem > 48 * 1024) {                                                                                         \
+            (void)hipFuncSetAttribute((const void*)k_alpha_mix<PP, Q, WG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem);                                                                       \
+            (void)hipGetLastError();                                                                                    \
+        }                                                                                                               \
+        if (getenv("DSQ_DEBUG_ROWS")) {                                                                                 \
+            int nb = -1;                                                                                                \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_alpha_mix<PP, Q, WG_>, 64 * nw, smem); \
+            fprintf(stderr, "[k_alpha_mix<%d,%d,%d>] smem %zu blocks %d x %d waves, n_list %d, occupancy %d blocks/CU\n", \
+                    PP, Q, (int)WG_, smem, blocks, nw, n_list, nb);                                                      \
+        }                                                                                                               \
+        hipLaunchKernelGGL((k_alpha_mix<PP, Q, WG_>), dim3(blocks), dim3(64 * nw), smem, st, ys, mu_s, D, cont_mask, list, \
+                           n_list, n_dev, queue, alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv, nfev, \
+                           grid_count, grid_list, nll_const, const_mode, eval_cap, resume, (Lbfgsb1d*)park_state,       \
+                           park_count, park_list);                                                                      \
+    } while (0)
 #define DSQ_MIX_LAUNCH(PP)                                                                                              \
     do {                                                                                                                \
         if constexpr (PP >= Q) {                                                                                        \
-            if (smem > 48 * 1024) {                                                                                     \
-                (void)hipFuncSetAttribute((const void*)k_alpha_mix<PP, Q>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                          (int)smem);                                                                   \
-                (void)hipGetLastError();                                                                                \
-            }                                                                                                           \
-            if (getenv("DSQ_DEBUG_ROWS")) {                                                                             \
-                int nb = -1;                                                                                            \
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_alpha_mix<PP, Q>, 64 * nw, smem); \
-                fprintf(stderr, "[k_alpha_mix<%d,%d>] smem %zu blocks %d x %d waves, n_list %d, occupancy %d blocks/CU\n", \
-                        PP, Q, smem, blocks, nw, n_list, nb);                                                           \
-            }                                                                                                           \
-            hipLaunchKernelGGL((k_alpha_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, ys, mu_s, D, cont_mask, list, \
-                               n_list, n_dev, queue, alpha_hat, min_disp, max_disp, prior_var, prior_reg, alpha, conv,  \
-                               nfev, grid_count, grid_list, nll_const, const_mode, eval_cap, resume,                    \
-                               (Lbfgsb1d*)park_state, park_count, park_list);                                           \
+            if (wg) DSQ_MIX_LAUNCH_K(PP, true);                                                                         \
+            else DSQ_MIX_LAUNCH_K(PP, false);                                                                           \
         }                                                                                                               \
     } while (0)
     switch (D.P) {
@@ -473,6 +531,7 @@ hipError_t DSQ_MIX_CAT(launch_alpha_mix_q, DSQ_MIX_Q)(
         case 8: DSQ_MIX_LAUNCH(8); break;
         default: return hipErrorInvalidValue;
     }
+#undef DSQ_MIX_LAUNCH_K
 #undef DSQ_MIX_LAUNCH
     return hipGetLastError();
 }

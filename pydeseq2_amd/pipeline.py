@@ -197,7 +197,9 @@ class DeseqPipeline:
         # under (row kernels: c2 / c3 5.92 -> 5.80 ms); the mixed-design family's lean kernel runs 2-3 ms past that tail at
         # 5000 samples, where sharing the compute units costs less than idling (c5: 51.7 vs 52.9 ms).  DSQ_MAP_WAIT=0 / 1.
         mw = os.environ.get("DSQ_MAP_WAIT")
-        self._map_waits_side = (self._row_mode != 3) if mw is None else (mw != "0")
+        # (c4, the many-cell row kernel: the robust kernel ends inside the tail - 7.09 / 7.12 ms without the wait, 7.11 / 7.20
+        # with it)
+        self._map_waits_side = (self._row_mode == 1) if mw is None else (mw != "0")
         self._work = None
         self.layers = {}
         self.time_kernels = False

@@ -16,7 +16,9 @@ def main():
     extra = sys.argv[3:]
     src = os.path.join(ROOT, "gpurun_out", tag)
     bench = [l for l in open(os.path.join(src, "bench_prof.log")) if l.startswith("{")][-1].strip()
-    out = [f"# {tag} — rocprofv3 --kernel-trace --stats -- python bench.py --config {cfg} --steps 5 --warmup 2  (MI355X)",
+    extra_args = os.environ.get("PROFILE_BENCH_ARGS", "")
+    out = [f"# {tag} — rocprofv3 --kernel-trace --stats -- python bench.py --config {cfg} --steps 5 --warmup 2 --no-extras"
+           f"{(' ' + extra_args) if extra_args else ''}  (MI355X)",
            "# bench line of the same (profiled) run:", bench, "", open(os.path.join(src, "stats.txt")).read(),
            "# separate PMC passes (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE; 1 step, no warmup).",
            "# Units KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE is doubled on gfx950, WRITE_SIZE taken as is."]

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Profile the bench on the GPU box: one rocprofv3 --kernel-trace --stats run of the default bench
-# command plus separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a single step.
+# Profile the bench on the GPU box: one rocprofv3 --kernel-trace --stats run of the bench command of ONE configuration
+# (--no-extras: the other configurations of the default run would mix their launches into the per-kernel table) plus separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a single step.
 #   usage (through gpurun):  bash tools/profile_round.sh <tag> [config]
 # Outputs under gpurun_out/<tag>/ ; tools/profile_collect.py turns them into profiles/<tag>_<config>.txt
 set -u
@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- \
-    python "$REPO/bench.py" --config "$CFG" --steps 5 --warmup 2 "$@" > "$OUT/bench_prof.log" 2> "$OUT/bench_prof.err"
+    python "$REPO/bench.py" --config "$CFG" --steps 5 --warmup 2 --no-extras "$@" > "$OUT/bench_prof.log" 2> "$OUT/bench_prof.err"
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$C" -o run -- \
         python "$REPO/bench.py" --config "$CFG" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > "$OUT/pmc_$C.log" 2>&1

@@ -395,6 +395,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->pc) {
         dsq_pc::destroy(*ctx->pc);
         delete ctx->pc;
+        ctx->pc = nullptr;
     }
     destroy_plugin_designs(ctx);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1057,11 +1058,6 @@ int dsq_dev_robust_disp2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double
     }
     if ((size_t)G + 1 > ctx->redo_cap) {
         if (ctx->d_redo) (void)hipFree(ctx->d_redo);
-    if (ctx->pc) {
-        dsq_pc::destroy(*ctx->pc);
-        delete ctx->pc;
-    }
-    destroy_plugin_designs(ctx);
         ctx->d_redo = nullptr; ctx->redo_cap = 0;
         DSQ_HIP(hipMalloc((void**)&ctx->d_redo, ((size_t)G + 1 + (size_t)G / 4) * sizeof(int32_t)));
         ctx->redo_cap = (size_t)G + 1 + (size_t)G / 4;

@@ -200,6 +200,8 @@ class DeseqPipeline:
         # (c4, the many-cell row kernel: the robust kernel ends inside the tail - 7.09 / 7.12 ms without the wait, 7.11 / 7.20
         # with it)
         self._map_waits_side = (self._row_mode == 1) if mw is None else (mw != "0")
+        # share of the genes whose robust dispersions run under the genewise stage's tail (the rest: under the MAP stage's)
+        self._robust_split = float(os.environ.get("DSQ_ROBUST_SPLIT", "0.78"))
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -740,14 +742,25 @@ class DeseqPipeline:
         # the parked dispersion fits, the grid-search pass, the trend / prior kernels on their reserved compute units)
         d_rd = S["rd"]
 
-        def launch_robust():
+        # Two parts (row-kernel designs, DSQ_ROBUST_SPLIT): the kernel (0.91 ms at c3) is a little longer than the latency-bound
+        # tail of the genewise stage it hides under (continuation, grid pass, trend, prior: 0.73 ms), and a MAP launch beside
+        # its end shares every compute unit with it.  Part one - the genes that fit under that tail - is forked inside the
+        # genewise fit as before; part two runs under the SAME tail of the MAP stage (its continuation and grid pass) and is
+        # joined before the LFC fit, whose epilogue is the first reader.  The MAP launch then starts when the prior is done.
+        split = self._robust_split if (self.overlap and self._map_waits_side and Gn >= 4096) else 1.0
+        g_cut = Gn if split >= 1.0 else max(1, min(Gn - 1, int(Gn * split) & ~3))
+
+        def launch_robust(part=0):
+            g0, g1 = (0, g_cut) if part == 0 else (g_cut, Gn)
+            if g1 <= g0:
+                return
             if self.overlap:
                 ctx.call("dsq_side_begin")
                 self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
             try:
-                self._k("robust_disp", Gn, "dsq_dev_robust_disp2", _vp(d_ynz.ptr), self.ldn, _vp(d_sf.ptr),
-                        _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole), D.max_cell,
-                        D.min_cell, N, Gn, _vp(d_rd.ptr))
+                self._k("robust_disp", g1 - g0, "dsq_dev_robust_disp2", _vp(d_ynz.ptr + 4 * self.ldn * g0), self.ldn,
+                        _vp(d_sf.ptr), _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole),
+                        D.max_cell, D.min_cell, N, g1 - g0, _vp(d_rd.ptr + 8 * g0))
             except BaseException:
                 if self.overlap:  # back on the main stream, both streams drained (a shared Context stays usable)
                     ctx.call("dsq_side_abort")
@@ -855,7 +868,25 @@ class DeseqPipeline:
             # its whole life (persistent workgroups) and pays more than the wait costs (A/B: DSQ_MAP_WAIT=0)
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        self._stage_map(d_ynz, d_mu_hat, Gn, d_sf, r.prior_disp_var, r.squared_logres, S)
+        hook2 = {"fired": False, "error": None}
+        if g_cut < Gn and want_robust and not self.time_kernels:
+            def _hook2(_arg):
+                hook2["fired"] = True
+                try:
+                    launch_robust(1)
+                except BaseException as e:  # (a ctypes callback cannot propagate it)
+                    hook2["error"] = e
+            self._alpha_hook2 = HOOK_FN(_hook2)
+            ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook2, C.c_void_p), None)
+        try:
+            self._stage_map(d_ynz, d_mu_hat, Gn, d_sf, r.prior_disp_var, r.squared_logres, S)
+        finally:
+            if g_cut < Gn:
+                ctx.call("dsq_set_alpha_hook", None, None)
+        if hook2["error"] is not None:
+            raise hook2["error"]
+        if g_cut < Gn and want_robust and not hook2["fired"]:
+            launch_robust(1)
         t4 = tick(); T["MAP"] = t4 - t3
 
         # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics

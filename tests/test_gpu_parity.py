@@ -1095,6 +1095,16 @@ def test_plugin_cache_hits_adoption_and_invalidation():
     bad[0, 0] = 0.0
     with pytest.raises(ValueError):
         inf.alpha_mle(counts, X, bad, k["mom"], 1e-8, maxd)
+    # the cache shares its context with a device-resident pipeline (bench.py does exactly this): a pipeline run in between -
+    # larger than anything the context has seen, so its grow-only workspaces are reallocated - leaves the cache intact
+    import pydeseq2_amd
+
+    s7 = inf.cache_stats()
+    c_big, X_big = orc.synth_counts(5000, 40, "2level", 3)
+    pydeseq2_amd.DeseqPipeline(c_big, X_big, ctx=inf.ctx).deseq2()
+    a_again, _ = inf.alpha_mle(counts, X, mu_copy, k["mom"], 1e-8, maxd)
+    s8 = inf.cache_stats()
+    assert (a_again == a1).all() and s8["hits"] == s7["hits"] + 2 and s8["misses"] == s7["misses"]
     # all-zero genes are dropped by fit_moments_dispersions as utils.py:878 does
     normed = counts / sf[:, None]
     normed[:, 4] = 0.0

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1
 }
 
 // designs of 13 ... 32 columns: run-time p, one gene per 64-thread workgroup (its workspace is 17 / 33 KB of LDS)
-template <int PMAX>
+// PB: the multiple of 8 the column loops walk (>= p)
+template <int PMAX, int PB = PMAX>
 __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ y, int ldn,
                                                     const double* __restrict__ offset, const double* __restrict__ Xt,
                                                     int ldx, int N, int G, int p, const double* __restrict__ size,
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ 
     ShrinkArgs A;
     A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
-    const int ok = shrink_gene_wide<DeviceWave, PMAX>(A, p, work, beta + (size_t)g * p,
-                                                      invh ? invh + (size_t)g * p * p : nullptr);
+    const int ok = shrink_gene_wide<DeviceWave, PMAX, decltype(work), PB>(A, p, work, beta + (size_t)g * p,
+                                                                          invh ? invh + (size_t)g * p * p : nullptr);
     if (threadIdx.x == 0) conv[g] = (uint8_t)ok;
 }
 
@@ -82,11 +83,14 @@ hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double
     if (P_ > DSQ_REG_MAX_P) {
         if (P_ > 32 || ih_entry != nullptr) return hipErrorInvalidValue;  // (the run-time-p kernel writes the whole inverse)
         if (P_ <= 16)
-            hipLaunchKernelGGL(k_shrink_wide<16>, dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size, sigma0,
-                               sigma, shrink_index, beta, invh, conv);
+            hipLaunchKernelGGL((k_shrink_wide<16, 16>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size,
+                               sigma0, sigma, shrink_index, beta, invh, conv);
+        else if (P_ <= 24)
+            hipLaunchKernelGGL((k_shrink_wide<32, 24>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size,
+                               sigma0, sigma, shrink_index, beta, invh, conv);
         else
-            hipLaunchKernelGGL(k_shrink_wide<32>, dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size, sigma0,
-                               sigma, shrink_index, beta, invh, conv);
+            hipLaunchKernelGGL((k_shrink_wide<32, 32>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size,
+                               sigma0, sigma, shrink_index, beta, invh, conv);
         return hipGetLastError();
     }
     const dim3 grid(genes_to_blocks(G)), block(kBlock);

@@ -405,19 +405,22 @@ struct IsWaveWideWork { static constexpr bool value = false; };
 template <int PMAX>
 struct IsWaveWideWork<ShrinkWorkWide<PMAX, true>> { static constexpr bool value = true; };
 
-template <class Wv, int PMAX>
+// PB: the column loops walk PB <= PMAX columns (a multiple of 8 >= p: round 5 - at p = 24 the 32-column walk of the first
+// version spent a quarter of its per-sample work on zeros); columns [p, PB) read as zero
+template <class Wv, int PMAX, int PB = PMAX>
 DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, double* g) {
+    static_assert(PB <= PMAX && PB % 8 == 0, "column block");
     const double lsz = log(A.size);
-    double b[PMAX], gr[PMAX];
+    double b[PB], gr[PB];
 #pragma unroll
-    for (int j = 0; j < PMAX; ++j) { b[j] = j < p ? xb[j] : 0.0; gr[j] = 0.0; }
+    for (int j = 0; j < PB; ++j) { b[j] = j < p ? xb[j] : 0.0; gr[j] = 0.0; }
     double s = 0.0;
     for (int n = Wv::lane(); n < A.N; n += Wv::W) {
         const double yv = (double)A.y[n];
-        double x[PMAX];
+        double x[PB];
         double eta = 0.0;
 #pragma unroll
-        for (int j = 0; j < PMAX; ++j) {
+        for (int j = 0; j < PB; ++j) {
             x[j] = j < p ? A.Xt[j * A.ldx + n] : 0.0;
             eta += x[j] * b[j];  // (x[j] b[j] = 0 exactly beyond p: the sum's value and rounding are those of p terms)
         }
@@ -429,22 +432,22 @@ DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, doubl
         if (g != nullptr) {
             const double gk = yv - (yv + A.size) * ((d > 0 ? 1.0 : e) * frcp(1.0 + e));
 #pragma unroll
-            for (int j = 0; j < PMAX; ++j) gr[j] += gk * x[j];
+            for (int j = 0; j < PB; ++j) gr[j] += gk * x[j];
         }
     }
     s = Wv::sum(s);
     double prior = 0.0, bs = 0.0;
 #pragma unroll
-    for (int j = 0; j < PMAX; ++j) {
+    for (int j = 0; j < PB; ++j) {
         if (j < p && j != A.shrink_index) prior += (b[j] * b[j]) / (2.0 * A.sigma0 * A.sigma0);
         bs = (j == A.shrink_index) ? b[j] : bs;
     }
     const double q = bs / A.sigma;
     prior += log1p(q * q);
     if (g != nullptr) {
-        Wv::template sum_n<PMAX>(gr);
+        Wv::template sum_n<PB>(gr);
 #pragma unroll
-        for (int j = 0; j < PMAX; ++j) {
+        for (int j = 0; j < PB; ++j) {
             if (j < p) {
                 const double dp = (j == A.shrink_index) ? 2.0 * b[j] / (A.sigma * A.sigma + bs * bs)
                                                         : b[j] / (A.sigma0 * A.sigma0);
@@ -456,13 +459,13 @@ DSQ_HD double shrink_fn_wide(const ShrinkArgs& A, int p, const double* xb, doubl
 }
 
 // beta[p] (out), inv_hessian[p*p] row-major (out, nullable); returns scipy's res.success
-template <class Wv, int PMAX, class Work>
+template <class Wv, int PMAX, class Work, int PB = PMAX>
 DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, Work& Wk, double* beta, double* inv_hessian) {
     constexpr bool kWave = IsWaveWideWork<Work>::value;
     double* const xw = [&]() { if constexpr (kWave) return Wk.lb.x; else return Wk.x; }();
     for (int j = 0; j < p; ++j) xw[j] = 0.0;
     Wv::sync();
-    const double f0 = shrink_fn_wide<Wv, PMAX>(A, p, xw, nullptr);
+    const double f0 = shrink_fn_wide<Wv, PMAX, PB>(A, p, xw, nullptr);
     const double cnst = f0 > 1.0 ? f0 : 1.0;  // np.maximum(scale_cnst, 1): NaN propagates like numpy
     const double cn = (f0 != f0) ? f0 : cnst;
     for (int j = 0; j < PMAX; ++j) {
@@ -475,10 +478,10 @@ DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, Work& Wk, double* beta, 
     }
     Wv::sync();
     auto fg = [&](const double* xb, double& f, double* g) {
-        double gg[PMAX];
-        f = shrink_fn_wide<Wv, PMAX>(A, p, xb, gg) / cn;
+        double gg[PB];
+        f = shrink_fn_wide<Wv, PMAX, PB>(A, p, xb, gg) / cn;
 #pragma unroll
-        for (int j = 0; j < PMAX; ++j)
+        for (int j = 0; j < PB; ++j)
             if (j < p) g[j] = gg[j] / cn;
     };
     LbfgsbResult res;
@@ -491,40 +494,49 @@ DSQ_HD int shrink_gene_wide(const ShrinkArgs& A, int p, Work& Wk, double* beta, 
     if (Wv::lane() == 0)
         for (int j = 0; j < p; ++j) beta[j] = xw[j];
     if (inv_hessian == nullptr) return res.success ? 1 : 0;
-    // Hessian (cnst = 1), one row per pass:  X^T diag(frac) X + h  with the reference's broadcasting quirk (h_j is added
-    // to every row of column j, utils.py:1099-1110; see shrink_gene)
-    double b[PMAX];
+    // Hessian (cnst = 1), TWO rows per pass over the samples (round 5: one row per pass recomputed the linear predictor and
+    // its exponential p times - at p = 24 a third of the kernel's instructions):  X^T diag(frac) X + h  with the
+    // reference's broadcasting quirk (h_j is added to every row of column j, utils.py:1099-1110; see shrink_gene).  Every
+    // entry keeps its own accumulator and summation order: the matrix is bit-identical to the one-row version's.
+    double b[PB];
 #pragma unroll
-    for (int j = 0; j < PMAX; ++j) b[j] = j < p ? xw[j] : 0.0;
+    for (int j = 0; j < PB; ++j) b[j] = j < p ? xw[j] : 0.0;
     const double bs = xw[A.shrink_index];
     const double s2 = A.sigma * A.sigma, b2 = bs * bs;
-    for (int i = 0; i < p; ++i) {
-        double r[PMAX];
+    for (int i = 0; i < p; i += 2) {
+        const bool two = i + 1 < p;
+        double r0[PB], r1[PB];
 #pragma unroll
-        for (int j = 0; j < PMAX; ++j) r[j] = 0.0;
+        for (int j = 0; j < PB; ++j) { r0[j] = 0.0; r1[j] = 0.0; }
         for (int n = Wv::lane(); n < A.N; n += Wv::W) {
             const double yv = (double)A.y[n];
-            double x[PMAX];
+            double x[PB];
             double eta = 0.0;
 #pragma unroll
-            for (int j = 0; j < PMAX; ++j) {
+            for (int j = 0; j < PB; ++j) {
                 x[j] = j < p ? A.Xt[j * A.ldx + n] : 0.0;
                 eta += x[j] * b[j];
             }
             const double e = exp(eta + A.offset[n]);
             const double fr = (yv + A.size) * A.size * e / ((A.size + e) * (A.size + e));
-            const double xw = A.Xt[i * A.ldx + n] * fr;
+            const double xw0 = A.Xt[i * A.ldx + n] * fr;
+            const double xw1 = two ? A.Xt[(i + 1) * A.ldx + n] * fr : 0.0;
 #pragma unroll
-            for (int j = 0; j < PMAX; ++j) r[j] += xw * x[j];
+            for (int j = 0; j < PB; ++j) { r0[j] += xw0 * x[j]; r1[j] += xw1 * x[j]; }
         }
-        Wv::template sum_n<PMAX>(r);
+        Wv::template sum_n<PB>(r0);
+        Wv::template sum_n<PB>(r1);
 #pragma unroll
-        for (int j = 0; j < PMAX; ++j) {
+        for (int j = 0; j < PB; ++j) {
             if (j < p && Wv::lane() == 0) {
                 const double hd = (j == A.shrink_index) ? 2.0 * (s2 - b2) / ((s2 + b2) * (s2 + b2))
                                                         : 1.0 / (A.sigma0 * A.sigma0);
-                Wk.Hm[i * p + j] = r[j] + hd;
+                Wk.Hm[i * p + j] = r0[j] + hd;
                 Wk.Iv[i * p + j] = (i == j) ? 1.0 : 0.0;
+                if (two) {
+                    Wk.Hm[(i + 1) * p + j] = r1[j] + hd;
+                    Wk.Iv[(i + 1) * p + j] = (i + 1 == j) ? 1.0 : 0.0;
+                }
             }
         }
     }

@@ -669,7 +669,9 @@ def main():
                 # the other BASELINE configurations on the same device (configs[1], [3] at full size, and one GPU's share
                 # of configs[4]): each with its step time, its dispersion-stage roofline fraction and an in-run parity check
                 oc = {}
-                for nm, gn, pg, st, wu in (("c2", 0, 2000, 20, 5), ("c4", 0, 0, 20, 5), ("c5", 7500, 300, 20, 5),
+                # (single-GPU runs only: in a multi-rank job the other ranks wait for rank 0 behind the control plane's
+                # socket timeout, and the driver's N = 1 run records these)
+                for nm, gn, pg, st, wu in () if world > 1 else (("c2", 0, 2000, 20, 5), ("c4", 0, 0, 20, 5), ("c5", 7500, 300, 20, 5),
                                            ("c5", 0, 0, 8, 3)):
                     key = nm if gn == 0 else f"{nm}_shard"
                     if key == "c5" and os.environ.get("DSQ_BENCH_NO_C5_FULL"):
@@ -680,7 +682,8 @@ def main():
                         oc[key] = {"error": repr(e)}
                 if "c4" in oc and "parity_c4" in extras:
                     oc["c4"]["parity"] = extras["parity_c4"]
-                extras["other_configs"] = oc
+                if oc:
+                    extras["other_configs"] = oc
         except Exception as e:  # noqa: BLE001 - the GPU measurement above stands on its own
             print(f"[bench] cpu_baseline / parity failed: {e!r}", file=sys.stderr)
     parity_ok = bool(parity and parity["ok"] and extras.get("parity_c4", {"ok": True})["ok"])

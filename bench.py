@@ -585,6 +585,7 @@ def main():
     # is still finishing (it no longer waits behind the trend fit): both averages are reported, the roofline object
     # uses the one over ALL full-size launches, which is what rocprofv3's per-kernel average of this command shows
     solo = [ms for (ms, g), nm in zip(launches, stages) if g > 0.5 * G and nm == "alpha_mle"]
+    maps = [ms for (ms, g), nm in zip(launches, stages) if g > 0.5 * G and nm == "alpha_map"]
     full_ms = float(np.mean([ms for ms, _ in big]))
     genes_full = float(np.mean([g for _, g in big]))
     alg_bytes = genes_full * (12.0 * N + 17.0)
@@ -612,9 +613,12 @@ def main():
         "full_launches_timed": len(big),
         "full_launch_ms_genewise_only": round(float(np.mean(solo)), 4) if solo else None,
         "frac_genewise_only": round(alg_bytes / (float(np.mean(solo)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if solo else None,
-        "overlap_note": "the genewise launches have the device to themselves; the MAP launches start while the "
-                        "robust-dispersion kernel of the side stream is still running (the shorter the trend fit, the longer "
-                        "that overlap) and are the longer for it - `achieved` / `frac` average over both, as rocprofv3 does",
+        "full_launch_ms_MAP_only": round(float(np.mean(maps)), 4) if maps else None,
+        "overlap_note": "round 5: for the row-kernel designs (c2, c3) the MAP launch no longer starts beside the end of the "
+                        "robust-dispersion kernel of the side stream (that kernel runs in two parts, under the tails of the "
+                        "genewise and of the MAP stage), so genewise and MAP launches take the same time; for the other "
+                        "designs the MAP launch still shares the machine with it - `achieved` / `frac` average over both, as "
+                        "rocprofv3 does",
         "avg_launch_ms_all": round(float(np.mean([ms for ms, _ in launches])), 4), "launches_timed": len(launches),
         "pipeline_algorithmic_GBps": round(G * 104.0 * N / (dt / args.steps) / 1e9, 2),
         "kernel_ms_per_step": stage_ms, "grid_fallback_genes_per_step": n_fallback,

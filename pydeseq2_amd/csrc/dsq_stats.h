@@ -499,6 +499,39 @@ DSQ_HD unsigned long long pos_key(double v) {  // order-preserving for v >= +0
     return b;
 }
 
+// body(buf[k]) for this lane's k = lane, lane + W, ... < n, the values fetched U at a time BEFORE the bodies run: with an
+// accessor that reads global memory (NormedValues) a wavefront keeps U loads in flight instead of one per trip through
+// LDS atomics (k_robust_disp_lean was 76 % SQ_WAIT_ANY at one).  Same order of the calls per lane as the plain loop.
+#ifndef DSQ_BATCH_U
+#define DSQ_BATCH_U 4
+#endif
+template <int U, class Buf>
+DSQ_HD void fetch_batch(const Buf& buf, int k0, int stride, int n, double (&v)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * stride;
+        v[u] = k < n ? buf[k] : 0.0;
+    }
+}
+struct NormedValues;  // (below; its fetch_batch overload loads without branches)
+template <int U>
+DSQ_HD void fetch_batch(const NormedValues& V, int k0, int stride, int n, double (&v)[U]);
+
+template <class Wv, int U = DSQ_BATCH_U, class Buf, class F>
+DSQ_HD void for_each_batched_k(const Buf& buf, int n, F&& body) {  // body(k, buf[k])
+    for (int k0 = Wv::lane(); k0 < n; k0 += Wv::W * U) {
+        double v[U];
+        fetch_batch<U>(buf, k0, Wv::W, n, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u * Wv::W < n) body(k0 + u * Wv::W, v[u]);
+    }
+}
+template <class Wv, int U = DSQ_BATCH_U, class Buf, class F>
+DSQ_HD void for_each_batched(const Buf& buf, int n, F&& body) {
+    for_each_batched_k<Wv, U>(buf, n, [&](int, double v) { body(v); });
+}
+
 // out = sum of the elements of ranks j_lo .. j_hi (ascending, 0-based, inclusive) among the ACTIVE entries
 // (buf[k] >= 0) of buf[0..n), of which there must be n_act.  false: not applicable here (a non-finite value, a
 // boundary bucket with more than kBucketGather entries) - nothing but W has been written.
@@ -515,14 +548,13 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
         vmin = range[0]; vmax = range[1];
     } else {
         int seen = 0;
-        for (int k = Wv::lane(); k < n; k += Wv::W) {
-            const double v = buf[k];
+        for_each_batched<Wv>(buf, n, [&](double v) {
             if (v >= 0.0) {
                 vmin = v < vmin ? v : vmin;
                 vmax = v > vmax ? v : vmax;
                 seen += 1;
             }
-        }
+        });
         vmin = -Wv::max(-vmin);
         vmax = Wv::max(vmax);
         seen = Wv::sumi(seen);
@@ -535,14 +567,13 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
     for (int b = Wv::lane(); b < kBuckets; b += Wv::W) { W.cnt[b] = 0u; W.sum[b] = 0.0; }
     for (int t = Wv::lane(); t < 2; t += Wv::W) W.n_edge[t] = 0u;
     Wv::sync();
-    for (int k = Wv::lane(); k < n; k += Wv::W) {
-        const double v = buf[k];
+    for_each_batched<Wv>(buf, n, [&](double v) {
         if (v >= 0.0) {
             const int b = (int)((pos_key(v) - kmin) >> shift);
             Wv::hist_add(&W.cnt[b]);
             Wv::cell_add(&W.sum[b], v);
         }
-    }
+    });
     Wv::sync();
     // the buckets of the two boundary ranks and the sum of everything strictly between them
     constexpr int BPL = kBuckets / (Wv::W < kBuckets ? Wv::W : kBuckets);  // consecutive buckets per lane
@@ -571,14 +602,13 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
     inside = Wv::sum(inside);
     // the entries of the boundary buckets, ranked one against the other
     const bool one = fb[0] == fb[1];
-    for (int k = Wv::lane(); k < n; k += Wv::W) {
-        const double v = buf[k];
+    for_each_batched<Wv>(buf, n, [&](double v) {
         if (v >= 0.0) {
             const int b = (int)((pos_key(v) - kmin) >> shift);
             if (b == fb[0]) W.edge[0][Wv::slot_add(&W.n_edge[0])] = v;
             else if (b == fb[1]) W.edge[1][Wv::slot_add(&W.n_edge[1])] = v;
         }
-    }
+    });
     Wv::sync();
     double part = 0.0;
 #pragma unroll
@@ -714,6 +744,65 @@ DSQ_HD double seg_trimmed_variances(const int32_t* y, const double* sf, const Ce
     return vmax;
 }
 
+// The k-th normalised count of a design cell (y / sf, as y * (1 / sf)), or its squared error against `tm`; -1 for a
+// zero count (inactive for bucket_rank_sum) - recomputed from the gene's row on every access instead of being kept in
+// a wave-private LDS buffer: the row is read from L1 / L2 three more times, the LDS footprint of a wavefront drops from
+// next_pow2(N) doubles (64 KB at N = 5000: two wavefronts per CU) to the bucket table (8 KB)
+struct NormedValues {
+    const int32_t* y;
+    const double* sf;
+    const int32_t* idx;  // the cell's sample indices, or null: samples 0 .. n-1
+    double tm;
+    bool squared;
+    DSQ_HD double operator[](int k) const {
+        const int s = idx != nullptr ? idx[k] : k;
+        const int yi = y[s];
+        if (yi == 0) return -1.0;
+        const double v = (double)yi * frcp_g(sf[s]);
+        if (!squared) return v;
+        const double d = v - tm;
+        return d * d;
+    }
+};
+
+// U values of a NormedValues at once, without a branch between the loads: the index loads go out together, then the
+// count and size-factor loads (the one-value accessor is a chain of three dependent loads with a branch on the count
+// in the middle; the compiler keeps that chain per value).  Positions past n re-read position k0 and are ignored by
+// for_each_batched.
+template <int U>
+DSQ_HD void fetch_batch(const NormedValues& V, int k0, int stride, int n, double (&v)[U]) {
+    int s[U];
+    if (V.idx != nullptr) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * stride;
+            s[u] = V.idx[k < n ? k : k0];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * stride;
+            s[u] = k < n ? k : k0;
+        }
+    }
+    int yi[U];
+    double f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        yi[u] = V.y[s[u]];
+        f[u] = V.sf[s[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        double x = (double)yi[u] * frcp_g(f[u]);
+        if (V.squared) {
+            const double d = x - V.tm;
+            x = d * d;
+        }
+        v[u] = yi[u] == 0 ? -1.0 : x;
+    }
+}
+
 // flags[n]: bit0 use_for_max (cell >= 3 replicates), bit1 replaceable (cell >= min_replicates)
 // Robust dispersion of utils.robust_method_of_moments_disp (utils.py:914-960): per design cell the trimmed
 // variance of the normalised counts around their trimmed mean, the largest cell variance vs the overall mean.
@@ -760,19 +849,17 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
             BucketWork& W = *(BucketWork*)hist;
             int zeros = 0, bad = 0;
             double lo1 = INFINITY, hi1 = -INFINITY;
-            for (int k = Wv::lane(); k < n; k += Wv::W) {
-                const int sidx = C.whole ? k : C.cell_index[beg + k];
-                const int yi = y[sidx];
-                const double v = (double)yi * frcp_g(sf[sidx]);
-                scratch[k] = yi == 0 ? -1.0 : v;
-                zeros += yi == 0 ? 1 : 0;
-                if (yi != 0) {
+            const NormedValues V{y, sf, C.whole ? nullptr : C.cell_index + beg, 0.0, false};
+            for_each_batched_k<Wv>(V, n, [&](int k, double v) {  // (v = -1: a zero count)
+                scratch[k] = v;
+                zeros += v < 0.0 ? 1 : 0;
+                if (!(v < 0.0)) {
                     bad |= (v >= 0.0 && v < INFINITY) ? 0 : 1;
                     lo1 = v < lo1 ? v : lo1;
                     hi1 = v > hi1 ? v : hi1;
                     cell_total += v;
                 }
-            }
+            });
             zeros = Wv::sumi(zeros);
             bad = Wv::sumi(bad);
             double range[2] = {-Wv::max(-lo1), Wv::max(hi1)};
@@ -870,27 +957,6 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
     return ar;
 }
 
-// The k-th normalised count of a design cell (y / sf, as y * (1 / sf)), or its squared error against `tm`; -1 for a
-// zero count (inactive for bucket_rank_sum) - recomputed from the gene's row on every access instead of being kept in
-// a wave-private LDS buffer: the row is read from L1 / L2 three more times, the LDS footprint of a wavefront drops from
-// next_pow2(N) doubles (64 KB at N = 5000: two wavefronts per CU) to the bucket table (8 KB)
-struct NormedValues {
-    const int32_t* y;
-    const double* sf;
-    const int32_t* idx;  // the cell's sample indices, or null: samples 0 .. n-1
-    double tm;
-    bool squared;
-    DSQ_HD double operator[](int k) const {
-        const int s = idx != nullptr ? idx[k] : k;
-        const int yi = y[s];
-        if (yi == 0) return -1.0;
-        const double v = (double)yi * frcp_g(sf[s]);
-        if (!squared) return v;
-        const double d = v - tm;
-        return d * d;
-    }
-};
-
 // robust_disp_gene for designs whose cells ALL take the bucket path (every cell - or the whole sample set - has at least
 // kTrimBucketMin samples), without a per-wave buffer of the cell's values (NormedValues).  failed = true: a boundary
 // bucket held too many values or a value was not finite - the caller hands the gene to robust_disp_gene (selection path).
@@ -912,8 +978,7 @@ DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const Ce
         NormedValues V{y, sf, C.whole ? nullptr : C.cell_index + beg, 0.0, false};
         int zeros = 0, bad = 0;
         double lo1 = INFINITY, hi1 = -INFINITY;
-        for (int k = Wv::lane(); k < n; k += Wv::W) {
-            const double v = V[k];
+        for_each_batched<Wv>(V, n, [&](double v) {
             zeros += v < 0.0 ? 1 : 0;
             if (!(v < 0.0)) {
                 bad |= (v >= 0.0 && v < INFINITY) ? 0 : 1;
@@ -921,7 +986,7 @@ DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const Ce
                 hi1 = v > hi1 ? v : hi1;
                 cell_total += v;
             }
-        }
+        });
         zeros = Wv::sumi(zeros);
         bad = Wv::sumi(bad);
         double range[2] = {-Wv::max(-lo1), Wv::max(hi1)};
@@ -940,15 +1005,14 @@ DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const Ce
         V.squared = true;
         int below = 0;  // values whose squared error sorts before the block of the zero counts
         double lo2 = INFINITY, hi2 = -INFINITY;
-        for (int k = Wv::lane(); k < n; k += Wv::W) {
-            const double q = V[k];
+        for_each_batched<Wv>(V, n, [&](double q) {
             if (q >= 0.0) {
                 below += q < tm2 ? 1 : 0;
                 bad |= (q < INFINITY) ? 0 : 1;
                 lo2 = q < lo2 ? q : lo2;
                 hi2 = q > hi2 ? q : hi2;
             }
-        }
+        });
         below = Wv::sumi(below);
         bad = Wv::sumi(bad);
         range[0] = -Wv::max(-lo2); range[1] = Wv::max(hi2);

@@ -485,7 +485,8 @@ constexpr int kBuckets = DSQ_BUCKETS;
 constexpr int kBucketGather = DSQ_BUCKET_GATHER;  // elements a boundary bucket may hold; beyond: the caller takes the selection path
 constexpr int kTrimBucketMin = 129; // cells from this size on take the bucket path (smaller ones sort in a few stages)
 struct BucketWork {                 // wave-private LDS
-    double sum[kBuckets];           // (doubles as the 2 * kTrimBins counters of trimmed_sum_select, the fallback)
+    double sum[kBuckets];           // the 2 * kTrimBins counters of trimmed_sum_select, the fallback (the bucket path itself
+                                    // only counts: bucket_rank_sum)
     unsigned int cnt[kBuckets];
     double edge[2][kBucketGather];
     unsigned int n_edge[2];
@@ -564,14 +565,13 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
     if (kmin == kmax) { out = (double)(j_hi - j_lo + 1) * vmin; return true; }
     int shift = 0;
     while (((kmax - kmin) >> shift) >= (unsigned long long)kBuckets) ++shift;
-    for (int b = Wv::lane(); b < kBuckets; b += Wv::W) { W.cnt[b] = 0u; W.sum[b] = 0.0; }
+    for (int b = Wv::lane(); b < kBuckets; b += Wv::W) W.cnt[b] = 0u;
     for (int t = Wv::lane(); t < 2; t += Wv::W) W.n_edge[t] = 0u;
     Wv::sync();
     for_each_batched<Wv>(buf, n, [&](double v) {
         if (v >= 0.0) {
             const int b = (int)((pos_key(v) - kmin) >> shift);
             Wv::hist_add(&W.cnt[b]);
-            Wv::cell_add(&W.sum[b], v);
         }
     });
     Wv::sync();
@@ -594,17 +594,15 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
 #pragma unroll
     for (int t = 0; t < 2; ++t) { fb[t] = Wv::sumi(fb[t]); fc[t] = Wv::sumi(fc[t]); fn[t] = Wv::sumi(fn[t]); }  // one lane hits
     if (fn[0] > kBucketGather || fn[1] > kBucketGather) return false;
-    double inside = 0.0;
-    for (int q = 0; q < BPL; ++q) {
-        const int b = b0 + q;
-        inside += (b > fb[0] && b < fb[1]) ? W.sum[b] : 0.0;
-    }
-    inside = Wv::sum(inside);
-    // the entries of the boundary buckets, ranked one against the other
+    // the entries of the boundary buckets, ranked one against the other; everything strictly between the two buckets is
+    // added up in registers on the way (the histogram pass counts only: an LDS atomic on a double per value cost more
+    // than the rest of that pass)
     const bool one = fb[0] == fb[1];
+    double inside = 0.0;
     for_each_batched<Wv>(buf, n, [&](double v) {
         if (v >= 0.0) {
             const int b = (int)((pos_key(v) - kmin) >> shift);
+            inside += (b > fb[0] && b < fb[1]) ? v : 0.0;
             if (b == fb[0]) W.edge[0][Wv::slot_add(&W.n_edge[0])] = v;
             else if (b == fb[1]) W.edge[1][Wv::slot_add(&W.n_edge[1])] = v;
         }
@@ -628,7 +626,7 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
             part += (r >= r_from && r <= r_to) ? e : 0.0;
         }
     }
-    out = inside + Wv::sum(part);
+    out = Wv::sum(inside + part);
     Wv::sync();  // W is free again
     return true;
 }

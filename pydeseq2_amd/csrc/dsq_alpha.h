@@ -450,6 +450,47 @@ DSQ_HD double alpha_const(const int32_t* y, const double* mu, int N) {
     return Wv::sum_comp(c);
 }
 
+// alpha_const and the gene's largest count in ONE pass, the rows fetched four samples per lane at a time (the grid
+// fallback's wavefronts walk global rows alone: a pass is a chain of load latencies, so it pays to have fewer passes
+// and more loads in flight).  Same terms in the same order per lane as alpha_const: the same constant, bit for bit.
+template <class Wv>
+DSQ_HD double alpha_const_max(const int32_t* y, const double* mu, int N, int& max_count) {
+    constexpr int U = 4;
+    KSum c;
+    int mx = 0;
+    for (int base = 0; base < N; base += Wv::W * U) {
+        int yi[U];
+        double m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = base + u * Wv::W + Wv::lane();
+            const int nn = n < N ? n : N - 1;
+            yi[u] = y[nn];
+            m[u] = mu[nn];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * Wv::W >= N) break;  // (alpha_const stops at the last partial group of W samples, too)
+            const bool valid = base + u * Wv::W + Wv::lane() < N;
+            const int yv_i = valid ? yi[u] : 0;
+            const double yv = (double)yv_i;
+            const double mm = valid ? m[u] : 1.0;
+            mx = yv_i > mx ? yv_i : mx;
+            const bool in_tab = yv_i < kLgammaIntN;
+            double lg = kLgammaInt[in_tab ? yv_i : 0];
+            if (Wv::any(!in_tab)) {
+                const double z = in_tab ? 300.0 : yv + 1.0;
+                const double lz = flog(z);
+                const double big = (z - 0.5) * lz - z + kHalfLog2Pi + stirling_tail(frcp(z));
+                if (!in_tab) lg = big;
+            }
+            c.add(lg - yv * flog_t(mm));
+        }
+    }
+    max_count = Wv::maxi(mx);
+    return Wv::sum_comp(c);
+}
+
 // one gene: L-BFGS-B in log(alpha) from log(alpha_hat).  RUN_GRID: on non-convergence run the
 // reference's grid search right here (host simulation / single-kernel use); otherwise only report
 // converged = 0 and the caller schedules grid_alpha_gene for the gene (device: second tiny kernel,

@@ -217,12 +217,11 @@ __global__ __launch_bounds__(kBlock) void k_alpha_grid_eval(const int32_t* __res
     AlphaArgs A;
     A.y = y + (size_t)g * ldn; A.mu = mu + (size_t)(mu_compact ? k : g) * ldn; A.Xt = Xt; A.ldx = ldx; A.N = N;
     A.la_hat = 0.0; A.prior_var = 1.0;
-    A.cst = alpha_const<DeviceWave>(A.y, A.mu, N);
     // the count memo of alpha_eval covers 64 * NB counts and relies on its caller to pick NB from the gene's
     // largest count (as k_alpha does); NB = 1 for a gene with counts >= 64 reads other counts' memo entries
     int maxc = 0;
-    for (int n = lane; n < N; n += 64) maxc = A.y[n] > maxc ? A.y[n] : maxc;
-    const int mb = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (DeviceWave::maxi(maxc) >> 6) + 1));
+    A.cst = alpha_const_max<DeviceWave>(A.y, A.mu, N, maxc);
+    const int mb = __builtin_amdgcn_readfirstlane(min(kMemoBlocks, (maxc >> 6) + 1));
     const double lo = stage == 0 ? lo0 : lohi[2 * k], hi = stage == 0 ? hi0 : lohi[2 * k + 1];
     const double la = linspace_at(lo, hi, kGridLen, i);
     double f, gu;

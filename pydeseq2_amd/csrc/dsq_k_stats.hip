@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp(const int32_t* __restr
 // Designs whose cells all have at least kTrimBucketMin samples (or no cells at all: one trimmed variance over every
 // sample - designs with continuous covariates): the bucket sums recompute the normalised counts from the gene's row on
 // every pass instead of keeping them in LDS (robust_disp_gene_lean).  At N = 5000 the buffered kernel held 70 KB of LDS
-// per wavefront - two wavefronts per CU, 13.3 ms for 60 000 genes; this one holds the 8 KB bucket table: 5.5 ms.  A gene on
+// per wavefront - two wavefronts per CU, 13.3 ms for 60 000 genes; this one holds the 8 KB bucket table: 5.5 ms, 2.6 ms with the
+// batched fetch of NormedValues (dsq_stats.h, fetch_batch).  A gene on
 // which a bucket pass gives up (a boundary bucket with more than kBucketGather values, a non-finite value) is listed
 // and redone by the buffered kernel.
 template <int WPB>
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp_lean(const int32_t* __
 }
 
 // ... where the buffer costs occupancy: from 2048 samples in the largest cell on (16 KB + 8 KB of LDS per wavefront).
-// Measured: c5 (one "cell" of 5000 samples) 13.3 -> 5.5 ms per 60 000 genes; c3 (two cells of 500: 12 KB per wavefront
+// Measured (before the batched fetch): c5 (one "cell" of 5000 samples) 13.3 -> 5.5 ms per 60 000 genes; c3 (two cells of 500: 12 KB per wavefront
 // either way) 0.84 -> 1.14 ms - the recomputation costs more than the buffer there, so c3 stays on the buffered kernel.
 bool robust_disp_lean_eligible(int min_cell, int max_cell, int whole, int N) {
     const bool off = getenv("DSQ_NO_ROBUST_LEAN") != nullptr;  // A/B switch (read per launch: the tests flip it)

@@ -1177,7 +1177,7 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
     }
     if (h_ridge != nullptr) {
         double* d_ridge = ctx->d_scratch + 16;
-        double* d_contrast = d_ridge + DSQ_MAX_P * DSQ_MAX_P;
+        double* d_contrast = d_ridge + P * P;  // (behind the matrix: both travel in one copy)
         // via page-locked memory: the caller's arrays may be temporaries, and a pageable source would make the
         // copy (and the launch behind it) wait for the host
         // (stream-ordered: a rescue kernel of the previous call may still be reading them; the slot itself is free
@@ -1185,8 +1185,7 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
         double* h_stage = (double*)(ctx->h_pin + 16);
         std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
         std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
-        DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        DSQ_HIP(hipMemcpyAsync(d_contrast, h_stage + P * P, (size_t)P * sizeof(double), hipMemcpyHostToDevice,
+        DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)(P * P + P) * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
         ex.ridge = d_ridge; ex.contrast = d_contrast; ex.lfc_null = lfc_null; ex.alt = alt;
         ex.pvals = d_pvals; ex.stats = d_stats; ex.se = d_se;

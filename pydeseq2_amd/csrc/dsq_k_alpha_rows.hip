@@ -719,7 +719,10 @@ hipError_t launch_alpha_rows(hipStream_t st, const int32_t* y, int ldn, int N, c
     return hipGetLastError();
 }
 
-// per gene: -1 when the row kernel cannot take it (a count that does not fit its 16-bit staging), else the number of its
+// per gene: -1 when the row / mixed kernels cannot take it (a count that does not fit their 16-bit staging: the slot-ordered
+// copies of the mixed designs keep 0xFFFF for padding and 0xFFFE for "saturated", k_mix_counts_to_slots, so the largest
+// count such a gene may hold is 65 533 - the same rule here, or a gene with a count of 65 534 / 65 535 would be fitted on
+// its saturated copy), else the number of its
 // samples with a count >= kRowTail (they cost a second sweep per evaluation: the host queues such genes together, first).
 // Depends on the counts only: evaluated once per data set.
 __global__ __launch_bounds__(kBlock) void k_count_big(const int32_t* __restrict__ y, int ldn, int N, int G,
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_count_big(const int32_t* __restrict_
     }
     nb = DeviceWave::sumi(nb);
     mx = DeviceWave::maxi(mx);
-    if ((threadIdx.x & 63) == 0) out[g] = mx > 65535 ? -1 : nb;
+    if ((threadIdx.x & 63) == 0) out[g] = mx >= 0xFFFE ? -1 : nb;
 }
 
 hipError_t launch_count_big(hipStream_t st, const int32_t* y, int ldn, int N, int G, int32_t* out) {

@@ -37,7 +37,7 @@
 
 namespace dsq {
 
-constexpr int kMixPad = 0xFFFF;  // count stored for a padding slot (real counts are <= 65534: dsq_dev_alpha_row_split)
+constexpr int kMixPad = 0xFFFF;  // count stored for a padding slot (real counts of the genes listed for this family are <= 65533: k_count_big)
 
 struct MixIrlsLds {  // wave-private LDS record (followed by the gene's counts, uint16 [Ns])
     double cellv[kMixMaxCells];                  // x_c . beta of the categorical part, per cell

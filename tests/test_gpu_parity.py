@@ -916,6 +916,39 @@ def test_mixed_design_pipeline_every_shape(P, Q, levels, N, monkeypatch):
     assert_close(res.dispersions[ok], ref17.dispersions[ok], 2e-6, 0, "matrix route vs general, final")
 
 
+def test_mixed_design_counts_at_the_sixteen_bit_boundary(monkeypatch):
+    """The slot-ordered uint16 copies of the mixed-design kernels keep 0xFFFF for padding and 0xFFFE for "saturated": a gene
+    whose largest count is 65 534 or 65 535 must NOT be fitted from that copy (it would silently be fitted with 65 534).
+    Genes with a largest count of 65 533 / 65 534 / 65 535 / 65 536 against the general kernels on the same counts (HIP vs
+    HIP, 1e-8 scale) and against the oracle; a one-count error of such a sample moves the genewise dispersion by ~3e-5."""
+    import pydeseq2_amd
+    from pydeseq2_amd import DeseqPipeline
+
+    P, Q, N, G = 5, 2, 420, 240
+    counts, X = _mixed_case(P, Q, N, G, 977, (3,))
+    edge = {20: 65533, 21: 65534, 22: 65535, 23: 65536}
+    for g, v in edge.items():
+        counts[:, g] = np.minimum(counts[:, g], 40000)
+        counts[3 + g, g] = v
+        counts[100 + g, g] = v - 7
+    pipe = DeseqPipeline(counts, X, device=0)
+    assert pipe._row_mode == 3
+    res = pipe.deseq2()
+    monkeypatch.setenv("DSQ_NO_ALPHA_MIX", "1")
+    gen = DeseqPipeline(counts, X, device=0)
+    assert gen._row_mode == 0
+    ref_hip = gen.deseq2()
+    monkeypatch.delenv("DSQ_NO_ALPHA_MIX")
+    ref = orc.deseq2(counts[:, :60], X, n_jobs=_jobs(), keep_layers=False)
+    sub = pydeseq2_amd.deseq2(counts[:, :60], X, device=0)
+    for g in edge:
+        assert res.genewise_converged[g] == ref_hip.genewise_converged[g]
+        assert_close(res.genewise_dispersions[[g]], ref_hip.genewise_dispersions[[g]], 2e-7, 0, f"count {edge[g]}, mix vs general")
+        assert_close(res.LFC[[g]], ref_hip.LFC[[g]], 2e-7, 1e-9, f"count {edge[g]}, LFC mix vs general")
+        if sub.genewise_converged[g] == ref.genewise_converged[g]:
+            assert_close(sub.genewise_dispersions[[g]], ref.genewise_dispersions[[g]], 2e-6, 0, f"count {edge[g]} vs oracle")
+
+
 @pytest.mark.parametrize("design,N", [("2level", 600), ("mixed", 700), ("2factor", 1200)])
 def test_robust_dispersions_without_the_lds_buffer(design, N, monkeypatch):
     """Designs whose cells all hold >= 129 samples (or that have no cells: continuous covariates) take

@@ -78,6 +78,14 @@ def _trigamma(x):
     return float(polygamma(1, x))
 
 
+class _Respeculate(Exception):
+    """The pass was enqueued on the previous pass's non-zero mask and the matrix has another one: run it again, in order."""
+
+
+class _Step:
+    """State of one pass of the path: device handles and host scalars the stages hand to each other."""
+
+
 class _View:
     """A vector inside a larger device buffer (only the address; the buffer is pool-owned)."""
 
@@ -246,6 +254,7 @@ class DeseqPipeline:
             self._side_pending = False
         self._pool_free.extend(self._pool_used)
         self._pool_used = []
+        self._serial = getattr(self, "_serial", 0) + 1  # an open pass (_Step) lives until the next reset
         if getattr(self, "_inflight", None):  # staging slabs of _up(): make sure their copies have run
             self.ctx.sync()
         self._inflight = []
@@ -451,7 +460,7 @@ class DeseqPipeline:
         D = self.design
         mh = type("MuHat", (), {})()
         mh.d_mu, mh.d_coef, mh.d_cell_mu, mh.d_beta, mh.row_lists = None, None, None, None, row_lists
-        mh.mix_slots, mh.d_mu_slots = mix_slots, None
+        mh.mix_slots, mh.d_mu_slots, mh.d_beta_fit = mix_slots, None, None
         if D.linear_mu:  # dds.py:747-756: MoM and the linear-model mu_hat share their sweeps
             mh.d_coef = self._dvec(Gs * self.P)
             # rows too long for the LDS staging of launch_alpha, or a design wider than the register kernels
@@ -485,6 +494,7 @@ class DeseqPipeline:
                     self._cells_arg(),
                     None, None, c_double(0.0), None, None, None, None, None,
                     None, None, c_double(0.0), 0, None, None, None, _vp(self._mix) if self._mix else None, 0)
+            mh.d_beta_fit = d_b  # (whatever the route: layer("_mu_hat") rebuilds the matrix from these on demand)
             if from_beta:
                 mh.d_beta = d_b
                 if mix_slots is not None:
@@ -649,6 +659,12 @@ class DeseqPipeline:
         return sq, float(max(sq - _trigamma((self.N - self.P) / 2), 0.25))
 
     # ------------------------------------------------------------------ the pipeline
+    # One pass = one _Step: the device handles and host scalars the stages hand to each other.  deseq2() runs all
+    # stages back to back (the benchmarked path: robust dispersions forked under the tails of the dispersion stages,
+    # read-backs speculated on the previous pass's mask); the user-level façade (api.py) opens a step and advances
+    # it stage by stage as the reference's fit_* methods are called (dds.py:584-1110), reading vectors in between.
+    STAGES = ("open", "size_factors", "genewise", "trend", "map", "lfc", "refit", "finish")
+
     def deseq2(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, profile=False,
                stop_after_trend=False, stop_after_size_factors=False, size_factors=None) -> DeseqResult:
         """Run size factors -> dispersions -> LFC -> Cook's (+refit) -> Wald.
@@ -657,34 +673,77 @@ class DeseqPipeline:
         scalars (trend coefficients, prior variance), the Cook's flags that decide the refit, and at
         the end one block copy of all result vectors.
         """
-        ctx, D, N, G, P = self.ctx, self.design, self.N, self.G, self.P
+        upto = "size_factors" if stop_after_size_factors else ("trend" if stop_after_trend else "finish")
+        while True:
+            st = self.begin_step(contrast, lfc_null, alt_hypothesis, profile=profile, size_factors=size_factors,
+                                 upto=upto)
+            try:
+                return self.advance(st, upto)
+            except _Respeculate:  # the non-zero mask the pass was enqueued on is not this matrix's: once more, in order
+                continue
+
+    def begin_step(self, contrast=None, lfc_null=0.0, alt_hypothesis=None, *, profile=False, size_factors=None,
+                   upto=None):
+        """Open a pass.  ``upto``: the stage the caller will stop at when it is known in advance ("finish": the whole path,
+        which lets the robust dispersions and the read-backs overlap the dispersion stages); None: stage by stage."""
         if alt_hypothesis not in ALT:
             raise KeyError(alt_hypothesis)
         if lfc_null < 0 and alt_hypothesis in {"greaterAbs", "lessAbs"}:
             raise ValueError(f"The alternative hypothesis being {alt_hypothesis}, please provide a "
                              f"positive lfc_null value (got {lfc_null}).")
         if contrast is None:
-            contrast = np.zeros(P)
+            contrast = np.zeros(self.P)
             contrast[-1] = 1.0
-        contrast = np.ascontiguousarray(contrast, dtype=np.float64)
-        r = DeseqResult()
-        T = r.timings
-
-        def tick():
-            if profile:
-                ctx.sync()
-            return time.perf_counter()
-
+        st = _Step()
+        st.contrast = np.ascontiguousarray(contrast, dtype=np.float64)
+        st.lfc_null, st.alt, st.profile = float(lfc_null), alt_hypothesis, bool(profile)
+        st.size_factors_in = size_factors
+        st.whole = upto == "finish"          # the pass is known to run to its end: overlap what can be overlapped
+        st.stop_at = upto
+        st.r = DeseqResult()
+        st.done = "open"
+        st.t = [None]
         self._pool_reset()
-        t0 = tick()
-        # ---- size factors (dds.py:692-708)
+        st.serial = self._serial
+        st.t0 = st.t_last = self._tick(st)
+        return st
+
+    def step_alive(self, st):
+        """Whether the device buffers of an open pass are still its own (no other pass has recycled the pool since)."""
+        return st is not None and getattr(st, "serial", -1) == getattr(self, "_serial", 0)
+
+    def advance(self, st, upto="finish"):
+        """Run the stages of an open pass up to and including ``upto``; returns the pass's DeseqResult (complete after
+        "finish", otherwise holding what the stages so far publish)."""
+        order = self.STAGES
+        while order.index(st.done) < order.index(upto):
+            nxt = order[order.index(st.done) + 1]
+            getattr(self, "_st_" + nxt)(st)
+            st.done = nxt
+        return st.r
+
+    def _tick(self, st):
+        if st.profile:
+            self.ctx.sync()
+        return time.perf_counter()
+
+    def _lap(self, st, name):
+        now = self._tick(st)
+        st.r.timings[name] = now - st.t_last
+        st.t_last = now
+
+    # ---- size factors (dds.py:692-708) and the compaction to the genes with a count (dds.py:729-731)
+    def _st_size_factors(self, st):
+        ctx, N, G = self.ctx, self.N, self.G
+        r, size_factors = st.r, st.size_factors_in
         d_lm, d_nz = self._dvec(G), self._dvec(G, np.uint8)
         self._k("logmeans", G, "dsq_dev_logmeans", _vp(self.d_y.ptr), self.ldn, N, G, _vp(d_lm.ptr), _vp(d_nz.ptr))
-        spec = None
+        st.spec = None
+        sf = None
         if size_factors is None and self.size_factors_fit_type != "iterative":
             d_sf = self._size_factors(d_lm)
             pred = getattr(self, "_nz_pred", None)
-            if pred is not None and not (profile or stop_after_size_factors or self.time_kernels):
+            if pred is not None and st.whole and not (st.profile or self.time_kernels):
                 # The host needs the size factors only for the result and for the NaN test below, and the non-zero
                 # mask only for the number of genes it compacts to.  Neither changes between two passes over the
                 # same counts: read both back asynchronously, enqueue the genewise stage on the previous pass's mask
@@ -692,13 +751,12 @@ class DeseqPipeline:
                 hs = self._host_slab(8 * N + G)
                 ctx.call("dsq_d2h_async", _vp(hs.ptr), _vp(d_sf.ptr), C.c_size_t(8 * N))
                 ctx.call("dsq_d2h_async", _vp(hs.ptr + 8 * N), _vp(d_nz.ptr), C.c_size_t(G))
-                spec = (hs.view(0, N, np.float64), hs.view(8 * N, G, np.uint8))
-                sf = None
+                st.spec = (hs.view(0, N, np.float64), hs.view(8 * N, G, np.uint8))
             else:
                 sf = self._down(d_sf, N)
-            if spec is None and np.isnan(sf).any():  # dds.py:682-690
+            if st.spec is None and np.isnan(sf).any():  # dds.py:682-690
                 warnings.warn("Every gene contains at least one zero, cannot compute log geometric means. "
-                              "Switching to iterative mode.", UserWarning, stacklevel=2)
+                              "Switching to iterative mode.", UserWarning, stacklevel=3)
                 size_factors = "iterative"
         if size_factors is None and self.size_factors_fit_type == "iterative":
             size_factors = "iterative"
@@ -714,107 +772,131 @@ class DeseqPipeline:
                         _vp(d_nz.ptr))
             sf = np.ascontiguousarray(size_factors, dtype=np.float64)
             d_sf = self._up(sf)
-        non_zero = pred.copy() if spec is not None else self._down(d_nz, G, np.uint8).astype(bool)
+        non_zero = pred.copy() if st.spec is not None else self._down(d_nz, G, np.uint8).astype(bool)
         r.size_factors, r.non_zero = sf, non_zero
-        self.d_sf = d_sf
-        if stop_after_size_factors:
-            return r
-        Gn = int(non_zero.sum())
-        all_nz = Gn == G
-        nzi = None if all_nz else np.nonzero(non_zero)[0]
-        t1 = tick(); T["size_factors"] = t1 - t0
-
-        # ---- compact to the non-zero genes (dds.py:729-731)
-        if all_nz:
-            d_ynz = self.d_y
+        self.d_sf = st.d_sf = d_sf
+        st.non_zero = non_zero
+        if st.stop_at == "size_factors":
+            return
+        Gn = st.Gn = int(non_zero.sum())
+        st.all_nz = Gn == G
+        st.nzi = None if st.all_nz else np.nonzero(non_zero)[0]
+        self._lap(st, "size_factors")
+        if st.all_nz:
+            st.d_ynz = self.d_y
         else:
-            d_idx = self._up(nzi.astype(np.int32), np.int32)
-            d_ynz = self._dmat(Gn, np.int32)
+            d_idx = self._up(st.nzi.astype(np.int32), np.int32)
+            st.d_ynz = self._dmat(Gn, np.int32)
             ctx.call("dsq_dev_gather_rows_i32", _vp(self.d_y.ptr), self.ldn, _vp(d_idx.ptr), Gn, N,
-                     _vp(d_ynz.ptr))
-        S = self._dev_slab(Gn)
+                     _vp(st.d_ynz.ptr))
+        st.S = self._dev_slab(Gn)
         # mixed designs: the counts in slot order (built once per non-zero mask, outside the steady-state step)
-        mix_slots = self._mix_slots_for(d_ynz, Gn, persistent_key=non_zero) if (self._mix and Gn > 0) else None
+        st.mix_slots = self._mix_slots_for(st.d_ynz, Gn, persistent_key=non_zero) if (self._mix and Gn > 0) else None
+        st.robust_done = [False, False]
 
-        # ---- genewise dispersions (dds.py:713-797)
-        # the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
-        # cells only: they run on a side stream underneath the latency-bound kernels of the path (the continuation of
-        # the parked dispersion fits, the grid-search pass, the trend / prior kernels on their reserved compute units)
-        d_rd = S["rd"]
+    # ---- the robust dispersions of the Cook's stage (utils.py:914-960) depend on counts, size factors and design
+    # cells only: in a whole pass they run on a side stream underneath the latency-bound kernels of the path (the
+    # continuation of the parked dispersion fits, the grid-search pass, the trend / prior kernels on their reserved
+    # compute units); stage by stage they are launched by the LFC stage, their first reader.
+    # Two parts (row-kernel designs, DSQ_ROBUST_SPLIT): the kernel (0.91 ms at c3) is a little longer than the
+    # latency-bound tail of the genewise stage it hides under (continuation, grid pass, trend, prior: 0.73 ms), and a MAP
+    # launch beside its end shares every compute unit with it.  Part one - the genes that fit under that tail - is
+    # forked inside the genewise fit; part two runs under the SAME tail of the MAP stage (its continuation and grid pass)
+    # and is joined before the LFC fit, whose epilogue is the first reader.
+    def _robust_cut(self, st):
+        split = self._robust_split if (st.whole and self.overlap and self._map_waits_side and st.Gn >= 4096) else 1.0
+        return st.Gn if split >= 1.0 else max(1, min(st.Gn - 1, int(st.Gn * split) & ~3))
 
-        # Two parts (row-kernel designs, DSQ_ROBUST_SPLIT): the kernel (0.91 ms at c3) is a little longer than the latency-bound
-        # tail of the genewise stage it hides under (continuation, grid pass, trend, prior: 0.73 ms), and a MAP launch beside
-        # its end shares every compute unit with it.  Part one - the genes that fit under that tail - is forked inside the
-        # genewise fit as before; part two runs under the SAME tail of the MAP stage (its continuation and grid pass) and is
-        # joined before the LFC fit, whose epilogue is the first reader.  The MAP launch then starts when the prior is done.
-        split = self._robust_split if (self.overlap and self._map_waits_side and Gn >= 4096) else 1.0
-        g_cut = Gn if split >= 1.0 else max(1, min(Gn - 1, int(Gn * split) & ~3))
-
-        def launch_robust(part=0):
-            g0, g1 = (0, g_cut) if part == 0 else (g_cut, Gn)
-            if g1 <= g0:
-                return
-            if self.overlap:
-                ctx.call("dsq_side_begin")
-                self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
-            try:
-                self._k("robust_disp", g1 - g0, "dsq_dev_robust_disp2", _vp(d_ynz.ptr + 4 * self.ldn * g0), self.ldn,
-                        _vp(d_sf.ptr), _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole),
-                        D.max_cell, D.min_cell, N, g1 - g0, _vp(d_rd.ptr + 8 * g0))
-            except BaseException:
-                if self.overlap:  # back on the main stream, both streams drained (a shared Context stays usable)
-                    ctx.call("dsq_side_abort")
-                    self._side_pending = False
-                raise
-            if self.overlap:
-                ctx.call("dsq_side_end")
-
-        want_robust = not (stop_after_trend or stop_after_size_factors)
-        early = want_robust and self.overlap and self._robust_early
-        # fork point: inside the genewise fit, when its full-size kernel is enqueued and only the continuation of the
-        # parked fits and the grid pass remain (dsq_set_alpha_hook) - the side stream then works underneath those, the
-        # trend fit and the prior; without the hook (profiling mode, DSQ_ROBUST_LATE) after the genewise stage
-        mid = want_robust and self.overlap and not early and not self.time_kernels and not self._robust_late
-        hook_state = {"fired": False, "error": None}
-        if mid:
-            def _hook(_arg):
-                hook_state["fired"] = True
-                try:
-                    launch_robust()
-                except BaseException as e:  # (a ctypes callback cannot propagate it)
-                    hook_state["error"] = e
-            self._alpha_hook = HOOK_FN(_hook)  # kept alive until the call has returned
-            ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook, C.c_void_p), None)
+    def _launch_robust(self, st, part=0, side=True):
+        D, ctx, Gn = self.design, self.ctx, st.Gn
+        g0, g1 = (0, st.g_cut) if part == 0 else (st.g_cut, Gn)
+        st.robust_done[part] = True
+        if g1 <= g0:
+            return
+        side = side and self.overlap
+        if side:
+            ctx.call("dsq_side_begin")
+            self._side_pending = True  # until dsq_side_wait: _pool_reset must not recycle what the side stream writes
         try:
-            d_mu_hat = self._stage_genewise(d_ynz, Gn, d_sf, S, self._row_lists_for(non_zero),
-                                            pre_alpha=launch_robust if early else None, mix_slots=mix_slots)
+            self._k("robust_disp", g1 - g0, "dsq_dev_robust_disp2", _vp(st.d_ynz.ptr + 4 * self.ldn * g0), self.ldn,
+                    _vp(st.d_sf.ptr), _vp(self.d_cell_off.ptr), _vp(self.d_cell_idx.ptr), D.n_cells, int(D.whole),
+                    D.max_cell, D.min_cell, self.N, g1 - g0, _vp(st.S["rd"].ptr + 8 * g0))
+        except BaseException:
+            if side:  # back on the main stream, both streams drained (a shared Context stays usable)
+                ctx.call("dsq_side_abort")
+                self._side_pending = False
+            raise
+        if side:
+            ctx.call("dsq_side_end")
+
+    def _with_alpha_hook(self, fn, launch):
+        """Run ``fn()`` (a dispersion stage) with ``launch()`` fired from inside it, when its full-size kernel is
+        enqueued and only the continuation of the parked fits and the grid pass remain (dsq_set_alpha_hook); returns
+        whether the hook fired."""
+        state = {"fired": False, "error": None}
+
+        def _hook(_arg):
+            state["fired"] = True
+            try:
+                launch()
+            except BaseException as e:  # (a ctypes callback cannot propagate it)
+                state["error"] = e
+
+        self._alpha_hook = HOOK_FN(_hook)  # kept alive until the call has returned
+        self.ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook, C.c_void_p), None)
+        try:
+            out = fn()
         finally:
-            if mid:
-                ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
-        if hook_state["error"] is not None:
-            raise hook_state["error"]
-        if spec is not None:  # the genewise stage has synchronised behind the two read-backs
+            self.ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
+        if state["error"] is not None:
+            raise state["error"]
+        return out, state["fired"]
+
+    # ---- genewise dispersions (dds.py:713-797)
+    def _st_genewise(self, st):
+        ctx, r, S, Gn = self.ctx, st.r, st.S, st.Gn
+        st.g_cut = self._robust_cut(st)
+        want_robust = st.whole
+        early = want_robust and self.overlap and self._robust_early
+        # fork point: inside the genewise fit (the hook); without it (profiling mode, DSQ_ROBUST_LATE) after the stage
+        mid = want_robust and self.overlap and not early and not self.time_kernels and not self._robust_late
+        fit = lambda: self._stage_genewise(st.d_ynz, Gn, st.d_sf, S, self._row_lists_for(st.non_zero),  # noqa: E731
+                                           pre_alpha=(lambda: self._launch_robust(st)) if early else None,
+                                           mix_slots=st.mix_slots)
+        if mid:
+            st.mh, fired = self._with_alpha_hook(fit, lambda: self._launch_robust(st))
+        else:
+            st.mh, fired = fit(), False
+        if st.spec is not None:  # the genewise stage has synchronised behind the two read-backs
             if Gn == 0:
                 ctx.sync()
-            sf = np.array(spec[0])
-            if np.isnan(sf).any() or not np.array_equal(spec[1].view(np.bool_), non_zero):
+            sf = np.array(st.spec[0])
+            if np.isnan(sf).any() or not np.array_equal(st.spec[1].view(np.bool_), st.non_zero):
                 self._nz_pred = None
                 if self._side_pending:
                     ctx.call("dsq_side_abort")
                     self._side_pending = False
-                return self.deseq2(contrast, lfc_null, alt_hypothesis, profile, stop_after_trend,
-                                   stop_after_size_factors, size_factors)
+                raise _Respeculate()
             r.size_factors = sf
+            st.spec = None
         self._last_gw_dev = (S["gw"], S["nm"])  # raw genewise dispersions / normalised means
-        if want_robust and not early and not hook_state["fired"]:
-            launch_robust()
-        t2 = tick(); T["genewise"] = t2 - t1
+        if want_robust and not early and not fired:
+            self._launch_robust(st)
+        self._lap(st, "genewise")
 
-        # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
+    # ---- trend (dds.py:799-838) + prior (dds.py:840-884): the cross-gene steps
+    def _st_trend(self, st):
+        r, S, Gn, N, P = st.r, st.S, st.Gn, self.N, self.P
         coeffs = None
         fused_sq = None
+        only_trend = st.stop_at == "trend"
         if self.fit_type == "parametric":
-            if not (stop_after_trend or self.time_kernels):
+            cls = type(self)
+            # (a subclass that overrides only the two separate hooks - as the gene-sharded pipeline once did - must not be
+            # bypassed by the fused call: it is taken when the class brings its own, or leaves all three alone)
+            fused_ok = (cls._trend_prior_fused is not DeseqPipeline._trend_prior_fused
+                        or (cls._fit_trend is DeseqPipeline._fit_trend and cls._prior is DeseqPipeline._prior))
+            if fused_ok and not (only_trend or self.time_kernels):
                 # trend fit, fitted values and prior in one call (one synchronisation instead of two and a launch gap);
                 # the gene-sharded pipeline runs the same call on the all-gathered vectors (distributed.py)
                 coeffs, fused_sq = self._trend_prior_fused(Gn, S["fit"])
@@ -822,156 +904,155 @@ class DeseqPipeline:
                 coeffs = self._fit_trend(Gn)
             if coeffs is None:
                 warnings.warn("The dispersion trend curve fitting did not converge. "
-                              "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=2)
+                              "Switching to a mean-based dispersion trend.", UserWarning, stacklevel=3)
         elif self.fit_type != "mean":
             raise NotImplementedError(f"Expected 'parametric' or 'mean' trend curve fit types, received "
                                       f"{self.fit_type}")
+        st.coeffs = coeffs
         if coeffs is not None:
             r.trend_coeffs, r.disp_function_type = coeffs, "parametric"
-            a0, a1 = float(coeffs[0]), float(coeffs[1])
+            st.a0, st.a1 = float(coeffs[0]), float(coeffs[1])
         else:
             r.disp_function_type = "mean"
             r.mean_disp = self._mean_trend(Gn)
-            a0, a1 = float(r.mean_disp), 0.0
-        if stop_after_trend:  # vst_fit (dds.py:384-438): size factors, genewise dispersions, trend
-            Hh = self._fetch(S, ["nm", "mom", "gw", "gconv"])
-
-            def fullv(v, fill=np.nan):
-                if all_nz:
-                    return np.array(v, dtype=float)
-                out = np.full(G, fill)
-                out[nzi] = v
-                return out
-
-            r.normed_means = fullv(Hh["nm"], 0.0)
-            r.mom_dispersions = fullv(Hh["mom"])
-            r.genewise_dispersions = fullv(np.clip(Hh["gw"], self.min_disp, self.max_disp))
-            r.genewise_converged = fullv(Hh["gconv"].astype(float))
-            return r
+            st.a0, st.a1 = float(r.mean_disp), 0.0
+        if only_trend:  # vst_fit (dds.py:384-438): size factors, genewise dispersions, trend
+            self.publish(st, ("nm", "mom", "gw", "gconv"))
+            return
         if fused_sq is None or coeffs is None:
-            ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(a0), c_double(a1), _vp(S["fit"].ptr))
+            self.ctx.call("dsq_dev_trend_eval", _vp(S["nm"].ptr), Gn, c_double(st.a0), c_double(st.a1), _vp(S["fit"].ptr))
         if (N - P) <= 3:
             warnings.warn("As the residual degrees of freedom is less than 3, the distribution of log "
                           "dispersions is especially asymmetric and likely to be poorly estimated by the MAD.",
-                          UserWarning, stacklevel=2)
+                          UserWarning, stacklevel=3)
         if fused_sq is not None and coeffs is not None:
             r.squared_logres = fused_sq
             r.prior_disp_var = float(max(fused_sq - _trigamma((N - P) / 2), 0.25))
         else:
             r.squared_logres, r.prior_disp_var = self._prior(Gn, S["fit"], r)
-        t3 = tick(); T["trend_prior"] = t3 - t2
+        self._lap(st, "trend_prior")
 
-        # ---- MAP dispersions + dispersion outliers (dds.py:886-935)
+    # ---- MAP dispersions + dispersion outliers (dds.py:886-935)
+    def _st_map(self, st):
+        ctx, r, S, Gn = self.ctx, st.r, st.S, st.Gn
         if self.overlap and self._map_waits_side and self._side_pending:
             # the robust-dispersion kernel of the side stream is (0.9 ms at c3) a little longer than the latency-bound tail
             # it runs under; a MAP launch that starts beside its last 0.15-0.25 ms shares every compute unit with it for
             # its whole life (persistent workgroups) and pays more than the wait costs (A/B: DSQ_MAP_WAIT=0)
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        hook2 = {"fired": False, "error": None}
-        if g_cut < Gn and want_robust and not self.time_kernels:
-            def _hook2(_arg):
-                hook2["fired"] = True
-                try:
-                    launch_robust(1)
-                except BaseException as e:  # (a ctypes callback cannot propagate it)
-                    hook2["error"] = e
-            self._alpha_hook2 = HOOK_FN(_hook2)
-            ctx.call("dsq_set_alpha_hook", C.cast(self._alpha_hook2, C.c_void_p), None)
-        try:
-            self._stage_map(d_ynz, d_mu_hat, Gn, d_sf, r.prior_disp_var, r.squared_logres, S)
-        finally:
-            if g_cut < Gn:
-                ctx.call("dsq_set_alpha_hook", None, None)
-        if hook2["error"] is not None:
-            raise hook2["error"]
-        if g_cut < Gn and want_robust and not hook2["fired"]:
-            launch_robust(1)
-        t4 = tick(); T["MAP"] = t4 - t3
+        fit = lambda: self._stage_map(st.d_ynz, st.mh, Gn, st.d_sf, r.prior_disp_var, r.squared_logres, S)  # noqa: E731
+        second = st.g_cut < Gn and st.whole
+        if second and not self.time_kernels:
+            _, fired = self._with_alpha_hook(fit, lambda: self._launch_robust(st, 1))
+        else:
+            fit()
+            fired = False
+        if second and not fired:
+            self._launch_robust(st, 1)
+        self._lap(st, "MAP")
 
-        # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics
-        # (ds.py:303-360) in its epilogue: mu and the hat diagonal are consumed from registers
-        cutoff = self._cooks_cutoff
+    # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics
+    # (ds.py:303-360) in its epilogue: mu and the hat diagonal are consumed from registers
+    def _st_lfc(self, st):
+        ctx, D, S, Gn, G, P = self.ctx, self.design, st.S, st.Gn, self.G, self.P
+        for part in (0, 1):  # stage by stage: nobody has launched the robust dispersions yet
+            if not st.robust_done[part]:
+                self._launch_robust(st, part, side=False)
+        st.cutoff = cutoff = self._cooks_cutoff
         ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
-        wald_args = (ridge, contrast, float(np.log(2) * lfc_null), ALT[alt_hypothesis])
-        cld = self._cooks_ld()
-        d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
+        st.wald_args = (ridge, st.contrast, float(np.log(2) * st.lfc_null), ALT[st.alt])
+        st.cld = cld = self._cooks_ld()
+        st.d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
         if self.overlap and self._side_pending:
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        d_mu, d_hat = self._stage_lfc(d_ynz, Gn, d_sf, S, wald_args, cooks=(d_rd, cutoff, d_cooks), mix_slots=mix_slots)
-        want_refit = self.refit_cooks and D.replaceable.sum() > 0
-        # Everything in S is final now except the rows the refit will replace: the block copy of the result vectors
-        # starts here, on the side stream, and runs underneath the refit's kernels; the host patches the (few)
-        # refitted rows afterwards from the refit's own small result block.  The main stream only carries the one
-        # flag vector that decides the refit, so waiting for it does not wait for the block copy.
-        flags_tok = self._fetch_begin(S, ["any_all"]) if want_refit else None
-        if self.overlap:
-            ctx.call("dsq_side_begin")
-            self._side_pending = True
-            try:
-                slab_tok = self._fetch_begin(S)
-            finally:
-                ctx.call("dsq_side_end")
-        else:
-            slab_tok = self._fetch_begin(S)
-        if all_nz and getattr(self, "_arange_G", None) is None:
+        d_mu, d_hat = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], cutoff, st.d_cooks),
+                                      mix_slots=st.mix_slots)
+        st.want_refit = self.refit_cooks and D.replaceable.sum() > 0
+        # Everything in S is final now except the rows the refit will replace: in a whole pass the block copy of the
+        # result vectors starts here, on the side stream, and runs underneath the refit's kernels; the host patches
+        # the (few) refitted rows afterwards from the refit's own small result block.  The main stream only carries
+        # the one flag vector that decides the refit, so waiting for it does not wait for the block copy.
+        st.flags_tok = self._fetch_begin(S, ["any_all"]) if st.want_refit else None
+        st.slab_tok = None
+        if st.whole:
+            self._begin_block_copy(st)
+        if st.all_nz and getattr(self, "_arange_G", None) is None:
             self._arange_G = np.arange(G)
         # the layers of THIS fit: cooks is always materialised, mu and the hat diagonals only with keep_layers,
         # otherwise layer() rebuilds them on demand from the fit's coefficients / dispersions (S is not patched by the
         # refit any more, so its vectors ARE those of this fit)
-        self.layers = {"nz_idx": self._arange_G if all_nz else nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
-                       "cooks": d_cooks, "_cooks_ld": cld, "_fit": (d_ynz, d_sf, S["beta"], S["disp"], Gn)}
-        t5 = tick(); T["LFC_cooks_wald"] = t5 - t4
-        t6 = t5
+        self.layers = {"nz_idx": self._arange_G if st.all_nz else st.nzi, "mu_LFC": d_mu, "hat_diagonals": d_hat,
+                       "cooks": st.d_cooks, "_cooks_ld": cld, "_fit": (st.d_ynz, st.d_sf, S["beta"], S["disp"], Gn)}
+        self._lap(st, "LFC_cooks_wald")
 
-        # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem on the replaced counts.  One host round trip
-        # (which genes?), then the whole chain - replacement, MoM, mu_hat, genewise fit, trend value, MAP fit, LFC fit,
-        # Wald - is enqueued without another: second passes are launched for the whole batch as a capacity
-        # (dsq_set_deferred), and genes that became all-zero keep their original row on the device (their results are
-        # discarded by the flag that comes back with the results).
-        replaced_nz = np.zeros(Gn, dtype=bool)
-        refitted_nz = np.zeros(Gn, dtype=bool)
-        new_zero_nz = np.zeros(Gn, dtype=bool)
-        patch = None
-        if want_refit:
+    def _begin_block_copy(self, st):
+        if self.overlap:
+            self.ctx.call("dsq_side_begin")
+            self._side_pending = True
+            try:
+                st.slab_tok = self._fetch_begin(st.S)
+            finally:
+                self.ctx.call("dsq_side_end")
+        else:
+            st.slab_tok = self._fetch_begin(st.S)
+
+    # ---- refit (dds.py:1042-1064, 1301-1458): a small sub-problem on the replaced counts.  One host round trip
+    # (which genes?), then the whole chain - replacement, MoM, mu_hat, genewise fit, trend value, MAP fit, LFC fit,
+    # Wald - is enqueued without another: second passes are launched for the whole batch as a capacity
+    # (dsq_set_deferred), and genes that became all-zero keep their original row on the device (their results are
+    # discarded by the flag that comes back with the results).
+    def _st_refit(self, st):
+        ctx, r, S, Gn, N = self.ctx, st.r, st.S, st.Gn, self.N
+        st.replaced_nz = np.zeros(Gn, dtype=bool)
+        st.patch = None
+        if getattr(st, "force_refit", False) and not st.want_refit and self.design.replaceable.sum() > 0:
+            # DeseqDataSet.refit() called by hand on a data set built with refit_cooks=False (dds.py:1042-1064)
+            st.want_refit, st.flags_tok = True, self._fetch_begin(S, ["any_all"])
+        if st.want_refit:
             ctx.sync()
-            replaced_nz = self._fetch_end(flags_tok)["any_all"].astype(bool)  # idx.any(axis=0), dds.py:1325-1326
-            rp = np.nonzero(replaced_nz)[0]
+            st.replaced_nz = self._fetch_end(st.flags_tok)["any_all"].astype(bool)  # idx.any(axis=0), dds.py:1325-1326
+            rp = np.nonzero(st.replaced_nz)[0]
             Gr = len(rp)
             if Gr > 0:
                 d_rp = self._up(rp.astype(np.int32), np.int32)
                 d_ysub = self._dmat(Gr, np.int32)
                 S2 = self._dev_slab(Gr)
                 d_az = S2["naz"]  # its own field: no stage of the sub-problem writes it
-                ctx.call("dsq_dev_replace_outliers2", _vp(d_ynz.ptr), _vp(d_cooks.ptr), self.ldn, _vp(d_sf.ptr),
-                         _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(cutoff), _vp(d_ysub.ptr),
-                         _vp(d_az.ptr), cld, _vp(self._mix) if cld else None)
-                deferred = not (profile or self.time_kernels or self.collect_nfev)
+                ctx.call("dsq_dev_replace_outliers2", _vp(st.d_ynz.ptr), _vp(st.d_cooks.ptr), self.ldn, _vp(st.d_sf.ptr),
+                         _vp(self.d_flags.ptr), _vp(d_rp.ptr), Gr, N, c_double(st.cutoff), _vp(d_ysub.ptr),
+                         _vp(d_az.ptr), st.cld, _vp(self._mix) if st.cld else None)
+                deferred = not (st.profile or self.time_kernels or self.collect_nfev)
                 if deferred:
                     ctx.call("dsq_set_deferred", 1)
                 sub_slots = self._mix_slots_for(d_ysub, Gr) if self._mix else None  # (the replaced counts' own copy)
                 try:
-                    s_mu = self._stage_genewise(d_ysub, Gr, d_sf, S2, mix_slots=sub_slots)
-                    ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gr, c_double(a0), c_double(a1),
+                    s_mu = self._stage_genewise(d_ysub, Gr, st.d_sf, S2, mix_slots=sub_slots)
+                    ctx.call("dsq_dev_trend_eval", _vp(S2["nm"].ptr), Gr, c_double(st.a0), c_double(st.a1),
                              _vp(S2["fit"].ptr))
-                    self._stage_map(d_ysub, s_mu, Gr, d_sf, r.prior_disp_var, r.squared_logres, S2)
-                    self._stage_lfc(d_ysub, Gr, d_sf, S2, wald_args, mix_slots=sub_slots)
+                    self._stage_map(d_ysub, s_mu, Gr, st.d_sf, r.prior_disp_var, r.squared_logres, S2)
+                    self._stage_lfc(d_ysub, Gr, st.d_sf, S2, st.wald_args, mix_slots=sub_slots)
                 finally:
                     if deferred:
                         ctx.call("dsq_set_deferred", 0)
-                patch = (rp, self._fetch_begin(S2))  # the sub-problem's whole (small) result block in one copy
-        t7 = tick(); T["refit"] = t7 - t6
+                st.patch = (rp, self._fetch_begin(S2))  # the sub-problem's whole (small) result block in one copy
+        self._lap(st, "refit")
 
-        # ---- the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues
+    # ---- host view of the results (reference field names), scattered to all G genes
+    def _st_finish(self, st):
+        ctx, r, G, Gn = self.ctx, st.r, self.G, st.Gn
+        if st.slab_tok is None:
+            self._begin_block_copy(st)
+        # the Wald statistics (ds.py:303-360) came out of the LFC fits' epilogues
         if self.overlap:
             ctx.call("dsq_side_wait")
             self._side_pending = False
         ctx.sync()
-        H = self._fetch_end(slab_tok)
-        t8 = tick(); T["wald"] = t8 - t7
+        H = self._fetch_end(st.slab_tok)
+        self._lap(st, "wald")
+        all_nz, nzi = st.all_nz, st.nzi
 
-        # ---- host view of the results (reference field names), scattered to all G genes
         def full(v, fill=np.nan, dtype=None):
             if all_nz:
                 return v if dtype is None else v.astype(dtype)
@@ -979,27 +1060,30 @@ class DeseqPipeline:
             out[nzi] = v
             return out
 
+        replaced_nz = st.replaced_nz
+        refitted_nz = np.zeros(Gn, dtype=bool)
+        new_zero_nz = np.zeros(Gn, dtype=bool)
         gw = H["gw"]  # clipped to [min_disp, max_disp] on the device (dds.py:792-794; k_select_disp)
         nm, fit, disp, beta = H["nm"], H["fit"], H["disp"], H["beta"]
-        pv, st, se = H["p"], H["stat"], H["se"]
-        if patch is not None:  # dds.py:1368-1458: the refitted genes take their new values
-            rp, h2 = patch[0], self._fetch_end(patch[1])
+        pv, stt, se = H["p"], H["stat"], H["se"]
+        if st.patch is not None:  # dds.py:1368-1458: the refitted genes take their new values
+            rp, h2 = st.patch[0], self._fetch_end(st.patch[1])
             naz = h2["naz"].astype(bool)  # all counts zero after the replacement (dds.py:1368-1383)
             new_zero_nz[rp[naz]] = True
             refitted_nz[rp[~naz]] = True
             rf, k = rp[~naz], np.nonzero(~naz)[0]
             nm[rf], fit[rf], disp[rf], beta[rf] = h2["nm"][k], h2["fit"][k], h2["disp"][k], h2["beta"][k]
             gw[rf] = np.clip(h2["gw"][k], self.min_disp, self.max_disp)
-            pv[rf], st[rf], se[rf] = h2["p"][k], h2["stat"][k], h2["se"][k]
+            pv[rf], stt[rf], se[rf] = h2["p"][k], h2["stat"][k], h2["se"][k]
             if naz.any():
                 zi = rp[naz]
                 nm[zi], beta[zi] = 0.0, 0.0            # dds.py:1380-1383
-                se[zi], st[zi], pv[zi] = 0.0, 0.0, 1.0  # ds.py:357-360
+                se[zi], stt[zi], pv[zi] = 0.0, 0.0, 1.0  # ds.py:357-360
         r.normed_means = full(nm, fill=0.0)  # all-zero genes have normed mean 0 (dds.py:708)
         r.mom_dispersions = full(H["mom"])
         r.genewise_dispersions = full(gw)
         r.genewise_converged = full(H["gconv"].astype(float))
-        r.fitted_dispersions = full(fit) if coeffs is not None else np.full(G, r.mean_disp)
+        r.fitted_dispersions = full(fit) if st.coeffs is not None else np.full(G, r.mean_disp)
         r.MAP_dispersions = full(H["map"])  # clipped on the device as well (dds.py:905-907)
         r.MAP_converged = full(H["mconv"].astype(float))
         r.outlier_genes = full(H["outl"].view(np.bool_), fill=False)
@@ -1013,13 +1097,85 @@ class DeseqPipeline:
         any_use, any_use_nr = H["any_use"].view(np.bool_), H["any_use_nr"].view(np.bool_)
         co_nz = np.where(refitted_nz, any_use_nr, any_use) if (self.refit_cooks and refitted_nz.any()) else any_use
         r.cooks_outlier = full(co_nz & H["few_above"].view(np.bool_), fill=False)
-        r.pvalue, r.stat, r.lfcSE = full(pv), full(st), full(se)
-        t9 = tick(); T["assemble"] = t9 - t8
-        T["total"] = t9 - t0
+        r.pvalue, r.stat, r.lfcSE = full(pv), full(stt), full(se)
+        self._lap(st, "assemble")
+        r.timings["total"] = st.t_last - st.t0
         if not self.keep_cooks:
             self.layers = {}
-        self._nz_pred = non_zero
+        self._nz_pred = st.non_zero
+
+    def publish(self, st, names):
+        """Host copies of per-gene vectors of an OPEN pass, scattered to all G genes and stored in its DeseqResult under the
+        reference's field names (what a fit_* method of the façade shows after its stage): names of the result slab
+        ("nm", "mom", "gw", "gconv", "fit", "map", "mconv", "disp", "outl", "beta", "lconv")."""
+        r, G = st.r, self.G
+        H = self._fetch(st.S, list(names))
+
+        def full(v, fill=np.nan, dtype=None):
+            v = np.array(v, dtype=dtype or (float if v.dtype == np.uint8 else v.dtype))
+            if st.all_nz:
+                return v
+            out = np.full((G,) + v.shape[1:], fill, dtype=v.dtype)
+            out[st.nzi] = v
+            return out
+
+        clip = lambda v: np.clip(v, self.min_disp, self.max_disp)  # noqa: E731
+        for k in names:
+            if k == "nm":
+                r.normed_means = full(H[k], 0.0)
+            elif k == "mom":
+                r.mom_dispersions = full(H[k])
+            elif k == "gw":  # raw on the device until the selection kernel of the MAP stage has clipped it in place
+                r.genewise_dispersions = full(clip(H[k]))
+            elif k == "gconv":
+                r.genewise_converged = full(H[k])
+            elif k == "fit":
+                r.fitted_dispersions = full(H[k]) if st.coeffs is not None else np.full(G, r.mean_disp)
+            elif k == "map":
+                r.MAP_dispersions = full(clip(H[k]))
+            elif k == "mconv":
+                r.MAP_converged = full(H[k])
+            elif k == "disp":
+                r.dispersions = full(H[k])
+            elif k == "outl":
+                r.outlier_genes = full(H[k].view(np.bool_), False, dtype=bool)
+            elif k == "beta":
+                r.LFC = full(H[k])
+            elif k == "lconv":
+                r.LFC_converged = full(H[k])
+            else:
+                raise KeyError(k)
         return r
+
+    def mu_hat_host(self, st):
+        """layers["_mu_hat"] of an open pass (dds.py:747-771), N x G with NaN columns for the all-zero genes: the matrix
+        when the pass materialised it, else rebuilt on the host from what the dispersion kernels rebuild it from - the
+        per-gene OLS coefficients (max(sf * X coef, min_mu), utils.py:682-715) or the IRLS coefficients
+        (sf * exp(X beta), unclamped as utils.py:435-437 returns it)."""
+        mh, Gn = st.mh, st.Gn
+        sf = np.asarray(st.r.size_factors, dtype=float)
+        if mh.d_mu is not None:
+            rows = self.ctx.d2h_rows(mh.d_mu.ptr, Gn, self.N, self.ldn).T
+        elif mh.d_coef is not None:
+            coef = self._down(mh.d_coef, Gn * self.P).reshape(Gn, self.P)
+            rows = np.maximum(sf[:, None] * (self.design.X @ coef.T), self.min_mu)
+        else:
+            beta = self._down(mh.d_beta_fit, Gn * self.P).reshape(Gn, self.P)
+            with np.errstate(over="ignore"):
+                rows = sf[:, None] * np.exp(self.design.X @ beta.T)
+        if st.all_nz:
+            return rows
+        out = np.full((self.N, self.G), np.nan)
+        out[:, st.nzi] = rows
+        return out
+
+    def set_dispersions(self, st, dispersions):
+        """Replace the final dispersions of an open pass by the caller's (a user who edits var["dispersions"] between
+        fit_MAP_dispersions() and fit_LFC(), as the reference's fields allow): G values, those of the genes with counts
+        go to the device."""
+        d = np.ascontiguousarray(np.asarray(dispersions, dtype=np.float64)[st.non_zero])
+        if d.size:
+            self.ctx.h2d(st.S["disp"].ptr, d)
 
     def vst_transform(self, size_factors, trend_coeffs=None, mean_disp=None):
         """Variance-stabilised counts N x G (dds.py:440-514) from the resident raw counts."""

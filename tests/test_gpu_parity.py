@@ -192,9 +192,16 @@ def _compare(res, ref, frac_noise=0.002):
         perr = np.abs(res.pvalue[ok] - ref.pvalue[ok]) / np.maximum(ref.pvalue[ok], 1e-300)
         perr = np.nan_to_num(perr / np.maximum(1.0, ref.stat[ok] ** 2))
     assert (np.isnan(res.pvalue[ok]) == np.isnan(ref.pvalue[ok])).all() and perr.max() <= RTOL, perr.max()
+    # the RAW p-value (north-star wording) next to the per-z^2 one: bounded by the reference's own noise floor (the reference
+    # against itself with mu_hat moved by one ulp: up to 0.33 % of the genes beyond 1e-5, worst 6.6e-5; bench.py)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        praw = np.nan_to_num(np.abs(res.pvalue[ok] - ref.pvalue[ok]) / np.maximum(ref.pvalue[ok], 1e-300))
+    assert (praw > 1e-5).sum() <= max(3, 4e-3 * G), f"{(praw > 1e-5).sum()} genes with a raw p-value difference beyond 1e-5"
+    assert praw.max() <= 3e-4, f"raw p-value difference {praw.max():.3e}"
     assert_close(res.lfcSE[ok], ref.lfcSE[ok], RTOL, 0, "lfcSE")
-    # the trend is fitted on all genes, so it carries the noise genes' influence
-    assert_close(res.trend_coeffs, ref.trend_coeffs, 1e-4, 0, "trend coeffs")
+    # the trend is fitted on all genes, so it carries the noise genes' influence: one flip of G genes moves it by ~2e-3 / G
+    # (measured: engine vs reference 8e-7 at 20 000 / 60 000 genes, 2.2e-6 at 2000; the reference against itself 1e-6 ... 3.8e-6)
+    assert_close(res.trend_coeffs, ref.trend_coeffs, max(2e-5, 0.02 / G), 0, "trend coeffs")
     return int(noisy.sum()), int(both_gw.sum() + both_map.sum())
 
 

@@ -21,7 +21,7 @@ from oracle import nbglm_oracle as orc  # noqa: E402
 
 
 def rel(a, b, floor=1e-300):
-    a, b = np.asarray(a, float), np.asarray(b, float)
+    a, b = np.atleast_1d(np.asarray(a, float)), np.atleast_1d(np.asarray(b, float))
     with np.errstate(invalid="ignore", divide="ignore"):
         d = np.abs(a - b) / np.maximum(np.abs(b), floor)
     d[np.isnan(a) & np.isnan(b)] = 0.0
@@ -60,8 +60,8 @@ def main():
                "mom_dispersions": stats(rel(res.mom_dispersions, ref.mom_dispersions), same),
                "genewise_dispersions": stats(rel(res.genewise_dispersions, ref.genewise_dispersions), same),
                "trend_coeffs": [float(x) for x in rel(res.trend_coeffs, ref.trend_coeffs)],
-               "prior_disp_var": float(rel(res.prior_disp_var, ref.prior_disp_var)),
-               "squared_logres": float(rel(res.squared_logres, ref.squared_logres)),
+               "prior_disp_var": float(rel(res.prior_disp_var, ref.prior_disp_var)[0]),
+               "squared_logres": float(rel(res.squared_logres, ref.squared_logres)[0]),
                "fitted_dispersions": stats(rel(res.fitted_dispersions, ref.fitted_dispersions), same),
                "MAP_dispersions": stats(rel(res.MAP_dispersions, ref.MAP_dispersions), same),
                "dispersions": stats(rel(res.dispersions, ref.dispersions), same),

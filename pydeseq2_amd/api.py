@@ -10,6 +10,7 @@ with the first sorted level as reference, numeric columns enter as they are) or 
 """
 from __future__ import annotations
 
+import copy as _copy
 import re
 import warnings
 
@@ -17,6 +18,7 @@ import numpy as np
 import pandas as pd
 
 from . import summary as _summary
+from ._design import DesignPack
 from ._lib import Context
 from .pipeline import DeseqPipeline
 
@@ -110,16 +112,40 @@ def check_counts(counts) -> None:
 
 
 class DeseqDataSet:
-    """Counts + metadata + design, fitted on the GPU (cf. ``pydeseq2.dds.DeseqDataSet``, dds.py:206-340)."""
+    """Counts + metadata + design, fitted on the GPU (cf. ``pydeseq2.dds.DeseqDataSet``, dds.py:206-340).
 
-    def __init__(self, *, counts: pd.DataFrame, metadata: pd.DataFrame, design="~condition", design_factors=None,
+    The fit runs as ONE open pass of the device pipeline (``DeseqPipeline.begin_step`` / ``advance``): ``deseq2()`` runs
+    it through, the stage-wise methods ``fit_size_factors`` … ``refit`` (dds.py:584-1110) advance it one stage at a
+    time with the reference's lazy prerequisite chaining (a stage whose input field is missing runs the stage that
+    writes it first) and publish the reference's fields after each stage.  The pipeline itself is created on first use,
+    so constructing, slicing (``dds[:, genes]``), copying and pickling a data set never touch the GPU; a pickled or
+    copied data set carries its host fields and rebuilds the device state when the next stage is asked for.
+    """
+
+    _PIPE_KEYS = ("min_mu", "min_disp", "max_disp", "refit_cooks", "min_replicates", "beta_tol", "fit_type",
+                  "size_factors_fit_type")
+
+    def __init__(self, *, counts: pd.DataFrame = None, metadata: pd.DataFrame = None, adata=None, design="~condition",
+                 design_factors=None,
                  continuous_factors=None, ref_level=None, refit_cooks=True,
                  min_mu=0.5, min_disp=1e-8, max_disp=10.0, beta_tol=1e-8, min_replicates=7, fit_type="parametric",
                  size_factors_fit_type="ratio", control_genes=None, device=0, ctx: Context | None = None, quiet=True,
                  n_cpus=None, inference=None, low_memory=False):
-        # n_cpus / inference / low_memory: accepted for signature compatibility (dds.py:206-229); the engine
-        # is the GPU pipeline.  design_factors (+ continuous_factors): the reference's older way to spell
-        # an additive design.
+        # n_cpus: accepted for signature compatibility (dds.py:206-229; the engine is the GPU pipeline).  inference: an
+        # object of the plug-in interface - a HipInference lends its device context, anything else is ignored.
+        # design_factors (+ continuous_factors): the reference's older way to spell an additive design.
+        pre_var = None
+        if adata is not None:
+            # an AnnData-like object (dds.py:231-249; anything with X / obs / var / obs_names / var_names): its counts and
+            # metadata are taken, fields it already carries in .var stay until a stage overwrites them
+            if counts is not None or metadata is not None:
+                raise ValueError("adata was provided; do not pass counts or metadata.")
+            xa = adata.X.toarray() if hasattr(adata.X, "toarray") else np.asarray(adata.X)
+            counts = pd.DataFrame(xa, index=adata.obs_names, columns=adata.var_names)
+            metadata = pd.DataFrame(adata.obs)
+            pre_var = pd.DataFrame(adata.var) if getattr(adata, "var", None) is not None else None
+        elif counts is None or metadata is None:
+            raise ValueError("Either adata or both counts and metadata arguments must be provided.")
         if design_factors is not None:
             fac = [design_factors] if isinstance(design_factors, str) else list(design_factors)
             design = "~" + " + ".join(fac)
@@ -141,61 +167,410 @@ class DeseqDataSet:
             raise ValueError("The design matrix and the metadata should have the same sample index.")
         self.obs_names, self.var_names = counts.index, counts.columns
         self.X = counts.to_numpy()
-        self.n_obs, self.n_vars = self.X.shape
+        if self.X.size and np.issubdtype(self.X.dtype, np.number) and float(self.X.max()) >= 2.0 ** 31:
+            raise ValueError("The count matrix should only contain non-negative integers below 2^31.")
         self.design = design
         dm = build_design(self.obs, design, ref_level)
-        self.obsm = {"design_matrix": dm}
+        self.obsm = _LazyObsm(self, {"design_matrix": dm})
+        DesignPack(dm.to_numpy(), min_replicates)  # (host-only: refuses a design wider than the engine takes, before any GPU work)
         if np.linalg.matrix_rank(dm.to_numpy()) < dm.shape[1]:  # dds.py:1550-1563
             warnings.warn("The design matrix is not full rank, so the model cannot be fitted, but some operations "
                           "like design-free VST remain possible. To perform differential expression analysis, "
                           "please remove the design variables that are linear combinations of others.",
                           UserWarning, stacklevel=2)
         self.var = pd.DataFrame(index=self.var_names)
+        if pre_var is not None and len(pre_var.columns):
+            self.var = pre_var.set_axis(self.var_names).copy()
         self.varm, self.layers, self.uns = {}, _LazyLayers(self), {}
-        self.refit_cooks, self.fit_type, self.quiet = refit_cooks, fit_type, quiet
-        if control_genes is not None:  # names, integer positions or a boolean mask (dds.py:640-650)
-            cg = np.asarray(control_genes)
-            control_genes = self.var_names.get_indexer(cg) if cg.dtype.kind in "OUS" else cg
-            if cg.dtype.kind in "OUS" and (np.asarray(control_genes) < 0).any():
+        self.refit_cooks, self.fit_type, self.quiet = bool(refit_cooks), fit_type, quiet
+        self.min_mu, self.min_disp, self.max_disp = min_mu, min_disp, max(max_disp, self.X.shape[0])  # dds.py:312
+        self.beta_tol, self.min_replicates = beta_tol, min_replicates
+        self.size_factors_fit_type = size_factors_fit_type
+        self.low_memory = bool(low_memory)
+        self.control_genes = control_genes
+        self._control_genes = self._control_index(control_genes)
+        self.inference = inference
+        if ctx is None and inference is not None and isinstance(getattr(inference, "ctx", None), Context):
+            ctx = inference.ctx
+        self._ctx, self._device = ctx, device
+        self._pipe_obj, self._step, self._res = None, None, None
+        self._sf_published = None
+
+    # ------------------------------------------------------------------ container surface (AnnData's, as far as the path uses it)
+    @property
+    def n_obs(self):
+        return self.X.shape[0]
+
+    @property
+    def n_vars(self):
+        return self.X.shape[1]
+
+    @property
+    def shape(self):
+        return self.X.shape
+
+    def _control_index(self, control_genes):
+        """names, integer positions or a boolean mask (dds.py:640-650) -> what the pipeline takes."""
+        if control_genes is None:
+            return None
+        cg = np.asarray(control_genes)
+        if cg.dtype.kind in "OUS":
+            idx = self.var_names.get_indexer(cg)
+            if (idx < 0).any():
                 raise KeyError("control_genes: unknown gene name")
-        self._control_genes = control_genes
-        self._pipe = DeseqPipeline(self.X, dm.to_numpy(), ctx=ctx, device=device, min_mu=min_mu, min_disp=min_disp,
-                                   max_disp=max_disp, refit_cooks=refit_cooks, min_replicates=min_replicates,
-                                   beta_tol=beta_tol, fit_type=fit_type, size_factors_fit_type=size_factors_fit_type,
-                                   control_genes=control_genes)
-        self._res = None
+            return idx
+        return cg
+
+    def _index(self, key, names, n):
+        """One axis of ``dds[rows, cols]``: slice, names, integer positions or a boolean mask -> integer positions."""
+        if isinstance(key, slice):
+            return np.arange(n)[key]
+        if isinstance(key, (str, bytes)):
+            key = [key]
+        k = np.asarray(key.to_numpy() if hasattr(key, "to_numpy") else key)
+        if k.dtype == bool:
+            if k.shape[0] != n:
+                raise IndexError("boolean index of the wrong length")
+            return np.nonzero(k)[0]
+        if k.dtype.kind in "OUS":
+            idx = names.get_indexer(k)
+            if (idx < 0).any():
+                raise KeyError(f"unknown names: {list(k[idx < 0])[:5]}")
+            return idx
+        return np.atleast_1d(k).astype(int)
+
+    def __getitem__(self, key):
+        """``dds[:, genes]`` / ``dds[samples]`` / ``dds[samples, genes]`` (names, positions, masks, slices): a new data set
+        on the sub-matrix with the fields sliced along (dds.py:868-873, 1330; AnnData semantics).  Layers that still live
+        on the device are fetched through the parent when read."""
+        if not isinstance(key, tuple):
+            key = (key, slice(None))
+        rows = self._index(key[0], self.obs_names, self.n_obs)
+        cols = self._index(key[1], self.var_names, self.n_vars)
+        new = object.__new__(type(self))
+        new.__dict__.update({k: v for k, v in self.__dict__.items()
+                             if k not in ("obs", "obsm", "var", "varm", "layers", "uns", "X", "_pipe_obj", "_step", "_res")})
+        new.X = self.X[np.ix_(rows, cols)]
+        new.obs, new.var = self.obs.iloc[rows].copy(), self.var.iloc[cols].copy()
+        new.obs_names, new.var_names = self.obs_names[rows], self.var_names[cols]
+        new.uns = dict(self.uns)
+        new.varm = {k: (v.iloc[cols].copy() if hasattr(v, "iloc") else np.asarray(v)[cols]) for k, v in self.varm.items()}
+        new.obsm = _LazyObsm(new, {"design_matrix": self.obsm["design_matrix"].iloc[rows].copy()})
+        for k in self.obsm.available():
+            if k != "design_matrix":  # N x (genes with counts): sliced by sample only
+                new.obsm.bind_parent(k, self, rows, None)
+        new.layers = _LazyLayers(new)
+        for k in self.layers.available():
+            new.layers.bind_parent(k, self, rows, cols)
+        new._control_genes = None if self._control_genes is None else np.nonzero(
+            np.isin(cols, np.arange(self.n_vars)[self._control_genes]))[0]
+        new._pipe_obj, new._step, new._res, new._sf_published = None, None, None, None
+        return new
+
+    def copy(self):
+        """A data set of its own: host fields copied (layers that live on the device are fetched first, unless
+        ``low_memory``), device state not shared - the copy rebuilds it when a stage is asked for."""
+        new = object.__new__(type(self))
+        new.__dict__.update(self._host_state())
+        new._ctx = self._ctx
+        return new
+
+    def _host_state(self):
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_pipe_obj", "_step", "_ctx", "layers", "obsm", "inference")}
+        d = _copy.deepcopy(d)
+        d["layers"] = self.layers.materialised_copy(skip=self.low_memory)
+        d["obsm"] = self.obsm.materialised_copy(skip=self.low_memory)
+        d["inference"] = None
+        d["_pipe_obj"], d["_step"], d["_ctx"] = None, None, None
+        return d
+
+    def __getstate__(self):
+        """Pickling (examples/plot_step_by_step.py:175-177; the reference needs to_picklable_anndata, dds.py:1112-1138):
+        the host fields travel, the device context and the open pass do not."""
+        return self._host_state()
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.layers._dds = self
+        self.obsm._dds = self
+
+    def to_picklable_anndata(self):
+        """The reference's name for "something that pickles" (dds.py:1112-1138): here the data set itself does."""
+        return self.copy()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def close(self):
+        """Release the device state (the host fields stay)."""
+        p = self.__dict__.get("_pipe_obj")
+        if p is not None:
+            p.close()
+        self._pipe_obj, self._step = None, None
+
+    # ------------------------------------------------------------------ the device pipeline behind the fields
+    @property
+    def _pipe(self) -> DeseqPipeline:
+        if self._pipe_obj is None:
+            self._pipe_obj = DeseqPipeline(
+                self.X, self.obsm["design_matrix"].to_numpy(), ctx=self._ctx, device=self._device, min_mu=self.min_mu,
+                min_disp=self.min_disp, max_disp=self.max_disp, refit_cooks=self.refit_cooks,
+                min_replicates=self.min_replicates, beta_tol=self.beta_tol, fit_type=self.fit_type,
+                size_factors_fit_type=self.size_factors_fit_type, control_genes=self._control_genes,
+                keep_cooks=not self.low_memory)
+            self._ctx = self._pipe_obj.ctx
+            self._step = None
+        p = self._pipe_obj
+        p.fit_type, p.refit_cooks = self.fit_type, bool(self.refit_cooks)  # (attributes a user may change between calls)
+        return p
+
+    def _given_size_factors(self):
+        """Size factors a pass must START from: those in ``obs`` when the user put them there (dds.py:724-726 only fits
+        them when the column is missing), None when they are the ones the engine published itself."""
+        if "size_factors" not in self.obs:
+            return None
+        sf = np.asarray(self.obs["size_factors"], dtype=float)
+        return sf
+
+    def _advance(self, upto, refit_size_factors=False):
+        """Bring the open pass to stage ``upto`` (opening a new one when there is none, when another use of the pipeline
+        has recycled its buffers, or when the size factors are to be fitted again), stage by stage."""
+        pipe = self._pipe
+        st = self._step
+        order = pipe.STAGES
+        if (st is None or refit_size_factors or not pipe.step_alive(st) or st.done == "finish"
+                or order.index(st.done) > order.index(upto)):
+            given = None if refit_size_factors else self._given_size_factors()
+            st = self._step = pipe.begin_step(size_factors=given)
+        if upto in ("lfc", "refit", "finish") and order.index(st.done) < order.index("lfc") and "dispersions" in self.var:
+            pipe.advance(st, "map")
+            mine = np.asarray(self.var["dispersions"], dtype=float)
+            pub = getattr(self, "_disp_published", None)
+            if pub is None or not np.array_equal(mine, pub, equal_nan=True):  # edited between the stages: honour it
+                pipe.set_dispersions(st, mine)
+        pipe.advance(st, upto)
+        return st
 
     # ------------------------------------------------------------------ the pipeline
-    def deseq2(self):
+    def deseq2(self, fit_type=None):
         """Size factors, dispersions, LFCs, Cook's outliers and their refit (dds.py:516-562)."""
-        r = self._res = self._pipe.deseq2()
+        if fit_type is not None:
+            self.fit_type = fit_type
+        pipe = self._pipe
+        self._step = None
+        r = pipe.deseq2()
+        self._publish_all(r)
+        return self
+
+    def _publish_all(self, r):
+        # (the pipeline's result vectors are views of ITS page-locked slabs: the data set keeps copies of its own)
+        self._res = type(r)(**{k: (np.array(v) if isinstance(v, np.ndarray) else v)
+                               for k, v in ((f, getattr(r, f)) for f in r.__dataclass_fields__)})
+        r = self._res
         v, cols = self.var, self.obsm["design_matrix"].columns
-        self.obs["size_factors"] = r.size_factors
-        v["non_zero"], v["_normed_means"] = r.non_zero, r.normed_means
-        v["_MoM_dispersions"], v["genewise_dispersions"] = r.mom_dispersions, r.genewise_dispersions
-        v["_genewise_converged"], v["fitted_dispersions"] = r.genewise_converged, r.fitted_dispersions
-        v["MAP_dispersions"], v["_MAP_converged"] = r.MAP_dispersions, r.MAP_converged
-        v["dispersions"], v["_outlier_genes"] = r.dispersions, r.outlier_genes
-        v["_LFC_converged"], v["replaced"], v["refitted"] = r.LFC_converged, r.replaced, r.refitted
-        v["_pvalue_cooks_outlier"] = r.cooks_outlier
-        self.varm["LFC"] = pd.DataFrame(r.LFC, index=self.var_names, columns=cols)
+        self._set_size_factors(r.size_factors)
+        v["non_zero"], v["_normed_means"] = np.array(r.non_zero), np.array(r.normed_means)
+        self.non_zero_idx = np.arange(self.n_vars)[np.asarray(r.non_zero, bool)]
+        v["_MoM_dispersions"], v["genewise_dispersions"] = np.array(r.mom_dispersions), np.array(r.genewise_dispersions)
+        v["_genewise_converged"], v["fitted_dispersions"] = np.array(r.genewise_converged), np.array(r.fitted_dispersions)
+        v["MAP_dispersions"], v["_MAP_converged"] = np.array(r.MAP_dispersions), np.array(r.MAP_converged)
+        v["dispersions"], v["_outlier_genes"] = np.array(r.dispersions), np.array(r.outlier_genes)
+        self._disp_published = np.array(r.dispersions)
+        v["_LFC_converged"] = np.array(r.LFC_converged)
+        if self._pipe_obj is None or self._pipe_obj.refit_cooks or getattr(self._step, "force_refit", False):
+            v["replaced"], v["refitted"] = np.array(r.replaced), np.array(r.refitted)  # dds.py:1317-1326: written by refit()
+        v["_pvalue_cooks_outlier"] = np.array(r.cooks_outlier)
+        self.new_all_zeroes_genes = self.var_names[np.asarray(r.new_all_zeroes, bool)]
+        self.varm["LFC"] = pd.DataFrame(np.array(r.LFC), index=self.var_names, columns=cols)
         self.uns["disp_function_type"] = r.disp_function_type
         if r.trend_coeffs is not None:
-            self.uns["trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
+            self.uns["trend_coeffs"] = pd.Series(np.array(r.trend_coeffs), index=["a0", "a1"])
         if r.mean_disp is not None:
             self.uns["mean_disp"] = r.mean_disp
         self.uns["_squared_logres"], self.uns["prior_disp_var"] = r.squared_logres, r.prior_disp_var
+        lay, obm = self.layers, self.obsm
+        lay.offer("normed_counts", "_mu_LFC", "_hat_diagonals")
+        obm.offer("_mu_LFC", "_hat_diagonals")
+        if not self.low_memory:  # dds.py:1103-1106: the Cook's layers do not survive cooks_outlier() in low-memory mode
+            lay.offer("cooks", "_mu_hat")
+            if "refitted" in v and np.asarray(r.refitted, bool).any():
+                lay.offer("replace_cooks")
+        else:  # dds.py:1032-1034
+            obm.withdraw("_mu_LFC", "_hat_diagonals")
+            lay.withdraw("_mu_LFC", "_hat_diagonals", "_mu_hat")
+
+    def _set_size_factors(self, sf):
+        self.obs["size_factors"] = np.array(sf, dtype=float)
+        self._sf_published = np.array(sf, dtype=float)
+
+    def fit_size_factors(self, fit_type=None, control_genes=None):
+        """Size factors only (dds.py:584-711): ``"ratio"`` (median of ratios), ``"poscounts"`` or ``"iterative"``;
+        ``control_genes`` given here override the data set's (dds.py:616-619).  Writes ``obs["size_factors"]``,
+        ``var["_normed_means"]`` and offers ``layers["normed_counts"]``."""
+        if fit_type is None:
+            fit_type = self.size_factors_fit_type
+        if fit_type not in ("ratio", "poscounts", "iterative"):
+            raise ValueError("fit_type: 'ratio', 'poscounts' or 'iterative'")
+        pipe = self._pipe
+        if control_genes is not None:
+            cg = self._control_index(control_genes)
+            m = np.zeros(self.n_vars, dtype=np.uint8)
+            m[np.asarray(cg)] = 1
+            pipe._control_mask = m
+        old, pipe.size_factors_fit_type = pipe.size_factors_fit_type, fit_type
+        try:
+            st = self._advance("size_factors", refit_size_factors=True)
+        finally:
+            pipe.size_factors_fit_type = old
+        self._set_size_factors(st.r.size_factors)
+        sf = self._sf_published
+        self.var["_normed_means"] = ((1.0 / sf) @ self.X) / self.n_obs  # (= normed_counts.mean(0), dds.py:708)
+        self.layers.offer("normed_counts")
         return self
 
-    def fit_size_factors(self, fit_type=None):
-        """Size factors only (dds.py:600-708): ``"ratio"`` (median of ratios) or ``"poscounts"``."""
-        if fit_type is not None:
-            if fit_type not in ("ratio", "poscounts", "iterative"):
-                raise ValueError("fit_type: 'ratio', 'poscounts' or 'iterative'")
-            self._pipe.size_factors_fit_type = fit_type
-        r = self._pipe.deseq2(stop_after_size_factors=True)
-        self.obs["size_factors"] = r.size_factors
+    def _fit_iterate_size_factors(self, niter: int = 10, quant: float = 0.95):
+        """The ``iterative`` mode by its reference name (dds.py:1460-1548; tests/test_pydeseq2.py:344-364)."""
+        if (niter, quant) != (10, 0.95):
+            raise NotImplementedError("iterative size factors: niter = 10, quant = 0.95 (the reference's defaults)")
+        return self.fit_size_factors("iterative")
+
+    def _need(self, where, key, stage_fn):
+        """The reference's lazy chaining (dds.py:725, 812, 849, 892, 944, 992): a stage whose input is not there yet runs
+        the stage that writes it."""
+        if key not in where:
+            stage_fn()
+
+    def fit_genewise_dispersions(self, vst=False):
+        """Genewise dispersions (dds.py:713-797): MoM start, mu_hat (linear model or IRLS), L-BFGS-B per gene."""
+        self._need(self.obs, "size_factors", lambda: self.fit_size_factors(fit_type=self.size_factors_fit_type))
+        st = self._advance("genewise")
+        r = self._pipe.publish(st, ("nm", "mom", "gw", "gconv"))
+        if self._sf_published is None or not np.array_equal(self._sf_published, np.asarray(self.obs["size_factors"], float)):
+            self._sf_published = np.asarray(self.obs["size_factors"], dtype=float).copy()
+        v = self.var
+        v["non_zero"] = np.array(r.non_zero)
+        self.non_zero_idx = np.arange(self.n_vars)[np.asarray(r.non_zero, bool)]
+        v["_normed_means"], v["_MoM_dispersions"] = r.normed_means, r.mom_dispersions
+        v["vst_genewise_dispersions" if vst else "genewise_dispersions"] = r.genewise_dispersions
+        v["_genewise_converged"] = r.genewise_converged
+        self.layers.offer("normed_counts", "_vst_mu_hat" if vst else "_mu_hat")
         return self
+
+    def fit_dispersion_trend(self, vst=False):
+        """Dispersion trend (dds.py:799-838): parametric gamma GLM with the mean-based fallback, or ``"mean"``."""
+        name = "vst_genewise_dispersions" if vst else "genewise_dispersions"
+        self._need(self.var, name, lambda: self.fit_genewise_dispersions(vst))
+        if vst:
+            old, self.fit_type = self.fit_type, getattr(self, "vst_fit_type", self.fit_type)
+        try:
+            st = self._advance("trend")
+        finally:
+            if vst:
+                self.fit_type = old
+        r = self._pipe.publish(st, ("fit",))
+        if r.disp_function_type == "parametric":
+            self.uns["vst_trend_coeffs" if vst else "trend_coeffs"] = pd.Series(np.array(r.trend_coeffs), index=["a0", "a1"])
+        else:
+            self.uns["mean_disp"] = r.mean_disp
+        if vst:
+            if r.disp_function_type != "parametric":
+                self.vst_fit_type = "mean"
+            if r.disp_function_type != "parametric":
+                self.var["fitted_dispersions"] = r.fitted_dispersions
+            return self
+        self.uns["disp_function_type"] = r.disp_function_type
+        self.var["fitted_dispersions"] = r.fitted_dispersions
+        return self
+
+    def disp_function(self, x):
+        """The fitted trend at normalised means ``x`` (dds.py:833-838)."""
+        x = np.asarray(x, dtype=float)
+        if self.uns["disp_function_type"] == "parametric":
+            c = np.asarray(self.uns["trend_coeffs"], dtype=float)
+            return c[0] + c[1] / x
+        return np.full_like(x, self.uns["mean_disp"])
+
+    def fit_dispersion_prior(self):
+        """Prior variance of the log dispersions around the trend (dds.py:840-884).  The device pass fits trend and prior
+        in one call, so this publishes what that call found."""
+        self._need(self.var, "fitted_dispersions", self.fit_dispersion_trend)
+        st = self._advance("trend")
+        self.uns["_squared_logres"], self.uns["prior_disp_var"] = st.r.squared_logres, st.r.prior_disp_var
+        return self
+
+    def fit_MAP_dispersions(self):
+        """MAP dispersions and the final ``dispersions`` (dds.py:886-935)."""
+        self._need(self.uns, "prior_disp_var", self.fit_dispersion_prior)
+        st = self._advance("map")
+        r = self._pipe.publish(st, ("map", "mconv", "disp", "outl", "gw"))
+        v = self.var
+        v["MAP_dispersions"], v["_MAP_converged"] = r.MAP_dispersions, r.MAP_converged
+        v["dispersions"], v["_outlier_genes"] = r.dispersions, r.outlier_genes
+        self._disp_published = np.array(r.dispersions)
+        if self.low_memory:  # dds.py:933-935
+            self.layers.withdraw("_mu_hat")
+        return self
+
+    def fit_LFC(self):
+        """Log fold changes by IRLS (dds.py:937-984); the engine's launch also leaves the per-sample half of the Cook's
+        stage and the Wald statistics of the default contrast behind."""
+        self._need(self.var, "dispersions", self.fit_MAP_dispersions)
+        st = self._advance("lfc")
+        r = self._pipe.publish(st, ("beta", "lconv"))
+        self.varm["LFC"] = pd.DataFrame(r.LFC, index=self.var_names, columns=self.obsm["design_matrix"].columns)
+        self.var["_LFC_converged"] = r.LFC_converged
+        self.obsm.offer("_mu_LFC", "_hat_diagonals")
+        self.layers.offer("_mu_LFC", "_hat_diagonals")
+        return self
+
+    def calculate_cooks(self):
+        """Cook's distances (dds.py:986-1040): ``layers["cooks"]``, computed in the LFC launch's epilogue."""
+        self._need(self.var, "dispersions", self.fit_MAP_dispersions)
+        self._advance("lfc")
+        if "LFC" not in self.varm:
+            self.fit_LFC()
+        self.layers.offer("cooks")
+        if self.low_memory:  # dds.py:1032-1034
+            self.obsm.withdraw("_mu_LFC", "_hat_diagonals")
+            self.layers.withdraw("_mu_LFC", "_hat_diagonals")
+        return self
+
+    def refit(self):
+        """Replace the Cook's outliers and refit the genes that had any (dds.py:1042-1064, 1301-1458)."""
+        if "cooks" not in self.layers.available():
+            self.calculate_cooks()
+        st = self._advance("lfc")
+        st.force_refit = True
+        self._finish()
+        return self
+
+    def _finish(self):
+        """Run the open pass to its end and publish every field (the refit's patches, the Cook's outlier mask)."""
+        st = self._advance("finish")
+        self._publish_all(st.r)
+        return st
+
+    def cooks_outlier(self) -> pd.Series:
+        """Genes whose p-value is to be masked for a Cook's outlier (dds.py:1066-1110)."""
+        if "_pvalue_cooks_outlier" not in self.var:
+            if "cooks" not in self.layers.available() and self._res is None:
+                self.calculate_cooks()
+            self._finish()
+        out = pd.Series(np.asarray(self.var["_pvalue_cooks_outlier"], dtype=bool), index=self.var_names)
+        if self.low_memory:  # dds.py:1103-1106
+            self.layers.withdraw("cooks", "replace_cooks")
+        return out
+
+    def _ensure_finished(self):
+        """DeseqStats needs the whole fit (LFC, dispersions, Cook's mask): finish an open stage-wise pass."""
+        if self._res is None or self._res.pvalue is None:
+            if "LFC" not in self.varm and self._step is None:
+                raise AttributeError("Please run deseq2() on the DeseqDataSet first.")
+            self._finish()
+        return self._res
 
     def vst(self, use_design: bool = False, fit_type=None):
         """Variance stabilising transformation into ``layers["vst_counts"]`` (dds.py:349-514): dispersions
@@ -230,8 +605,9 @@ class DeseqDataSet:
             if pipe is not p0:
                 pipe.close()
         if pipe is p0:
-            self.layers.clear()  # the device layers of an earlier deseq2() were recycled by this run
-        self.obs["size_factors"] = r.size_factors
+            self._step = None  # (the device layers of an earlier fit were recycled by this run: rebuilt when read)
+        self._set_size_factors(r.size_factors)
+        self.layers.offer("normed_counts")
         self.var["vst_genewise_dispersions"] = r.genewise_dispersions
         if r.disp_function_type == "parametric":
             self.uns["vst_trend_coeffs"] = pd.Series(r.trend_coeffs, index=["a0", "a1"])
@@ -253,35 +629,118 @@ class DeseqDataSet:
             return self._pipe.vst_transform(self.obs["size_factors"].to_numpy(), **self._vst_params)
         return self._pipe.vst_transform_new(np.asarray(counts), self.logmeans, self.filtered_genes, **self._vst_params)
 
-    def cooks_outlier(self) -> pd.Series:
-        return pd.Series(np.asarray(self._res.cooks_outlier, dtype=bool), index=self.var_names)
-
     @property
     def non_zero_genes(self):
         return self.var_names[np.asarray(self.var["non_zero"], dtype=bool)]
 
 
-class _LazyLayers(dict):
-    """N x G layers stay on the device until asked for (``normed_counts``, ``_mu_LFC``, ``_hat_diagonals``,
-    ``cooks``)."""
+class _Lazy(dict):
+    """N x G (layers) or N x genes-with-counts (obsm) matrices that stay on the device until they are read: a stage
+    OFFERS a key, reading it fetches (and keeps) the host copy, ``withdraw`` removes it (``low_memory``, dds.py:228).
+    An offered matrix whose device copy has been recycled by a later pass is rebuilt by running the (deterministic) pass
+    again up to the stage that writes it - milliseconds on the device - so an offer never goes stale."""
 
-    def __init__(self, dds):
-        super().__init__()
+    def __init__(self, dds, init=None):
+        super().__init__(init or {})
         self._dds = dds
+        self._offered = set()
+        self._parents = {}
+
+    def offer(self, *keys):
+        for k in keys:
+            if not dict.__contains__(self, k):
+                self._offered.add(k)
+
+    def withdraw(self, *keys):
+        for k in keys:
+            self._offered.discard(k)
+            self._parents.pop(k, None)
+            if dict.__contains__(self, k):
+                dict.__delitem__(self, k)
+
+    def bind_parent(self, key, parent, rows, cols):
+        self._parents[key] = (parent, rows, cols)
+
+    def available(self):
+        return set(dict.keys(self)) | self._offered | set(self._parents)
+
+    def __contains__(self, key):
+        return key in self.available()
+
+    def keys(self):
+        return self.available()
+
+    def __delitem__(self, key):
+        if key not in self.available():
+            raise KeyError(key)
+        self.withdraw(key)
 
     def __missing__(self, key):
-        dds = self._dds
-        if dds._res is None:
-            raise KeyError(key)
-        if key == "normed_counts":
-            val = dds.X / np.asarray(dds.obs["size_factors"])[:, None]
+        if key in self._parents:
+            parent, rows, cols = self._parents[key]
+            full = type(self).__getitem__(getattr(parent, self._attr), key)
+            val = full[rows] if cols is None else full[np.ix_(rows, cols)]
+        elif key in self._offered:
+            val = self._fetch(key)
+            self._offered.discard(key)
         else:
-            name = {"_mu_LFC": "mu_LFC", "_hat_diagonals": "hat_diagonals", "cooks": "cooks"}.get(key)
-            if name is None:
-                raise KeyError(key)
-            val = dds._pipe.layer(name)
-        self[key] = val
+            raise KeyError(key)
+        dict.__setitem__(self, key, val)
         return val
+
+    def materialised_copy(self, skip=False):
+        """A detached copy for copy() / pickling: what was offered is fetched first (unless ``skip``)."""
+        new = type(self)(None)
+        for k in list(self.available()):
+            if dict.__contains__(self, k) or not skip:
+                try:
+                    v = self[k]
+                except Exception:  # noqa: BLE001 - the device copy is gone (another pass recycled it): not part of the state
+                    continue
+                dict.__setitem__(new, k, v.copy() if hasattr(v, "copy") else v)
+        return new
+
+
+class _LazyLayers(_Lazy):
+    """``normed_counts``, ``_mu_hat``, ``_mu_LFC``, ``_hat_diagonals``, ``cooks``, ``replace_cooks``: N x G, NaN columns for
+    the genes without counts."""
+
+    _attr = "layers"
+
+    def _fetch(self, key):
+        dds = self._dds
+        if key == "normed_counts":
+            return dds.X / np.asarray(dds.obs["size_factors"], dtype=float)[:, None]
+        if key in ("_mu_hat", "_vst_mu_hat"):
+            st = dds._step
+            if st is None or not dds._pipe.step_alive(st) or getattr(st, "mh", None) is None:
+                # deseq2() in one go keeps no open pass: mu_hat is a function of the fit's inputs, rebuild the stage
+                st = dds._advance("genewise")
+            return dds._pipe.mu_hat_host(st)
+        if key == "replace_cooks":  # dds.py:1449-1458: the Cook's distances with the replaceable samples of the refitted genes zeroed
+            ck = np.array(self["cooks"])
+            rep = np.asarray(dds._pipe.design.replaceable, dtype=bool)
+            for j in np.nonzero(np.asarray(dds.var["refitted"], dtype=bool))[0]:
+                ck[rep, j] = 0.0
+            return ck
+        name = {"_mu_LFC": "mu_LFC", "_hat_diagonals": "hat_diagonals", "cooks": "cooks"}.get(key)
+        if name is None:
+            raise KeyError(key)
+        pipe = dds._pipe
+        if name not in pipe.layers:  # recycled by a later pass (or the pipeline is new: a copy, an unpickled data set)
+            dds._advance("lfc")
+        return pipe.layer(name)
+
+
+class _LazyObsm(_Lazy):
+    """``design_matrix`` plus the reference's ``_mu_LFC`` / ``_hat_diagonals`` (dds.py:975-976): N x (genes with counts)."""
+
+    _attr = "obsm"
+
+    def _fetch(self, key):
+        dds = self._dds
+        full = dds.layers[key]
+        return np.ascontiguousarray(full[:, np.asarray(dds.var["non_zero"], dtype=bool)])
 
 
 class DeseqStats:
@@ -289,8 +748,14 @@ class DeseqStats:
 
     def __init__(self, dds: DeseqDataSet, contrast, alpha=0.05, cooks_filter=True, independent_filter=True,
                  prior_LFC_var=None, lfc_null=0.0, alt_hypothesis=None, inference=None, quiet=True, n_cpus=None):
-        if dds._res is None:
+        finish = getattr(dds, "_ensure_finished", None)
+        if finish is not None:
+            finish()  # (a stage-wise pass left open after fit_LFC() / calculate_cooks() is run to its end)
+        elif dds._res is None:
             raise AttributeError("Please run deseq2() on the DeseqDataSet first.")
+        if getattr(dds, "refit_cooks", False) and "replaced" not in dds.var:  # ds.py:208-216
+            raise AttributeError("dds has 'refit_cooks' set to True but Cooks outliers have not been refitted. Please run "
+                                 "'dds.refit()' first or set 'dds.refit_cooks' to False.")
         self.dds, self.alpha, self.prior_LFC_var = dds, alpha, prior_LFC_var
         self.cooks_filter, self.independent_filter = cooks_filter, independent_filter
         self.lfc_null, self.alt_hypothesis, self.quiet = lfc_null, alt_hypothesis, quiet
@@ -350,13 +815,12 @@ class DeseqStats:
         if not hasattr(self, "p_values") or getattr(self, "_wald_key", None) != (self.lfc_null, self.alt_hypothesis):
             self.run_wald_test()
         if not hasattr(self, "padj"):
-            pv = self.p_values.to_numpy().copy()
             if self.cooks_filter:
-                pv[self.dds.cooks_outlier().to_numpy()] = np.nan
-            self.p_values = pd.Series(pv, index=self.dds.var_names)
-            padj, self._padj_info = _summary.adjusted_pvalues(self.dds._pipe.ctx, self.base_mean.to_numpy(), pv,
-                                                              self.alpha, self.independent_filter)
-            self.padj = pd.Series(padj, index=self.dds.var_names)
+                self._cooks_filtering()
+            if self.independent_filter:
+                self._independent_filtering()
+            else:
+                self._p_value_adjustment()
         df = pd.DataFrame(index=self.dds.var_names)
         df["baseMean"] = self.base_mean
         df["log2FoldChange"] = self.LFC.to_numpy() @ self.contrast_vector / np.log(2)
@@ -364,6 +828,55 @@ class DeseqStats:
         df["stat"], df["pvalue"], df["padj"] = self.statistics, self.p_values, self.padj
         self.results_df = df
         return df
+
+    def plot_MA(self, log: bool = True, save_path=None, **kwargs):
+        """MA plot (ds.py:449-484).  Plotting is outside this engine's scope: the reference's precondition is kept (an
+        AttributeError before ``summary()``), the figure itself needs matplotlib and is a scatter of ``results_df``."""
+        if not hasattr(self, "results_df"):
+            raise AttributeError("Trying to make an MA plot but p-values were not computed yet. "
+                                 "Please run the summary() method first.")
+        try:
+            import matplotlib.pyplot as plt
+        except ImportError as e:  # pragma: no cover - matplotlib is not a dependency of the engine
+            raise NotImplementedError("plot_MA needs matplotlib, which this engine does not depend on") from e
+        df = self.results_df
+        sig = (df["padj"] < self.alpha).to_numpy()
+        fig, ax = plt.subplots()
+        ax.scatter(df["baseMean"], df["log2FoldChange"], c=np.where(sig, "red", "grey"), s=kwargs.pop("s", 8), **kwargs)
+        if log:
+            ax.set_xscale("log")
+        ax.set_xlabel("mean of normalized counts")
+        ax.set_ylabel("log2 fold change")
+        if save_path is not None:
+            fig.savefig(save_path, bbox_inches="tight")
+        return ax
+
+    def _cooks_filtering(self):
+        """p-values of the Cook's outlier genes -> NaN (ds.py:544-550)."""
+        if not hasattr(self, "p_values"):
+            self.run_wald_test()
+        pv = self.p_values.to_numpy().copy()
+        pv[self.dds.cooks_outlier().to_numpy()] = np.nan
+        self.p_values = pd.Series(pv, index=self.dds.var_names)
+
+    def _adjust(self, independent_filter):
+        if not hasattr(self, "p_values"):
+            self.run_wald_test()
+        padj, self._padj_info = _summary.adjusted_pvalues(self.dds._pipe.ctx, self.base_mean.to_numpy(),
+                                                          self.p_values.to_numpy(), self.alpha, independent_filter)
+        self.padj = pd.Series(padj, index=self.dds.var_names)
+
+    def _independent_filtering(self):
+        """Adjusted p-values with the baseMean cut-off that maximises the rejections (ds.py:486-527), on the device."""
+        self._adjust(True)
+
+    def _p_value_adjustment(self):
+        """Benjamini-Hochberg over all genes with a p-value (ds.py:529-542)."""
+        self._adjust(False)
+
+    def __getstate__(self):
+        """Pickles with its data set (examples/plot_step_by_step.py:243-246); device buffers are not part of the state."""
+        return dict(self.__dict__)
 
     def lfc_shrink(self, coeff: str, adapt: bool = True) -> pd.DataFrame:
         """apeGLM shrinkage of one LFC column, p-values unchanged (ds.py:363-447)."""

@@ -848,6 +848,7 @@ class DeseqPipeline:
             out = fn()
         finally:
             self.ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
+            self._alpha_hook = None  # (its closure holds the pass - and with it the page-locked slabs of its read-backs)
         if state["error"] is not None:
             raise state["error"]
         return out, state["fired"]
@@ -1103,6 +1104,7 @@ class DeseqPipeline:
         if not self.keep_cooks:
             self.layers = {}
         self._nz_pred = st.non_zero
+        st.slab_tok = st.flags_tok = st.patch = None  # (the result's arrays are the only views of the host slabs left)
 
     def publish(self, st, names):
         """Host copies of per-gene vectors of an OPEN pass, scattered to all G genes and stored in its DeseqResult under the

@@ -144,3 +144,37 @@ def test_documented_limits_are_refused_with_a_clear_error():
     with pytest.raises(ValueError, match="at most 32"):
         DesignPack(X)
     assert DesignPack(X[:, :MAX_DESIGN_COLUMNS]).P == MAX_DESIGN_COLUMNS
+
+
+def test_construction_slicing_copy_and_pickling_never_touch_the_gpu():
+    """The device pipeline behind the facade is created on first use: building a data set, dds[:, genes] (dds.py:868-873,
+    1330), copy() and pickling (examples/plot_step_by_step.py:175-177) are host operations."""
+    import pickle
+
+    from pydeseq2_amd.api import DeseqDataSet
+
+    meta = pd.DataFrame({"condition": list("ABABAB"), "x": np.arange(6.0)}, index=[f"s{i}" for i in range(6)])
+    counts = pd.DataFrame(np.arange(24).reshape(6, 4), index=meta.index, columns=list("wxyz"))
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition + x", low_memory=True)
+    assert dds._pipe_obj is None and dds.n_obs == 6 and dds.n_vars == 4 and dds.low_memory
+    dds.var["note"] = [1, 2, 3, 4]
+    for key, names in ((["x", "z"], ["x", "z"]), (np.array([False, True, False, True]), ["x", "z"]), ([1, 3], ["x", "z"]),
+                       (slice(1, 3), ["x", "y"]), ("w", ["w"])):
+        sub = dds[:, key]
+        assert list(sub.var_names) == names and sub.X.shape == (6, len(names)) and list(sub.var["note"]) == \
+            [dds.var.loc[n, "note"] for n in names]
+    sub = dds[["s1", "s4"], ["w"]]
+    assert sub.X.tolist() == [[4], [16]] and list(sub.obs_names) == ["s1", "s4"] and sub.obsm["design_matrix"].shape == (2, 3)
+    with pytest.raises(KeyError):
+        dds[:, ["nope"]]
+    cp = dds.copy()
+    cp.X[0, 0] = 99
+    cp.var["note"] = 0
+    assert dds.X[0, 0] == 0 and list(dds.var["note"]) == [1, 2, 3, 4]
+    back = pickle.loads(pickle.dumps(dds))
+    assert back._pipe_obj is None and np.array_equal(back.X, dds.X) and back.obs.equals(dds.obs) and back.var.equals(dds.var)
+    assert list(back.obsm["design_matrix"].columns) == ["Intercept", "condition[T.B]", "x"] and back.low_memory
+    with pytest.raises(ValueError, match="below 2\\^31"):
+        DeseqDataSet(counts=counts * 2 ** 29, metadata=meta, design="~condition")
+    with pytest.raises(ValueError):
+        DeseqDataSet(metadata=meta, design="~condition")

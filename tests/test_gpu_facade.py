@@ -280,3 +280,77 @@ def test_upload_narrows_chunks_to_uint16_where_the_counts_fit(dtype, monkeypatch
     ctx.call("dsq_upload_counts_i32", C.c_void_p(host.ctypes.data), 0 if dtype == np.int32 else 1, C.c_size_t(n),
              C.c_void_p(d.ptr), C.byref(bad))
     assert bad.value == 1
+
+
+def test_stage_wise_lazy_chaining_and_user_edited_fields():
+    """dds.py:725, 812, 849, 892, 944, 992: a stage whose input field is missing runs the stage that writes it - fit_LFC()
+    on a fresh data set runs everything before it; size factors the user put into obs (dds.py:724-726 fits them only when
+    the column is missing) and dispersions edited between fit_MAP_dispersions() and fit_LFC() are honoured."""
+    import pydeseq2_amd
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    one_go = DeseqDataSet(counts=counts, metadata=meta, design="~group + condition").deseq2()
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~group + condition")
+    dds.fit_LFC()
+    for f in ("genewise_dispersions", "fitted_dispersions", "MAP_dispersions", "dispersions"):
+        np.testing.assert_array_equal(dds.var[f].to_numpy(), one_go.var[f].to_numpy(), err_msg=f)
+    assert "prior_disp_var" in dds.uns and "size_factors" in dds.obs
+    np.testing.assert_array_equal(dds.varm["LFC"].to_numpy(), one_go.varm["LFC"].to_numpy())
+    # the open pass is finished when somebody needs the whole fit
+    df = __import__("pydeseq2_amd.api", fromlist=["DeseqStats"]).DeseqStats(dds, contrast=["condition", "B", "A"]).summary()
+    assert df["padj"].notna().all()
+    # user-provided size factors
+    sf = np.linspace(0.7, 1.4, len(meta))
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition")
+    dds.obs["size_factors"] = sf
+    dds.fit_genewise_dispersions()
+    X = dds.obsm["design_matrix"].to_numpy()
+    ref = pydeseq2_amd.DeseqPipeline(counts.to_numpy(), X, device=0).deseq2(size_factors=sf)
+    np.testing.assert_array_equal(dds.obs["size_factors"].to_numpy(), sf)
+    np.testing.assert_allclose(dds.var["genewise_dispersions"], ref.genewise_dispersions, rtol=1e-12)
+    # dispersions edited between the stages
+    dds.fit_MAP_dispersions()
+    mine = dds.var["dispersions"].to_numpy() * 1.5
+    dds.var["dispersions"] = mine
+    dds.fit_LFC()
+    beta, _, _, _ = orc.irls(counts.to_numpy(), sf, X, mine, n_jobs=1)
+    np.testing.assert_allclose(dds.varm["LFC"].to_numpy(), beta, rtol=1e-6, atol=1e-9)
+
+
+def test_layers_are_rebuilt_on_demand_copy_and_slices():
+    """The N x G layers live on the device until read; one that a later pass has recycled is rebuilt by running the pass
+    again (layers["_mu_hat"] after deseq2(), then layers["cooks"]): all of them against the oracle's layers.  copy() gives
+    an independent data set, dds[:, genes] slices the fitted fields and the layers."""
+    from oracle import nbglm_oracle as orc
+    from pydeseq2_amd.api import DeseqDataSet
+
+    counts, meta = load_dataset("synthetic")
+    c = counts.copy()
+    c["gene3"] = 0
+    dds = DeseqDataSet(counts=c, metadata=meta, design="~group + condition").deseq2()
+    ref = orc.deseq2(c.to_numpy(), dds.obsm["design_matrix"].to_numpy(), n_jobs=1, keep_layers=True)
+    mu_hat = dds.layers["_mu_hat"]       # re-opens a pass: the LFC fit's device layers are recycled ...
+    cooks = dds.layers["cooks"]          # ... and rebuilt here
+    nz = ref.non_zero
+    np.testing.assert_allclose(mu_hat[:, nz], ref.mu_hat[:, nz], rtol=1e-6)
+    assert np.isnan(mu_hat[:, ~nz]).all() and np.isnan(cooks[:, ~nz]).all()
+    np.testing.assert_allclose(cooks[:, nz], ref.cooks[:, nz], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(dds.obsm["_mu_LFC"], ref.mu_LFC, rtol=1e-6)
+    np.testing.assert_allclose(dds.obsm["_hat_diagonals"], ref.hat_diagonals, rtol=1e-6)
+    np.testing.assert_allclose(dds.layers["normed_counts"], c.to_numpy() / ref.size_factors[:, None], rtol=1e-12)
+    sub = dds[:, ["gene1", "gene3", "gene7"]]
+    assert sub.n_vars == 3 and list(sub.var_names) == ["gene1", "gene3", "gene7"]
+    np.testing.assert_array_equal(sub.var["dispersions"].to_numpy(), dds.var.loc[["gene1", "gene3", "gene7"], "dispersions"])
+    assert np.isnan(sub.varm["LFC"].loc["gene3"]).all()
+    np.testing.assert_array_equal(sub.layers["cooks"], cooks[:, [0, 2, 6]])
+    rows = dds[["sample1", "sample5"]]
+    assert rows.n_obs == 2 and rows.obsm["design_matrix"].shape[0] == 2
+    cp = dds.copy()
+    cp.var["dispersions"] = 1.0
+    assert not np.allclose(dds.var["dispersions"].dropna(), 1.0)
+    np.testing.assert_array_equal(cp.layers["cooks"], cooks)
+    cp.fit_type = "mean"
+    cp.deseq2()  # a copy fits on its own
+    assert cp.uns["disp_function_type"] == "mean" and dds.uns["disp_function_type"] == "parametric"

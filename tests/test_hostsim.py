@@ -586,3 +586,23 @@ def test_robust_dispersion_small_cells_batched(shape):
     got = hs.robust_disp_seg(counts, sf, X, max(seg, 2))
     assert_close(got, ref, 1e-11, 1e-13, "batched cells")
     assert_close(hs.robust_disp_seg(counts, sf, X, 0), ref, 1e-11, 1e-13, "one cell at a time")
+
+
+@pytest.mark.parametrize("mu, alpha", [(10, 0.5), (10, 0.1), (3, 0.5), (9, 0.05)])
+def test_ref_nb_nll_moments(mu, alpha):
+    """The reference's tests/test_utils.py:11-33 (`test_nb_nll_moments`) on the ENGINE's loss (the device templates of
+    dsq_alpha.h, host instantiation) and on the oracle's: exp(-nll) over the counts 0 ... 10 (mu + mu^2 / alpha) is a
+    probability distribution with the NB mean mu and variance mu + alpha mu^2 (sums instead of the reference's Monte Carlo
+    draw, so the tolerances are tight)."""
+    ys = np.arange(int(10 * (mu + mu ** 2 / alpha)))
+    one = np.ones((1, 1))
+    f_engine = np.array([hs.alpha_eval(np.array([y]), np.array([float(mu)]), one, np.log(alpha), cr_reg=False)[0] for y in ys])
+    f_oracle = np.array([orc.nb_nll(np.array([y]), np.array([float(mu)]), alpha) for y in ys])
+    for f in (f_engine, f_oracle):
+        p = np.exp(-f)
+        assert abs(p.sum() - 1.0) < 1e-9
+        mean = (ys * p).sum()
+        var = ((ys - mean) ** 2 * p).sum()
+        assert abs(mean - mu) < 1e-6 * mu
+        assert abs(var - (mu * alpha + 1) * mu) < 1e-5 * (mu * alpha + 1) * mu
+    np.testing.assert_allclose(f_engine, f_oracle, rtol=1e-11, atol=1e-11)

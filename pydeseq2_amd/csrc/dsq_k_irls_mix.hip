@@ -533,7 +533,41 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
             double etac = 0.0, Ac = 0.0, bc[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) bc[q] = 0.0;
+            // Round 6: this pass was 4 sweeps long (0.86 ms of the 2.2 ms launch at 7500 x 5000) although it computes about
+            // what ONE sweep computes - its six global loads per sample (slot permutation, log size factor, flags, covariates)
+            // were issued inside the iteration that consumes them, with two wavefronts per SIMD to hide them behind.  The
+            // loads of the next iteration are now issued ahead of this one's arithmetic, as the sweeps do, and the exponentials
+            // of an iteration are computed together before the dependent chains that follow them.
+            int pn_[U], fn_[U];
+            double ln_[U], zn_[U][Q];
+            auto issue_e = [&](int t0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s = (t0 + u) * 64 + lane;
+                    pn_[u] = D.perm[s];
+                    ln_[u] = lsfs[s];
+                    fn_[u] = (int)flags_s[s];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) zn_[u][q] = D.Zs[(size_t)q * Ns + s];
+                }
+            };
+            issue_e(0);
+#if defined(DSQ_EPI_SKIP_LOOP)
+            for (int t0 = 0; t0 < 0; t0 += U) {
+#else
             for (int t0 = 0; t0 < ntrips; t0 += U) {
+#endif
+                int pq_[U], fl_[U];
+                double lsf_[U], z_[U][Q];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    pq_[u] = pn_[u];
+                    fl_[u] = fn_[u];
+                    lsf_[u] = ln_[u];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) z_[u][q] = zn_[u][q];
+                }
+                issue_e(t0 + U < ntrips ? t0 + U : t0);  // (the last iteration re-reads its own slots: no branch)
                 const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[t0]);
                 if (cell != cur) {
                     if (cur >= 0 && want_wald) fold(cur);
@@ -543,17 +577,23 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 #pragma unroll
                     for (int q = 0; q < Q; ++q) bc[q] = DeviceWave::uniform(L->cellq[cur][1 + q]);
                 }
+                double mu_raw_[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    double t = etac;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) t = fma(z_[u][q], bz[q], t);
+                    mu_raw_[u] = DSQ_MIX_EXP(t + lsf_[u]);
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int s = (t0 + u) * 64 + lane;
-                    const int pq = D.perm[s];
+                    const int pq = pq_[u];
                     const bool valid = pq >= 0;
                     const int n = valid ? pq : 0;
                     const int yi = valid ? (big_gene ? yg[n] : (int)y16[s]) : 0;
-                    double z[Q], t = etac;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) { z[q] = D.Zs[(size_t)q * Ns + s]; t = fma(z[q], bz[q], t); }
-                    const double mu_raw = DSQ_MIX_EXP(t + lsfs[s]);
+                    const double mu_raw = mu_raw_[u];
+                    const double (&z)[Q] = z_[u];
                     if (valid && mu_row != nullptr) mu_row[n] = mu_raw;
                     double wv = 0.0;
                     if (have_w) {
@@ -571,7 +611,11 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                         if (valid && hat_row != nullptr) hat_row[n] = h;
                         if (want_cooks) {
                             double ck = 0.0;
-                            if (valid) ck = acc.add(n, (double)yi, mu_raw, h, flags_s[s]);
+#if !defined(DSQ_EPI_NO_ACC)
+                            if (valid) ck = acc.add(n, (double)yi, mu_raw, h, fl_[u]);
+#else
+                            ck = h;
+#endif
                             if (cooks_row != nullptr) {
                                 if (cooks_slots) cooks_row[s] = ck;
                                 else if (valid) cooks_row[n] = ck;
@@ -593,7 +637,25 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                     }
                 }
             }
-            if (want_cooks) cko = acc.finish(yg, N);
+#if !defined(DSQ_EPI_NO_FINISH)
+            if (want_cooks) {
+                // "fewer than three samples above the one with the largest Cook's distance" (dds.py:1094-1101): counted over
+                // the gene's LDS-resident counts (any order will do), not over its global int32 row - that loop's 79
+                // dependent trips were 0.25 ms of the 2.2 ms launch at 7500 x 5000
+                if (big_gene) {
+                    cko = acc.finish(yg, N);
+                } else {
+                    cko = acc.finish_counted(N, [&](int yref) {
+                        int above = 0;
+                        for (int s = lane; s < Ns; s += 64) {
+                            const int v = y16[s];
+                            above += (v != kMixPad && v > yref) ? 1 : 0;
+                        }
+                        return above;
+                    });
+                }
+            }
+#endif
             if (want_wald) {
                 fold(cur);
                 DeviceWave::template sum_n<QQ>(zz);

@@ -1049,6 +1049,7 @@ struct CooksAcc {
     double ar, cutoff, invP;
     int g_all = 0, g_use = 0, g_use_nr = 0;
     double best = -INFINITY;
+    double best_y = 0.0;  // the count of the sample that holds `best` (finish_counted: no second look at the row)
     int best_idx = 0x7fffffff;
     bool best_nan = false;
     DSQ_HD CooksAcc(double robust_disp, double cutoff_, int P) : ar(robust_disp), cutoff(cutoff_), invP(1.0 / (double)P) {}
@@ -1061,21 +1062,21 @@ struct CooksAcc {
         const double ck = (r * r) * frcp_g(V) * invP * (h * frcp_g(omh * omh));
         const bool gt = ck > cutoff;
         g_all |= gt ? 1 : 0;
-        if (gt && (fl & 1)) { g_use = 1; if (!(fl & 2)) g_use_nr = 1; }
+        g_use |= (gt && (fl & 1)) ? 1 : 0;
+        g_use_nr |= (gt && (fl & 1) && !(fl & 2)) ? 1 : 0;
         // np.argmax: first NaN wins, else first maximum - whatever order the samples arrive in (the mixed-design kernels
-        // walk them sorted by design cell): ties go to the smaller sample index
+        // walk them sorted by design cell): ties go to the smaller sample index.  Selects, no branches (round 6: the
+        // four-way branch of this update was a sixth of the mixed-design LFC launch).
         const bool isn = (ck != ck);
-        if (isn) {
-            best_idx = (best_nan && best_idx < n) ? best_idx : n;
-            best_nan = true;
-        } else if (!best_nan && (ck > best || (ck == best && n < best_idx))) {
-            best = ck;
-            best_idx = n;
-        }
+        const bool take = isn ? (!best_nan || n < best_idx) : (!best_nan && (ck > best || (ck == best && n < best_idx)));
+        best = (take && !isn) ? ck : best;
+        best_idx = take ? n : best_idx;
+        best_y = take ? yv : best_y;
+        best_nan = best_nan || isn;
         return ck;
     }
-    DSQ_HD CooksOut finish(const int32_t* y, int N) {
-        CooksOut o;
+    // wave reduction of the flags and of the argmax; returns the winning sample's index and count
+    DSQ_HD void reduce(CooksOut& o, int& bi, double& yref) {
         o.robust_disp = ar;
         o.any_gt_all = Wv::sumi(g_all) > 0;
         o.any_gt_use = Wv::sumi(g_use) > 0;
@@ -1090,12 +1091,32 @@ struct CooksAcc {
             cand = (best == wmax) ? best_idx : 0x7fffffff;
         }
         const double ci = -Wv::max(-(double)cand);  // min index over lanes
-        const int bi = (int)ci;
+        bi = (int)ci;
+        yref = Wv::max((cand == bi && best_idx == bi) ? best_y : -INFINITY);  // (one lane holds sample bi)
+    }
+    DSQ_HD CooksOut finish(const int32_t* y, int N) {
+        CooksOut o;
+        int bi;
+        double yref_d;
+        reduce(o, bi, yref_d);
         int above = 0;
         if (bi >= 0 && bi < N) {
             const int yref = y[bi];
             for (int n = Wv::lane(); n < N; n += Wv::W) above += (y[n] > yref) ? 1 : 0;
         }
+        o.few_above = Wv::sumi(above) < 3;
+        return o;
+    }
+    // the same with the caller counting the samples above the winner's count (it holds the gene's counts closer than the
+    // global row: count_above(yref) -> this lane's share of #{n: y_n > yref})
+    template <class F>
+    DSQ_HD CooksOut finish_counted(int N, F&& count_above) {
+        CooksOut o;
+        int bi;
+        double yref;
+        reduce(o, bi, yref);
+        int above = 0;
+        if (bi >= 0 && bi < N) above = count_above((int)yref);
         o.few_above = Wv::sumi(above) < 3;
         return o;
     }

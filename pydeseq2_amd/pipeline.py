@@ -833,12 +833,16 @@ class DeseqPipeline:
         """Run ``fn()`` (a dispersion stage) with ``launch()`` fired from inside it, when its full-size kernel is
         enqueued and only the continuation of the parked fits and the grid pass remain (dsq_set_alpha_hook); returns
         whether the hook fired."""
-        state = {"fired": False, "error": None}
+        # (a ctypes callback object sits in a reference cycle of its own and is only freed by the garbage collector: what its
+        # closure can reach must not include the pass - whose result vectors are views of a page-locked slab that would then
+        # return to the pool late, and the next pass would allocate a fresh 6 MB slab: 0.3 ms per step at c3 - so the
+        # launcher travels in a cell that is emptied when the call returns)
+        state = {"fired": False, "error": None, "launch": launch}
 
         def _hook(_arg):
             state["fired"] = True
             try:
-                launch()
+                state["launch"]()
             except BaseException as e:  # (a ctypes callback cannot propagate it)
                 state["error"] = e
 
@@ -848,7 +852,8 @@ class DeseqPipeline:
             out = fn()
         finally:
             self.ctx.call("dsq_set_alpha_hook", None, None)  # (not fired: no gene reached the fit)
-            self._alpha_hook = None  # (its closure holds the pass - and with it the page-locked slabs of its read-backs)
+            self._alpha_hook = None
+            state["launch"] = None
         if state["error"] is not None:
             raise state["error"]
         return out, state["fired"]

@@ -126,7 +126,9 @@ int dsq_abi_version(void);   /* DSQ_ABI_VERSION of the loaded library */
 int dsq_plugin_cache_config(dsq_ctx* ctx, int enabled, long long budget_bytes);
 int dsq_plugin_cache_clear(dsq_ctx* ctx);   /* frees every resident matrix and pooled buffer */
 /* out[0..n): hits, misses, adopted (resident outputs), evictions, bytes uploaded, bytes downloaded (N x G layers), host
- * milliseconds spent in digests, resident bytes, pooled free bytes, resident matrices, hipMalloc calls, budget bytes */
+ * milliseconds spent in digests, resident bytes, pooled free bytes, resident matrices, hipMalloc calls, budget bytes,
+ * hits that were re-uploaded and compared byte for byte with the resident copy (environment DSQ_PLUGIN_CACHE_VERIFY: a
+ * mismatch - a digest collision - fails the call with DSQ_ERR_ARG) */
 int dsq_plugin_cache_stats(dsq_ctx* ctx, double* out, int n);
 /* The digest itself (needs no context / GPU): elem_type 0 int32, 1 int64 (counts: digest of the VALUES, so both types of
  * the same matrix agree), 2 double (bit patterns); layout as dsq_layout; out2 = the two 64-bit halves.  Independent of

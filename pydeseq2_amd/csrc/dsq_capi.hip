@@ -1656,6 +1656,7 @@ dsq_pc::Cache& plugin_cache(dsq_ctx* ctx) {
         int hw = (int)std::thread::hardware_concurrency();
         c.hash_threads = hw >= 64 ? 32 : (hw >= 4 ? hw / 2 : 1);
         if (const char* e = getenv("DSQ_HASH_THREADS")) c.hash_threads = std::max(1, atoi(e));
+        c.verify = getenv("DSQ_PLUGIN_CACHE_VERIFY") != nullptr;
     }
     return *ctx->pc;
 }
@@ -1697,6 +1698,22 @@ int pc_upload_small(dsq_ctx* ctx, const void* src, size_t bytes, PcBuf& dst) {
     return DSQ_OK;
 }
 
+// verify mode: two gene-major device matrices ([G][ld_words] 32-bit words, n_words used per row) must agree word for word
+int pc_verify(dsq_ctx* ctx, const void* fresh, const void* resident, int ld_words, int n_words, int G) {
+    dsq_pc::Cache& c = plugin_cache(ctx);
+    DSQ_HIP(hipMemsetAsync(c.d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(dsq_pc::k_count_diff, dim3(std::min(G, 2048)), dim3(256), 0, ctx->stream, (const uint32_t*)fresh,
+                       (const uint32_t*)resident, ld_words, n_words, G, c.d_acc);
+    DSQ_HIP(hipGetLastError());
+    DSQ_HIP(hipMemcpyAsync(c.h_acc, c.d_acc, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    ++c.st.verified;
+    if (c.h_acc[3] != 0)
+        return fail(ctx, DSQ_ERR_ARG, "plug-in cache: a matrix with the digest of a resident one differs from it "
+                                           "(DSQ_PLUGIN_CACHE_VERIFY)");
+    return DSQ_OK;
+}
+
 // host count matrix -> resident gene-major int32 [G][ldn] (the cache's, not to be freed by the caller)
 int pc_counts(dsq_ctx* ctx, const void* counts, int count_type, int layout, int N, int G, int ldn,
               const int32_t** d_y, dsq_pc::Entry** ent = nullptr) {
@@ -1708,13 +1725,14 @@ int pc_counts(dsq_ctx* ctx, const void* counts, int count_type, int layout, int 
                                   ? dsq_pc::digest_host((const int64_t*)counts, layout, N, G, c.hash_threads)
                                   : dsq_pc::digest_host((const int32_t*)counts, layout, N, G, c.hash_threads);
     c.st.hash_ms += t.ms();
-    if (dsq_pc::Entry* e = dsq_pc::find(c, dsq_pc::kCounts, N, G, dg)) {
+    dsq_pc::Entry* hit = dsq_pc::find(c, dsq_pc::kCounts, N, G, dg);
+    if (hit != nullptr && !c.verify) {
         ++c.st.hits;
-        *d_y = (const int32_t*)e->d;
-        if (ent) *ent = e;
+        *d_y = (const int32_t*)hit->d;
+        if (ent) *ent = hit;
         return DSQ_OK;
     }
-    ++c.st.misses;
+    if (hit == nullptr) ++c.st.misses;
     PcBuf raw, y;
     DSQ_HIP(raw.alloc(ctx, (size_t)N * G * sizeof(int32_t)));
     DSQ_HIP(y.alloc(ctx, (size_t)G * ldn * sizeof(int32_t)));
@@ -1724,6 +1742,14 @@ int pc_counts(dsq_ctx* ctx, const void* counts, int count_type, int layout, int 
     c.st.h2d_bytes += (size_t)N * G * (count_type == DSQ_I64 ? 8 : 4);
     DSQ_HIP(dsq::launch_transpose_counts(ctx->stream, raw.p, DSQ_I32, layout, N, G, y.as<int32_t>(), ldn,
                                          (int*)ctx->d_scratch));
+    if (hit != nullptr) {  // DSQ_PLUGIN_CACHE_VERIFY: the digest matched - do the bytes?
+        int rc2;
+        if ((rc2 = pc_verify(ctx, y.p, hit->d, ldn, N, G))) return rc2;
+        ++c.st.hits;
+        *d_y = (const int32_t*)hit->d;
+        if (ent) *ent = hit;
+        return DSQ_OK;
+    }
     dsq_pc::Entry e;
     e.kind = dsq_pc::kCounts; e.N = N; e.G = G; e.ld = ldn; e.dg = dg; e.d = y.p; e.cap = y.cap;
     y.release();
@@ -1743,6 +1769,15 @@ int pc_f64(dsq_ctx* ctx, const double* src, int layout, int N, int G, int ldn, b
     const dsq_pc::Digest dg = dsq_pc::digest_host(src, layout, N, G, c.hash_threads);
     c.st.hash_ms += t.ms();
     dsq_pc::Entry* e = dsq_pc::find(c, dsq_pc::kF64, N, G, dg);
+    if (e != nullptr && c.verify) {  // DSQ_PLUGIN_CACHE_VERIFY: upload again and compare with the resident copy
+        PcBuf raw, m;
+        DSQ_HIP(raw.alloc(ctx, (size_t)N * G * sizeof(double)));
+        DSQ_HIP(m.alloc(ctx, (size_t)G * ldn * sizeof(double)));
+        DSQ_HIP(hipMemcpyAsync(raw.p, src, (size_t)N * G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DSQ_HIP(dsq::launch_transpose_f64(ctx->stream, raw.as<double>(), layout, N, G, m.as<double>(), ldn));
+        int rc2;
+        if ((rc2 = pc_verify(ctx, m.p, e->d, 2 * ldn, 2 * N, G))) return rc2;
+    }
     if (e != nullptr) {
         ++c.st.hits;
     } else {
@@ -1908,10 +1943,11 @@ int dsq_plugin_cache_clear(dsq_ctx* ctx) {
 
 int dsq_plugin_cache_stats(dsq_ctx* ctx, double* out, int n) {
     dsq_pc::Cache& c = plugin_cache(ctx);
-    const double v[12] = {(double)c.st.hits, (double)c.st.misses, (double)c.st.adopted, (double)c.st.evictions,
+    const double v[13] = {(double)c.st.hits, (double)c.st.misses, (double)c.st.adopted, (double)c.st.evictions,
                           (double)c.st.h2d_bytes, (double)c.st.d2h_bytes, c.st.hash_ms, (double)c.resident,
-                          (double)c.pooled, (double)c.ents.size(), (double)c.st.mallocs, (double)c.budget};
-    for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
+                          (double)c.pooled, (double)c.ents.size(), (double)c.st.mallocs, (double)c.budget,
+                          (double)c.st.verified};
+    for (int i = 0; i < n && i < 13; ++i) out[i] = v[i];
     return DSQ_OK;
 }
 

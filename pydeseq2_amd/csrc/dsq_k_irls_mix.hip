@@ -17,6 +17,7 @@
 // Diverged genes (|beta| > max_beta or maxiter) go to the general rescue kernel through the fallback list, as k_irls does.
 // Compiled once per number of continuous covariates (-DDSQ_MIX_Q=1|2|3).
 #include <cstdio>
+#include <type_traits>
 
 #include "dsq_alpha_rows.h"
 #include "dsq_irls.h"
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 
         // ---------------------------------------------------------------- one sweep: S, M = X^T W X, r = X^T W z at beta
         double M[T], r[P], S = 0.0;
+        bool swept_clamped = false;  // some sample of the LAST sweep sat on the min_mu clamp (wave-uniform)
         auto sweep = [&]() {
             if (lane < kMixMaxCells) {
                 double e = 0.0;
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
             for (int q = 0; q < Q; ++q) bz[q] = at_col(beta, D.zcol[q]);
             DeviceWave::sync();
             double sc[2 + Q], zz[QQ], zr[Q], Me = 0.0, re = 0.0, sdev = 0.0;  // per-cell: w, w z_q, w zwork
+            bool clamp_l = false;
 #pragma unroll
             for (int i = 0; i < 2 + Q; ++i) sc[i] = 0.0;
 #pragma unroll
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                     const bool valid = yi[u] >= 0;
                     const double yv = valid ? (double)yi[u] : 0.0;
                     const bool clamped = !(e[u] > min_mu);
+                    clamp_l = clamp_l || (valid && clamped);
                     const double mu = clamped ? min_mu : e[u];
                     const double lmu = clamped ? lmin : eta0[u] + lsf[u];
                     const double sd = (yv + a) * flog_t(a + mu) - yv * lmu;
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                 Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
             if (rj_cont) re = pick3(rj_q, zr[0], zr[q1], zr[q2]);
             S = DeviceWave::sum(sdev);
+            swept_clamped = DeviceWave::any(clamp_l);
             if (lane < T) L->ent[lane] = Me;
             if (lane < P) L->ent[T + lane] = re;
             DeviceWave::sync();
@@ -462,6 +467,16 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
         WaldOut wo{};
         if (mu_row != nullptr || hat_row != nullptr || want_cooks || want_wald) {
             const bool have_w = hat_row != nullptr || want_cooks;
+            // Wald's X^T W X is taken at the UNclamped mu (ds.py:320-324).  The last sweep summed the same matrix at the
+            // clamped mu, entry by entry in the same order: where no sample of the gene sat on the clamp (the usual gene) the
+            // two are the same numbers, and the pass below leaves its ten accumulations per sample out.
+            const bool wald_acc = want_wald && (swept_clamped || !have_w);
+            if (want_wald && !wald_acc) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) L->ent[i] = M[i];
+                }
+            }
             double Dq[QQ];  // H at the covariates' columns
 #pragma unroll
             for (int i = 0; i < QQ; ++i) Dq[i] = 0.0;
@@ -552,6 +567,8 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                 }
             };
             issue_e(0);
+            auto epi_loop = [&](auto wald_tag) {
+            constexpr bool WALD = decltype(wald_tag)::value;
 #if defined(DSQ_EPI_SKIP_LOOP)
             for (int t0 = 0; t0 < 0; t0 += U) {
 #else
@@ -570,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                 issue_e(t0 + U < ntrips ? t0 + U : t0);  // (the last iteration re-reads its own slots: no branch)
                 const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[t0]);
                 if (cell != cur) {
-                    if (cur >= 0 && want_wald) fold(cur);
+                    if (WALD && cur >= 0) fold(cur);
                     cur = cell;
                     etac = DeviceWave::uniform(L->cellv[cur]);
                     Ac = DeviceWave::uniform(L->cellq[cur][0]);
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                             }
                         }
                     }
-                    if (want_wald) {
+                    if constexpr (WALD) {
                         double wu = wv;  // the same number unless a lane was clamped
                         if (!have_w || DeviceWave::any(!(mu_raw >= min_mu))) wu = mu_raw * frcp_g(1.0 + mu_raw * dsp);
                         wu = valid ? wu : 0.0;
@@ -637,6 +654,9 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                     }
                 }
             }
+            };
+            if (wald_acc) epi_loop(std::true_type{});
+            else epi_loop(std::false_type{});
 #if !defined(DSQ_EPI_NO_FINISH)
             if (want_cooks) {
                 // "fewer than three samples above the one with the largest Cook's distance" (dds.py:1094-1101): counted over
@@ -657,11 +677,13 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
             }
 #endif
             if (want_wald) {
-                fold(cur);
-                DeviceWave::template sum_n<QQ>(zz);
-                if (kind == 2)
-                    Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
-                if (lane < T) L->ent[lane] = Me;
+                if (wald_acc) {
+                    fold(cur);
+                    DeviceWave::template sum_n<QQ>(zz);
+                    if (kind == 2)
+                        Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
+                    if (lane < T) L->ent[lane] = Me;
+                }  // (else: L->ent holds the last sweep's matrix)
                 DeviceWave::sync();
                 double Mw[T];
 #pragma unroll

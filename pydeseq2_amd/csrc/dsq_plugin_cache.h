@@ -164,6 +164,17 @@ __global__ __launch_bounds__(256) void k_rows_all_zero(const double* __restrict_
     if ((threadIdx.x & 63) == 0) flags[g] = nz ? 0 : 1;
 }
 
+// number of 32-bit words in which two gene-major pitched matrices [G][ld words], N words used per row, differ (verify mode)
+__global__ __launch_bounds__(256) void k_count_diff(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                    int ld_words, int n_words, int G, unsigned long long* __restrict__ acc) {
+    unsigned long long d = 0;
+    for (int g = blockIdx.x; g < G; g += gridDim.x)
+        for (int n = threadIdx.x; n < n_words; n += 256)
+            d += a[(size_t)g * ld_words + n] != b[(size_t)g * ld_words + n];
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(&acc[3], d);
+}
+
 enum Kind { kCounts = 0, kF64 = 1 };
 
 struct Entry {
@@ -181,12 +192,13 @@ struct Entry {
 };
 
 struct Stats {
-    uint64_t hits = 0, misses = 0, adopted = 0, evictions = 0, h2d_bytes = 0, d2h_bytes = 0, mallocs = 0;
+    uint64_t hits = 0, misses = 0, adopted = 0, evictions = 0, h2d_bytes = 0, d2h_bytes = 0, mallocs = 0, verified = 0;
     double hash_ms = 0.0;
 };
 
 struct Cache {
     bool enabled = true;
+    bool verify = false;  // DSQ_PLUGIN_CACHE_VERIFY: a hit is re-uploaded and compared with the resident copy
     size_t budget = 0, resident = 0, pooled = 0;
     uint64_t tick = 0, call_tick = 0;
     int hash_threads = 32;
@@ -213,10 +225,26 @@ inline hipError_t take(Cache& c, size_t bytes, void** p, size_t* cap) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) {  // out of memory: drop the free list (and, if need be, the cache) and retry once
+    if (e != hipSuccess) {  // out of memory: drop the free list and retry ...
         for (auto& f : c.free_bufs) (void)hipFree(f.second);
         c.free_bufs.clear();
         c.pooled = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    while (e != hipSuccess) {  // ... then the resident matrices the running call has not touched, least recently used first
+        int lru = -1;
+        for (int i = 0; i < (int)c.ents.size(); ++i)
+            if (c.ents[(size_t)i].tick <= c.call_tick && (lru < 0 || c.ents[(size_t)i].tick < c.ents[(size_t)lru].tick))
+                lru = i;
+        if (lru < 0) break;
+        Entry& v = c.ents[(size_t)lru];
+        c.resident -= v.cap + v.lists_cap;
+        (void)hipFree(v.d);
+        if (v.d_lists) (void)hipFree(v.d_lists);
+        c.ents.erase(c.ents.begin() + lru);
+        ++c.st.evictions;
+        (void)hipGetLastError();
         e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess) {
@@ -230,8 +258,9 @@ inline void give(Cache& c, void* p, size_t cap) {
     if (p == nullptr) return;
     c.free_bufs.emplace_back(cap, p);
     c.pooled += cap;
-    // the free list may hold about as much as the cache (the layers of one call: raw staging, hat diagonals, ...)
-    while (c.pooled > c.budget && !c.free_bufs.empty()) {
+    // free list and resident matrices share ONE budget (a context used to be able to pin twice the budget: the cache plus
+    // as much again on the free list); the free list keeps what the resident matrices leave of it
+    while (c.pooled + c.resident > c.budget && !c.free_bufs.empty()) {
         int big = 0;
         for (int i = 1; i < (int)c.free_bufs.size(); ++i)
             if (c.free_bufs[(size_t)i].first > c.free_bufs[(size_t)big].first) big = i;

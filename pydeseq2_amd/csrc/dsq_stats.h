@@ -1059,7 +1059,7 @@ struct CooksAcc {
         const double V = (mv * mv) * ar + mv;
         const double r = yv - mv;
         const double omh = 1.0 - h;
-        const double ck = (r * r) * frcp_g(V) * invP * (h * frcp_g(omh * omh));
+        const double ck = ((r * r) * invP) * h * frcp_g(V * (omh * omh));  // (one reciprocal: round 6)
         const bool gt = ck > cutoff;
         g_all |= gt ? 1 : 0;
         g_use |= (gt && (fl & 1)) ? 1 : 0;

@@ -85,10 +85,10 @@ class HipInference:
     # ---- the device cache behind the entry points (include/deseq_hip.h, csrc/dsq_plugin_cache.h)
     def cache_stats(self) -> dict:
         """Counters of the content-addressed device cache of this context."""
-        v = (c_double * 12)()
-        self.ctx.call("dsq_plugin_cache_stats", v, 12)
+        v = (c_double * 13)()
+        self.ctx.call("dsq_plugin_cache_stats", v, 13)
         keys = ("hits", "misses", "adopted_outputs", "evictions", "h2d_bytes", "d2h_bytes", "hash_ms", "resident_bytes",
-                "pooled_free_bytes", "resident_matrices", "device_mallocs", "budget_bytes")
+                "pooled_free_bytes", "resident_matrices", "device_mallocs", "budget_bytes", "verified_hits")
         return {k: (round(float(x), 3) if k == "hash_ms" else int(x)) for k, x in zip(keys, v)}
 
     def cache_config(self, enabled: bool | None = None, budget_bytes: int | None = None):

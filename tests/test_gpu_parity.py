@@ -1154,3 +1154,25 @@ def test_plugin_cache_hits_adoption_and_invalidation():
     mde = inf.fit_moments_dispersions(normed, sf)
     assert len(mde) == G - 1
     assert_close(mde, orc.moments_dispersions(normed, sf), 1e-10, 1e-14, "moments with a zero gene")
+
+
+def test_plugin_cache_verify_mode_and_hits_of_a_whole_fit(monkeypatch):
+    """DSQ_PLUGIN_CACHE_VERIFY: every cache hit is re-uploaded and compared with the resident device copy word for word (a
+    digest collision would fail the call) - through one whole deseq2() + Wald under the reference's orchestration, with
+    the hit / miss / verified counters of that fit checked: the count matrix is uploaded once, the two mu matrices the
+    engine produced are recognised when they come back, and the results equal those of a run without the mode."""
+    from pydeseq2_amd import HipInference
+    from pydeseq2_amd._lib import Context
+
+    counts, X = orc.synth_counts(600, 80, "2level", 17)
+    plain = orc.deseq2(counts, X, n_jobs=1, keep_layers=False, inference=HipInference(device=0))
+    monkeypatch.setenv("DSQ_PLUGIN_CACHE_VERIFY", "1")
+    inf = HipInference(ctx=Context(0))  # (a context of its own: the mode is read when the context's cache is created)
+    s0 = inf.cache_stats()
+    res = orc.deseq2(counts, X, n_jobs=1, keep_layers=False, inference=inf)
+    s1 = inf.cache_stats()
+    assert s1["verified_hits"] > 0 and s1["verified_hits"] == s1["hits"] - s0["hits"]
+    # misses: normed counts (fp64), the counts (int64), and nothing else that is N x G - mu_hat and mu come back adopted
+    assert s1["misses"] - s0["misses"] <= 3 and s1["adopted_outputs"] - s0["adopted_outputs"] >= 2
+    for f in ("dispersions", "LFC", "pvalue", "genewise_dispersions"):
+        np.testing.assert_array_equal(getattr(res, f), getattr(plain, f), err_msg=f)

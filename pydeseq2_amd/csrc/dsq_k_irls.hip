@@ -455,8 +455,9 @@ size_t irls_mix_work_bytes(const MixDesign& D, int G, int n_layers) {
     if (D.Q == 1) irls_mix_grid_q1(D.Ns, D.P, G, &blocks, &nw);
     else if (D.Q == 2) irls_mix_grid_q2(D.Ns, D.P, G, &blocks, &nw);
     else if (D.Q == 3) irls_mix_grid_q3(D.Ns, D.P, G, &blocks, &nw);
-    (void)blocks; (void)nw; (void)n_layers; (void)G;  // (no per-wavefront rows: the layers are written in place)
-    return (size_t)D.Ns * 17 + 64;
+    (void)blocks; (void)nw; (void)n_layers;  // (no per-wavefront rows: the layers are written in place)
+    // slot-ordered size factors, their logs, Cook's flags + the last sweep's X^T W X of every gene for k_mix_epilogue
+    return (((size_t)D.Ns * 17 + 63) & ~(size_t)63) + (size_t)(G > 0 ? G : 0) * (kMixMaxP * (kMixMaxP + 1) / 2) * sizeof(double) + 64;
 }
 
 static hipError_t launch_irls_mix(hipStream_t st, const int32_t* y, int ldn, const MixDesign& D, const double* sf, int G,

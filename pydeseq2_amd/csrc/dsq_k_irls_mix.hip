@@ -42,7 +42,6 @@ constexpr int kMixPad = 0xFFFF;  // count stored for a padding slot (real counts
 
 struct MixIrlsLds {  // wave-private LDS record (followed by the gene's counts, uint16 [Ns])
     double cellv[kMixMaxCells];                  // x_c . beta of the categorical part, per cell
-    double cellq[kMixMaxCells][1 + kMixMaxQ];    // epilogue: A_c = x_c^T H x_c and b_c = (H x_c) at the covariates' columns
     double ent[kMixMaxP * (kMixMaxP + 1) / 2 + kMixMaxP];  // X^T W X and X^T W z on their way to all lanes
     unsigned int hist[kMixTail];
     uint16_t tail[kMixTail];
@@ -74,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
     const MixDesign D, unsigned cont_mask, const double* __restrict__ sfs,
     const double* __restrict__ lsfs, const uint8_t* __restrict__ flags_s, int G, int32_t* __restrict__ queue,
     const double* __restrict__ disp, double min_mu, double beta_tol, double max_beta, int maxiter,
-    double* __restrict__ beta_out, double* __restrict__ mu_out, double* __restrict__ hat_out,
+    double* __restrict__ beta_out, double* __restrict__ m_out,
     uint8_t* __restrict__ conv, int32_t* __restrict__ iters, int32_t* __restrict__ fb_count,
-    int32_t* __restrict__ fb_list, IrlsExtras ex) {
+    int32_t* __restrict__ fb_list) {
     constexpr int T = Tri<P>::N;
     constexpr int QQ = Q * (Q + 1) / 2;
     constexpr int U = kMixU;
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
 
         // ---------------------------------------------------------------- one sweep: S, M = X^T W X, r = X^T W z at beta
         double M[T], r[P], S = 0.0;
-        bool swept_clamped = false;  // some sample of the LAST sweep sat on the min_mu clamp (wave-uniform)
         auto sweep = [&]() {
             if (lane < kMixMaxCells) {
                 double e = 0.0;
@@ -306,7 +304,6 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
             for (int q = 0; q < Q; ++q) bz[q] = at_col(beta, D.zcol[q]);
             DeviceWave::sync();
             double sc[2 + Q], zz[QQ], zr[Q], Me = 0.0, re = 0.0, sdev = 0.0;  // per-cell: w, w z_q, w zwork
-            bool clamp_l = false;
 #pragma unroll
             for (int i = 0; i < 2 + Q; ++i) sc[i] = 0.0;
 #pragma unroll
@@ -374,7 +371,6 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                     const bool valid = yi[u] >= 0;
                     const double yv = valid ? (double)yi[u] : 0.0;
                     const bool clamped = !(e[u] > min_mu);
-                    clamp_l = clamp_l || (valid && clamped);
                     const double mu = clamped ? min_mu : e[u];
                     const double lmu = clamped ? lmin : eta0[u] + lsf[u];
                     const double sd = (yv + a) * flog_t(a + mu) - yv * lmu;
@@ -403,7 +399,6 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
                 Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
             if (rj_cont) re = pick3(rj_q, zr[0], zr[q1], zr[q2]);
             S = DeviceWave::sum(sdev);
-            swept_clamped = DeviceWave::any(clamp_l);
             if (lane < T) L->ent[lane] = Me;
             if (lane < P) L->ent[T + lane] = re;
             DeviceWave::sync();
@@ -451,262 +446,317 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
             continue;
         }
 
-        // ---------------------------------------------------------------- finish: mu, hat diagonal, Cook's, Wald
-        const bool want_cooks = ex.flags != nullptr, want_wald = ex.ridge != nullptr;
-        double* const mu_row = mu_out != nullptr ? mu_out + (size_t)g * ldn : nullptr;
-        double* const hat_row = hat_out != nullptr ? hat_out + (size_t)g * ldn : nullptr;
-        // the Cook's layer: ex.cooks_ld == 0: sample order, pitch ldn; else SLOT order with that pitch (>= Ns) - one
-        // coalesced 512-byte store per trip instead of 64 scattered 8-byte stores (which, over the 40 KB rows of 2048
-        // wavefronts, evicted half-written lines from L2: rocprofv3 showed 5 x the layer's bytes written to HBM); the
-        // readers (outlier replacement, DeseqPipeline.layer) go through MixDesign::slot_of
-        const bool cooks_slots = ex.cooks_ld > 0;
-        double* const cooks_row = (want_cooks && ex.cooks != nullptr)
-                                      ? ex.cooks + (size_t)g * (cooks_slots ? (size_t)ex.cooks_ld : (size_t)ldn)
-                                      : nullptr;
-        CooksOut cko{};
-        WaldOut wo{};
-        if (mu_row != nullptr || hat_row != nullptr || want_cooks || want_wald) {
-            const bool have_w = hat_row != nullptr || want_cooks;
-            // Wald's X^T W X is taken at the UNclamped mu (ds.py:320-324).  The last sweep summed the same matrix at the
-            // clamped mu, entry by entry in the same order: where no sample of the gene sat on the clamp (the usual gene) the
-            // two are the same numbers, and the pass below leaves its ten accumulations per sample out.
-            const bool wald_acc = want_wald && (swept_clamped || !have_w);
-            if (want_wald && !wald_acc) {
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < T; ++i) L->ent[i] = M[i];
-                }
-            }
-            double Dq[QQ];  // H at the covariates' columns
-#pragma unroll
-            for (int i = 0; i < QQ; ++i) Dq[i] = 0.0;
-            if (have_w) {
-                double inv[T];
-#pragma unroll
-                for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
-                chol<P>(M);
-                chol_inverse<P>(M, inv);
-#pragma unroll
-                for (int qa = 0; qa < Q; ++qa)
-#pragma unroll
-                    for (int qb = 0; qb <= qa; ++qb) {
-                        // (dynamic column index into a register array: selected entry by entry)
-                        double v = 0.0;
-#pragma unroll
-                        for (int i = 0; i < P; ++i)
-#pragma unroll
-                            for (int j = 0; j <= i; ++j)
-                                v = ((i == D.zcol[qa] && j == D.zcol[qb]) || (i == D.zcol[qb] && j == D.zcol[qa])) ? inv[tri(i, j)] : v;
-                        Dq[tri(qa, qb)] = DeviceWave::uniform(v);
-                    }
-                if (lane < kMixMaxCells) {
-                    const int c = lane < C ? lane : 0;
-                    double x[P], hx[P];
-#pragma unroll
-                    for (int j = 0; j < P; ++j) x[j] = xc_s[c * P + j];
-                    sym_matvec<P>(inv, x, hx);
-                    double A = 0.0;
-#pragma unroll
-                    for (int j = 0; j < P; ++j) A += x[j] * hx[j];
-                    L->cellq[lane][0] = A;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int j = 0; j < P; ++j) v = (j == D.zcol[q]) ? hx[j] : v;
-                        L->cellq[lane][1 + q] = v;
-                    }
-                }
-            }
-            if (lane < kMixMaxCells) {  // eta_c at the final beta (the last sweep ran there, but keep the table explicit)
-                double e = 0.0;
-                if (lane < C) {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) e += xc_s[lane * P + j] * beta[j];
-                }
-                L->cellv[lane] = e;
-            }
-            double bz[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) bz[q] = at_col(beta, D.zcol[q]);
-            DeviceWave::sync();
-            CooksAcc<DeviceWave> acc(want_cooks ? ex.robust_disp[g] : 0.0, want_cooks ? ex.cutoff : 0.0, P);
-            double sc[1 + Q], zz[QQ], Me = 0.0;  // Wald: X^T W X at the UNclamped mu (ds.py:320-324)
-#pragma unroll
-            for (int i = 0; i < 1 + Q; ++i) sc[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < QQ; ++i) zz[i] = 0.0;
-            auto fold = [&](int c) {
-                DeviceWave::template sum_n<1 + Q>(sc);
-                const double va = xc_s[c * P + xa], vb = xc_s[c * P + xb];
-                const double s1 = pick3(qz, sc[1], sc[1 + q1], sc[1 + q2]);
-                Me += kind == 0 ? (va * vb) * sc[0] : (kind == 1 ? va * s1 : 0.0);
-#pragma unroll
-                for (int i = 0; i < 1 + Q; ++i) sc[i] = 0.0;
-            };
-            int cur = -1;
-            double etac = 0.0, Ac = 0.0, bc[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) bc[q] = 0.0;
-            // Round 6: this pass was 4 sweeps long (0.86 ms of the 2.2 ms launch at 7500 x 5000) although it computes about
-            // what ONE sweep computes - its six global loads per sample (slot permutation, log size factor, flags, covariates)
-            // were issued inside the iteration that consumes them, with two wavefronts per SIMD to hide them behind.  The
-            // loads of the next iteration are now issued ahead of this one's arithmetic, as the sweeps do, and the exponentials
-            // of an iteration are computed together before the dependent chains that follow them.
-            int pn_[U], fn_[U];
-            double ln_[U], zn_[U][Q];
-            auto issue_e = [&](int t0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int s = (t0 + u) * 64 + lane;
-                    pn_[u] = D.perm[s];
-                    ln_[u] = lsfs[s];
-                    fn_[u] = (int)flags_s[s];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) zn_[u][q] = D.Zs[(size_t)q * Ns + s];
-                }
-            };
-            issue_e(0);
-            auto epi_loop = [&](auto wald_tag) {
-            constexpr bool WALD = decltype(wald_tag)::value;
-#if defined(DSQ_EPI_SKIP_LOOP)
-            for (int t0 = 0; t0 < 0; t0 += U) {
-#else
-            for (int t0 = 0; t0 < ntrips; t0 += U) {
-#endif
-                int pq_[U], fl_[U];
-                double lsf_[U], z_[U][Q];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    pq_[u] = pn_[u];
-                    fl_[u] = fn_[u];
-                    lsf_[u] = ln_[u];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) z_[u][q] = zn_[u][q];
-                }
-                issue_e(t0 + U < ntrips ? t0 + U : t0);  // (the last iteration re-reads its own slots: no branch)
-                const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[t0]);
-                if (cell != cur) {
-                    if (WALD && cur >= 0) fold(cur);
-                    cur = cell;
-                    etac = DeviceWave::uniform(L->cellv[cur]);
-                    Ac = DeviceWave::uniform(L->cellq[cur][0]);
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) bc[q] = DeviceWave::uniform(L->cellq[cur][1 + q]);
-                }
-                double mu_raw_[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    double t = etac;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) t = fma(z_[u][q], bz[q], t);
-                    mu_raw_[u] = DSQ_MIX_EXP(t + lsf_[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int s = (t0 + u) * 64 + lane;
-                    const int pq = pq_[u];
-                    const bool valid = pq >= 0;
-                    const int n = valid ? pq : 0;
-                    const int yi = valid ? (big_gene ? yg[n] : (int)y16[s]) : 0;
-                    const double mu_raw = mu_raw_[u];
-                    const double (&z)[Q] = z_[u];
-                    if (valid && mu_row != nullptr) mu_row[n] = mu_raw;
-                    double wv = 0.0;
-                    if (have_w) {
-                        const double mu = dmax(mu_raw, min_mu);
-                        wv = mu * frcp_g(1.0 + mu * dsp);
-                        double qf = Ac;  // x_n^T H x_n = A_c + 2 b_c . z + z^T D z
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            double dz = 0.0;
-#pragma unroll
-                            for (int q2 = 0; q2 < Q; ++q2) dz = fma(Dq[tris(q, q2)], z[q2], dz);
-                            qf = fma(z[q], 2.0 * bc[q] + dz, qf);
-                        }
-                        const double h = wv * qf;
-                        if (valid && hat_row != nullptr) hat_row[n] = h;
-                        if (want_cooks) {
-                            double ck = 0.0;
-#if !defined(DSQ_EPI_NO_ACC)
-                            if (valid) ck = acc.add(n, (double)yi, mu_raw, h, fl_[u]);
-#else
-                            ck = h;
-#endif
-                            if (cooks_row != nullptr) {
-                                if (cooks_slots) cooks_row[s] = ck;
-                                else if (valid) cooks_row[n] = ck;
-                            }
-                        }
-                    }
-                    if constexpr (WALD) {
-                        double wu = wv;  // the same number unless a lane was clamped
-                        if (!have_w || DeviceWave::any(!(mu_raw >= min_mu))) wu = mu_raw * frcp_g(1.0 + mu_raw * dsp);
-                        wu = valid ? wu : 0.0;
-                        sc[0] += wu;
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            const double wq = wu * z[q];
-                            sc[1 + q] += wq;
-#pragma unroll
-                            for (int q2 = 0; q2 <= q; ++q2) zz[tri(q, q2)] = fma(wq, z[q2], zz[tri(q, q2)]);
-                        }
-                    }
-                }
-            }
-            };
-            if (wald_acc) epi_loop(std::true_type{});
-            else epi_loop(std::false_type{});
-#if !defined(DSQ_EPI_NO_FINISH)
-            if (want_cooks) {
-                // "fewer than three samples above the one with the largest Cook's distance" (dds.py:1094-1101): counted over
-                // the gene's LDS-resident counts (any order will do), not over its global int32 row - that loop's 79
-                // dependent trips were 0.25 ms of the 2.2 ms launch at 7500 x 5000
-                if (big_gene) {
-                    cko = acc.finish(yg, N);
-                } else {
-                    cko = acc.finish_counted(N, [&](int yref) {
-                        int above = 0;
-                        for (int s = lane; s < Ns; s += 64) {
-                            const int v = y16[s];
-                            above += (v != kMixPad && v > yref) ? 1 : 0;
-                        }
-                        return above;
-                    });
-                }
-            }
-#endif
-            if (want_wald) {
-                if (wald_acc) {
-                    fold(cur);
-                    DeviceWave::template sum_n<QQ>(zz);
-                    if (kind == 2)
-                        Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
-                    if (lane < T) L->ent[lane] = Me;
-                }  // (else: L->ent holds the last sweep's matrix)
-                DeviceWave::sync();
-                double Mw[T];
-#pragma unroll
-                for (int i = 0; i < T; ++i) Mw[i] = L->ent[i];
-                DeviceWave::sync();
-                wo = wald_from_M<P>(Mw, beta, ex.ridge, ex.contrast, ex.lfc_null, ex.alt);
-            }
-        }
+        // ---------------------------------------------------------------- finish
+        // Round 6: mu / hat diagonal / Cook's / Wald run in a kernel of their own (k_mix_epilogue below).  Inside this kernel
+        // that pass was 0.7 ms of the 2.1 ms LFC launch at 7500 x 5000 - four sweeps' time for one sweep's arithmetic: the
+        // register allocation of this kernel peaks in the sweeps and the p x p algebra between them (256 VGPRs, 170 spilled),
+        // and the values spilled for that peak were reloaded from scratch on every trip of the epilogue's sample loop (8
+        // scratch loads per 64 samples, two wavefronts per SIMD to hide them behind).  The IRLS kernel now hands over the
+        // coefficients and the last sweep's X^T W X (36 doubles per gene).
+        if (lane < T && m_out != nullptr) m_out[(size_t)g * T + lane] = L->ent[lane];  // (the last sweep left it there)
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < P; ++j) beta_out[(size_t)g * P + j] = beta[j];
             conv[g] = 1;
             if (iters != nullptr) iters[g] = it;
-            if (want_cooks) {
-                ex.any_all[g] = (uint8_t)cko.any_gt_all;
-                ex.any_use[g] = (uint8_t)cko.any_gt_use;
-                ex.any_use_nr[g] = (uint8_t)cko.any_gt_use_nr;
-                ex.few_above[g] = (uint8_t)cko.few_above;
-            }
-            if (want_wald) { ex.pvals[g] = wo.p; ex.stats[g] = wo.stat; ex.se[g] = wo.se; }
         }
         DeviceWave::sync();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The per-sample half of what follows a converged fit: mu = sf exp(X beta) (utils.py:435-437), the hat diagonal
+// h_n = w_n x_n^T (X^T W X + ridge)^-1 x_n (utils.py:427-433), Cook's distances with their per-gene flags (dds.py:986-1040,
+// 1066-1110) and the Wald statistics (utils.py:718-811) - one gene per wavefront, samples in slot order, from the
+// coefficients and the last sweep's X^T W X that k_irls_mix left behind.  A kernel of its own (round 6): nothing of the
+// IRLS kernel's register peak lives here (no spill in the sample loop), four wavefronts per SIMD hide its loads.
+struct MixEpiLds {  // wave-private LDS record
+    double cellv[kMixMaxCells];                // x_c . beta of the categorical part, per cell
+    double cellq[kMixMaxCells][1 + kMixMaxQ];  // A_c = x_c^T H x_c and b_c = (H x_c) at the covariates' columns
+    double ent[kMixMaxP * (kMixMaxP + 1) / 2];  // Wald's X^T W X on its way to all lanes
+};
+
+template <int P, int Q>
+__global__ __launch_bounds__(256, 3) void k_mix_epilogue(
+    const int32_t* __restrict__ y, int ldn, const uint16_t* __restrict__ ys, const uint8_t* __restrict__ ys_big,
+    const MixDesign D, unsigned cont_mask, const double* __restrict__ lsfs, const uint8_t* __restrict__ flags_s, int G,
+    const double* __restrict__ disp, double min_mu, const double* __restrict__ beta_in, const double* __restrict__ m_in,
+    const uint8_t* __restrict__ conv, double* __restrict__ mu_out, double* __restrict__ hat_out, IrlsExtras ex) {
+    constexpr int T = Tri<P>::N;
+    constexpr int QQ = Q * (Q + 1) / 2;
+    constexpr int U = kMixU;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int Ns = D.Ns, ntrips = Ns >> 6, C = D.C, N = D.N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* const xc_s = dyn;                                   // [C][P]
+    uint8_t* const tc_s = (uint8_t*)(xc_s + kMixMaxCells * P);  // [ntrips]
+    MixEpiLds* const L = (MixEpiLds*)((char*)dyn + (size_t)kMixMaxCells * P * 8 + (size_t)(((Ns >> 6) + 15) & ~15)) + w;
+    for (int i = threadIdx.x; i < C * P; i += blockDim.x) xc_s[i] = D.Xc[i];
+    for (int i = threadIdx.x; i < ntrips; i += blockDim.x) tc_s[i] = D.trip_cell[i];
+    __syncthreads();
+    const int g = blockIdx.x * 4 + w;
+    if (g >= G) return;
+    if (__builtin_amdgcn_readfirstlane((int)conv[g]) == 0) return;  // diverged: the rescue kernel writes this gene's outputs
+
+    // lane e owns entry e = tri(ei, ej) of X^T W X (as in k_irls_mix)
+    int ei = 0, ej = 0;
+    {
+        const int e = lane < T ? lane : T - 1;
+        while ((ei + 1) * (ei + 2) / 2 <= e) ++ei;
+        ej = e - ei * (ei + 1) / 2;
+    }
+    const bool ci = ((cont_mask >> ei) & 1u) != 0, cj = ((cont_mask >> ej) & 1u) != 0;
+    const int qi = __popc(cont_mask & ((1u << ei) - 1u)), qj = __popc(cont_mask & ((1u << ej) - 1u));
+    const int kind = (ci ? 1 : 0) + (cj ? 1 : 0);
+    const int xa = ci ? ej : ei, xb = ej, qz = ci ? qi : qj;
+    const int zzk = tri(qi > qj ? qi : qj, qi > qj ? qj : qi);
+    auto pick3 = [](int k, double v0, double v1, double v2) { return k == 1 ? v1 : (k == 2 ? v2 : v0); };
+    auto pick6 = [](int k, double v0, double v1, double v2, double v3, double v4, double v5) {
+        double r = v0;
+        r = k == 1 ? v1 : r;
+        r = k == 2 ? v2 : r;
+        r = k == 3 ? v3 : r;
+        r = k == 4 ? v4 : r;
+        r = k == 5 ? v5 : r;
+        return r;
+    };
+    constexpr int q1 = Q > 1 ? 1 : 0, q2 = Q > 2 ? 2 : 0;
+    constexpr int L_ = QQ - 1;
+
+    const double dsp = DeviceWave::uniform(disp[g]);
+    const int32_t* const yg = y + (size_t)g * ldn;
+    const uint16_t* const ysg = ys + (size_t)g * Ns;
+    const bool big_gene = __builtin_amdgcn_readfirstlane((int)ys_big[g]) != 0;
+    double beta[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) beta[j] = DeviceWave::uniform(beta_in[(size_t)g * P + j]);
+
+    const bool want_cooks = ex.flags != nullptr, want_wald = ex.ridge != nullptr;
+    double* const mu_row = mu_out != nullptr ? mu_out + (size_t)g * ldn : nullptr;
+    double* const hat_row = hat_out != nullptr ? hat_out + (size_t)g * ldn : nullptr;
+    // the Cook's layer: ex.cooks_ld == 0: sample order, pitch ldn; else SLOT order with that pitch (>= Ns) - one coalesced
+    // 512-byte store per trip instead of 64 scattered 8-byte stores; the readers (outlier replacement,
+    // DeseqPipeline.layer) go through MixDesign::slot_of
+    const bool cooks_slots = ex.cooks_ld > 0;
+    double* const cooks_row = (want_cooks && ex.cooks != nullptr)
+                                  ? ex.cooks + (size_t)g * (cooks_slots ? (size_t)ex.cooks_ld : (size_t)ldn)
+                                  : nullptr;
+    const bool have_w = hat_row != nullptr || want_cooks;
+    double Dq[QQ];  // H at the covariates' columns
+#pragma unroll
+    for (int i = 0; i < QQ; ++i) Dq[i] = 0.0;
+    if (have_w) {
+        double M[T], inv[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) M[i] = DeviceWave::uniform(m_in[(size_t)g * T + i]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) M[tri(j, j)] += 1e-6;
+        chol<P>(M);
+        chol_inverse<P>(M, inv);
+#pragma unroll
+        for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+            for (int qb = 0; qb <= qa; ++qb) {
+                double v = 0.0;  // (dynamic column index into a register array: selected entry by entry)
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j)
+                        v = ((i == D.zcol[qa] && j == D.zcol[qb]) || (i == D.zcol[qb] && j == D.zcol[qa])) ? inv[tri(i, j)] : v;
+                Dq[tri(qa, qb)] = DeviceWave::uniform(v);
+            }
+        if (lane < kMixMaxCells) {
+            const int c = lane < C ? lane : 0;
+            double x[P], hx[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) x[j] = xc_s[c * P + j];
+            sym_matvec<P>(inv, x, hx);
+            double A = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) A += x[j] * hx[j];
+            L->cellq[lane][0] = A;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) v = (j == D.zcol[q]) ? hx[j] : v;
+                L->cellq[lane][1 + q] = v;
+            }
+        }
+    }
+    if (lane < kMixMaxCells) {  // eta_c at the final beta
+        double e = 0.0;
+        if (lane < C) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) e += xc_s[lane * P + j] * beta[j];
+        }
+        L->cellv[lane] = e;
+    }
+    double bz[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        double v = beta[0];
+#pragma unroll
+        for (int j = 1; j < P; ++j) v = (j == D.zcol[q]) ? beta[j] : v;
+        bz[q] = v;
+    }
+    DeviceWave::sync();
+    CooksAcc<DeviceWave> acc(want_cooks ? ex.robust_disp[g] : 0.0, want_cooks ? ex.cutoff : 0.0, P);
+    double sc[1 + Q], zz[QQ], Me = 0.0;  // Wald: X^T W X at the UNclamped mu (ds.py:320-324)
+#pragma unroll
+    for (int i = 0; i < 1 + Q; ++i) sc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < QQ; ++i) zz[i] = 0.0;
+    auto fold = [&](int c) {
+        DeviceWave::template sum_n<1 + Q>(sc);
+        const double va = xc_s[c * P + xa], vb = xc_s[c * P + xb];
+        const double s1 = pick3(qz, sc[1], sc[1 + q1], sc[1 + q2]);
+        Me += kind == 0 ? (va * vb) * sc[0] : (kind == 1 ? va * s1 : 0.0);
+#pragma unroll
+        for (int i = 0; i < 1 + Q; ++i) sc[i] = 0.0;
+    };
+    int cur = -1;
+    double etac = 0.0, Ac = 0.0, bc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) bc[q] = 0.0;
+    // the loads of the next iteration are issued ahead of this one's arithmetic
+    int pn_[U], fn_[U], yn_[U];
+    double ln_[U], zn_[U][Q];
+    auto issue_e = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = (t0 + u) * 64 + lane;
+            pn_[u] = D.perm[s];
+            yn_[u] = (int)ysg[s];
+            ln_[u] = lsfs[s];
+            fn_[u] = (int)flags_s[s];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) zn_[u][q] = D.Zs[(size_t)q * Ns + s];
+        }
+    };
+    issue_e(0);
+    for (int t0 = 0; t0 < ntrips; t0 += U) {
+        int pq_[U], fl_[U], yv_[U];
+        double lsf_[U], z_[U][Q];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pq_[u] = pn_[u];
+            fl_[u] = fn_[u];
+            yv_[u] = yn_[u];
+            lsf_[u] = ln_[u];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) z_[u][q] = zn_[u][q];
+        }
+        issue_e(t0 + U < ntrips ? t0 + U : t0);  // (the last iteration re-reads its own slots: no branch)
+        const int cell = __builtin_amdgcn_readfirstlane((int)tc_s[t0]);
+        if (cell != cur) {
+            if (want_wald && cur >= 0) fold(cur);
+            cur = cell;
+            etac = DeviceWave::uniform(L->cellv[cur]);
+            Ac = DeviceWave::uniform(L->cellq[cur][0]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) bc[q] = DeviceWave::uniform(L->cellq[cur][1 + q]);
+        }
+        double mu_raw_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double t = etac;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) t = fma(z_[u][q], bz[q], t);
+            mu_raw_[u] = DSQ_MIX_EXP(t + lsf_[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = (t0 + u) * 64 + lane;
+            const int pq = pq_[u];
+            const bool valid = pq >= 0;
+            const int n = valid ? pq : 0;
+            const int yi = valid ? (big_gene ? yg[n] : yv_[u]) : 0;
+            const double mu_raw = mu_raw_[u];
+            const double(&z)[Q] = z_[u];
+            if (valid && mu_row != nullptr) mu_row[n] = mu_raw;
+            double wv = 0.0;
+            if (have_w) {
+                const double mu = dmax(mu_raw, min_mu);
+                wv = mu * frcp_g(1.0 + mu * dsp);
+                double qf = Ac;  // x_n^T H x_n = A_c + 2 b_c . z + z^T D z
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    double dz = 0.0;
+#pragma unroll
+                    for (int qq = 0; qq < Q; ++qq) dz = fma(Dq[tris(q, qq)], z[qq], dz);
+                    qf = fma(z[q], 2.0 * bc[q] + dz, qf);
+                }
+                const double h = wv * qf;
+                if (valid && hat_row != nullptr) hat_row[n] = h;
+                if (want_cooks) {
+                    double ck = 0.0;
+                    if (valid) ck = acc.add(n, (double)yi, mu_raw, h, fl_[u]);
+                    if (cooks_row != nullptr) {
+                        if (cooks_slots) cooks_row[s] = ck;
+                        else if (valid) cooks_row[n] = ck;
+                    }
+                }
+            }
+            if (want_wald) {
+                double wu = wv;  // the same number unless a lane was clamped
+                if (!have_w || DeviceWave::any(!(mu_raw >= min_mu))) wu = mu_raw * frcp_g(1.0 + mu_raw * dsp);
+                wu = valid ? wu : 0.0;
+                sc[0] += wu;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const double wq = wu * z[q];
+                    sc[1 + q] += wq;
+#pragma unroll
+                    for (int qq = 0; qq <= q; ++qq) zz[tri(q, qq)] = fma(wq, z[qq], zz[tri(q, qq)]);
+                }
+            }
+        }
+    }
+    CooksOut cko{};
+    WaldOut wo{};
+    if (want_cooks) {
+        // "fewer than three samples above the one with the largest Cook's distance" (dds.py:1094-1101): counted over the
+        // gene's slot-ordered uint16 row (any order will do; it is in L2 from the pass above)
+        if (big_gene) {
+            cko = acc.finish(yg, N);
+        } else {
+            cko = acc.finish_counted(N, [&](int yref) {
+                int above = 0;
+#pragma unroll 4
+                for (int s = lane; s < Ns; s += 64) {
+                    const int v = ysg[s];
+                    above += (v != kMixPad && v > yref) ? 1 : 0;
+                }
+                return above;
+            });
+        }
+    }
+    if (want_wald) {
+        fold(cur);
+        DeviceWave::template sum_n<QQ>(zz);
+        if (kind == 2)
+            Me = pick6(zzk, zz[0], zz[1 < L_ ? 1 : L_], zz[2 < L_ ? 2 : L_], zz[3 < L_ ? 3 : L_], zz[4 < L_ ? 4 : L_], zz[L_]);
+        if (lane < T) L->ent[lane] = Me;
+        DeviceWave::sync();
+        double Mw[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) Mw[i] = L->ent[i];
+        wo = wald_from_M<P>(Mw, beta, ex.ridge, ex.contrast, ex.lfc_null, ex.alt);
+    }
+    if (lane == 0) {
+        if (want_cooks) {
+            ex.any_all[g] = (uint8_t)cko.any_gt_all;
+            ex.any_use[g] = (uint8_t)cko.any_gt_use;
+            ex.any_use_nr[g] = (uint8_t)cko.any_gt_use_nr;
+            ex.few_above[g] = (uint8_t)cko.few_above;
+        }
+        if (want_wald) { ex.pvals[g] = wo.p; ex.stats[g] = wo.stat; ex.se[g] = wo.se; }
+    }
+}
+
+DSQ_HD size_t mix_epi_shared_bytes(int Ns, int P) {
+    return (size_t)kMixMaxCells * P * 8 + (size_t)(((Ns >> 6) + 15) & ~15) + 4 * sizeof(MixEpiLds);
 }
 
 static int mixi_waves_per_block(int Ns, int P) {
@@ -749,11 +799,15 @@ hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
     if (ex.cooks_ld != 0 && ex.cooks_ld < D.Ns) return hipErrorInvalidValue;
     int blocks = 0, nw = 0;
     DSQ_MIX_CAT(irls_mix_grid_q, DSQ_MIX_Q)(D.Ns, D.P, G, &blocks, &nw);
-    if (blocks == 0 || (size_t)D.Ns * 17 + 64 > work_bytes) return hipErrorInvalidValue;
+    const bool epilogue = mu != nullptr || hat != nullptr || ex.flags != nullptr || ex.ridge != nullptr;
+    const size_t m_off = ((size_t)D.Ns * 17 + 63) & ~(size_t)63;  // (after the three slot-ordered vectors)
+    if (blocks == 0 || m_off + (epilogue ? (size_t)G * Tri<kMixMaxP>::N * sizeof(double) : 0) > work_bytes)
+        return hipErrorInvalidValue;
     const size_t smem = mixi_shared_bytes(D.Ns, D.P) + mixi_wave_bytes(D.Ns) * nw + 64;
     double* sfs = (double*)work;
     double* lsfs = sfs + D.Ns;
     uint8_t* flags_s = (uint8_t*)(lsfs + D.Ns);
+    double* m_buf = epilogue ? (double*)((char*)work + m_off) : nullptr;  // the last sweep's X^T W X, [G][T]
     hipLaunchKernelGGL(k_mix_prep<Q>, dim3((D.Ns + 255) / 256), dim3(256), 0, st, sf, ex.flags, D.perm, D.Ns, sfs, lsfs,
                        flags_s);
     {
@@ -778,7 +832,14 @@ hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
             }                                                                                                           \
             hipLaunchKernelGGL((k_irls_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, y, ldn, ys, ys_big, D,      \
                                cont_mask, sfs, lsfs, flags_s, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, \
-                               mu, hat, conv, iters, fb_count, fb_list, ex);                                            \
+                               m_buf, conv, iters, fb_count, fb_list);                                                  \
+            if (epilogue) {                                                                                             \
+                const hipError_t e1 = hipGetLastError();                                                                \
+                if (e1 != hipSuccess) return e1;                                                                        \
+                hipLaunchKernelGGL((k_mix_epilogue<PP, Q>), dim3((G + 3) / 4), dim3(256),                               \
+                                   mix_epi_shared_bytes(D.Ns, PP), st, y, ldn, ys, ys_big, D, cont_mask, lsfs, flags_s, \
+                                   G, disp, min_mu, beta, m_buf, conv, mu, hat, ex);                                    \
+            }                                                                                                           \
         }                                                                                                               \
     } while (0)
     switch (D.P) {

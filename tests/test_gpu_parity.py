@@ -1172,7 +1172,8 @@ def test_plugin_cache_verify_mode_and_hits_of_a_whole_fit(monkeypatch):
     res = orc.deseq2(counts, X, n_jobs=1, keep_layers=False, inference=inf)
     s1 = inf.cache_stats()
     assert s1["verified_hits"] > 0 and s1["verified_hits"] == s1["hits"] - s0["hits"]
-    # misses: normed counts (fp64), the counts (int64), and nothing else that is N x G - mu_hat and mu come back adopted
-    assert s1["misses"] - s0["misses"] <= 3 and s1["adopted_outputs"] - s0["adopted_outputs"] >= 2
+    # misses: the normed counts (fp64), the counts (int64) and the sub-matrices of the outlier refit - the two N x G
+    # matrices the engine produced (mu_hat, mu) come back as hits of their adopted device copies
+    assert s1["misses"] - s0["misses"] <= 8 and s1["adopted_outputs"] - s0["adopted_outputs"] >= 2
     for f in ("dispersions", "LFC", "pvalue", "genewise_dispersions"):
         np.testing.assert_array_equal(getattr(res, f), getattr(plain, f), err_msg=f)

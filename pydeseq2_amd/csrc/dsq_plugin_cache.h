@@ -12,7 +12,7 @@
 // matrix mutated in place has another digest.  Device buffers come from a size-matched free list (hipMalloc / hipFree of
 // 0.5 GB per call cost milliseconds and hipFree synchronises the device).
 //
-// Host glue only (no model math): included by dsq_capi.hip.
+// Host glue only (no model math): included by dsq_capi_inf.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

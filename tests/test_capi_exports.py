@@ -130,3 +130,14 @@ def test_plugin_cache_digest_is_layout_dtype_and_thread_independent():
     m2 = m.copy()
     m2[17, 1000] = np.nextafter(m2[17, 1000], np.inf)  # one ulp
     assert dg(m2) != bm
+
+
+def test_every_environment_knob_is_registered():
+    """tools/knobs.py holds the registry of the DSQ_* switches (kind, default, effect): a knob read anywhere in the package
+    that is missing there - or one registered that nothing reads - fails here, and so does a stale table in README.md."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "knobs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

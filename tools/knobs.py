@@ -71,7 +71,9 @@ def scan():
         for p in paths:
             for i, line in enumerate(open(p, errors="replace"), 1):
                 for m in re.finditer(r'(?:getenv\("|environ\.get\("|environ\[")(DSQ_[A-Z0-9_]+)"', line):
-                    found.setdefault(m.group(1), []).append(f"{os.path.relpath(p, ROOT)}:{i}")
+                    where = os.path.relpath(p, ROOT)  # (the file, not the line: the table must not go stale with every edit)
+                    if where not in found.setdefault(m.group(1), []):
+                        found[m.group(1)].append(where)
     return found
 
 

@@ -400,6 +400,17 @@ class _PinnedPool:
         self.ctx.call("dsq_host_alloc", c_size_t(int(nbytes)), C.byref(p))
         return _PinnedSlab(self, int(nbytes), p.value)
 
+    def take_free(self, nbytes):
+        """A pooled buffer of at least nbytes (best fit, as take), or None - never allocates."""
+        best = None
+        for k, (cap, ptr) in enumerate(self.free):
+            if nbytes <= cap <= 2 * nbytes + 65536 and (best is None or cap < self.free[best][0]):
+                best = k
+        if best is None:
+            return None
+        cap, ptr = self.free.pop(best)
+        return _PinnedSlab(self, cap, ptr)
+
     def release(self, cap, ptr):
         if self.closed:
             self.ctx.call("dsq_host_free", _vp(ptr))

@@ -351,6 +351,7 @@ int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size
 
 int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out) {
     DSQ_CHECK_ARG(out != nullptr, "null output pointer");
+    DSQ_HIP(hipSetDevice(ctx->device));  // (callable from a helper thread: HipInference page-locks its output layers there)
     DSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
     return DSQ_OK;
 }

@@ -28,12 +28,15 @@
 #error "compile with -DDSQ_MIX_Q=1, 2 or 3"
 #endif
 
-// the exponential of the sweeps (one per sample and sweep): -DDSQ_MIX_FEXP selects the table-driven fexp_t (dsq_math.h,
-// <= 1 ulp, ~22 instructions + one LDS read) instead of the library's
-#if defined(DSQ_MIX_FEXP)
-#define DSQ_MIX_EXP(x) fexp_t(x)
-#else
+// the exponential of the sweeps (one per sample and sweep): the table-driven fexp_t (dsq_math.h, <= 1 ulp, ~22 instructions
+// + one LDS read; its 1 KB table is filled per workgroup).  Round 5 measured it at +37 spilled registers inside the kernel
+// that still held the epilogue and left the library's in; with the epilogue in a kernel of its own (round 6) the sweeps
+// have the registers: c5 shard 7.80 -> 7.67 ms per step.  -DDSQ_MIX_LIBEXP selects the library's for the A/B.
+#if defined(DSQ_MIX_LIBEXP)
 #define DSQ_MIX_EXP(x) exp(x)
+#else
+#define DSQ_MIX_FEXP 1
+#define DSQ_MIX_EXP(x) fexp_t(x)
 #endif
 
 namespace dsq {
@@ -491,6 +494,9 @@ __global__ __launch_bounds__(256, 3) void k_mix_epilogue(
     double* const xc_s = dyn;                                   // [C][P]
     uint8_t* const tc_s = (uint8_t*)(xc_s + kMixMaxCells * P);  // [ntrips]
     MixEpiLds* const L = (MixEpiLds*)((char*)dyn + (size_t)kMixMaxCells * P * 8 + (size_t)(((Ns >> 6) + 15) & ~15)) + w;
+#if defined(DSQ_MIX_FEXP)
+    exp_tab_fill();
+#endif
     for (int i = threadIdx.x; i < C * P; i += blockDim.x) xc_s[i] = D.Xc[i];
     for (int i = threadIdx.x; i < ntrips; i += blockDim.x) tc_s[i] = D.trip_cell[i];
     __syncthreads();

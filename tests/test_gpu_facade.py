@@ -354,3 +354,22 @@ def test_layers_are_rebuilt_on_demand_copy_and_slices():
     cp.fit_type = "mean"
     cp.deseq2()  # a copy fits on its own
     assert cp.uns["disp_function_type"] == "mean" and dds.uns["disp_function_type"] == "parametric"
+
+
+def test_statistics_on_a_gene_slice_of_a_fitted_data_set():
+    """dds[:, genes] of a fitted data set carries the fit in its fields (AnnData semantics): DeseqStats on the slice runs the
+    Wald test with the parent's size factors, dispersions and LFCs - p-values equal the parent's for those genes, no refit."""
+    from pydeseq2_amd.api import DeseqDataSet, DeseqStats
+
+    counts, meta = load_dataset("synthetic")
+    dds = DeseqDataSet(counts=counts, metadata=meta, design="~condition").deseq2()
+    full = DeseqStats(dds, contrast=["condition", "B", "A"], independent_filter=False)
+    full.summary()
+    genes = ["gene2", "gene5", "gene9"]
+    sub = dds[:, genes]
+    assert sub._res is None and sub._pipe_obj is None
+    part = DeseqStats(sub, contrast=["condition", "B", "A"], independent_filter=False)
+    part.run_wald_test()
+    np.testing.assert_allclose(part.p_values.to_numpy(), full.p_values.loc[genes].to_numpy(), rtol=1e-10)
+    np.testing.assert_allclose(part.SE.to_numpy(), full.SE.loc[genes].to_numpy(), rtol=1e-10)
+    np.testing.assert_array_equal(sub.var["dispersions"].to_numpy(), dds.var.loc[genes, "dispersions"].to_numpy())

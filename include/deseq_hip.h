@@ -355,6 +355,9 @@ int dsq_mix_slots(const dsq_mix* mix, int32_t* h_slot_of);
  * dispersion fit (dsq_dev_alpha_mle*) or IRLS fit (dsq_dev_lfc_fit*, dsq_dev_irls) of the context - one-shot; a fit of a
  * mixed design that finds nothing bound builds its own copies per call. */
 int dsq_mix_bind(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const double* d_mu_slots);
+/* The same with the gene count the copies were built for: a consuming fit whose G differs ignores the binding and builds its
+ * own copies (dsq_mix_bind leaves the count unknown: no check). */
+int dsq_mix_bind2(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const double* d_mu_slots, int G);
 int dsq_dev_mix_counts_to_slots(dsq_ctx* ctx, const int32_t* d_y, int ldn, int G, const dsq_mix* mix, uint16_t* d_ys,
                                 uint8_t* d_big);
 int dsq_dev_mix_mu_slots(dsq_ctx* ctx, const dsq_mix* mix, const double* d_beta, const double* d_sf, int G,

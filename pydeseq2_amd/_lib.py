@@ -88,6 +88,7 @@ def load():
     proto("dsq_plugin_cache_stats", _vp, C.POINTER(c_double), c_int)
     proto("dsq_comm_info", _vp, C.POINTER(c_int), C.POINTER(c_int))
     proto("dsq_mix_bind", _vp, _vp, _vp, _vp)
+    proto("dsq_mix_bind2", _vp, _vp, _vp, _vp, c_int)
     proto("dsq_dev_mix_counts_to_slots", _vp, _vp, c_int, c_int, _vp, _vp, _vp)
     proto("dsq_dev_mix_mu_slots", _vp, _vp, _vp, _vp, c_int, _vp)
     proto("dsq_host_sync_count", res=C.c_ulonglong)
@@ -232,7 +233,7 @@ EXPORTS = [
     "dsq_inf_irls2", "dsq_inf_alpha_mle2", "dsq_inf_lfc_shrink_nbinom_glm2", "dsq_inf_fit_moments_dispersions2",
     "dsq_abi_version", "dsq_plugin_cache_config", "dsq_plugin_cache_clear", "dsq_plugin_cache_stats",
     "dsq_plugin_digest_host", "dsq_comm_info", "dsq_host_sync_count", "dsq_dev_pack2", "dsq_dev_unzip2",
-    "dsq_mix_bind", "dsq_dev_mix_counts_to_slots", "dsq_dev_mix_mu_slots",
+    "dsq_mix_bind", "dsq_mix_bind2", "dsq_dev_mix_counts_to_slots", "dsq_dev_mix_mu_slots",
 ]
 
 

@@ -385,7 +385,14 @@ int dsq_mix_bind(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const
     ctx->bind_ys = d_ys;
     ctx->bind_big = d_big;
     ctx->bind_mu = d_mu_slots;
+    ctx->bind_G = 0;
     return DSQ_OK;
+}
+
+int dsq_mix_bind2(dsq_ctx* ctx, const uint16_t* d_ys, const uint8_t* d_big, const double* d_mu_slots, int G) {
+    const int rc = dsq_mix_bind(ctx, d_ys, d_big, d_mu_slots);
+    ctx->bind_G = (rc == DSQ_OK && G > 0) ? G : 0;
+    return rc;
 }
 int dsq_dev_mix_counts_to_slots(dsq_ctx* ctx, const int32_t* d_y, int ldn, int G, const dsq_mix* mix, uint16_t* d_ys,
                                 uint8_t* d_big) {

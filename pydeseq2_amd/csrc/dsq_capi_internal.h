@@ -77,6 +77,7 @@ struct dsq_ctx {
     const uint16_t* bind_ys = nullptr;  // dsq_mix_bind (one-shot: the next dispersion / IRLS fit consumes it)
     const uint8_t* bind_big = nullptr;
     const double* bind_mu = nullptr;
+    int bind_G = 0;               // genes the bound copies were built for (dsq_mix_bind2; 0: not stated)
     void* d_mixw = nullptr;       // slot-ordered per-sample vectors of the mixed-design IRLS kernel (grow-only)
     size_t mixw_cap = 0;
     int32_t* d_redo = nullptr;    // genes the buffer-less robust-dispersion kernel hands back (side stream; grow-only)
@@ -115,6 +116,7 @@ int fail(dsq_ctx* c, int code, const std::string& msg) {
         c->bind_ys = nullptr;
         c->bind_big = nullptr;
         c->bind_mu = nullptr;
+        c->bind_G = 0;
     }
     return code;
 }
@@ -226,8 +228,11 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     struct Unbind {  // dsq_mix_bind is one-shot: whatever this call does with it, the next one starts unbound
         dsq_ctx* c;
-        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; }
+        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; c->bind_G = 0; }
     } unbind{ctx};
+    if (ctx->bind_G != 0 && ctx->bind_G != G) {  // copies of another matrix (a failed or skipped call left them): not ours
+        ctx->bind_ys = nullptr; ctx->bind_big = nullptr; ctx->bind_mu = nullptr; ctx->bind_G = 0;
+    }
     DSQ_HIP(ensure_list(ctx, (size_t)G));
     // [0] grid-search genes, [1] gene queue of the row kernel, [2] parked genes, [3] gene queue of the continuation launch
     int32_t* d_cnt = ctx->d_counter + 4;
@@ -386,8 +391,11 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     struct Unbind {  // (see run_alpha)
         dsq_ctx* c;
-        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; }
+        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; c->bind_G = 0; }
     } unbind{ctx};
+    if (ctx->bind_G != 0 && ctx->bind_G != G) {  // (see run_alpha)
+        ctx->bind_ys = nullptr; ctx->bind_big = nullptr; ctx->bind_mu = nullptr; ctx->bind_G = 0;
+    }
     dsq::IrlsExtras ex_local{};
     if (extras != nullptr) ex_local = *extras;
     const dsq::MixDesign* const extras_in_mix = ex_local.mix;

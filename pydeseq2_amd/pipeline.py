@@ -447,10 +447,12 @@ class DeseqPipeline:
             self._mix_ys_cache = (np.array(persistent_key, copy=True), d_ys, d_big)
         return d_ys, d_big
 
-    def _mix_bind(self, slots, d_mu_slots=None):
-        """Hand the slot-ordered copies to the next fit of the context (one-shot, csrc: dsq_mix_bind)."""
+    def _mix_bind(self, slots, d_mu_slots=None, genes=0):
+        """Hand the slot-ordered copies to the next fit of the context (one-shot, csrc: dsq_mix_bind2: a fit over another
+        number of genes than the copies were built for ignores them)."""
         if slots is not None:
-            self.ctx.call("dsq_mix_bind", _vp(slots[0].ptr), _vp(slots[1].ptr), _vp(d_mu_slots.ptr) if d_mu_slots else None)
+            self.ctx.call("dsq_mix_bind2", _vp(slots[0].ptr), _vp(slots[1].ptr), _vp(d_mu_slots.ptr) if d_mu_slots else None,
+                          int(genes))
 
     def _stage_genewise(self, d_y, Gs, d_sf, S, row_lists=None, pre_alpha=None, mix_slots=None):
         """MoM -> mu_hat -> genewise alpha for Gs genes (dds.py:713-797).  Writes S[nm, mom, gw (raw,
@@ -486,7 +488,7 @@ class DeseqPipeline:
             d_b, d_c = self._dvec(Gs * self.P), self._dvec(Gs, np.uint8)
             # the iteration counts of this fit order the genes of the LFC fit (dsq_irls_order_hint)
             S["_irls_it"] = self._dvec(Gs, np.int32)
-            self._mix_bind(mix_slots)
+            self._mix_bind(mix_slots, genes=Gs)
             self._k("irls_mu", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                     _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["mom"].ptr),
                     c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
@@ -522,7 +524,7 @@ class DeseqPipeline:
         # (d_rows, n_rows, d_waves, n_waves) or None; the mixed-design kernel also takes its rows from a mu_hat matrix
         rows = getattr(mh, "row_lists", None) if (mh.d_mu is None or mix) else None
         if mix and rows:
-            self._mix_bind(getattr(mh, "mix_slots", None), getattr(mh, "d_mu_slots", None))
+            self._mix_bind(getattr(mh, "mix_slots", None), getattr(mh, "d_mu_slots", None), genes=Gs)
         self._k(name, Gs, "dsq_dev_alpha_mle4", _vp(d_y.ptr), _vp(mh.d_mu.ptr) if mh.d_mu else None, self.ldn,
                 _vp(self.d_Xt.ptr), self.design.ldx, self.N, Gs, self.P, _vp(d_start.ptr), c_double(self.min_disp),
                 c_double(self.max_disp), c_double(prior_var), 1, int(prior_reg), _vp(d_out.ptr), _vp(d_conv.ptr),
@@ -562,7 +564,7 @@ class DeseqPipeline:
                  [_vp(S[x].ptr) for x in ("any_all", "any_use", "any_use_nr", "few_above")]
         if S.get("_irls_it") is not None:
             self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
-        self._mix_bind(mix_slots)
+        self._mix_bind(mix_slots, genes=Gs)
         self._k("lfc_fit", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,

@@ -20,7 +20,7 @@
  *     pitch `ldn` (elements), a multiple of 16.
  *   - counts are non-negative integers < 2^31 (int32 or int64 storage); everything else
  *     is IEEE double.  Natural-log fold changes, dispersion alpha with var = mu + alpha mu^2.
- *   - N = samples, G = genes, P = design columns (1..DSQ_MAX_P = 32).
+ *   - N = samples, G = genes, P = design columns (1..DSQ_MAX_P = 48).
  *   - statistical non-convergence is NOT an error: it is reported in the `converged`
  *     arrays exactly like the reference does.
  */
@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define DSQ_ABI_VERSION 5   /* bumped whenever an exported signature changes; dsq_abi_version() returns the library's */
-#define DSQ_MAX_P 32        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path */
+#define DSQ_MAX_P 48        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path (round 6: 32 -> 48) */
 #define DSQ_SHRINK_MAX_P 32 /* apeGLM shrinkage (dsq_*_lfc_shrink*): up to 12 columns in registers, 13 ... 32 run-time p */
 #define DSQ_BFGS_MAX_P 12   /* optimizer = "BFGS" of the dispersion fit / the IRLS rescue: register kernels only */
 

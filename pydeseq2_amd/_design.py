@@ -4,7 +4,7 @@ from __future__ import annotations
 import numpy as np
 
 
-MAX_DESIGN_COLUMNS = 32  # DSQ_MAX_P of include/deseq_hip.h
+MAX_DESIGN_COLUMNS = 48  # DSQ_MAX_P of include/deseq_hip.h
 
 
 def pad16(n: int) -> int:

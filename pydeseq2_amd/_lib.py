@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSQ_LIB", os.path.join(_HERE, "libdeseq_hip.so"))  # DSQ_LIB: developer A/B builds
 
-DSQ_MAX_P = 32
+DSQ_MAX_P = 48
 _DEBUG = bool(os.environ.get("DSQ_DEBUG"))
 SAMPLE_MAJOR, GENE_MAJOR = 0, 1
 I32, I64 = 0, 1

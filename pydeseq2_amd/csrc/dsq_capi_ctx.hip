@@ -20,7 +20,7 @@ int dsq_create(int device_id, dsq_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->evk1);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch, kScratchBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 64);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pin, 16384, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pin, 65536, hipHostMallocDefault);
     if (e != hipSuccess) {
         fprintf(stderr, "dsq_create: %s\n", hipGetErrorString(e));
         delete ctx;

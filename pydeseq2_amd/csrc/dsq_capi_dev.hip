@@ -504,13 +504,15 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
         ex.any_all = d_any_all; ex.any_use = d_any_use; ex.any_use_nr = d_any_use_nr; ex.few_above = d_few_above;
     }
     if (h_ridge != nullptr) {
-        double* d_ridge = ctx->d_scratch + 16;
+        double* d_ridge = ctx->d_scratch + 1664;  // (behind the trend kernels' partials and outputs)
         double* d_contrast = d_ridge + P * P;  // (behind the matrix: both travel in one copy)
         // via page-locked memory: the caller's arrays may be temporaries, and a pageable source would make the
         // copy (and the launch behind it) wait for the host
         // (stream-ordered: a rescue kernel of the previous call may still be reading them; the slot itself is free
         // again because every call ends behind a synchronisation that follows its copies)
-        double* h_stage = (double*)(ctx->h_pin + 16);
+        // (ints [16, 3072) of the page-locked block hold up to 32 x 32 + 32 doubles; wider designs stage behind the trend's
+        // outputs at int 4096, where 48 x 48 + 48 doubles fit into the block's second half)
+        double* h_stage = (double*)(ctx->h_pin + (P <= 32 ? 16 : 4096));
         std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
         std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
         DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)(P * P + P) * sizeof(double), hipMemcpyHostToDevice,
@@ -573,7 +575,7 @@ int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, 
                  double* d_se) {
     DSQ_CHECK_ARG(P >= 1 && P <= DSQ_MAX_P, "P out of range");
     DSQ_CHECK_ARG(alt >= 0 && alt <= 4, "unknown alternative hypothesis");
-    double* d_ridge = ctx->d_scratch + 16;
+    double* d_ridge = ctx->d_scratch + 1664;  // (behind the trend kernels' partials and outputs)
     double* d_contrast = d_ridge + DSQ_MAX_P * DSQ_MAX_P;
     DSQ_HIP(hipMemcpyAsync(d_ridge, h_ridge, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     DSQ_HIP(hipMemcpyAsync(d_contrast, h_contrast, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

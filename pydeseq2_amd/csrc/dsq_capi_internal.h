@@ -50,7 +50,7 @@ struct dsq_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     float last_kernel_ms = 0.0f;  // k_alpha launch of the last dsq_*_alpha_mle call (HIP events)
     int last_n_grid = 0;          // genes that took the grid-search fallback in that call
-    double* d_scratch = nullptr;  // 8 KiB of device scratch (scalars, trend partials)
+    double* d_scratch = nullptr;  // 32 KiB of device scratch (kScratchBytes: scalars, trend partials, ridge / contrast)
     int32_t* d_counter = nullptr; // IRLS fallback / dispersion grid-search counters
     int32_t* d_list = nullptr;    // gene index list of the rare second-pass kernels (grown on demand)
     size_t list_cap = 0;
@@ -67,7 +67,8 @@ struct dsq_ctx {
     void (*alpha_hook)(void*) = nullptr;  // dsq_set_alpha_hook (one-shot)
     void* alpha_hook_arg = nullptr;
     int deferred = 0;             // dsq_set_deferred: second passes of small batches enqueued without a host round trip
-    int32_t* h_pin = nullptr;     // 16 KiB of page-locked host memory: counters read back / small arguments sent
+    int32_t* h_pin = nullptr;     // 64 KiB of page-locked host memory: counters read back / small arguments sent (ints [0, 16): counters;
+                                  // [16, 3072) + [4096, 16384): ridge / contrast staging up to p = 48; [3072, 4096): trend outputs)
     void* d_ws = nullptr;         // workspace of the rare second-pass kernels (grown on demand, never shrunk)
     size_t ws_cap = 0;
     void* d_resume = nullptr;     // parked optimiser states + gene list of the two-phase dispersion launch (grow-only)
@@ -105,7 +106,7 @@ void fire_alpha_hook(void* c) {
 
 namespace {
 
-constexpr size_t kScratchBytes = 16 * 1024;
+constexpr size_t kScratchBytes = 32 * 1024;  // doubles [0, 1664): scalars, trend partials and outputs; [1664, 4096): ridge + contrast (48 x 48 + 48)
 constexpr int kDeferredMaxGenes = 2048;  // deferred second passes are launched for every gene of the batch
 
 int fail(dsq_ctx* c, int code, const std::string& msg) {

@@ -1,5 +1,5 @@
 // dsq_k_wide.hip — kernels of the run-time-P path (dsq_wide.h): designs wider than the register path's 12 columns
-// (up to kWideMaxP = 32), and — optionally — narrower designs without cell structure, whose p(p+1) register
+// (up to kWideMaxP = 48), and — optionally — narrower designs without cell structure, whose p(p+1) register
 // accumulators spill.  One gene per wavefront; the wave's p x p matrices, the staged design chunk and the small
 // vectors live in a wave-private segment of dynamic LDS whose size follows P (1, 2 or 4 waves per workgroup);
 // X^T W X is accumulated by v_mfma_f64_16x16x4_f64 (or from per-cell sums for cell designs).

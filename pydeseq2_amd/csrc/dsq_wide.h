@@ -23,7 +23,7 @@
 
 namespace dsq {
 
-constexpr int kWideMaxP = 32;
+constexpr int kWideMaxP = 48;  // (round 6: 32 -> 48; 5 p x p matrices of a gene at p = 48 are 92 KB of the 160 KB of LDS)
 constexpr int kWideXsLd = 65;  // leading dimension of the staged design chunk xs[j][n] (odd: conflict-free)
 
 DSQ_HD int wide_ld(int P) { return P | 1; }
@@ -172,12 +172,15 @@ template <class Wv, bool TWO>
 struct WideGram {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 f0[3], f1[3];  // lower-triangle tiles (0,0), (1,0), (1,1) of the two matrices (P <= 8 and TWO: only f0[0], stacked)
+    // lower-triangle tiles (0,0), (1,0), (1,1), (2,0), (2,1), (2,2) of the two matrices: up to three 16-row blocks, P <= 48
+    // (P <= 8 and TWO: only f0[0], stacked)
+    static constexpr int kTiles = 6;
+    d4 f0[kTiles], f1[kTiles];
 #endif
     DSQ_HD void begin(const WideWork& W) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { f0[t] = d4{0.0, 0.0, 0.0, 0.0}; f1[t] = d4{0.0, 0.0, 0.0, 0.0}; }
+        for (int t = 0; t < kTiles; ++t) { f0[t] = d4{0.0, 0.0, 0.0, 0.0}; f1[t] = d4{0.0, 0.0, 0.0, 0.0}; }
 #else
         for (int e = 0; e < W.P * W.ld; ++e) { W.M[e] = 0.0; if (TWO) W.dM[e] = 0.0; }
 #endif
@@ -209,6 +212,17 @@ struct WideGram {
                     if (TWO) {
                         f1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_hi * w1, x_lo, f1[1], 0, 0, 0);
                         f1[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_hi * w1, x_hi, f1[2], 0, 0, 0);
+                    }
+                    if (nt > 2) {  // 33 ... 48 columns: the third block of rows
+                        const double x_3 = W.xs[(32 + r) * kWideXsLd + n];
+                        f0[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w0, x_lo, f0[3], 0, 0, 0);
+                        f0[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w0, x_hi, f0[4], 0, 0, 0);
+                        f0[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w0, x_3, f0[5], 0, 0, 0);
+                        if (TWO) {
+                            f1[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w1, x_lo, f1[3], 0, 0, 0);
+                            f1[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w1, x_hi, f1[4], 0, 0, 0);
+                            f1[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x_3 * w1, x_3, f1[5], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -248,9 +262,9 @@ struct WideGram {
         } else {
             const int nt = W.rows / 16;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {  // static fragment indices (no dynamic register indexing)
-                if (t > 0 && nt == 1) continue;
-                const int ti = t == 0 ? 0 : 1, tj = t == 2 ? 1 : 0;
+            for (int t = 0; t < kTiles; ++t) {  // static fragment indices (no dynamic register indexing)
+                const int ti = t == 0 ? 0 : (t < 3 ? 1 : 2), tj = (t == 2 || t == 4) ? 1 : (t == 5 ? 2 : 0);
+                if (ti >= nt) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = 16 * ti + rq + 4 * q, j = 16 * tj + col;

@@ -396,6 +396,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "widths":  # round 4: design widths 1, 9, 11 and the mixed p = 8 design
         width_cases(ut, gs, pp, di)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "wider":  # round 6: design widths 40 and 48 (the engine's limit moved 32 -> 48)
+        wider_cases(ut, gs, pp, di)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":  # only the files added in round 2
         wide_cases(ut, gs, pp, di)
         hard_cases(ut, gs)
@@ -452,6 +455,25 @@ def wide_cases(ut, gs, pp, di):
             cols.append(rng.normal(0, 0.6, N))
         X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
         kat_case(f"p{pw}", synth(32, N, X, seed, eff=0.35), X, ut, gs, pp, di)
+
+
+def wider_cases(ut, gs, pp, di):
+    """cases P, Q (round 6): p = 40 and p = 48 - three 16-row tiles of the matrix-core Gram accumulation; the same design family
+    as the other wide cases (a 2-level and a 4-level factor + continuous covariates)."""
+    for pw, N, seed in ((40, 260, 41), (48, 300, 42)):
+        rng = np.random.default_rng(100 + pw)
+        a, b = np.arange(N) % 2, (np.arange(N) // 2) % 4
+        cols = [np.ones(N), (a == 1)] + [(b == k) for k in (1, 2, 3)]
+        while len(cols) < pw:
+            cols.append(rng.normal(0, 0.6, N))
+        X = np.column_stack([np.asarray(v, dtype=float) for v in cols])
+        # expressed genes only: with 40+ coefficients on ~6 samples each, a gene of mean count 3 sends the reference's IRLS
+        # to its 250-iteration limit and through the L-BFGS-B rescue, whose stopping point on that flat likelihood is the
+        # chaos kat_hard.npz pins separately - here the widths themselves are what is tested
+        c = synth(80, N, X, seed, eff=0.3)
+        c = c[:, c.mean(0) >= 40][:, :24]
+        assert c.shape[1] == 24
+        kat_case(f"p{pw}", c, X, ut, gs, pp, di)
 
 
 def narrow_cases(ut, gs, pp, di):

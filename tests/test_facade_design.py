@@ -141,7 +141,7 @@ def test_documented_limits_are_refused_with_a_clear_error():
 
     rng = np.random.default_rng(0)
     X = np.column_stack([np.ones(200)] + [rng.normal(size=200) for _ in range(MAX_DESIGN_COLUMNS)])
-    with pytest.raises(ValueError, match="at most 32"):
+    with pytest.raises(ValueError, match=f"at most {MAX_DESIGN_COLUMNS}"):
         DesignPack(X)
     assert DesignPack(X[:, :MAX_DESIGN_COLUMNS]).P == MAX_DESIGN_COLUMNS
 

@@ -64,7 +64,7 @@ def test_dispersion_kernel_every_design_width(inf, P):
         assert (rel > 1e-6).mean() <= 0.03 and rel.max() < 5e-3, (P, bool(kw), np.sort(rel)[-5:])
 
 
-@pytest.mark.parametrize("case", ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12", "p16", "p24"])
+@pytest.mark.parametrize("case", ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12", "p16", "p24", "p40", "p48"])
 def test_inference_vs_reference_kats(inf, case):
     """Every Inference method on the device against the outputs of the unmodified reference kernels.
     p = 10, 12: the split second sweep of the register path; p = 16, 24: the LDS / MFMA path for designs
@@ -335,9 +335,14 @@ def _wide_case(kind, G, N, seed):
         lv = np.arange(N) % 16
         rng.shuffle(lv)
         X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, 16)])
-    else:  # a 2-level and a 4-level factor + 9 continuous covariates: P = 14, no cell structure
+    elif kind == "factor40":  # one factor with 40 levels (round 6: up to 48 columns): P = 40 = number of cells
+        lv = np.arange(N) % 40
+        rng.shuffle(lv)
+        X = np.column_stack([np.ones(N)] + [(lv == k).astype(float) for k in range(1, 40)])
+    else:  # a 2-level and a 4-level factor + 9 (mixed14) or 39 (mixed44) continuous covariates: no cell structure
         a, b = np.arange(N) % 2, (np.arange(N) // 2) % 4
-        X = np.column_stack([np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)] + [rng.normal(0, 0.5, N) for _ in range(9)])
+        n_cont = 39 if kind == "mixed44" else 9
+        X = np.column_stack([np.ones(N), a == 1] + [(b == k) for k in (1, 2, 3)] + [rng.normal(0, 0.5, N) for _ in range(n_cont)])
         X = X.astype(float)
     P = X.shape[1]
     beta = np.zeros((P, G))
@@ -351,13 +356,18 @@ def _wide_case(kind, G, N, seed):
     return counts, X
 
 
-@pytest.mark.parametrize("kind,G,N", [("factor16", 600, 160), ("mixed14", 500, 120)])
+@pytest.mark.parametrize("kind,G,N", [("factor16", 600, 160), ("mixed14", 500, 120), ("factor40", 300, 480),
+                                      ("mixed44", 240, 520)])
 def test_pipeline_with_designs_wider_than_12_columns(kind, G, N):
     """The reference has no limit on the design width (utils.py:345-371): designs beyond the 12 columns of the
-    register kernels run the LDS / matrix-core path (dsq_wide.h), end to end against the oracle."""
+    register kernels run the LDS / matrix-core path (dsq_wide.h), end to end against the oracle - up to the engine's 48
+    columns (round 6: a 40-level factor = 40 design cells, and 44 columns without cell structure: three 16-row tiles of the
+    matrix-core Gram accumulation)."""
     import pydeseq2_amd
 
     counts, X = _wide_case(kind, G, N, 31)
+    if X.shape[1] > 32:  # expressed genes only: a low-count gene with 40 coefficients goes through the IRLS rescue, whose
+        counts = counts[:, counts.mean(0) >= 30]  # stopping point on a flat likelihood is pinned by kat_hard, not here
     counts[:, 4] = 0
     c = np.zeros(X.shape[1])
     c[1] = 1.0

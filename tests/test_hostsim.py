@@ -467,7 +467,7 @@ def test_cell_path_matches_the_general_path_and_the_reference(case):
         assert_close(c["se"], k["wald_se_none"], 1e-9, 0, "cell wald se vs reference")
 
 
-@pytest.mark.parametrize("case", ["p4", "p8", "p12", "p16", "p24"])
+@pytest.mark.parametrize("case", ["p4", "p8", "p12", "p16", "p24", "p40", "p48"])
 def test_wide_path_vs_reference_kats(case):
     """Run-time-P path (dsq_wide.h: LDS matrices, lane-parallel Cholesky / inverse, chunked Gram accumulation)
     against the reference KATs, incl. the widths the register path cannot hold (p = 16, 24); with and without the

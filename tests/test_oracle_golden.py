@@ -9,7 +9,7 @@ import pytest
 from oracle import nbglm_oracle as orc
 from tests.helpers import assert_close, load_dataset, load_kat, max_rel_err, r_csv, treatment_design
 
-CASES = ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12", "p16", "p24"]
+CASES = ["p1", "p2", "p3", "p4", "p5", "p6", "p7", "p8", "p8m", "p9", "p10", "p11", "p12", "p16", "p24", "p40", "p48"]
 
 
 @pytest.mark.parametrize("case", CASES)

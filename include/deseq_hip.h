@@ -483,6 +483,31 @@ int dsq_dev_wald(dsq_ctx* ctx, const double* d_mu, int ldn, const double* d_sf, 
 int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_means, int n, double min_disp,
                         double max_disp, uint8_t* d_keep, double* d_fitted, double* d_work, double* h_coeffs2,
                         int* h_ok, int* h_n_outer, double* h_squared_logres);
+/* An LFC fit in two launches (dds.py:937-984 is per gene: a gene's fit needs its own final dispersion only).  The genes
+ * whose MAP fit finished - and converged - in the dispersion stage's full-size launch are fitted from a stream of their
+ * own while the main stream still runs that stage's latency-bound tail (the continuation of the parked fits, the
+ * grid-search pass); the rest follow in a second launch that joins the first.  The pipeline's sequence, from inside the
+ * hook of dsq_set_alpha_hook (the MAP flags were filled with 0xFF and dsq_lfc_prepare called before the stage):
+ *   dsq_lfc_fork_begin; dsq_dev_select_dispersions_part(mode 1); dsq_lfc_set_part(part, 1, 1); dsq_dev_lfc_fit2;
+ *   dsq_lfc_fork_end;
+ * and, after the dispersion stage has returned:
+ *   dsq_dev_select_dispersions_part(mode 0); dsq_lfc_set_part(part, 0, 2); dsq_dev_lfc_fit2 (the same arguments).
+ * Every gene is fitted exactly once: the results are those of the single launch.  dsq_lfc_takes_parts: does the kernel
+ * family of this design honour the part vector (the run-time-P LDS kernels do not)?  dsq_side_abort also ends a fork whose
+ * second launch will not come. */
+int dsq_lfc_fork_begin(dsq_ctx* ctx);
+int dsq_lfc_fork_end(dsq_ctx* ctx);
+int dsq_lfc_set_part(dsq_ctx* ctx, const uint8_t* d_part, int want, int phase);
+int dsq_lfc_takes_parts(int N, int P, const dsq_cells* cells, const dsq_mix* mix, int full_rank);
+/* dsq_dev_select_dispersions for one part of the genes: mode 1 - the genes g < ready_limit with d_map_converged[g] == 1
+ * (d_part[g] = 1 for them, 0 for the others, which are left alone); mode 0 - the genes with d_part[g] == 0. */
+int dsq_dev_select_dispersions_part(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw, const double* d_fitted, int n,
+                                    double min_disp, double max_disp, double squared_logres, double* d_disp,
+                                    uint8_t* d_outlier, const uint8_t* d_map_converged, uint8_t* d_part, int mode,
+                                    int ready_limit);
+/* The small operations of the first launch (logs of the size factors, ridge and contrast of the Wald test, zeroed
+ * counters), enqueued on the main stream ahead of the dispersion stage instead of beside its tail. */
+int dsq_lfc_prepare(dsq_ctx* ctx, const double* d_sf, int N, const double* h_ridge, const double* h_contrast, int P);
 int dsq_dev_trend_eval(dsq_ctx* ctx, const double* d_normed_means, int n, double a0, double a1,
                        double* d_fitted);
 /* dispersion-outlier rule and final dispersions (dds.py:909-935); the genewise and MAP dispersions are clipped to

@@ -46,6 +46,10 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->d_mix) (void)hipFree(ctx->d_mix);
     if (ctx->d_mixw) (void)hipFree(ctx->d_mixw);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->d_lfc_aux) (void)hipFree(ctx->d_lfc_aux);
+    if (ctx->lfc_stream) (void)hipStreamDestroy(ctx->lfc_stream);
+    if (ctx->ev_lfc_fork) (void)hipEventDestroy(ctx->ev_lfc_fork);
+    if (ctx->ev_lfc_done) (void)hipEventDestroy(ctx->ev_lfc_done);
     dsq_internal_destroy_plugin(ctx);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
@@ -205,12 +209,53 @@ int dsq_side_end(dsq_ctx* ctx) {
 // dsq_side_begin and dsq_side_end) and wait until everything queued on either stream has run, so that buffers the
 // side stream was writing may be recycled.  A no-op on a context that never forked.
 int dsq_side_abort(dsq_ctx* ctx) {
+    if (ctx->lfc_stream != nullptr) {  // a forked LFC launch (dsq_lfc_fork_begin) whose partner will not come
+        if (ctx->stream == ctx->lfc_stream && ctx->lfc_return != nullptr) ctx->stream = ctx->lfc_return;
+        (void)hipStreamSynchronize(ctx->lfc_stream);
+        ctx->lfc_pending_G = 0;
+        ctx->lfc_part = nullptr; ctx->lfc_phase = 0;
+    }
     if (ctx->main_stream != nullptr) ctx->stream = ctx->main_stream;
     if (ctx->side_stream != nullptr) {
         (void)hipEventRecord(ctx->ev_join, ctx->side_stream);
         DSQ_HIP(hipStreamSynchronize(ctx->side_stream));
     }
     DSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return DSQ_OK;
+}
+
+// Fork for the first launch of an LFC fit in two (dsq_lfc_set_part): a stream of its own - every compute unit, unlike the
+// side stream - that starts behind what the current stream holds now (the dispersion stage's full-size launch) and behind
+// the side stream's last dsq_side_end (the robust dispersions its epilogue reads); calls made until dsq_lfc_fork_end go
+// there.  The second launch of the fit (phase 2) joins it.
+int dsq_lfc_fork_begin(dsq_ctx* ctx) {
+    DSQ_CHECK_ARG(ctx->lfc_stream == nullptr || ctx->stream != ctx->lfc_stream, "already forked");
+    DSQ_CHECK_ARG(ctx->side_stream == nullptr || ctx->stream != ctx->side_stream, "on the side stream");
+    DSQ_CHECK_ARG(ctx->lfc_pending_G == 0, "a forked LFC launch is still waiting for its second launch");
+    if (ctx->lfc_stream == nullptr) {
+        // lowest priority: the main stream's small kernels (the tail of the dispersion stage, one workgroup to a few hundred)
+        // must find slots while this stream's full-size launch fills the device (at equal priority a 4 us kernel waited
+        // 0.9 ms beside it)
+        int least = 0, greatest = 0;
+        DSQ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = getenv("DSQ_LFC_FLAT_PRIORITY") != nullptr;  // A/B switch
+        DSQ_HIP(hipStreamCreateWithPriority(&ctx->lfc_stream, hipStreamNonBlocking, flat ? (least + greatest) / 2 : least));
+        DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_lfc_fork, hipEventDisableTiming));
+        DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_lfc_done, hipEventDisableTiming));
+    }
+    DSQ_HIP(hipEventRecord(ctx->ev_lfc_fork, ctx->stream));
+    DSQ_HIP(hipStreamWaitEvent(ctx->lfc_stream, ctx->ev_lfc_fork, 0));
+    // (behind the side stream's work up to its last dsq_side_end: the caller forks before it puts more there)
+    if (ctx->side_stream != nullptr) DSQ_HIP(hipStreamWaitEvent(ctx->lfc_stream, ctx->ev_join, 0));
+    ctx->lfc_return = ctx->stream;
+    ctx->stream = ctx->lfc_stream;
+    return DSQ_OK;
+}
+
+int dsq_lfc_fork_end(dsq_ctx* ctx) {
+    DSQ_CHECK_ARG(ctx->lfc_stream != nullptr && ctx->stream == ctx->lfc_stream, "not forked");
+    ctx->stream = ctx->lfc_return;  // first: a failing record must not leave the context on the forked stream
+    DSQ_HIP(hipEventRecord(ctx->ev_lfc_done, ctx->lfc_stream));
     return DSQ_OK;
 }
 

@@ -512,11 +512,18 @@ int dsq_dev_lfc_fit2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_
         // again because every call ends behind a synchronisation that follows its copies)
         // (ints [16, 3072) of the page-locked block hold up to 32 x 32 + 32 doubles; wider designs stage behind the trend's
         // outputs at int 4096, where 48 x 48 + 48 doubles fit into the block's second half)
-        double* h_stage = (double*)(ctx->h_pin + (P <= 32 ? 16 : 4096));
-        std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
-        std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
-        DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)(P * P + P) * sizeof(double), hipMemcpyHostToDevice,
-                               ctx->stream));
+        // (the second launch of a fit in two, dsq_lfc_set_part: the first one's copy - the same arguments - is in place,
+        // and that launch may still be reading it)
+        const bool in_place = ctx->lfc_part != nullptr &&
+                              (ctx->lfc_phase == 2 || (ctx->lfc_phase == 1 && ctx->lfc_prepared_wald &&
+                                                       ctx->lfc_prepared_N == N && ctx->lfc_prepared_P == P));
+        if (!in_place) {
+            double* h_stage = (double*)(ctx->h_pin + (P <= 32 ? 16 : 4096));
+            std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
+            std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
+            DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)(P * P + P) * sizeof(double), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        }
         ex.ridge = d_ridge; ex.contrast = d_contrast; ex.lfc_null = lfc_null; ex.alt = alt;
         ex.pvals = d_pvals; ex.stats = d_stats; ex.se = d_se;
     }
@@ -639,6 +646,60 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, double* d_genewise_raw, double* d_m
     DSQ_HIP(dsq::launch_select_disp(ctx->stream, d_genewise_raw, d_map_raw, d_fitted, n, min_disp, max_disp,
                                     2.0 * sqrt(squared_logres), d_disp, d_outlier));
     return DSQ_OK;
+}
+
+int dsq_dev_select_dispersions_part(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw, const double* d_fitted, int n,
+                                    double min_disp, double max_disp, double squared_logres, double* d_disp,
+                                    uint8_t* d_outlier, const uint8_t* d_map_converged, uint8_t* d_part, int mode,
+                                    int ready_limit) {
+    DSQ_CHECK_ARG((mode == 0 || mode == 1) && d_part != nullptr && (mode == 0 || d_map_converged != nullptr),
+                  "mode 1 (the finished genes; needs the MAP flags) or 0 (the rest), and the part vector");
+    DSQ_HIP(dsq::launch_select_disp_part(ctx->stream, d_genewise_raw, d_map_raw, d_fitted, n, min_disp, max_disp,
+                                         2.0 * sqrt(squared_logres), d_disp, d_outlier, d_map_converged, d_part, mode,
+                                         ready_limit));
+    return DSQ_OK;
+}
+
+// What the first launch of an LFC fit in two would otherwise enqueue in front of its kernel - on a stream that shares the
+// device with the dispersion stage's tail, where every small operation waits tens of microseconds for a slot: the logs of
+// the size factors, the Wald test's ridge and contrast, the zeroed counters.  Called on the main stream BEFORE the
+// dispersion stage; consumed (one-shot) by the phase-1 call with the same N and P.
+int dsq_lfc_prepare(dsq_ctx* ctx, const double* d_sf, int N, const double* h_ridge, const double* h_contrast, int P) {
+    DSQ_CHECK_ARG(N >= 1 && P >= 1 && P <= DSQ_MAX_P, "N, P out of range");
+    DSQ_CHECK_ARG(ctx->lfc_pending_G == 0, "a forked LFC launch is still waiting for its second launch");
+    if ((size_t)N > ctx->lsf_cap) {
+        if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
+        ctx->d_lsf = nullptr; ctx->lsf_cap = 0;
+        DSQ_HIP(hipMalloc((void**)&ctx->d_lsf, (size_t)N * sizeof(double)));
+        ctx->lsf_cap = (size_t)N;
+    }
+    DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
+    DSQ_HIP(hipMemsetAsync(ctx->d_counter + 8, 0, 2 * sizeof(int32_t), ctx->stream));
+    ctx->lfc_prepared_wald = 0;
+    if (h_ridge != nullptr && h_contrast != nullptr) {
+        double* d_ridge = ctx->d_scratch + 1664;
+        double* h_stage = (double*)(ctx->h_pin + (P <= 32 ? 16 : 4096));
+        std::memcpy(h_stage, h_ridge, (size_t)P * P * sizeof(double));
+        std::memcpy(h_stage + P * P, h_contrast, (size_t)P * sizeof(double));
+        DSQ_HIP(hipMemcpyAsync(d_ridge, h_stage, (size_t)(P * P + P) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        ctx->lfc_prepared_wald = 1;
+    }
+    ctx->lfc_prepared_N = N;
+    ctx->lfc_prepared_P = P;
+    return DSQ_OK;
+}
+
+int dsq_lfc_set_part(dsq_ctx* ctx, const uint8_t* d_part, int want, int phase) {
+    DSQ_CHECK_ARG(d_part == nullptr || phase == 1 || phase == 2, "phase: 1 (forked launch) or 2 (the rest, join, rescue)");
+    ctx->lfc_part = d_part;
+    ctx->lfc_want = want;
+    ctx->lfc_phase = d_part != nullptr ? phase : 0;
+    return DSQ_OK;
+}
+
+int dsq_lfc_takes_parts(int N, int P, const dsq_cells* cells, const dsq_mix* mix, int full_rank) {
+    return dsq::irls_takes_parts(N, P, cells != nullptr ? cells->n_cells : 0, mix != nullptr ? &mix->d : nullptr, full_rank)
+               ? 1 : 0;
 }
 
 int dsq_dev_scatter_rows_f64(dsq_ctx* ctx, const double* d_src, const int32_t* d_idx, int n_idx, int width,

@@ -83,6 +83,16 @@ struct dsq_ctx {
     size_t mixw_cap = 0;
     int32_t* d_redo = nullptr;    // genes the buffer-less robust-dispersion kernel hands back (side stream; grow-only)
     size_t redo_cap = 0;
+    // An LFC fit in two launches (dsq_lfc_fork_begin / dsq_lfc_set_part): the genes whose MAP dispersion is final after the
+    // dispersion stage's full-size launch are fitted on lfc_stream while the main stream runs that stage's latency-bound tail
+    hipStream_t lfc_stream = nullptr, lfc_return = nullptr;
+    hipEvent_t ev_lfc_fork = nullptr, ev_lfc_done = nullptr;
+    const uint8_t* lfc_part = nullptr;  // dsq_lfc_set_part (one-shot: the next LFC fit consumes it)
+    int lfc_want = 0, lfc_phase = 0;
+    int lfc_prepared_N = 0, lfc_prepared_P = 0, lfc_prepared_wald = 0;  // dsq_lfc_prepare (one-shot, consumed by phase 1)
+    int lfc_pending_G = 0;        // genes of a phase-1 launch whose phase-2 partner (join, rescue of both lists) is still to come
+    int32_t* d_lfc_aux = nullptr; // the phase-1 launch's own fallback list and slot order (ctx->d_list serves the main stream)
+    size_t lfc_aux_cap = 0;
     dsq_pc::Cache* pc = nullptr;  // device-buffer cache + pool of the Inference-level entry points (dsq_plugin_cache.h)
     struct PluginDesign* designs = nullptr;  // factorised designs (+ mixed-design descriptors) of the last few calls
     void* comm = nullptr;         // ncclComm_t (RCCL), set by dsq_comm_init
@@ -403,24 +413,61 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     ex_local.optimizer = optimizer;
     DSQ_CHECK_ARG(optimizer == 0 || P <= DSQ_BFGS_MAX_P, "optimizer=\"BFGS\": designs of at most 12 columns");
     extras = &ex_local;
+    // A fit in two launches (dsq_lfc_set_part, one-shot).  Phase 1: the genes with part[g] == want, on the current stream
+    // (the caller forked: dsq_lfc_fork_begin), with a fallback list, counters and slot order of its own - no host round trip,
+    // no rescue.  Phase 2: the other genes; then the join with phase 1, ONE synchronisation, the rescue of both lists.
+    const uint8_t* const part = ctx->lfc_part;
+    const int part_want = ctx->lfc_want, phase = part != nullptr ? ctx->lfc_phase : 0;
+    ctx->lfc_part = nullptr; ctx->lfc_phase = 0;
+    if (phase != 0) {
+        DSQ_CHECK_ARG(phase == 1 || phase == 2, "dsq_lfc_set_part: phase 1 or 2");
+        DSQ_CHECK_ARG(optimizer == 0 && !ctx->deferred &&
+                          dsq::irls_takes_parts(N, P, ex_local.cells.C, ex_local.mix, full_rank),
+                      "a fit in two launches: the default rescue optimiser, not deferred, a design the part-aware kernels take");
+        DSQ_CHECK_ARG(phase == 1 ? ctx->lfc_pending_G == 0 : ctx->lfc_pending_G == G,
+                      "a fit in two launches: phase 2 follows the phase 1 of the same genes");
+        ex_local.part = part;
+        ex_local.part_want = part_want;
+        ex_local.part_shared_ready = phase == 2 ? 1 : 0;
+    }
     // sixteen-lane kernel: slots ordered by the predicted number of sweeps (the list lives behind the fallback list)
     const bool ordered = G >= kIrlsOrderMinGenes && dsq::irls_takes_rows(N, P, ex_local.cells.C) && irls_order_enabled();
-    DSQ_HIP(ensure_list(ctx, (size_t)G * (ordered ? 2 : 1) + (ordered ? (size_t)dsq::irls_order_work_ints() : 0)));
+    const size_t list_ints = (size_t)G * (ordered ? 2 : 1) + (ordered ? (size_t)dsq::irls_order_work_ints() : 0);
+    int32_t* fb_list = nullptr;
+    int32_t* fb_count = ctx->d_counter;  // [0] fallback genes, [1] gene queue
+    if (phase == 1) {
+        if (list_ints > ctx->lfc_aux_cap) {
+            if (ctx->d_lfc_aux) (void)hipFree(ctx->d_lfc_aux);
+            ctx->d_lfc_aux = nullptr; ctx->lfc_aux_cap = 0;
+            DSQ_HIP(hipMalloc((void**)&ctx->d_lfc_aux, list_ints * sizeof(int32_t)));
+            ctx->lfc_aux_cap = list_ints;
+        }
+        fb_list = ctx->d_lfc_aux;
+        fb_count = ctx->d_counter + 8;   // [8] fallback genes, [9] gene queue of the phase-1 launch
+    } else {
+        DSQ_HIP(ensure_list(ctx, list_ints));
+        fb_list = ctx->d_list;
+    }
     if (ordered) {
-        int32_t* d_order = ctx->d_list + G;
+        int32_t* d_order = fb_list + G;
         DSQ_HIP(dsq::launch_irls_order(ctx->stream, d_disp, ctx->irls_hint_genes == G ? ctx->d_irls_hint : nullptr, G,
                                        d_order, d_order + G));
         ex_local.order = d_order;
     }
     ctx->d_irls_hint = nullptr; ctx->irls_hint_genes = 0;  // one-shot
-    if ((size_t)N > ctx->lsf_cap) {
-        if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
-        ctx->d_lsf = nullptr; ctx->lsf_cap = 0;
-        DSQ_HIP(hipMalloc((void**)&ctx->d_lsf, (size_t)N * sizeof(double)));
-        ctx->lsf_cap = (size_t)N;
+    // (dsq_lfc_prepare did this launch's small operations on the main stream, ahead of the dispersion stage)
+    const bool prepared = phase == 1 && ctx->lfc_prepared_N == N && ctx->lfc_prepared_P == P;
+    ctx->lfc_prepared_N = 0; ctx->lfc_prepared_P = 0; ctx->lfc_prepared_wald = 0;
+    if (phase != 2 && !prepared) {  // (phase 2: the vector of phase 1 - the same size factors - which that launch may still be reading)
+        if ((size_t)N > ctx->lsf_cap) {
+            if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
+            ctx->d_lsf = nullptr; ctx->lsf_cap = 0;
+            DSQ_HIP(hipMalloc((void**)&ctx->d_lsf, (size_t)N * sizeof(double)));
+            ctx->lsf_cap = (size_t)N;
+        }
+        DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
     }
-    DSQ_HIP(dsq::launch_log_vec(ctx->stream, d_sf, N, ctx->d_lsf));
-    DSQ_HIP(hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(int32_t), ctx->stream));  // [0] fallback genes, [1] gene queue
+    if (!prepared) DSQ_HIP(hipMemsetAsync(fb_count, 0, 2 * sizeof(int32_t), ctx->stream));
     if (ex_local.mix != nullptr && dsq::irls_takes_mix(ex_local.mix, full_rank)) {
         const int n_layers = ((ex_local.flags != nullptr && ex_local.cooks != nullptr) ? 1 : 0) + (d_mu != nullptr ? 1 : 0) +
                              (d_hat != nullptr ? 1 : 0);
@@ -433,7 +480,7 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
         }
         ex_local.mix_work = ctx->d_mixw;
         ex_local.mix_work_bytes = ctx->mixw_cap;
-        ex_local.mix_queue = ctx->d_counter + 1;
+        ex_local.mix_queue = fb_count + 1;
         // the counts in slot order: the caller's copy (dsq_mix_bind) or one built here
         ex_local.mix_ys = ctx->bind_ys;
         ex_local.mix_big = ctx->bind_big;
@@ -456,29 +503,43 @@ int run_irls(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, cons
     }
     DSQ_HIP(dsq::launch_irls(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, G, P, full_rank, d_disp,
                              min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu, d_hat,
-                             d_converged, d_iters, ctx->d_counter, ctx->d_list, extras));
+                             d_converged, d_iters, fb_count, fb_list, extras));
+    if (phase == 1) {  // its partner joins, synchronises and rescues
+        ctx->lfc_pending_G = G;
+        return DSQ_OK;
+    }
     int32_t* h_cnt = ctx->h_pin;
     // deferred mode (see run_alpha): the rescue pass is enqueued for all G genes as a capacity, count on the device
     const bool deferred = ctx->deferred && G <= kDeferredMaxGenes && optimizer == 0 &&
                           !dsq::irls_is_wide(P, extras->cells.C);
-    int32_t n_fb = G;
+    int32_t n_fb = G, n_fb1 = 0;
+    if (phase == 2) {  // behind the phase-1 launch from here on (dsq_lfc_fork_end recorded its end)
+        ctx->lfc_pending_G = 0;
+        DSQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_lfc_done, 0));
+        DSQ_HIP(hipMemcpyAsync(h_cnt + 2, ctx->d_counter + 8, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (!deferred) {
         DSQ_HIP(hipMemcpyAsync(h_cnt, ctx->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         DSQ_HIP(hipStreamSynchronize(ctx->stream));
         n_fb = *h_cnt;
+        if (phase == 2) n_fb1 = h_cnt[2];
     }
-    if (n_fb > 0) {  // stream-ordered ahead of the caller's next work: no second synchronisation
+    ex_local.part = nullptr;  // (the rescue kernels run from the lists)
+    for (int leg = 0; leg < 2; ++leg) {
+        const int32_t n_leg = leg == 0 ? n_fb : n_fb1;
+        const int32_t* list_leg = leg == 0 ? ctx->d_list : ctx->d_lfc_aux;
+        if (n_leg <= 0) continue;  // stream-ordered ahead of the caller's next work: no second synchronisation
         if (ex_local.cooks_ld != 0 && ex_local.cooks != nullptr && ex_local.flags != nullptr) {
             // slot-ordered Cook's layer (mixed designs): the general rescue kernels write sample order - into scratch rows
             // that launch_irls_rescue scatters through MixDesign::slot_of
-            DSQ_HIP(ensure_ws(ctx, (size_t)n_fb * ldn * sizeof(double)));
+            DSQ_HIP(ensure_ws(ctx, (size_t)(n_fb > n_fb1 ? n_fb : n_fb1) * ldn * sizeof(double)));
             ex_local.cooks_tmp = (double*)ctx->d_ws;
             ex_local.mix = extras_in_mix;
         }
         DSQ_HIP(dsq::launch_irls_rescue(ctx->stream, d_y, ldn, d_sf, ctx->d_lsf, d_Xt, d_pinvXt, ldx, N, P, full_rank,
                                         d_disp, min_mu, beta_tol, min_beta, max_beta, maxiter, d_beta, d_mu,
-                                        d_hat, d_converged, d_iters, ctx->d_list, n_fb, extras,
-                                        deferred ? ctx->d_counter : nullptr));
+                                        d_hat, d_converged, d_iters, list_leg, n_leg, extras,
+                                        (deferred && leg == 0) ? ctx->d_counter : nullptr));
     }
     return DSQ_OK;
 }

@@ -55,6 +55,15 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
     extern __shared__ __attribute__((aligned(16))) double irls_lds[];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * kWavesPerBlock + w;
+    if (ex.part != nullptr) {  // a fit in two launches: a workgroup none of whose genes is in this launch's part leaves at once
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) {
+            const int gk = blockIdx.x * kWavesPerBlock + k;
+            any = any || (gk < G && ex.part[gk] == (uint8_t)ex.part_want);
+        }
+        if (!any) return;
+    }
     log_tab_fill();  // the table of flog_t (dsq_math.h); the barrier below covers it
     double* lds_next = irls_lds;
     if (CELL) {  // the cells' tables once per workgroup into LDS (read by every entry-parallel rebuild)
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(kBlock, CELL == 1 ? cell_min_waves(P) : irls_min_wa
     }
     __syncthreads();
     if (g >= G) return;
+    if (ex.part != nullptr && ex.part[g] != (uint8_t)ex.part_want) return;
 #if defined(DSQ_PHASE_TIMING)
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < kPhases; ++k) g_ph_acc[w][k] = 0;
@@ -147,7 +157,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
     constexpr int T = Tri<P>::N;
     const int row = threadIdx.x >> 4;
     const int slot = blockIdx.x * kRowGenes + row;
-    const int g = slot < G ? (ex.order != nullptr ? ex.order[slot] : slot) : G;
+    int g = slot < G ? (ex.order != nullptr ? ex.order[slot] : slot) : G;
+    if (ex.part != nullptr && g < G && ex.part[g] != (uint8_t)ex.part_want) g = G;  // not in this launch's part
+    if (ex.part != nullptr && __syncthreads_count(g < G) == 0) return;
     log_tab_fill();
     double* sXX = irls_lds;
     double* sXc = sXX + ex.cells.C * T;
@@ -418,6 +430,12 @@ static size_t row_lds_bytes(int C, int P, int N) {
 static int irls_row_min_genes() {  // (read per launch: tests pin both kernels to the reference KATs in one process)
     const char* e = getenv("DSQ_IRLS_ROW_MIN_G");
     return e ? atoi(e) : 1024;
+}
+
+bool irls_takes_parts(int N, int P_, int n_cells, const MixDesign* mix, int full_rank) {
+    (void)N;
+    if (mix != nullptr && irls_takes_mix(mix, full_rank)) return true;
+    return !(P_ > DSQ_REG_MAX_P || (P_ >= wide_min_p() && (n_cells == 0 || wide_with_cells())));
 }
 
 bool irls_takes_rows(int N, int P_, int n_cells) {

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
     const double* __restrict__ disp, double min_mu, double beta_tol, double max_beta, int maxiter,
     double* __restrict__ beta_out, double* __restrict__ m_out,
     uint8_t* __restrict__ conv, int32_t* __restrict__ iters, int32_t* __restrict__ fb_count,
-    int32_t* __restrict__ fb_list) {
+    int32_t* __restrict__ fb_list, const uint8_t* __restrict__ part, int part_want) {
     constexpr int T = Tri<P>::N;
     constexpr int QQ = Q * (Q + 1) / 2;
     constexpr int U = kMixU;
@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256, 2) void k_irls_mix(
         if (lane == 0) g = atomicAdd(queue, 1);
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= G) break;
+        // (a fit in two launches, IrlsExtras::part: the other launch's genes are left alone)
+        if (part != nullptr && __builtin_amdgcn_readfirstlane((int)part[g]) != part_want) continue;
         const double dsp = DeviceWave::uniform(disp[g]);
         const double a = DeviceWave::uniform(1.0 / dsp);
         const int32_t* const yg = y + (size_t)g * ldn;
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(256, 3) void k_mix_epilogue(
     __syncthreads();
     const int g = blockIdx.x * 4 + w;
     if (g >= G) return;
+    if (ex.part != nullptr && __builtin_amdgcn_readfirstlane((int)ex.part[g]) != ex.part_want) return;  // the other launch's
     if (__builtin_amdgcn_readfirstlane((int)conv[g]) == 0) return;  // diverged: the rescue kernel writes this gene's outputs
 
     // lane e owns entry e = tri(ei, ej) of X^T W X (as in k_irls_mix)
@@ -814,8 +817,9 @@ hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
     double* lsfs = sfs + D.Ns;
     uint8_t* flags_s = (uint8_t*)(lsfs + D.Ns);
     double* m_buf = epilogue ? (double*)((char*)work + m_off) : nullptr;  // the last sweep's X^T W X, [G][T]
-    hipLaunchKernelGGL(k_mix_prep<Q>, dim3((D.Ns + 255) / 256), dim3(256), 0, st, sf, ex.flags, D.perm, D.Ns, sfs, lsfs,
-                       flags_s);
+    if (!(ex.part != nullptr && ex.part_shared_ready))  // (the partner launch of a two-launch fit may still be reading them)
+        hipLaunchKernelGGL(k_mix_prep<Q>, dim3((D.Ns + 255) / 256), dim3(256), 0, st, sf, ex.flags, D.perm, D.Ns, sfs, lsfs,
+                           flags_s);
     {
         const hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return e0;
@@ -838,7 +842,7 @@ hipError_t DSQ_MIX_CAT(launch_irls_mix_q, DSQ_MIX_Q)(
             }                                                                                                           \
             hipLaunchKernelGGL((k_irls_mix<PP, Q>), dim3(blocks), dim3(64 * nw), smem, st, y, ldn, ys, ys_big, D,      \
                                cont_mask, sfs, lsfs, flags_s, G, queue, disp, min_mu, beta_tol, max_beta, maxiter, beta, \
-                               m_buf, conv, iters, fb_count, fb_list);                                                  \
+                               m_buf, conv, iters, fb_count, fb_list, ex.part, ex.part_want);                           \
             if (epilogue) {                                                                                             \
                 const hipError_t e1 = hipGetLastError();                                                                \
                 if (e1 != hipSuccess) return e1;                                                                        \

@@ -1404,6 +1404,35 @@ __global__ void k_select_disp(double* __restrict__ gw_raw, double* __restrict__ 
     if (map_raw[i] == map_raw[i]) map_raw[i] = mp;
 }
 
+// The same selection for one part of the genes (an LFC fit in two launches, dsq_dev_select_dispersions_part):
+// mode 1: the genes whose MAP fit has finished AND converged in the stage's full-size launch (map_conv[i] == 1; the vector
+//         was filled with 0xFF before that launch, parked genes have not written theirs) - part[i] = 1 for them, 0 for the rest;
+// mode 0: the rest (part[i] == 0), once the continuation launch and the grid-search pass have run.
+__global__ void k_select_disp_part(double* __restrict__ gw_raw, double* __restrict__ map_raw,
+                                   const double* __restrict__ fitted, int n, double min_disp, double max_disp,
+                                   double two_sd, double* __restrict__ disp, uint8_t* __restrict__ outlier,
+                                   const uint8_t* __restrict__ map_conv, uint8_t* __restrict__ part, int mode,
+                                   int ready_limit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (mode == 1) {
+        // (genes from ready_limit on wait for the second launch whatever their fit: their robust dispersions - read by the
+        // LFC fit's epilogue - are computed beside the first one)
+        const bool ready = map_conv[i] == 1 && i < ready_limit;
+        part[i] = ready ? 1 : 0;
+        if (!ready) return;
+    } else if (part[i] != 0) {
+        return;
+    }
+    const double gw = fmin(fmax(gw_raw[i], min_disp), max_disp);
+    const double mp = fmin(fmax(map_raw[i], min_disp), max_disp);
+    const bool out = log(gw) > log(fitted[i]) + two_sd;
+    disp[i] = out ? gw : mp;
+    outlier[i] = out ? 1 : 0;
+    if (gw_raw[i] == gw_raw[i]) gw_raw[i] = gw;
+    if (map_raw[i] == map_raw[i]) map_raw[i] = mp;
+}
+
 // dst[idx[k]][0..width) = src[k][0..width)   (results of the outlier refit back into the full vectors)
 __global__ void k_scatter_rows(const double* __restrict__ src, const int32_t* __restrict__ idx, int n_idx,
                                int width, double* __restrict__ dst, const int32_t* __restrict__ n_dev) {
@@ -1506,6 +1535,14 @@ hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, c
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_select_disp, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, map_raw, fitted, n,
                        min_disp, max_disp, two_sd, disp, outlier);
+    return hipGetLastError();
+}
+hipError_t launch_select_disp_part(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted, int n,
+                                   double min_disp, double max_disp, double two_sd, double* disp, uint8_t* outlier,
+                                   const uint8_t* map_conv, uint8_t* part, int mode, int ready_limit) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select_disp_part, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, map_raw, fitted, n, min_disp,
+                       max_disp, two_sd, disp, outlier, map_conv, part, mode, ready_limit);
     return hipGetLastError();
 }
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,

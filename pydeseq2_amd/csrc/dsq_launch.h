@@ -206,7 +206,15 @@ struct IrlsExtras {
     int32_t* mix_queue;
     const uint16_t* mix_ys;      // [G][Ns] counts in slot order (launch_mix_counts_to_slots) and, per gene, whether a count
     const uint8_t* mix_big;      // did not fit its 16 bits (such a gene gathers its counts from the int32 row)
+    // a fit in two launches (dsq_lfc_set_part): part != null: only the genes with part[g] == part_want are fitted, the
+    // others are left alone (no output of theirs is touched).  The register kernels and the mixed-design kernels take it
+    // (irls_takes_parts); part_shared_ready: the launch's shared tables (mix_work) were written by the partner launch.
+    const uint8_t* part;
+    int part_want;
+    int part_shared_ready;
 };
+// does launch_irls honour IrlsExtras::part for this design?  (the run-time-P LDS kernels do not)
+bool irls_takes_parts(int N, int P, int n_cells, const MixDesign* mix, int full_rank);
 bool irls_takes_mix(const MixDesign* mix, int full_rank);
 // device scratch of a mixed-design fit of G genes that writes n_layers N x G layers (Cook's distances, mu, hat diagonal)
 size_t irls_mix_work_bytes(const MixDesign& D, int G, int n_layers);
@@ -315,6 +323,9 @@ hipError_t launch_trend_eval_dev(hipStream_t st, const double* nm, int n, const 
 hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted,
                               int n, double min_disp, double max_disp, double two_sd, double* disp,
                               uint8_t* outlier);
+hipError_t launch_select_disp_part(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted, int n,
+                                   double min_disp, double max_disp, double two_sd, double* disp, uint8_t* outlier,
+                                   const uint8_t* map_conv, uint8_t* part, int mode, int ready_limit);
 // n_dev (here and below): the kernel is launched for n_* rows as a CAPACITY and reads the actual count from device
 // memory - second passes can be enqueued without the host having seen how many genes need them
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,

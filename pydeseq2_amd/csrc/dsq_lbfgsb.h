@@ -169,6 +169,13 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
     int* iwhere = W.iwhere;
     int* indx2 = W.indx2;
 
+    {   // scipy hands setulb zero-initialised work arrays (numpy.zeros in _minimize_lbfgsb) and the routine, as written in
+        // Fortran, reads entries of them it has not written yet (bounded problems: seen on a gene whose IRLS rescue changed
+        // its iterates from pass to pass with whatever the previous workgroup had left in LDS): they are 0 there, and here
+        uint32_t* wz = (uint32_t*)&W;
+        for (int i = Wv::lane(); i < (int)(sizeof(W) / 4); i += Wv::W) wz[i] = 0u;
+        Wv::sync();
+    }
     LbfgsbResult R;
     int col = 0, head = 1, itail = 0, iupdat = 0, iter = 0, nfev = 0, nfree = n, nenter = 0,
         ileave = 0, nseg = 0;

@@ -210,6 +210,22 @@ class DeseqPipeline:
         self._map_waits_side = (self._row_mode == 1) if mw is None else (mw != "0")
         # share of the genes whose robust dispersions run under the genewise stage's tail (the rest: under the MAP stage's)
         self._robust_split = float(os.environ.get("DSQ_ROBUST_SPLIT", "0.78"))
+        # LFC fit in two launches: the genes whose MAP dispersion is final after the MAP stage's full-size launch are fitted
+        # underneath that stage's latency-bound tail (_fork_lfc); DSQ_LFC_OVERLAP=0: one launch after the stage (A/B switch)
+        # Measured on one box, ms per step with / without: c4 7.08 / 7.37, c5 shard of 7500 genes 7.22 / 7.78 (their tails are
+        # 0.5-0.8 ms of a few workgroups on an otherwise idle device); c4 shard of 7500 2.47 / 2.52.  No gain where the device
+        # is busy during the tail anyway or the tail is short: c5 whole 45.0 / 44.75 (the robust-dispersion kernel of the side stream
+        # runs 2-3 ms past the tail there, see above), c3 5.74 / 5.60, c2 1.84 / 1.69, c3 shard 1.80 / 1.79 (<= 4 cells: a 0.35 ms
+        # tail that already carries the robust dispersions' part two - the device is 88 % busy without the fork and the small
+        # launches beside a full-size kernel cost more than the rest is worth), general kernels 16.95 / 16.67.  Hence: the
+        # many-cell family always, the mixed-design family up to DSQ_LFC_OVERLAP_MAX_WORK = 1.5e8 counts per device.
+        lo = os.environ.get("DSQ_LFC_OVERLAP")
+        max_work = float(os.environ.get("DSQ_LFC_OVERLAP_MAX_WORK", "1.5e8"))
+        auto = self._row_mode == 2 or (self._row_mode == 3 and float(self.G) * self.N <= max_work)
+        self._lfc_overlap = auto if lo is None else (lo != "0")
+        self._lfc_min_genes = int(os.environ.get("DSQ_LFC_OVERLAP_MIN_GENES", "2048"))
+        self._lfc_forked = False
+        self.lfc_forks = 0  # passes whose LFC fit ran in two launches (tests)
         self._work = None
         self.layers = {}
         self.time_kernels = False
@@ -249,9 +265,12 @@ class DeseqPipeline:
         return ptr
 
     def _pool_reset(self):
-        if getattr(self, "_side_pending", False):  # a previous step died between the fork and the join of the side
-            self.ctx.call("dsq_side_abort")        # stream: its kernel may still be writing pooled buffers
+        if getattr(self, "_side_pending", False) or getattr(self, "_lfc_forked", False):
+            # a previous step died between a fork and its join (side stream, forked LFC launch): their kernels may still be
+            # writing pooled buffers
+            self.ctx.call("dsq_side_abort")
             self._side_pending = False
+            self._lfc_forked = False
         self._pool_free.extend(self._pool_used)
         self._pool_used = []
         self._serial = getattr(self, "_serial", 0) + 1  # an open pass (_Step) lives until the next reset
@@ -537,23 +556,32 @@ class DeseqPipeline:
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
 
-    def _stage_map(self, d_y, mh, Gs, d_sf, prior_var, squared_logres, S):
+    def _stage_map(self, d_y, mh, Gs, d_sf, prior_var, squared_logres, S, part_of=None):
         """MAP dispersions (dds.py:886-935) from S[fit] -> S[map (raw), mconv], then the final
         dispersions S[disp] and the dispersion-outlier flags S[outl]."""
         self._alpha_fit("alpha_map", d_y, mh, Gs, d_sf, S["fit"], prior_var, 1, S["map"], S["mconv"], 2)
-        self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
-                      c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
-                      _vp(S["disp"].ptr), _vp(S["outl"].ptr))
+        d_part = part_of() if part_of is not None else None
+        if d_part is not None:  # the finished genes took theirs inside the fit (_fork_lfc): the rest
+            self.ctx.call("dsq_dev_select_dispersions_part", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
+                          c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
+                          _vp(S["disp"].ptr), _vp(S["outl"].ptr), None, _vp(d_part.ptr), 0, 0)
+        else:
+            self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
+                          c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
+                          _vp(S["disp"].ptr), _vp(S["outl"].ptr))
 
-    def _stage_lfc(self, d_y, Gs, d_sf, S, wald, cooks=None, mix_slots=None):
+    def _stage_lfc(self, d_y, Gs, d_sf, S, wald, cooks=None, mix_slots=None, bufs=None, part=None):
         """IRLS LFC fit (dds.py:937-984) with S[disp] -> S[beta, lconv] and, fused into its epilogue, the Wald
         statistics S[p, stat, se] (ds.py:303-360; wald = (ridge, contrast, lfc_null, alt)) and - cooks =
         (robust dispersions, cutoff, cooks layer) - the per-sample half of the Cook's stage (dds.py:986-1040,
         1066-1110): S[any_all, any_use, any_use_nr, few_above].  Returns device (mu, hat) when keep_layers."""
         D = self.design
         want = self.keep_layers and cooks is not None
-        d_mu = self._dmat(Gs) if want else None
-        d_hat = self._dmat(Gs) if want else None
+        if bufs is not None:  # the second launch of a fit in two (part): the layers of the first
+            d_mu, d_hat = bufs
+        else:
+            d_mu = self._dmat(Gs) if want else None
+            d_hat = self._dmat(Gs) if want else None
         ridge, contrast, lfc_null, alt = wald
         ck = [None, None, c_double(0.0), None, None, None, None, None]
         cooks_ld = 0
@@ -565,6 +593,8 @@ class DeseqPipeline:
         if S.get("_irls_it") is not None:
             self.ctx.call("dsq_irls_order_hint", _vp(S["_irls_it"].ptr), Gs)
         self._mix_bind(mix_slots, genes=Gs)
+        if part is not None:  # (device vector, value of this launch's genes, phase): csrc dsq_lfc_set_part, one-shot
+            self.ctx.call("dsq_lfc_set_part", _vp(part[0].ptr), int(part[1]), int(part[2]))
         self._k("lfc_fit", Gs, "dsq_dev_lfc_fit2", _vp(d_y.ptr), self.ldn, _vp(d_sf.ptr), _vp(self.d_Xt.ptr),
                 _vp(self.d_pinv.ptr), D.ldx, self.N, Gs, self.P, int(D.full_rank), _vp(S["disp"].ptr),
                 c_double(self.min_mu), c_double(self.beta_tol), c_double(-30.0), c_double(30.0), self.irls_maxiter,
@@ -949,16 +979,73 @@ class DeseqPipeline:
             # its whole life (persistent workgroups) and pays more than the wait costs (A/B: DSQ_MAP_WAIT=0)
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        fit = lambda: self._stage_map(st.d_ynz, st.mh, Gn, st.d_sf, r.prior_disp_var, r.squared_logres, S)  # noqa: E731
         second = st.g_cut < Gn and st.whole
-        if second and not self.time_kernels:
-            _, fired = self._with_alpha_hook(fit, lambda: self._launch_robust(st, 1))
+        # The LFC fit of a gene needs that gene's final dispersion only (dds.py:937-984).  In a whole pass the genes whose MAP
+        # fit is finished after the stage's full-size launch (~99 %: converged, not parked) start their LFC fit from the hook,
+        # on a stream of their own; the continuation of the parked fits, the host round trip and the grid-search pass - the
+        # latency-bound 0.3-0.4 ms that used to stand between the two full-size kernels - run beside it, and the rest of the
+        # genes follow in a second launch (_st_lfc).
+        fork = (self._lfc_overlap and self.overlap and st.whole and not self.time_kernels and not st.profile
+                and Gn >= self._lfc_min_genes
+                and bool(ctx.lib.dsq_lfc_takes_parts(self.N, self.P, self._cells_arg(), _vp(self._mix) if self._mix else None,
+                                                     int(self.design.full_rank))))
+        st.lfc_forked = False
+        if fork:
+            self._lfc_prepare(st)
+            st.d_part = self._dvec(Gn, np.uint8)
+            ctx.call("dsq_memset", _vp(S["mconv"].ptr), 0xFF, C.c_size_t(Gn))  # "not finished": the fits write 0 / 1
+            # (the first launch's small operations here, on an idle device, instead of beside the stage's tail)
+            ctx.call("dsq_lfc_prepare", _vp(st.d_sf.ptr), self.N, _vp(st.wald_args[0].ctypes.data),
+                     _vp(st.wald_args[1].ctypes.data), self.P)
+
+        def launch():
+            # the fork first: its launch starts behind the robust dispersions the side stream holds NOW (part one); the genes
+            # of part two - computed beside it - take the second launch (ready_limit)
+            if fork:
+                self._fork_lfc(st)
+            if second or not st.robust_done[1]:
+                self._launch_robust(st, 1)
+
+        fit = lambda: self._stage_map(st.d_ynz, st.mh, Gn, st.d_sf, r.prior_disp_var, r.squared_logres, S,  # noqa: E731
+                                      part_of=(lambda: st.d_part if st.lfc_forked else None) if fork else None)
+        if (second or fork) and not self.time_kernels:
+            _, fired = self._with_alpha_hook(fit, launch)
         else:
             fit()
             fired = False
         if second and not fired:
             self._launch_robust(st, 1)
         self._lap(st, "MAP")
+
+    def _lfc_prepare(self, st):
+        """Arguments and buffers of the LFC fit (the Wald test's ridge and contrast, the Cook's layer) - once per pass."""
+        P, Gn = self.P, st.Gn
+        st.cutoff = self._cooks_cutoff
+        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
+        st.wald_args = (ridge, st.contrast, float(np.log(2) * st.lfc_null), ALT[st.alt])
+        st.cld = cld = self._cooks_ld()
+        st.d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
+
+    def _fork_lfc(self, st):
+        """From inside the MAP stage, its full-size launch enqueued (the hook): final dispersions of the finished genes and
+        their LFC fit on the forked stream (csrc dsq_lfc_fork_begin: behind that launch and the robust dispersions)."""
+        ctx, r, S, Gn = self.ctx, st.r, st.S, st.Gn
+        ctx.call("dsq_lfc_fork_begin")
+        self._lfc_forked = True  # until the second launch has joined (_pool_reset: dsq_side_abort)
+        try:
+            ctx.call("dsq_dev_select_dispersions_part", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gn,
+                     c_double(self.min_disp), c_double(self.max_disp), c_double(r.squared_logres), _vp(S["disp"].ptr),
+                     _vp(S["outl"].ptr), _vp(S["mconv"].ptr), _vp(st.d_part.ptr), 1,
+                     int(Gn if st.robust_done[1] else st.g_cut))
+            st.lfc_bufs = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], st.cutoff, st.d_cooks),
+                                          mix_slots=st.mix_slots, part=(st.d_part, 1, 1))
+            ctx.call("dsq_lfc_fork_end")
+        except BaseException:
+            ctx.call("dsq_side_abort")  # back on the main stream, the forked one drained
+            self._lfc_forked = False
+            raise
+        st.lfc_forked = True
+        self.lfc_forks += 1
 
     # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics
     # (ds.py:303-360) in its epilogue: mu and the hat diagonal are consumed from registers
@@ -967,16 +1054,20 @@ class DeseqPipeline:
         for part in (0, 1):  # stage by stage: nobody has launched the robust dispersions yet
             if not st.robust_done[part]:
                 self._launch_robust(st, part, side=False)
-        st.cutoff = cutoff = self._cooks_cutoff
-        ridge = np.ascontiguousarray(np.diag(np.repeat(1e-6, P)))
-        st.wald_args = (ridge, st.contrast, float(np.log(2) * st.lfc_null), ALT[st.alt])
-        st.cld = cld = self._cooks_ld()
-        st.d_cooks = self._pooled((max(Gn, 1), cld), np.float64, ld=cld) if cld else self._dmat(Gn)
+        forked = getattr(st, "lfc_forked", False)
+        if not forked:
+            self._lfc_prepare(st)
+        cutoff, cld = st.cutoff, st.cld
         if self.overlap and self._side_pending:
             ctx.call("dsq_side_wait")
             self._side_pending = False
-        d_mu, d_hat = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], cutoff, st.d_cooks),
-                                      mix_slots=st.mix_slots)
+        if forked:  # the genes the MAP stage's tail finished; the call joins the first launch and rescues for both
+            d_mu, d_hat = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], cutoff, st.d_cooks),
+                                          mix_slots=st.mix_slots, bufs=st.lfc_bufs, part=(st.d_part, 0, 2))
+            self._lfc_forked = False
+        else:
+            d_mu, d_hat = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], cutoff, st.d_cooks),
+                                          mix_slots=st.mix_slots)
         st.want_refit = self.refit_cooks and D.replaceable.sum() > 0
         # Everything in S is final now except the rows the refit will replace: in a whole pass the block copy of the
         # result vectors starts here, on the side stream, and runs underneath the refit's kernels; the host patches
@@ -1254,9 +1345,10 @@ class DeseqPipeline:
 
     def close(self):
         """Release the pooled device buffers."""
-        if getattr(self, "_side_pending", False):
+        if getattr(self, "_side_pending", False) or getattr(self, "_lfc_forked", False):
             self.ctx.call("dsq_side_abort")
             self._side_pending = False
+            self._lfc_forked = False
         for _cap, ptr in self._pool_free + self._pool_used:
             self.ctx.free(ptr)
         self._pool_free, self._pool_used = [], []

@@ -436,6 +436,86 @@ def test_sixteen_lane_irls_equals_the_wavefront_kernel():
     assert_close(b["se"][same], a["se"][same], 1e-6, 0, "lfcSE")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["2level", "3factor", "mixed", "2level_layers", "continuous"])
+def test_lfc_fit_in_two_launches_equals_the_single_launch(kind):
+    """In a whole pass the genes whose MAP dispersion is final after the MAP stage's full-size launch start their LFC fit
+    from inside that stage, on a stream of their own, and the rest follow in a second launch that joins it
+    (pipeline._fork_lfc, csrc dsq_lfc_set_part).  Every gene is fitted exactly once with its final dispersion: the results
+    are BIT-identical to the single launch (DSQ_LFC_OVERLAP=0), over the wavefront kernel (two cells), the sixteen-lane
+    kernel (30 cells), the mixed-design kernels and the general kernel, with zero genes, injected outliers (the refit)
+    and, once, the N x G layers kept."""
+    from pydeseq2_amd import DeseqPipeline
+
+    if kind == "mixed":
+        counts, X = _mixed_case(8, 3, 1400, 3000, 5, (2, 4))
+    elif kind == "3factor":
+        counts, X = orc.synth_counts(3200, 120, "3factor", 11)
+    elif kind == "continuous":  # four covariates: beyond the mixed-design kernels, no cells - the general kernel
+        counts, X = _mixed_case(5, 4, 200, 3000, 12, ())
+    else:
+        counts, X = orc.synth_counts(6000, 200, "2level", 13)
+    counts = counts.copy()
+    counts[:, 17] = 0
+    counts[3, 40:44] = 150000  # Cook's outliers: replaced, refitted
+    keep = kind.endswith("_layers")
+    pipe = DeseqPipeline(counts, X, device=0)
+    pipe.keep_layers = keep
+    pipe._lfc_overlap = True  # (the default depends on the design family: DSQ_LFC_OVERLAP)
+    forks = pipe.lfc_forks
+    a = pipe.deseq2()
+    assert pipe.lfc_forks == forks + 1, "the LFC fit did not fork"
+    la = {k: pipe.layer(k).copy() for k in (("mu_LFC", "hat_diagonals", "cooks") if keep else ("cooks",))}
+    a2 = pipe.deseq2()  # a second pass on recycled buffers
+    pipe._lfc_overlap = False
+    b = pipe.deseq2()
+    assert pipe.lfc_forks == forks + 2
+    lb = {k: pipe.layer(k).copy() for k in la}
+    if kind in ("2level", "2level_layers", "3factor"):  # (continuous covariates: no sample is replaceable, dds.py:1301-1330)
+        assert a.refitted.sum() >= 1
+    # the sixteen-lane kernel (30 cells) is not bit-reproducible from pass to pass whatever the launch: a row that has
+    # converged keeps sweeping until the slowest of its wavefront's four genes has, and which four share a wavefront is
+    # decided by atomics (differences of a few ulp, with or without the fork)
+    exact = kind != "3factor"
+    for f in ("size_factors", "genewise_dispersions", "MAP_dispersions", "MAP_converged", "dispersions", "outlier_genes", "LFC",
+              "LFC_converged", "lfcSE", "stat", "pvalue", "cooks_outlier", "replaced", "refitted"):
+        for x in (a, a2):
+            va, vb = np.asarray(getattr(x, f)), np.asarray(getattr(b, f))
+            assert va.shape == vb.shape
+            if exact or va.dtype.kind != "f":
+                assert np.array_equal(va, vb, equal_nan=va.dtype.kind == "f"), f
+            else:
+                ok = np.isfinite(vb)
+                assert (np.isfinite(va) == ok).all(), f
+                assert_close(va[ok], vb[ok], 1e-9, 1e-12, f)
+    for k in la:
+        if exact:
+            assert np.array_equal(la[k], lb[k], equal_nan=True), k
+        else:
+            ok = np.isfinite(lb[k])
+            assert_close(la[k][ok], lb[k][ok], 1e-9, 1e-12, k)
+
+
+@pytest.mark.gpu
+def test_rescued_gene_is_reproducible_from_pass_to_pass():
+    """A gene whose IRLS diverges is rescued by the bounded L-BFGS-B (utils.py:389-399).  scipy hands that routine
+    zero-initialised work arrays and the routine reads entries it has not written yet; the device workspace lives in LDS,
+    which holds whatever the previous workgroup left: before it was zeroed (dsq_lbfgsb.h) such a gene took 14, 18, 20 or 22
+    iterations from one whole pass to the next and its dispersions moved in the sixth digit."""
+    from pydeseq2_amd import DeseqPipeline
+
+    counts, X = _mixed_case(5, 4, 200, 3000, 12, ())  # four covariates: the general kernels
+    counts = counts.copy()
+    counts[3, 40:44] = 150000  # one sample with a count three orders of magnitude beyond the rest, in four genes
+    pipe = DeseqPipeline(counts, X, device=0)
+    seen = set()
+    for _ in range(10):
+        r = pipe.deseq2()
+        seen.add((r.genewise_dispersions[40:44].tobytes(), r.dispersions[40:44].tobytes(), r.LFC[40:44].tobytes(),
+                  r.pvalue[40:44].tobytes()))
+    assert len(seen) == 1
+
+
 def test_hip_inference_under_the_reference_orchestration():
     """All Inference methods of the plug-in driven in DeseqDataSet.deseq2()'s call order with the reference's
     keyword arguments (dds.py:713-984, ds.py:303-360; the orchestration is the oracle's restatement of it, since

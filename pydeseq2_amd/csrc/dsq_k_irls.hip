@@ -171,12 +171,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_irls_row(const int32_t* __restric
     int32_t* s_rep = s_cell + npad;  // one sample of each cell
     for (int i = threadIdx.x; i < ex.cells.C * T; i += kBlock) sXX[i] = ex.cells.XX[i];
     for (int i = threadIdx.x; i < ex.cells.C * P; i += kBlock) sXc[i] = ex.cells.Xc[i];
+    // the cell's FIRST sample represents it: the columns of pinv(X) of two samples with the same design row agree to
+    // rounding only, and "whichever thread wrote last" made the start values - hence the last bits of the fit - differ
+    // from launch to launch
+    if (full_rank) {
+        for (int i = threadIdx.x; i < ex.cells.C; i += kBlock) s_rep[i] = 0x7fffffff;
+        __syncthreads();
+    }
     for (int n = threadIdx.x; n < N; n += kBlock) {
         s_sf[n] = sf[n];
         s_lsf[n] = lsf != nullptr ? lsf[n] : 0.0;
         const int c = ex.cells.cell_of[n];
         s_cell[n] = c;
-        s_rep[c] = n;  // any sample of the cell will do
+        if (full_rank) atomicMin(&s_rep[c], n);
     }
     if (full_rank) {
         __syncthreads();

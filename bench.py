@@ -322,9 +322,11 @@ def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs, 
         pipe.deseq2()
     pipe.kernel_log = {}
     ctx.sync()
+    forks0 = pipe.lfc_forks
     t0 = time.perf_counter()
     wall, gpu = timed_steps(pipe, ctx, steps)
     loop_ms = (time.perf_counter() - t0) * 1e3 / steps
+    lfc_forked = pipe.lfc_forks > forks0
     dt = float(np.median(wall)) * 1e-3
     big = [(ms, g) for ms, g in pipe.kernel_log.get("k_alpha", []) if g > 0.5 * G]
     full_ms = float(np.median([ms for ms, _ in big])) if big else None
@@ -338,6 +340,10 @@ def measure_other_config(name, genes, ctx, steps, warmup, parity_genes, n_jobs, 
            "timing_note": "ms_per_step = median wall time of the individually timed passes; gpu_events = HIP events on the "
                           "engine's stream around the same passes (a host stall widens wall only)",
            "generator_s": round(t_gen, 2),
+           "lfc_fit_in_two_launches": bool(lfc_forked),
+           "lfc_note": ("the LFC fit of the genes whose MAP dispersion is final starts under the MAP stage's tail (DESIGN 5): the "
+                        "MAP launch's continuation shares the device with it, so full_launch_ms of that stage is 4-6 % longer "
+                        "than alone (DSQ_LFC_OVERLAP=0) while the step is shorter") if lfc_forked else None,
            "dispersion_stage": None if full_ms is None else {
                "full_launch_ms": round(full_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                "achieved_GBps": round(alg / (full_ms * 1e-3) / 1e9, 2),

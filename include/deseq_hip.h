@@ -487,7 +487,8 @@ int dsq_dev_trend_prior(dsq_ctx* ctx, const double* d_disp, const double* d_mean
  * whose MAP fit finished - and converged - in the dispersion stage's full-size launch are fitted from a stream of their
  * own while the main stream still runs that stage's latency-bound tail (the continuation of the parked fits, the
  * grid-search pass); the rest follow in a second launch that joins the first.  The pipeline's sequence, from inside the
- * hook of dsq_set_alpha_hook (the MAP flags were filled with 0xFF and dsq_lfc_prepare called before the stage):
+ * hook of dsq_set_alpha_hook (before the stage: MAP flags and late flags filled with 0xFF, dsq_alpha_set_late_flags,
+ * dsq_lfc_prepare):
  *   dsq_lfc_fork_begin; dsq_dev_select_dispersions_part(mode 1); dsq_lfc_set_part(part, 1, 1); dsq_dev_lfc_fit2;
  *   dsq_lfc_fork_end;
  * and, after the dispersion stage has returned:
@@ -500,11 +501,16 @@ int dsq_lfc_fork_end(dsq_ctx* ctx);
 int dsq_lfc_set_part(dsq_ctx* ctx, const uint8_t* d_part, int want, int phase);
 int dsq_lfc_takes_parts(int N, int P, const dsq_cells* cells, const dsq_mix* mix, int full_rank);
 /* dsq_dev_select_dispersions for one part of the genes: mode 1 - the genes g < ready_limit with d_map_converged[g] == 1
- * (d_part[g] = 1 for them, 0 for the others, which are left alone); mode 0 - the genes with d_part[g] == 0. */
+ * (d_part[g] = 1 for them, 0 for the others, which are left alone); mode 0 - the genes with d_part[g] == 0, whose late
+ * flags (d_conv_late, may be NULL) move into d_map_converged.  dsq_alpha_set_late_flags (one-shot, before the dispersion
+ * fit): the launches of that fit enqueued after its hook's point write their convergence flags to d_conv_late instead
+ * of d_converged - both filled with 0xFF by the caller -, so that d_converged holds, from the end of the full-size launch
+ * on, exactly the flags of the genes that launch finished: what mode 1 reads cannot depend on how far the tail has come. */
 int dsq_dev_select_dispersions_part(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw, const double* d_fitted, int n,
                                     double min_disp, double max_disp, double squared_logres, double* d_disp,
-                                    uint8_t* d_outlier, const uint8_t* d_map_converged, uint8_t* d_part, int mode,
-                                    int ready_limit);
+                                    uint8_t* d_outlier, uint8_t* d_map_converged, const uint8_t* d_conv_late, uint8_t* d_part,
+                                    int mode, int ready_limit);
+int dsq_alpha_set_late_flags(dsq_ctx* ctx, uint8_t* d_conv_late);
 /* The small operations of the first launch (logs of the size factors, ridge and contrast of the Wald test, zeroed
  * counters), enqueued on the main stream ahead of the dispersion stage instead of beside its tail. */
 int dsq_lfc_prepare(dsq_ctx* ctx, const double* d_sf, int N, const double* h_ridge, const double* h_contrast, int P);

@@ -185,8 +185,9 @@ def load():
     proto("dsq_lfc_fork_end", _vp)
     proto("dsq_lfc_set_part", _vp, _vp, c_int, c_int)
     proto("dsq_lfc_takes_parts", c_int, c_int, cells_p, _vp, c_int)
-    proto("dsq_dev_select_dispersions_part", _vp, _vp, _vp, _vp, c_int, c_double, c_double, c_double, _vp, _vp, _vp, _vp,
+    proto("dsq_dev_select_dispersions_part", _vp, _vp, _vp, _vp, c_int, c_double, c_double, c_double, _vp, _vp, _vp, _vp, _vp,
           c_int, c_int)
+    proto("dsq_alpha_set_late_flags", _vp, _vp)
     proto("dsq_lfc_prepare", _vp, _vp, c_int, _vp, _vp, c_int)
     proto("dsq_irls_order_hint", _vp, _vp, c_int)
     proto("dsq_set_alpha_hook", _vp, _vp, _vp)  # (fn: a HOOK_FN cast to void*, or None)
@@ -241,7 +242,7 @@ EXPORTS = [
     "dsq_abi_version", "dsq_plugin_cache_config", "dsq_plugin_cache_clear", "dsq_plugin_cache_stats",
     "dsq_plugin_digest_host", "dsq_comm_info", "dsq_host_sync_count", "dsq_dev_pack2", "dsq_dev_unzip2",
     "dsq_mix_bind", "dsq_mix_bind2", "dsq_dev_mix_counts_to_slots", "dsq_dev_mix_mu_slots",
-    "dsq_lfc_fork_begin", "dsq_lfc_fork_end", "dsq_lfc_set_part", "dsq_lfc_takes_parts", "dsq_dev_select_dispersions_part", "dsq_lfc_prepare",
+    "dsq_lfc_fork_begin", "dsq_lfc_fork_end", "dsq_lfc_set_part", "dsq_lfc_takes_parts", "dsq_dev_select_dispersions_part", "dsq_lfc_prepare", "dsq_alpha_set_late_flags",
 ]
 
 

@@ -50,6 +50,7 @@ void dsq_destroy(dsq_ctx* ctx) {
     if (ctx->lfc_stream) (void)hipStreamDestroy(ctx->lfc_stream);
     if (ctx->ev_lfc_fork) (void)hipEventDestroy(ctx->ev_lfc_fork);
     if (ctx->ev_lfc_done) (void)hipEventDestroy(ctx->ev_lfc_done);
+    if (ctx->ev_lfc_part) (void)hipEventDestroy(ctx->ev_lfc_part);
     dsq_internal_destroy_plugin(ctx);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_lsf) (void)hipFree(ctx->d_lsf);
@@ -242,6 +243,7 @@ int dsq_lfc_fork_begin(dsq_ctx* ctx) {
         DSQ_HIP(hipStreamCreateWithPriority(&ctx->lfc_stream, hipStreamNonBlocking, flat ? (least + greatest) / 2 : least));
         DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_lfc_fork, hipEventDisableTiming));
         DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_lfc_done, hipEventDisableTiming));
+        DSQ_HIP(hipEventCreateWithFlags(&ctx->ev_lfc_part, hipEventDisableTiming));
     }
     DSQ_HIP(hipEventRecord(ctx->ev_lfc_fork, ctx->stream));
     DSQ_HIP(hipStreamWaitEvent(ctx->lfc_stream, ctx->ev_lfc_fork, 0));

@@ -650,13 +650,26 @@ int dsq_dev_select_dispersions(dsq_ctx* ctx, double* d_genewise_raw, double* d_m
 
 int dsq_dev_select_dispersions_part(dsq_ctx* ctx, double* d_genewise_raw, double* d_map_raw, const double* d_fitted, int n,
                                     double min_disp, double max_disp, double squared_logres, double* d_disp,
-                                    uint8_t* d_outlier, const uint8_t* d_map_converged, uint8_t* d_part, int mode,
-                                    int ready_limit) {
-    DSQ_CHECK_ARG((mode == 0 || mode == 1) && d_part != nullptr && (mode == 0 || d_map_converged != nullptr),
-                  "mode 1 (the finished genes; needs the MAP flags) or 0 (the rest), and the part vector");
+                                    uint8_t* d_outlier, uint8_t* d_map_converged, const uint8_t* d_conv_late, uint8_t* d_part,
+                                    int mode, int ready_limit) {
+    DSQ_CHECK_ARG((mode == 0 || mode == 1) && d_part != nullptr && d_map_converged != nullptr,
+                  "mode 1 (the genes the full-size launch finished) or 0 (the rest), the MAP flags and the part vector");
+    if (mode == 0 && ctx->lfc_pending_G != 0 && ctx->ev_lfc_part != nullptr)
+        // the part vector is written on the forked stream (first thing there, long done - by construction from here on)
+        DSQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_lfc_part, 0));
     DSQ_HIP(dsq::launch_select_disp_part(ctx->stream, d_genewise_raw, d_map_raw, d_fitted, n, min_disp, max_disp,
-                                         2.0 * sqrt(squared_logres), d_disp, d_outlier, d_map_converged, d_part, mode,
-                                         ready_limit));
+                                         2.0 * sqrt(squared_logres), d_disp, d_outlier, d_map_converged, d_conv_late,
+                                         d_part, mode, ready_limit));
+    if (mode == 1 && ctx->lfc_stream != nullptr && ctx->stream == ctx->lfc_stream)
+        DSQ_HIP(hipEventRecord(ctx->ev_lfc_part, ctx->lfc_stream));
+    return DSQ_OK;
+}
+
+// The launches of the next dispersion fit that are enqueued after its hook's point (continuation of the parked fits, genes
+// beside the row kernels) write their convergence flags to d_conv_late (one-shot): d_converged then holds, from the end of
+// the full-size launch on, only what that launch wrote.  dsq_dev_select_dispersions_part (mode 0) merges them back.
+int dsq_alpha_set_late_flags(dsq_ctx* ctx, uint8_t* d_conv_late) {
+    ctx->alpha_conv_late = d_conv_late;
     return DSQ_OK;
 }
 

@@ -86,9 +86,10 @@ struct dsq_ctx {
     // An LFC fit in two launches (dsq_lfc_fork_begin / dsq_lfc_set_part): the genes whose MAP dispersion is final after the
     // dispersion stage's full-size launch are fitted on lfc_stream while the main stream runs that stage's latency-bound tail
     hipStream_t lfc_stream = nullptr, lfc_return = nullptr;
-    hipEvent_t ev_lfc_fork = nullptr, ev_lfc_done = nullptr;
+    hipEvent_t ev_lfc_fork = nullptr, ev_lfc_done = nullptr, ev_lfc_part = nullptr;
     const uint8_t* lfc_part = nullptr;  // dsq_lfc_set_part (one-shot: the next LFC fit consumes it)
     int lfc_want = 0, lfc_phase = 0;
+    uint8_t* alpha_conv_late = nullptr;  // dsq_alpha_set_late_flags (one-shot: the next dispersion fit consumes it)
     int lfc_prepared_N = 0, lfc_prepared_P = 0, lfc_prepared_wald = 0;  // dsq_lfc_prepare (one-shot, consumed by phase 1)
     int lfc_pending_G = 0;        // genes of a phase-1 launch whose phase-2 partner (join, rescue of both lists) is still to come
     int32_t* d_lfc_aux = nullptr; // the phase-1 launch's own fallback list and slot order (ctx->d_list serves the main stream)
@@ -239,7 +240,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
     DSQ_CHECK_ARG(optimizer == 0 || optimizer == 1, "optimizer: 0 (L-BFGS-B) or 1 (BFGS)");
     struct Unbind {  // dsq_mix_bind is one-shot: whatever this call does with it, the next one starts unbound
         dsq_ctx* c;
-        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; c->bind_G = 0; }
+        ~Unbind() { c->bind_ys = nullptr; c->bind_big = nullptr; c->bind_mu = nullptr; c->bind_G = 0; c->alpha_conv_late = nullptr; }
     } unbind{ctx};
     if (ctx->bind_G != 0 && ctx->bind_G != G) {  // copies of another matrix (a failed or skipped call left them): not ours
         ctx->bind_ys = nullptr; ctx->bind_big = nullptr; ctx->bind_mu = nullptr; ctx->bind_G = 0;
@@ -266,6 +267,7 @@ int run_alpha(dsq_ctx* ctx, const int32_t* d_y, const double* d_mu, int ldn, con
         ex2.resume_count = d_cnt + 2;
         ex2.mid_hook = ctx->alpha_hook != nullptr ? fire_alpha_hook : nullptr;
         ex2.mid_arg = ctx;
+        ex2.conv_late = ctx->alpha_conv_late;
         if (ex2.mix != nullptr && ex2.rows != nullptr && ex2.n_rows > 0) {
             if (!dsq::alpha_mix_fits(*ex2.mix)) {
                 ex2.mix = nullptr;  // rows too long for that kernel: the general one takes every gene

@@ -392,6 +392,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                                         ex.resume_list);
         if (e != hipSuccess) return e;
         if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
+        if (ex.conv_late != nullptr) conv = ex.conv_late;  // (everything from here on is "late")
         if (park) {
             // continuation of the parked fits: the same kernel, one gene per wavefront again, launched for a capacity
             // (the count is on the device); queue + 2: its own gene counter (run_alpha zeroes both)
@@ -420,6 +421,7 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
                                     ex.resume_state, ex.resume_count, ex.resume_list);
         if (e != hipSuccess) return e;
         if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
+        if (ex.conv_late != nullptr) conv = ex.conv_late;  // (everything from here on is "late")
         parked = park;
         if (parked && rows_reg && alpha_wg_eligible(N)) {
             // the parked fits continue one per WORKGROUP (k_alpha_wg): ~3 us per evaluation instead of ~15 with the 64
@@ -481,7 +483,10 @@ hipError_t launch_alpha(hipStream_t st, const int32_t* y, const double* mu, int 
         } else {
             DSQ_DISPATCH_P(P_, DSQ_ALPHA_LAUNCH((k_alpha<P, false, false>), (size_t)0))
         }
-        if (ex.mid_hook != nullptr) { ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr; }
+        if (ex.mid_hook != nullptr) {
+            ex.mid_hook(ex.mid_arg); ex.mid_hook = nullptr;
+            if (ex.conv_late != nullptr) conv = ex.conv_late;  // (a second pass of this loop is "late")
+        }
     }
 #undef DSQ_ALPHA_LAUNCH
     return hipGetLastError();

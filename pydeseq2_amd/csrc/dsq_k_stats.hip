@@ -1405,14 +1405,17 @@ __global__ void k_select_disp(double* __restrict__ gw_raw, double* __restrict__ 
 }
 
 // The same selection for one part of the genes (an LFC fit in two launches, dsq_dev_select_dispersions_part):
-// mode 1: the genes whose MAP fit has finished AND converged in the stage's full-size launch (map_conv[i] == 1; the vector
-//         was filled with 0xFF before that launch, parked genes have not written theirs) - part[i] = 1 for them, 0 for the rest;
-// mode 0: the rest (part[i] == 0), once the continuation launch and the grid-search pass have run.
+// mode 1: the genes whose MAP fit has finished AND converged in the stage's full-size launch (map_conv[i] == 1: the vector
+//         was filled with 0xFF before the stage and only that launch writes it - the later launches of the stage write
+//         conv_late, dsq_alpha_set_late_flags -, so what this kernel reads does not depend on how far those have come) -
+//         part[i] = 1 for them, 0 for the rest;
+// mode 0: the rest (part[i] == 0), once the continuation launch and the grid-search pass have run; their late flags move
+//         into map_conv.
 __global__ void k_select_disp_part(double* __restrict__ gw_raw, double* __restrict__ map_raw,
                                    const double* __restrict__ fitted, int n, double min_disp, double max_disp,
                                    double two_sd, double* __restrict__ disp, uint8_t* __restrict__ outlier,
-                                   const uint8_t* __restrict__ map_conv, uint8_t* __restrict__ part, int mode,
-                                   int ready_limit) {
+                                   uint8_t* __restrict__ map_conv, const uint8_t* __restrict__ conv_late,
+                                   uint8_t* __restrict__ part, int mode, int ready_limit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (mode == 1) {
@@ -1421,8 +1424,9 @@ __global__ void k_select_disp_part(double* __restrict__ gw_raw, double* __restri
         const bool ready = map_conv[i] == 1 && i < ready_limit;
         part[i] = ready ? 1 : 0;
         if (!ready) return;
-    } else if (part[i] != 0) {
-        return;
+    } else {
+        if (part[i] != 0) return;
+        if (conv_late != nullptr && conv_late[i] != 0xFF) map_conv[i] = conv_late[i];
     }
     const double gw = fmin(fmax(gw_raw[i], min_disp), max_disp);
     const double mp = fmin(fmax(map_raw[i], min_disp), max_disp);
@@ -1539,10 +1543,11 @@ hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, c
 }
 hipError_t launch_select_disp_part(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted, int n,
                                    double min_disp, double max_disp, double two_sd, double* disp, uint8_t* outlier,
-                                   const uint8_t* map_conv, uint8_t* part, int mode, int ready_limit) {
+                                   uint8_t* map_conv, const uint8_t* conv_late, uint8_t* part, int mode,
+                                   int ready_limit) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_select_disp_part, dim3((n + 255) / 256), dim3(256), 0, st, gw_raw, map_raw, fitted, n, min_disp,
-                       max_disp, two_sd, disp, outlier, map_conv, part, mode, ready_limit);
+                       max_disp, two_sd, disp, outlier, map_conv, conv_late, part, mode, ready_limit);
     return hipGetLastError();
 }
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,

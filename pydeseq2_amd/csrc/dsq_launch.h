@@ -104,6 +104,10 @@ struct AlphaExtras {
     // tail (continuation of the parked fits, second passes) is about to be (dsq_set_alpha_hook); may be null
     void (*mid_hook)(void*);
     void* mid_arg;
+    // non-null: the launches enqueued AFTER the hook's point (continuation of the parked fits, the genes of `waves`) write
+    // their convergence flags here instead of `conv` - which then holds, from the end of the full-size launch on, exactly
+    // the flags of the genes that launch finished (dsq_alpha_set_late_flags: what the forked LFC launch selects its genes by)
+    uint8_t* conv_late;
     // Mixed designs (dsq_mix.h, dsq_k_alpha_mix.hip): the genes of `rows` run k_alpha_mix.
     // mix_ys [G][Ns] uint16: the counts in slot order (launch_mix_counts_to_slots); mix_mu [G][Ns]: mu_hat in slot order
     // (launch_mix_mu_slots from the IRLS coefficients, or launch_mix_f64_to_slots from a caller's matrix) - the kernel
@@ -325,7 +329,8 @@ hipError_t launch_select_disp(hipStream_t st, double* gw_raw, double* map_raw, c
                               uint8_t* outlier);
 hipError_t launch_select_disp_part(hipStream_t st, double* gw_raw, double* map_raw, const double* fitted, int n,
                                    double min_disp, double max_disp, double two_sd, double* disp, uint8_t* outlier,
-                                   const uint8_t* map_conv, uint8_t* part, int mode, int ready_limit);
+                                   uint8_t* map_conv, const uint8_t* conv_late, uint8_t* part, int mode,
+                                   int ready_limit);
 // n_dev (here and below): the kernel is launched for n_* rows as a CAPACITY and reads the actual count from device
 // memory - second passes can be enqueued without the host having seen how many genes need them
 hipError_t launch_scatter_rows(hipStream_t st, const double* src, const int32_t* idx, int n_idx, int width,

@@ -212,16 +212,18 @@ class DeseqPipeline:
         self._robust_split = float(os.environ.get("DSQ_ROBUST_SPLIT", "0.78"))
         # LFC fit in two launches: the genes whose MAP dispersion is final after the MAP stage's full-size launch are fitted
         # underneath that stage's latency-bound tail (_fork_lfc); DSQ_LFC_OVERLAP=0: one launch after the stage (A/B switch)
-        # Measured on one box, ms per step with / without: c4 7.08 / 7.37, c5 shard of 7500 genes 7.22 / 7.78 (their tails are
-        # 0.5-0.8 ms of a few workgroups on an otherwise idle device); c4 shard of 7500 2.47 / 2.52.  No gain where the device
-        # is busy during the tail anyway or the tail is short: c5 whole 45.0 / 44.75 (the robust-dispersion kernel of the side stream
-        # runs 2-3 ms past the tail there, see above), c3 5.74 / 5.60, c2 1.84 / 1.69, c3 shard 1.80 / 1.79 (<= 4 cells: a 0.35 ms
-        # tail that already carries the robust dispersions' part two - the device is 88 % busy without the fork and the small
-        # launches beside a full-size kernel cost more than the rest is worth), general kernels 16.95 / 16.67.  Hence: the
-        # many-cell family always, the mixed-design family up to DSQ_LFC_OVERLAP_MAX_WORK = 1.5e8 counts per device.
+        # Measured (same box each, ms per step with / without): mixed designs - c5 shard of 7500 genes 7.15-7.18 / 7.73-7.79,
+        # 15000 genes 13.0 / 13.3-13.5, 30000 genes 23.3-23.5 / 23.5-23.9 (a tail of 0.8 ms - continuation 0.6, host round
+        # trip, grid pass 0.16 - on a few workgroups), the whole c5 matrix 45.0 / 44.75 (the robust-dispersion kernel of the
+        # side stream runs 2-3 ms past the tail there, see above: nothing idle to fill).  Many cells: c4 6.80-6.84 / 6.77-6.84,
+        # its shards the same to 0.05 ms (one box showed 7.08 / 7.37; three others nothing).  <= 4 cells: c3 5.74 / 5.60, c2
+        # 1.84 / 1.69, c3 shard 1.80 / 1.79 - a 0.35 ms tail that already carries the robust dispersions' part two, the device is
+        # 88 % busy without the fork, and the small launches beside a full-size kernel cost more than the rest is worth.
+        # General kernels 16.95 / 16.67.  Hence: on for the mixed-design family up to DSQ_LFC_OVERLAP_MAX_WORK = 1.5e8 counts
+        # per device (the shards of a multi-GPU job), off elsewhere.
         lo = os.environ.get("DSQ_LFC_OVERLAP")
         max_work = float(os.environ.get("DSQ_LFC_OVERLAP_MAX_WORK", "1.5e8"))
-        auto = self._row_mode == 2 or (self._row_mode == 3 and float(self.G) * self.N <= max_work)
+        auto = self._row_mode == 3 and float(self.G) * self.N <= max_work
         self._lfc_overlap = auto if lo is None else (lo != "0")
         self._lfc_min_genes = int(os.environ.get("DSQ_LFC_OVERLAP_MIN_GENES", "2048"))
         self._lfc_forked = False
@@ -556,15 +558,23 @@ class DeseqPipeline:
         if d_nfev:
             self.kernel_log.setdefault("nfev", []).append((float(self._down(d_nfev, Gs, np.int32).sum()), Gs))
 
-    def _stage_map(self, d_y, mh, Gs, d_sf, prior_var, squared_logres, S, part_of=None):
+    def _stage_map(self, d_y, mh, Gs, d_sf, prior_var, squared_logres, S, fork=None):
         """MAP dispersions (dds.py:886-935) from S[fit] -> S[map (raw), mconv], then the final
-        dispersions S[disp] and the dispersion-outlier flags S[outl]."""
+        dispersions S[disp] and the dispersion-outlier flags S[outl].  ``fork`` = (part vector, late flags, forked()):
+        the stage was set up for an LFC fit in two launches (_st_map) - the launches behind the hook's point write their
+        convergence flags to the late vector, and the selection covers the genes the fork has not taken (all of them when
+        the hook did not fork after all)."""
+        if fork is not None:
+            self.ctx.call("dsq_alpha_set_late_flags", _vp(fork[1].ptr))
         self._alpha_fit("alpha_map", d_y, mh, Gs, d_sf, S["fit"], prior_var, 1, S["map"], S["mconv"], 2)
-        d_part = part_of() if part_of is not None else None
-        if d_part is not None:  # the finished genes took theirs inside the fit (_fork_lfc): the rest
+        if fork is not None:
+            d_part, d_late, forked = fork
+            if not forked():
+                self.ctx.call("dsq_memset", _vp(d_part.ptr), 0, C.c_size_t(Gs))
             self.ctx.call("dsq_dev_select_dispersions_part", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
                           c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
-                          _vp(S["disp"].ptr), _vp(S["outl"].ptr), None, _vp(d_part.ptr), 0, 0)
+                          _vp(S["disp"].ptr), _vp(S["outl"].ptr), _vp(S["mconv"].ptr), _vp(d_late.ptr), _vp(d_part.ptr),
+                          0, 0)
         else:
             self.ctx.call("dsq_dev_select_dispersions", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gs,
                           c_double(self.min_disp), c_double(self.max_disp), c_double(squared_logres),
@@ -993,7 +1003,11 @@ class DeseqPipeline:
         if fork:
             self._lfc_prepare(st)
             st.d_part = self._dvec(Gn, np.uint8)
-            ctx.call("dsq_memset", _vp(S["mconv"].ptr), 0xFF, C.c_size_t(Gn))  # "not finished": the fits write 0 / 1
+            # "not finished" in both flag vectors: the stage's full-size launch writes 0 / 1 into the first, its later
+            # launches into the second (csrc dsq_alpha_set_late_flags) - the fork selects its genes by the first alone
+            st.d_mconv_late = self._dvec(Gn, np.uint8)
+            ctx.call("dsq_memset", _vp(S["mconv"].ptr), 0xFF, C.c_size_t(Gn))
+            ctx.call("dsq_memset", _vp(st.d_mconv_late.ptr), 0xFF, C.c_size_t(Gn))
             # (the first launch's small operations here, on an idle device, instead of beside the stage's tail)
             ctx.call("dsq_lfc_prepare", _vp(st.d_sf.ptr), self.N, _vp(st.wald_args[0].ctypes.data),
                      _vp(st.wald_args[1].ctypes.data), self.P)
@@ -1007,7 +1021,7 @@ class DeseqPipeline:
                 self._launch_robust(st, 1)
 
         fit = lambda: self._stage_map(st.d_ynz, st.mh, Gn, st.d_sf, r.prior_disp_var, r.squared_logres, S,  # noqa: E731
-                                      part_of=(lambda: st.d_part if st.lfc_forked else None) if fork else None)
+                                      fork=(st.d_part, st.d_mconv_late, lambda: st.lfc_forked) if fork else None)
         if (second or fork) and not self.time_kernels:
             _, fired = self._with_alpha_hook(fit, launch)
         else:
@@ -1035,7 +1049,7 @@ class DeseqPipeline:
         try:
             ctx.call("dsq_dev_select_dispersions_part", _vp(S["gw"].ptr), _vp(S["map"].ptr), _vp(S["fit"].ptr), Gn,
                      c_double(self.min_disp), c_double(self.max_disp), c_double(r.squared_logres), _vp(S["disp"].ptr),
-                     _vp(S["outl"].ptr), _vp(S["mconv"].ptr), _vp(st.d_part.ptr), 1,
+                     _vp(S["outl"].ptr), _vp(S["mconv"].ptr), None, _vp(st.d_part.ptr), 1,
                      int(Gn if st.robust_done[1] else st.g_cut))
             st.lfc_bufs = self._stage_lfc(st.d_ynz, Gn, st.d_sf, S, st.wald_args, cooks=(S["rd"], st.cutoff, st.d_cooks),
                                           mix_slots=st.mix_slots, part=(st.d_part, 1, 1))

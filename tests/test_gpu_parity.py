@@ -641,18 +641,25 @@ def test_full_size_properties():
     assert_close(res.genewise_dispersions[sel][same & c], np.clip(a, 1e-8, 200)[same & c], RTOL, 0, "gw subset")
 
 
-def test_distributed_pipeline_world1_equals_single():
+@pytest.mark.parametrize("kind", ["2level", "mixed"])
+def test_distributed_pipeline_world1_equals_single(kind):
     """RCCL path with a one-rank communicator: dlopen(librccl), comm init, all-reduce / all-gather
-    on device buffers, per-pass size-factor kernels, gathered trend fit == single-GPU pipeline."""
+    on device buffers, per-pass size-factor kernels, gathered trend fit == single-GPU pipeline.  "mixed": a shard of the
+    size whose LFC fit runs in two launches (the c5 shards of a multi-GPU job), forked from inside the sharded pipeline."""
     import pydeseq2_amd
     from pydeseq2_amd._lib import Context
     from pydeseq2_amd.distributed import DistDeseqPipeline, RcclComm
 
-    counts, X = orc.synth_counts(1200, 40, "2level", 4)
+    if kind == "mixed":
+        counts, X = _mixed_case(5, 2, 300, 2600, 3, (3,))
+    else:
+        counts, X = orc.synth_counts(1200, 40, "2level", 4)
     counts[:, 7] = 0
     ctx = Context(0)
     comm = RcclComm(ctx, RcclComm.unique_id(ctx), 0, 1)
-    res_d = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx).deseq2()
+    pipe_d = DistDeseqPipeline(counts, X, comm=comm, ctx=ctx)
+    res_d = pipe_d.deseq2()
+    assert pipe_d.lfc_forks == (1 if kind == "mixed" else 0)
     res_s = pydeseq2_amd.DeseqPipeline(counts, X, ctx=ctx).deseq2()
     assert_close(res_d.size_factors, res_s.size_factors, 1e-15, 0, "sf")
     assert_close(res_d.trend_coeffs, res_s.trend_coeffs, 1e-12, 0, "trend")

@@ -1064,7 +1064,7 @@ class DeseqPipeline:
     # ---- LFC (dds.py:937-984) with the per-sample half of Cook's (dds.py:986-1040) and the Wald statistics
     # (ds.py:303-360) in its epilogue: mu and the hat diagonal are consumed from registers
     def _st_lfc(self, st):
-        ctx, D, S, Gn, G, P = self.ctx, self.design, st.S, st.Gn, self.G, self.P
+        ctx, D, S, Gn, G = self.ctx, self.design, st.S, st.Gn, self.G
         for part in (0, 1):  # stage by stage: nobody has launched the robust dispersions yet
             if not st.robust_done[part]:
                 self._launch_robust(st, part, side=False)

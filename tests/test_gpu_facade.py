@@ -373,3 +373,42 @@ def test_statistics_on_a_gene_slice_of_a_fitted_data_set():
     np.testing.assert_allclose(part.p_values.to_numpy(), full.p_values.loc[genes].to_numpy(), rtol=1e-10)
     np.testing.assert_allclose(part.SE.to_numpy(), full.SE.loc[genes].to_numpy(), rtol=1e-10)
     np.testing.assert_array_equal(sub.var["dispersions"].to_numpy(), dds.var.loc[genes, "dispersions"].to_numpy())
+
+
+def test_mixed_design_through_the_facade_with_the_lfc_fit_in_two_launches():
+    """A categorical factor + a continuous covariate at a size where deseq2() fits the LFCs in two launches (mixed designs,
+    pipeline._fork_lfc): the one-go fit, the stage-by-stage fit (one launch: the pass is not known to run to its end) and
+    a one-go fit with the fork switched off give the same fields bit for bit; layers (Cook's distances in slot order on
+    the device) included."""
+    import pandas as pd
+
+    from pydeseq2_amd.api import DeseqDataSet, DeseqStats
+
+    rng = np.random.default_rng(5)
+    N, G = 384, 2600  # (three cells of 128 samples: whole 64-sample trips, the mixed-design kernels take it)
+    cond = np.array(["A", "B", "C"])[np.arange(N) % 3]
+    x = rng.normal(0, 1, N)
+    meta = pd.DataFrame({"condition": cond, "x": x}, index=[f"s{i}" for i in range(N)])
+    base = np.exp(rng.normal(4, 1.5, G))
+    mu = base[None, :] * np.exp(0.3 * x)[:, None] * np.where(cond == "B", 1.4, 1.0)[:, None]
+    size = 1.0 / (4.0 / base + 0.1)
+    counts = pd.DataFrame(rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu)), index=meta.index,
+                          columns=[f"g{j}" for j in range(G)])
+    counts.iloc[:, 11] = 0
+    one = DeseqDataSet(counts=counts, metadata=meta, design="~condition + x", continuous_factors=["x"]).deseq2()
+    assert one._pipe._row_mode == 3 and one._pipe.lfc_forks == 1
+    off = DeseqDataSet(counts=counts, metadata=meta, design="~condition + x", continuous_factors=["x"])
+    off._pipe._lfc_overlap = False
+    off.deseq2()
+    assert off._pipe.lfc_forks == 0
+    step = DeseqDataSet(counts=counts, metadata=meta, design="~condition + x", continuous_factors=["x"])
+    step.fit_size_factors(); step.fit_genewise_dispersions(); step.fit_dispersion_trend(); step.fit_dispersion_prior()
+    step.fit_MAP_dispersions(); step.fit_LFC(); step.calculate_cooks(); step.refit()
+    for other in (off, step):
+        for k in ("genewise_dispersions", "MAP_dispersions", "dispersions"):
+            np.testing.assert_array_equal(one.var[k].to_numpy(), other.var[k].to_numpy(), err_msg=k)
+        np.testing.assert_array_equal(one.varm["LFC"].to_numpy(), other.varm["LFC"].to_numpy())
+        np.testing.assert_array_equal(one.layers["cooks"], other.layers["cooks"])
+    a = DeseqStats(one, contrast=["condition", "B", "A"]).summary()
+    b = DeseqStats(off, contrast=["condition", "B", "A"]).summary()
+    pd.testing.assert_frame_equal(a, b)

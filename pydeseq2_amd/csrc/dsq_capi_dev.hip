@@ -442,8 +442,7 @@ int dsq_dev_alpha_row_split(dsq_ctx* ctx, const int32_t* d_y, int ldn, int N, in
 int dsq_dev_robust_disp2(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double* d_sf, const int32_t* d_cell_offsets,
                          const int32_t* d_cell_index, int n_cells, int whole, int max_cell, int min_cell, int N, int G,
                          double* d_robust_disp) {
-    DSQ_CHECK_ARG((whole ? N : max_cell) <= 16384, "a design cell with more than 16384 samples is not supported");
-    if (whole) min_cell = N;
+    if (whole) min_cell = N;  // (cells of any size: beyond a wavefront's LDS the buffer-less kernel takes the design)
     {   // (runs on the side stream from inside another call: attribute an error left behind by an earlier launch to it)
         const hipError_t pend = hipGetLastError();
         if (pend != hipSuccess)
@@ -561,7 +560,6 @@ int dsq_dev_replace_outliers2(dsq_ctx* ctx, const int32_t* d_y, const double* d_
                               const double* d_sf, const uint8_t* d_flags, const int32_t* d_gene_idx,
                               int n_sel, int N, double cutoff, int32_t* d_y_out, uint8_t* d_all_zero, int cooks_ld,
                               const dsq_mix* mix) {
-    DSQ_CHECK_ARG(N <= 16384, "more than 16384 samples is not supported by the outlier replacement");
     DSQ_CHECK_ARG(cooks_ld == 0 || (mix != nullptr && mix->d.N == N && cooks_ld >= mix->d.Ns),
                   "cooks_ld: a slot-ordered Cook's layer comes with the mixed design that wrote it");
     DSQ_HIP(dsq::launch_replace(ctx->stream, d_y, d_cooks, ldn, d_sf, d_flags, d_gene_idx, n_sel, N, cutoff,

@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp_lean(const int32_t* __
                                                                int whole, int N, int G,
                                                                double* __restrict__ robust_disp,
                                                                int32_t* __restrict__ redo_count,
-                                                               int32_t* __restrict__ redo_list) {
+                                                               int32_t* __restrict__ redo_list, int can_redo) {
     __shared__ BucketWork W[WPB];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x * WPB + w;
@@ -1209,8 +1209,10 @@ __global__ __launch_bounds__(64 * WPB) void k_robust_disp_lean(const int32_t* __
     bool failed;
     const double ar = robust_disp_gene_lean<DeviceWave>(y + (size_t)g * ldn, sf, C, N, W[w], failed);
     if ((threadIdx.x & 63) == 0) {
-        if (failed) redo_list[atomicAdd(redo_count, 1)] = g;
-        else robust_disp[g] = ar;
+        // failed: a normalised count that is not finite (a size factor of 0 / inf / NaN).  The buffered kernel orders such
+        // values as numpy.sort does; where a cell is too long for its LDS the gene's robust dispersion is NaN (can_redo == 0)
+        if (failed && can_redo) redo_list[atomicAdd(redo_count, 1)] = g;
+        else robust_disp[g] = failed ? NAN : ar;
     }
 }
 
@@ -1230,18 +1232,6 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
                               const int32_t* cell_offsets, const int32_t* cell_index, int n_cells, int whole,
                               int max_cell, int N, int G, double* robust_disp, int min_cell, int32_t* redo) {
     if (G <= 0) return hipSuccess;
-    const bool lean = redo != nullptr && robust_disp_lean_eligible(min_cell, max_cell, whole, N);
-    if (lean) {
-        hipError_t e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) return e;
-        constexpr int WPB = 4;
-        hipLaunchKernelGGL((k_robust_disp_lean<WPB>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, ldn, sf,
-                           cell_offsets, cell_index, n_cells, whole, N, G, robust_disp, redo, redo + 1);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    const int32_t* list = lean ? redo + 1 : nullptr;
-    const int32_t* n_dev = lean ? redo : nullptr;
     const int biggest = whole ? N : max_cell;
     // designs whose cells all have at most kSegMaxCell samples: several cells per sorting pass (seg_trimmed_variances)
     static const bool seg_off = getenv("DSQ_NO_SEG_CELLS") != nullptr;  // A/B switch
@@ -1250,7 +1240,23 @@ hipError_t launch_robust_disp(hipStream_t st, const int32_t* y, int ldn, const d
     const int stride = cap + trim_work_doubles(biggest);
     const size_t per_wave = (size_t)stride * sizeof(double);
     const bool big = biggest >= kTrimBucketMin;
-    if (per_wave > 160 * 1024) return hipErrorInvalidValue;  // (a cell of > 13 000 samples that the lean kernel did not take)
+    // a cell of more than ~13 000 samples does not fit a wavefront's LDS: the buffer-less kernel takes the design whatever
+    // its other cells look like (it selects where it cannot bucket), and there is no buffered second pass
+    const bool buffered_fits = per_wave <= 160 * 1024;
+    if (!buffered_fits && redo == nullptr) return hipErrorInvalidValue;
+    const bool lean = redo != nullptr && (!buffered_fits || robust_disp_lean_eligible(min_cell, max_cell, whole, N));
+    if (lean) {
+        hipError_t e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return e;
+        constexpr int WPB = 4;
+        hipLaunchKernelGGL((k_robust_disp_lean<WPB>), dim3((G + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, ldn, sf,
+                           cell_offsets, cell_index, n_cells, whole, N, G, robust_disp, redo, redo + 1,
+                           buffered_fits ? 1 : 0);
+        e = hipGetLastError();
+        if (e != hipSuccess || !buffered_fits) return e;
+    }
+    const int32_t* list = lean ? redo + 1 : nullptr;
+    const int32_t* n_dev = lean ? redo : nullptr;
 #define DSQ_RD_LAUNCH(WPB) \
     do { if (big) DSQ_RD_LAUNCH_(WPB, true); else DSQ_RD_LAUNCH_(WPB, false); } while (0)
 #define DSQ_RD_LAUNCH_(WPB, BIG)                                                                             \
@@ -1311,6 +1317,39 @@ __global__ __launch_bounds__(64 * WPB) void k_replace(const int32_t* __restrict_
         for (int n = DeviceWave::lane(); n < N; n += 64) y_out[(size_t)k * ldn + n] = yr[n];
 }
 
+// The same for rows too long for a wavefront's LDS (more than ~8 000 samples: next_pow2(N) doubles + the bucket table):
+// the trimmed mean from the buffer-less routine (trimmed_base_mean_lean) - any number of samples.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_replace_lean(const int32_t* __restrict__ y,
+                                                           const double* __restrict__ cooks, int ldn,
+                                                           const double* __restrict__ sf,
+                                                           const uint8_t* __restrict__ flags,
+                                                           const int32_t* __restrict__ gene_idx, int n_sel, int N,
+                                                           double cutoff, int32_t* __restrict__ y_out,
+                                                           uint8_t* __restrict__ all_zero, int cooks_ld,
+                                                           const int32_t* __restrict__ slot_of) {
+    __shared__ BucketWork W[WPB];
+    const int w = threadIdx.x >> 6;
+    const int k = blockIdx.x * WPB + w;
+    if (k >= n_sel) return;
+    const int g = gene_idx[k];
+    const int32_t* yr = y + (size_t)g * ldn;
+    const double* ck = cooks + (size_t)g * (slot_of != nullptr ? (size_t)cooks_ld : (size_t)ldn);
+    bool failed;
+    const double tbm = trimmed_base_mean_lean<DeviceWave>(yr, sf, N, 0.2, W[w], failed);
+    int nonzero = 0;
+    for (int n = DeviceWave::lane(); n < N; n += 64) {
+        int v = yr[n];
+        if ((flags[n] & 2) && ck[slot_of != nullptr ? slot_of[n] : n] > cutoff) v = (int)(tbm * sf[n]);  // truncation (astype(int))
+        y_out[(size_t)k * ldn + n] = v;
+        nonzero |= (v != 0);
+    }
+    nonzero = DeviceWave::sumi(nonzero);
+    if ((threadIdx.x & 63) == 0) all_zero[k] = (uint8_t)(nonzero == 0);
+    if (nonzero == 0)  // (see k_replace)
+        for (int n = DeviceWave::lane(); n < N; n += 64) y_out[(size_t)k * ldn + n] = yr[n];
+}
+
 hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks, int ldn,
                           const double* sf, const uint8_t* flags, const int32_t* gene_idx, int n_sel,
                           int N, double cutoff, int32_t* y_out, uint8_t* all_zero, int cooks_ld,
@@ -1319,7 +1358,13 @@ hipError_t launch_replace(hipStream_t st, const int32_t* y, const double* cooks,
     const int cap = next_pow2(N);  // (the sort is the fallback of the bucket path: power-of-two room either way)
     const int stride = cap + trim_work_doubles(N);
     const size_t per_wave = (size_t)stride * sizeof(double);
-    if (per_wave > 160 * 1024) return hipErrorInvalidValue;
+    static const bool force_lean = getenv("DSQ_REPLACE_LEAN") != nullptr;  // A/B switch (tests: the buffer-less kernel on short rows)
+    if (per_wave > 160 * 1024 || force_lean) {
+        constexpr int WPB = 4;
+        hipLaunchKernelGGL(k_replace_lean<WPB>, dim3((n_sel + WPB - 1) / WPB), dim3(64 * WPB), 0, st, y, cooks, ldn, sf,
+                           flags, gene_idx, n_sel, N, cutoff, y_out, all_zero, cooks_ld, slot_of);
+        return hipGetLastError();
+    }
 #define DSQ_REPL_LAUNCH(WPB)                                                                         \
     do {                                                                                             \
         if (per_wave * WPB > 48 * 1024) {                                                            \

@@ -631,6 +631,92 @@ DSQ_HD bool bucket_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi
     return true;
 }
 
+// The same sum by radix selection - the algorithm of trimmed_sum_select over an accessor, among the ACTIVE entries only:
+// what bucket_rank_sum's callers fall back to where no buffer of the cell's values exists (robust_disp_gene_lean; cells of
+// tens of thousands of samples put more than kBucketGather values into a boundary bucket as a rule).  Every active entry
+// must be finite; range: their smallest and largest value.  hist: 2 * kTrimBins counters private to the wave.
+template <class Wv, class Buf>
+DSQ_HD double select_rank_sum(const Buf& buf, int n, int n_act, int j_lo, int j_hi, unsigned int* hist,
+                              const double* range) {
+    if (n_act <= 0 || j_hi < j_lo) return 0.0;
+    const unsigned long long kmin = pos_key(range[0]), kmax = pos_key(range[1]);
+    if (kmin == kmax) return (double)(j_hi - j_lo + 1) * range[0];
+    int hb = 63;
+    while (!(((kmin ^ kmax) >> hb) & 1ull)) --hb;
+    int shift = (hb >> 3) << 3;  // byte that holds the first differing bit
+    unsigned long long pre[2];
+    pre[0] = pre[1] = (shift == 56) ? 0ull : (kmin >> (shift + 8));
+    int rank[2] = {j_lo, j_hi};
+    int cnt[2] = {n_act, n_act};
+    constexpr int BPL = kTrimBins / (Wv::W < kTrimBins ? Wv::W : kTrimBins);  // bins per lane
+    for (;;) {
+        for (int b = Wv::lane(); b < 2 * kTrimBins; b += Wv::W) hist[b] = 0u;
+        Wv::sync();
+        const unsigned long long p0 = pre[0], p1 = pre[1];
+        for_each_batched<Wv>(buf, n, [&](double v) {
+            if (v >= 0.0) {
+                const unsigned long long key = pos_key(v);
+                const unsigned long long hi = (shift == 56) ? 0ull : (key >> (shift + 8));
+                const int dg = (int)((key >> shift) & 255ull);
+                if (hi == p0) Wv::hist_add(hist + dg);
+                if (hi == p1) Wv::hist_add(hist + kTrimBins + dg);
+            }
+        });
+        Wv::sync();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned int* h = hist + t * kTrimBins;
+            const int b0 = Wv::lane() * BPL;
+            int c[BPL], tot = 0;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) { c[q] = (b0 + q < kTrimBins) ? (int)h[b0 + q] : 0; tot += c[q]; }
+            int cum = Wv::excl_scan_i(tot);
+            int fbin = 0, fcum = 0, fcnt = 0;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                const bool hit = rank[t] >= cum && rank[t] < cum + c[q];
+                if (hit) { fbin = b0 + q; fcum = cum; fcnt = c[q]; }
+                cum += c[q];
+            }
+            fbin = Wv::sumi(fbin); fcum = Wv::sumi(fcum); fcnt = Wv::sumi(fcnt);  // exactly one lane hits
+            pre[t] = (pre[t] << 8) | (unsigned long long)fbin;
+            rank[t] -= fcum;
+            cnt[t] = fcnt;
+        }
+        if (shift == 0 || (cnt[0] == 1 && cnt[1] == 1)) break;
+        shift -= 8;
+    }
+    // the two boundary values: any active element whose key starts with the selected prefix
+    double lo = -INFINITY, hi = -INFINITY;
+    {
+        const unsigned long long p0 = pre[0], p1 = pre[1];
+        for_each_batched<Wv>(buf, n, [&](double v) {
+            if (v >= 0.0) {
+                const unsigned long long kk = pos_key(v) >> shift;
+                if (kk == p0) lo = v;
+                if (kk == p1) hi = v;
+            }
+        });
+    }
+    lo = Wv::max(lo);
+    hi = Wv::max(hi);
+    if (!(lo < hi)) return (double)(j_hi - j_lo + 1) * lo;
+    double sm = 0.0;
+    int below_lo = 0, eq_lo = 0, below_hi = 0;
+    for_each_batched<Wv>(buf, n, [&](double v) {
+        if (v >= 0.0) {
+            sm += (v > lo && v < hi) ? v : 0.0;
+            below_lo += v < lo ? 1 : 0;
+            eq_lo += v == lo ? 1 : 0;
+            below_hi += v < hi ? 1 : 0;
+        }
+    });
+    sm = Wv::sum(sm);
+    below_lo = Wv::sumi(below_lo); eq_lo = Wv::sumi(eq_lo); below_hi = Wv::sumi(below_hi);
+    Wv::sync();  // hist is free again
+    return sm + lo * (double)(below_lo + eq_lo - j_lo) + hi * (double)((j_hi + 1) - below_hi);
+}
+
 struct CooksOut {
     double robust_disp;
     int any_gt_all;      // any sample with cooks > cutoff                     (dds.py:1325-1326)
@@ -955,9 +1041,11 @@ DSQ_HD double robust_disp_gene(const int32_t* y, const double* sf, const CellPla
     return ar;
 }
 
-// robust_disp_gene for designs whose cells ALL take the bucket path (every cell - or the whole sample set - has at least
-// kTrimBucketMin samples), without a per-wave buffer of the cell's values (NormedValues).  failed = true: a boundary
-// bucket held too many values or a value was not finite - the caller hands the gene to robust_disp_gene (selection path).
+// robust_disp_gene without a per-wave buffer of the cell's values (NormedValues): the bucket path for cells of at least
+// kTrimBucketMin samples, radix selection over the same accessor for smaller ones and where a boundary bucket holds too
+// many values - cells of any size (round 6; it used to hand such genes back to the buffered kernel, whose LDS ends at
+// ~13 000 samples per cell).  failed = true: a value was not finite - the caller hands the gene to robust_disp_gene, which
+// orders NaNs as numpy.sort does.
 template <class Wv>
 DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const CellPlan& C, int N, BucketWork& W,
                                     bool& failed) {
@@ -992,10 +1080,12 @@ DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const Ce
         if (bad != 0) { failed = true; return NAN; }
         const int r_lo = nt, r_hi = n - nt - 1, n_act = n - zeros;
         double s1 = 0.0, s2 = 0.0;
-        if (!bucket_rank_sum<Wv>(V, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1, range)) {
-            failed = true;
-            return NAN;
-        }
+        // (small cells, and cells whose boundary bucket holds more than kBucketGather values: radix selection over the
+        // same accessor - no buffer either way, so a cell may have any number of samples)
+        const bool by_bucket = n >= kTrimBucketMin;
+        if (!by_bucket || !bucket_rank_sum<Wv>(V, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, W, s1, range))
+            s1 = select_rank_sum<Wv>(V, n, n_act, r_lo > zeros ? r_lo - zeros : 0, r_hi - zeros, (unsigned int*)W.sum,
+                                     range);
         const double tm = s1 / (double)(n - 2 * nt);
         const double d0 = 0.0 - tm;
         const double tm2 = d0 * d0;
@@ -1019,10 +1109,8 @@ DSQ_HD double robust_disp_gene_lean(const int32_t* y, const double* sf, const Ce
         const int j_lo = r_lo < below ? r_lo : (r_lo - zeros > below ? r_lo - zeros : below);
         const int j_hi = r_hi < below ? r_hi : (r_hi < below + zeros ? below - 1 : r_hi - zeros);
         const int b_lo = r_lo > below ? r_lo : below, b_hi = r_hi < below + zeros - 1 ? r_hi : below + zeros - 1;
-        if (!bucket_rank_sum<Wv>(V, n, n_act, j_lo, j_hi, W, s2, range)) {
-            failed = true;
-            return NAN;
-        }
+        if (!by_bucket || !bucket_rank_sum<Wv>(V, n, n_act, j_lo, j_hi, W, s2, range))
+            s2 = select_rank_sum<Wv>(V, n, n_act, j_lo, j_hi, (unsigned int*)W.sum, range);
         const double ts = s2 + (b_hi >= b_lo ? (double)(b_hi - b_lo + 1) * tm2 : 0.0);
         const double tv = scales[cls] * (ts / (double)(n - 2 * nt));
         vmax = (tv > vmax || tv != tv) ? tv : vmax;
@@ -1161,6 +1249,44 @@ DSQ_HD double trimmed_base_mean(const int32_t* y, const double* sf, int N, doubl
     for (int k = Wv::lane(); k < N; k += Wv::W) scratch[k] = (double)y[k] / sf[k];
     sorter(scratch, N);
     return range_sum<Wv>(scratch, nt, N - nt) / (double)(N - 2 * nt);
+}
+
+// The same without a buffer of the row's values (rows beyond what a wavefront's LDS holds: k_replace_lean): the
+// normalised counts are recomputed on every pass - by IEEE division, as above, because the result is truncated to an
+// integer count - and the trimmed sum comes from the bucket pass or, where that is not applicable, from the radix
+// selection over the same accessor.  failed: a normalised count was not finite (the result is NaN then).
+struct ExactNormedValues {
+    const int32_t* y;
+    const double* sf;
+    DSQ_HD double operator[](int k) const {
+        const int yi = y[k];
+        return yi == 0 ? -1.0 : (double)yi / sf[k];
+    }
+};
+template <class Wv>
+DSQ_HD double trimmed_base_mean_lean(const int32_t* y, const double* sf, int N, double trim, BucketWork& W, bool& failed) {
+    const int nt = (int)floor((double)N * trim);
+    const ExactNormedValues V{y, sf};
+    int zeros = 0, bad = 0;
+    double lo = INFINITY, hi = -INFINITY;
+    for_each_batched<Wv>(V, N, [&](double v) {
+        zeros += v < 0.0 ? 1 : 0;
+        if (!(v < 0.0)) {
+            bad |= (v >= 0.0 && v < INFINITY) ? 0 : 1;
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+    });
+    zeros = Wv::sumi(zeros);
+    bad = Wv::sumi(bad);
+    failed = bad != 0;
+    if (failed) return NAN;
+    const double range[2] = {-Wv::max(-lo), Wv::max(hi)};
+    const int n_act = N - zeros, j_lo = nt > zeros ? nt - zeros : 0, j_hi = N - nt - 1 - zeros;
+    double s = 0.0;
+    if (N < kTrimBucketMin || !bucket_rank_sum<Wv>(V, N, n_act, j_lo, j_hi, W, s, range))
+        s = select_rank_sum<Wv>(V, N, n_act, j_lo, j_hi, (unsigned int*)W.sum, range);
+    return s / (double)(N - 2 * nt);
 }
 
 }  // namespace dsq

@@ -9,3 +9,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a rendezvous, a device queue) must fail after minutes, not hold the box until the caller's
+    limit: every `gpu` test gets a time limit where pytest-timeout is installed (it is in this image)."""
+    import pytest
+
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))

@@ -234,6 +234,39 @@ def robust_disp_seg(counts, sf, X, seg_len):
     return out
 
 
+def robust_disp_lean(counts, sf, X):
+    """robust_disp_gene_lean (no buffer of a cell's values: bucket pass or radix selection over an accessor, any cell size):
+    (robust dispersions [G], failed [G])"""
+    y = gene_major(counts)
+    G, N = y.shape
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    off, idx, ncell, whole, flags = cell_plan(X, 7)
+    out, failed = np.empty(G), np.empty(G, np.uint8)
+    rc = lib().hs_robust_disp_lean(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), _p(off, C.c_int32),
+                                   _p(idx, C.c_int32), C.c_int(ncell), C.c_int(whole), C.c_int(N), C.c_int(G),
+                                   _p(out, C.c_double), _p(failed, C.c_uint8))
+    assert rc == 0
+    return out, failed.astype(bool)
+
+
+def trimmed_base_mean_lean(counts, sf, trim=0.2):
+    y = gene_major(counts)
+    G, N = y.shape
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    out = np.empty(G)
+    lib().hs_trimmed_base_mean_lean(_p(y, C.c_int32), C.c_int(N), _p(sf, C.c_double), C.c_int(N), C.c_int(G),
+                                    C.c_double(trim), _p(out, C.c_double))
+    return out
+
+
+def select_rank_sum(buf, j_lo, j_hi):
+    """sum of the ranks j_lo .. j_hi (inclusive) among the entries >= 0 of buf, by the accessor-based radix selection"""
+    b = np.ascontiguousarray(buf, dtype=np.float64)
+    f = lib().hs_select_rank_sum
+    f.restype = C.c_double
+    return float(f(_p(b, C.c_double), C.c_int(len(b)), C.c_int(int(j_lo)), C.c_int(int(j_hi))))
+
+
 def trimmed_base_mean(counts, sf, trim=0.2):
     y = gene_major(counts)
     G, N = y.shape

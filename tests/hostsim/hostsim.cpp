@@ -466,6 +466,37 @@ int hs_trimmed_base_mean(const int32_t* y, int ldn, const double* sf, int N, int
     return 0;
 }
 
+// the buffer-less routines of cells / rows of any length (k_robust_disp_lean, k_replace_lean)
+int hs_robust_disp_lean(const int32_t* y, int ldn, const double* sf, const int32_t* cell_offsets,
+                        const int32_t* cell_index, int n_cells, int whole, int N, int G, double* out, uint8_t* failed) {
+    std::vector<BucketWork> bw(1);
+    CellPlan C{cell_offsets, cell_index, n_cells, whole};
+    for (int g = 0; g < G; ++g) {
+        bool f = false;
+        out[g] = robust_disp_gene_lean<HostWave>(y + (size_t)g * ldn, sf, C, N, bw[0], f);
+        failed[g] = f ? 1 : 0;
+    }
+    return 0;
+}
+
+int hs_trimmed_base_mean_lean(const int32_t* y, int ldn, const double* sf, int N, int G, double trim, double* out) {
+    std::vector<BucketWork> bw(1);
+    for (int g = 0; g < G; ++g) {
+        bool f = false;
+        out[g] = trimmed_base_mean_lean<HostWave>(y + (size_t)g * ldn, sf, N, trim, bw[0], f);
+    }
+    return 0;
+}
+
+double hs_select_rank_sum(const double* buf, int n, int j_lo, int j_hi) {
+    std::vector<unsigned int> hist(2 * kTrimBins);
+    int n_act = 0;
+    double range[2] = {INFINITY, -INFINITY};
+    for (int k = 0; k < n; ++k)
+        if (buf[k] >= 0.0) { ++n_act; range[0] = buf[k] < range[0] ? buf[k] : range[0]; range[1] = buf[k] > range[1] ? buf[k] : range[1]; }
+    return select_rank_sum<HostWave>(buf, n, n_act, j_lo, j_hi, hist.data(), range);
+}
+
 // loss/gradient of one gene at log_alpha (debug / unit tests)
 int hs_alpha_eval(const int32_t* y, const double* mu, const double* Xt, int ldx, int N, int P_,
                   double la, double la_hat, double prior_var, int cr_reg, int prior_reg, double* f,

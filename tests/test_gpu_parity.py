@@ -392,7 +392,7 @@ def test_matrix_core_path_equals_register_path_at_p8():
     for env in ({}, {"DSQ_WIDE_MIN_P": "5"}):
         f = tempfile.mktemp(suffix=".npz")
         subprocess.run([sys.executable, "-c", "import sys; " + code, f], check=True, env={**os.environ, **env},
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=400)
         outs.append(dict(np.load(f)))
     a, b = outs
     same = (a["g"] == b["g"]) & (a["m"] == b["m"])
@@ -420,7 +420,7 @@ def test_sixteen_lane_irls_equals_the_wavefront_kernel():
     for env in ({}, {"DSQ_NO_ROW_WAVE": "1"}):
         f = tempfile.mktemp(suffix=".npz")
         subprocess.run([sys.executable, "-c", "import sys; " + code, f], check=True, env={**os.environ, **env},
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=400)
         outs.append(dict(np.load(f)))
     a, b = outs
     assert (a["f"] == b["f"]).all() and (a["c"] == b["c"]).all() and (a["lc"] == b["lc"]).all()
@@ -527,6 +527,70 @@ def test_rescued_gene_is_reproducible_from_pass_to_pass():
         seen.add((r.genewise_dispersions[40:44].tobytes(), r.dispersions[40:44].tobytes(), r.LFC[40:44].tobytes(),
                   r.pvalue[40:44].tobytes()))
     assert len(seen) == 1
+
+
+@pytest.mark.parametrize("kind", ["two cells of 18000", "17000 + 60", "no cells, 20000 samples"])
+def test_design_cells_and_rows_beyond_a_wavefronts_lds(kind):
+    """The reference sorts whatever it is given (utils.py:567-650, 914-960; dds.py:1332-1352).  The robust dispersions and the
+    outlier replacement used to buffer a design cell / a gene's row in a wavefront's LDS and refused cells of more than
+    16 384 samples; the buffer-less kernels (k_robust_disp_lean, k_replace_lean: bucket pass or radix selection over
+    recomputed values) take any size.  End to end against the oracle, with injected outliers that are replaced and
+    refitted."""
+    import pydeseq2_amd
+
+    rng = np.random.default_rng(31)
+    G = 40
+    if kind == "two cells of 18000":
+        N = 36000
+        cell = np.arange(N) % 2
+        X = np.column_stack([np.ones(N), cell.astype(float)])
+    elif kind == "17000 + 60":
+        N = 17060
+        cell = (np.arange(N) >= 17000).astype(int)
+        X = np.column_stack([np.ones(N), cell.astype(float)])
+    else:
+        N = 20000
+        cell = np.arange(N) % 2
+        X = np.column_stack([np.ones(N), cell.astype(float), rng.normal(0, 1, N)])
+    beta0 = rng.normal(4, 1.5, G)
+    lfc = rng.normal(0, 0.4, G)
+    sf = np.exp(rng.normal(0, 0.2, N))
+    mu = sf[:, None] * np.exp(beta0[None, :] + lfc[None, :] * cell[:, None])
+    disp = 4 / np.exp(beta0) + 0.1
+    size = 1 / disp
+    counts = rng.negative_binomial(size[None, :], size[None, :] / (size[None, :] + mu)).astype(np.int64)
+    counts[:, 3] = rng.negative_binomial(1, 0.7, N)  # mostly zeros
+    counts[7, 5] = 3000000                           # outliers
+    counts[N - 3, 6] = 900000
+    res = pydeseq2_amd.deseq2(counts, X, device=0)
+    ref = orc.deseq2(counts, X, n_jobs=_jobs(), keep_layers=False)
+    if kind != "no cells, 20000 samples":  # (continuous covariate: no replaceable sample, the outliers only flag)
+        assert ref.replaced.sum() >= 2 and (res.replaced == ref.replaced).all() and (res.refitted == ref.refitted).all()
+    assert (res.cooks_outlier == ref.cooks_outlier).all()
+    _compare(res, ref, frac_noise=0.06)
+
+
+def test_replacement_through_the_buffer_less_kernel_equals_the_buffered_one(monkeypatch):
+    """DSQ_REPLACE_LEAN=1 sends rows of ordinary length through k_replace_lean: the same replaced counts (the trimmed mean is
+    the same sum in the same order when the bucket pass applies, and agrees to rounding otherwise), hence the same refit."""
+    import subprocess
+    import sys
+    import tempfile
+
+    code = ("import numpy as np, sys, pydeseq2_amd; from oracle import nbglm_oracle as orc; "
+            "counts, X = orc.synth_counts(1500, 300, '2level', 17); counts[5, :60] = 400000; counts[40, 70] = 90000; "
+            "r = pydeseq2_amd.deseq2(counts, X, device=0); "
+            "np.savez(sys.argv[1], d=r.dispersions, l=r.LFC, p=r.pvalue, f=r.refitted, r=r.replaced)")
+    outs = []
+    for env in ({}, {"DSQ_REPLACE_LEAN": "1"}):
+        f = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env},
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=400)
+        outs.append(dict(np.load(f)))
+    a, b = outs
+    assert a["f"].sum() >= 30 and (a["f"] == b["f"]).all() and (a["r"] == b["r"]).all()
+    assert_close(b["d"], a["d"], 1e-9, 0, "dispersions")
+    assert_close(b["l"], a["l"], 1e-9, 1e-12, "LFC")
 
 
 def test_hip_inference_under_the_reference_orchestration():

@@ -341,6 +341,60 @@ def test_trimmed_sum_by_selection_matches_sort():
             assert abs(got - ref) <= 1e-12 * max(1.0, np.abs(v).sum()), (n, nt, got, ref)
 
 
+def test_rank_sums_by_selection_over_an_accessor():
+    """select_rank_sum (the buffer-less fallback of the bucket pass: cells of any size): sum of the ranks j_lo .. j_hi among
+    the active (>= 0) entries == the sorted slice, with inactive markers (zero counts) scattered in, heavy ties, ranges that
+    share their leading bytes, single ranks and empty ranges."""
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 5, 64, 129, 1000, 20000):
+        for kind in range(4):
+            if kind == 0:
+                v = rng.integers(1, 7, n) / 1.37
+            elif kind == 1:
+                v = rng.negative_binomial(2, 0.01, n) / rng.uniform(0.5, 2, n) + 1e-3
+            elif kind == 2:
+                v = 1000.0 + rng.uniform(0, 1e-9, n)
+            else:
+                v = np.full(n, 3.25)
+            v = v.astype(float)
+            v[rng.random(n) < 0.3] = -1.0  # inactive
+            act = np.sort(v[v >= 0])
+            m = len(act)
+            for (a, b) in {(0, m - 1), (m // 8, m - m // 8 - 1), (m // 3, m // 3), (m // 2, m // 2 - 1), (0, 0)}:
+                if m == 0 or a < 0 or b >= m:
+                    continue
+                ref = act[a:b + 1].sum() if b >= a else 0.0
+                got = hs.select_rank_sum(v, a, b)
+                assert abs(got - ref) <= 1e-12 * max(1.0, act.sum()), (n, kind, a, b, got, ref)
+
+
+def test_buffer_less_robust_dispersions_and_trimmed_means():
+    """robust_disp_gene_lean / trimmed_base_mean_lean (kernels of cells and rows beyond a wavefront's LDS) against the
+    reference's utils.robust_method_of_moments_disp / trimmed_mean restated in the oracle: small cells (selection), cells at
+    the bucket threshold, cells of 9000 samples whose boundary buckets overflow (selection again), unbalanced designs,
+    rows with many zeros."""
+    rng = np.random.default_rng(8)
+    for N, levels, G in ((60, 3, 12), (300, 2, 10), (1290, 10, 8), (18000, 2, 6), (4000, 1, 6)):
+        cell = np.arange(N) % levels
+        if levels == 2 and N == 300:
+            cell = (np.arange(N) < 40).astype(int)  # 40 / 260
+        X = np.column_stack([np.ones(N)] + [(cell == k).astype(float) for k in range(1, levels)])
+        if levels == 1:
+            X = np.column_stack([np.ones(N), rng.normal(0, 1, N)])  # no cells: one trimmed variance over every sample
+        sf = np.exp(rng.normal(0, 0.3, N))
+        mu = np.exp(rng.normal(3, 2, G))
+        counts = rng.negative_binomial(3, 3 / (3 + mu[None, :] * sf[:, None])).astype(np.int64)
+        counts[:, 0] = rng.negative_binomial(1, 0.6, N)  # mostly zeros
+        counts[5, 1] = 500000
+        rd, failed = hs.robust_disp_lean(counts, sf, X)
+        assert not failed.any()
+        normed = counts / sf[:, None]
+        ref = orc.robust_mom_disp(normed, X)
+        assert_close(rd, ref, 1e-10, 0, f"robust disp N={N}")
+        tbm = hs.trimmed_base_mean_lean(counts, sf, 0.2)
+        assert_close(tbm, orc.trimmed_mean(normed, 0.2), 1e-12, 0, f"trimmed mean N={N}")
+
+
 @pytest.mark.parametrize("case", ["p2", "p4", "p8"])
 def test_apeglm_shrinkage_templates_match_reference(case):
     """shrink_gene (unbounded n-dim L-BFGS-B with ftol = gtol = 1e-8, apeGLM objective, the reference's

@@ -51,6 +51,7 @@ KNOBS = {
     "DSQ_LFC_FLAT_PRIORITY": ("A/B", "off", "the forked LFC launch's stream at normal instead of lowest priority"),
     "DSQ_LFC_OVERLAP_MAX_WORK": ("tuning", "1.5e8", "mixed designs: most counts (genes x samples) per device for which the LFC fit is split"),
     "DSQ_LFC_OVERLAP_MIN_GENES": ("tuning", "2048", "fewest genes for which the LFC fit is split into two launches"),
+    "DSQ_REPLACE_LEAN": ("A/B", "off", "outlier replacement through the buffer-less kernel (rows beyond a wavefront's LDS) whatever the row length"),
     "DSQ_MAP_WAIT": ("A/B", "per design family", "1 / 0: the MAP launch waits / does not wait for the side stream"),
     "DSQ_UPLOAD_THREADS": ("tuning", "half the cores, <= 16", "host threads narrowing the int64 counts during the upload"),
     "DSQ_UPLOAD_NO_U16": ("A/B", "off", "upload int32 chunks even where the counts fit 16 bits"),

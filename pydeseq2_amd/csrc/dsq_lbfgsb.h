@@ -172,9 +172,16 @@ DSQ_HD LbfgsbResult lbfgsb_nd(FG&& fg, int n, double* x, const double* l, const 
     {   // scipy hands setulb zero-initialised work arrays (numpy.zeros in _minimize_lbfgsb) and the routine, as written in
         // Fortran, reads entries of them it has not written yet (bounded problems: seen on a gene whose IRLS rescue changed
         // its iterates from pass to pass with whatever the previous workgroup had left in LDS): they are 0 there, and here
+#if !defined(DSQ_LBFGSB_NO_ZERO)  // (developer builds only: does an input notice what the workspace held?)
         uint32_t* wz = (uint32_t*)&W;
+#if defined(DSQ_LBFGSB_POISON)     // (developer builds only, -DDSQ_LBFGSB_POISON=0xFFFFFFFFu: that word instead of zeros - a
+                                   // result that changes has read an entry before writing it)
+        for (int i = Wv::lane(); i < (int)(sizeof(W) / 4); i += Wv::W) wz[i] = (uint32_t)(DSQ_LBFGSB_POISON);
+#else
         for (int i = Wv::lane(); i < (int)(sizeof(W) / 4); i += Wv::W) wz[i] = 0u;
+#endif
         Wv::sync();
+#endif
     }
     LbfgsbResult R;
     int col = 0, head = 1, itail = 0, iupdat = 0, iter = 0, nfev = 0, nfree = n, nenter = 0,

@@ -32,6 +32,11 @@ def design_pack(X):
     return Xt, pinv, full_rank
 
 
+def set_workspace_fill(byte):
+    """What the routines' wave-private workspaces hold when they start (device: stale LDS): 0x00, 0xFF (NaNs), ..."""
+    lib().hs_set_workspace_fill(C.c_int(int(byte)))
+
+
 def lgamma_digamma(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     lg, dg = np.empty_like(x), np.empty_like(x)

@@ -34,7 +34,15 @@ struct HostSorter {
 };
 }  // namespace
 
+// What the wave-private workspaces (LDS on the device: whatever the previous workgroup left there) hold when a routine
+// starts.  0 was what every entry point here used - and what hid, on the host, a read of an unwritten L-BFGS-B work entry that
+// made a rescued gene's iterates vary from launch to launch on the device (round 6): the tests now run the routines on
+// workspaces filled with 0x00, 0xFF (NaNs) and 0x5A and ask for identical results.
+static int g_hs_fill = 0;
+
 extern "C" {
+
+void hs_set_workspace_fill(int byte) { g_hs_fill = byte & 0xFF; }
 
 void hs_lgamma_digamma(const double* x, int n, double* lg, double* dg) {
     for (int i = 0; i < n; ++i) lgamma_digamma<true>(x[i], lg[i], dg[i]);
@@ -108,7 +116,7 @@ int hs_irls_bfgs(const int32_t* y, int ldn, const double* sf, const double* Xt, 
         IrlsOut o = irls_gene<HostWave, P>(A, b, mo, ho);
         if (o.fallback) {
             static IrlsRescueWork<P> Wk;
-            std::memset(&Wk, 0, sizeof(Wk));
+            std::memset(&Wk, g_hs_fill, sizeof(Wk));
             o = irls_rescue_gene<HostWave, P>(A, Wk, b, mo, ho, nullptr, 1);
         }
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -149,7 +157,7 @@ int hs_irls(const int32_t* y, int ldn, const double* sf, const double* Xt, const
         IrlsOut o = irls_gene<HostWave, P>(A, b, mo, ho);
         if (o.fallback) {
             static IrlsRescueWork<P> Wk;
-            std::memset(&Wk, 0, sizeof(Wk));
+            std::memset(&Wk, g_hs_fill, sizeof(Wk));
             o = irls_rescue_gene<HostWave, P>(A, Wk, b, mo, ho);
         }
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -170,6 +178,7 @@ int hs_alpha_mle_cell(const int32_t* y, const double* mu, int ldn, const double*
     CellDesign D{cell_of, Xc, XX, C};
     DSQ_DISPATCH_P(P_, {
         static CellWork<P> Wk;
+        std::memset(&Wk, g_hs_fill, sizeof(Wk));
         CellCtx cctx{D, (void*)&Wk};
         for (int g = 0; g < G; ++g) {
             AlphaOut o = fit_alpha_gene<HostWave, P, false, false, true>(
@@ -193,6 +202,7 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
     CellDesign D{cell_of, Xc, XX, C};
     DSQ_DISPATCH_P(P_, {
         static CellWork<P> Wk;
+        std::memset(&Wk, g_hs_fill, sizeof(Wk));
         for (int g = 0; g < G; ++g) {
             IrlsArgs A;
             A.y = y + (size_t)g * ldn; A.sf = sf; A.lsf = nullptr; A.Xt = Xt; A.pinvXt = pinvXt; A.ldx = ldx; A.N = N;
@@ -219,7 +229,7 @@ int hs_lfc_fit(const int32_t* y, int ldn, const double* sf, const double* Xt, co
             } else o = irls_gene<HostWave, P, 0>(A, b, mo, ho, &E);
             if (o.fallback) {
                 static IrlsRescueWork<P> Rk;
-                std::memset(&Rk, 0, sizeof(Rk));
+                std::memset(&Rk, g_hs_fill, sizeof(Rk));
                 o = irls_rescue_gene<HostWave, P>(A, Rk, b, mo, ho, &E);
             }
             for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -284,7 +294,7 @@ int hs_lfc_fit_wide(const int32_t* y, int ldn, const double* sf, const double* X
         double* ho = H ? H + (size_t)g * ldn : nullptr;
         IrlsOut o = irls_gene_wide<HostWave>(A, W, mo, ho, &E);
         if (o.fallback) {
-            std::memset(&Lb, 0, sizeof(Lb));
+            std::memset(&Lb, g_hs_fill, sizeof(Lb));
             o = irls_rescue_wide<HostWave>(A, W, Lb, xlu.data(), nbd.data(), mo, ho, &E);
         }
         for (int j = 0; j < P_; ++j) beta[(size_t)g * P_ + j] = W.v(0)[j];
@@ -327,7 +337,7 @@ int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt,
             A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
             A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
             static ShrinkWorkAlt<P> Wa;
-            std::memset(&Wa, 0, sizeof(Wa));
+            std::memset(&Wa, g_hs_fill, sizeof(Wa));
             double b[P];
             conv[g] = (uint8_t)shrink_gene<HostWave, P>(A, Wa, b, invh + (size_t)g * P * P, nullptr, optimizer);
             for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -340,7 +350,7 @@ int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt,
             ShrinkArgs A;
             A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
             A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
-            std::memset(&Ww, 0, sizeof(Ww));
+            std::memset(&Ww, g_hs_fill, sizeof(Ww));
             conv[g] = (uint8_t)shrink_gene_wide<HostWave, 32>(A, P_, Ww, beta + (size_t)g * P_, invh + (size_t)g * P_ * P_);
         }
         return 0;
@@ -350,7 +360,7 @@ int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt,
         A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
         A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
         static ShrinkWork<P> Wk;
-        std::memset(&Wk, 0, sizeof(Wk));
+        std::memset(&Wk, g_hs_fill, sizeof(Wk));
         double b[P];
         conv[g] = (uint8_t)shrink_gene<HostWave, P>(A, Wk, b, invh + (size_t)g * P * P);
         for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
@@ -517,7 +527,7 @@ int hs_lbfgsb_nd(fgn_cb cb, int n, double* x, const double* l, const double* u, 
                  double* f, int* success, int* nfev, int* nit, int* status) {
     if (n < 1 || n > 16) return -1;
     static LbfgsbWork<16> W;
-    std::memset(&W, 0, sizeof(W));
+    std::memset(&W, g_hs_fill, sizeof(W));
     auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
     LbfgsbResult r = lbfgsb_nd<16>(fg, n, x, l, u, nbd, W);
     *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
@@ -528,7 +538,7 @@ int hs_trend_fit(const double* disp, const double* means, int n, double min_disp
                  double* coeffs, int* ok, int* n_outer) {
     std::vector<uint8_t> keep(n + 1);
     static TrendWork W;
-    std::memset(&W, 0, sizeof(W));
+    std::memset(&W, g_hs_fill, sizeof(W));
     TrendOut o = trend_fit<HostWave>(disp, means, n, min_disp, max_disp, keep.data(), W);
     coeffs[0] = o.a0; coeffs[1] = o.a1; *ok = o.ok; *n_outer = o.n_outer;
     return 0;
@@ -537,6 +547,7 @@ int hs_trend_fit(const double* disp, const double* means, int n, double min_disp
 int hs_bfgs(fgn_cb cb, int n, double* x, int* success, int* nfev, int* nit, int* status) {
     if (n < 1 || n > 16) return -1;
     static BfgsWork<16> W;
+    std::memset(&W, g_hs_fill, sizeof(W));
     auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
     const BfgsResult r = bfgs_min<16>(fg, n, x, W);
     *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;
@@ -547,6 +558,7 @@ int hs_lbfgsb_dense(fgn_cb cb, int n, double* x, const double* l, const double* 
                     double* f, int* success, int* nfev, int* nit, int* status) {
     if (n < 1 || n > 4) return -1;
     static LbfgsbDenseWork<4> W;
+    std::memset(&W, g_hs_fill, sizeof(W));
     auto fg = [&](const double* xx, double& ff, double* gg) { cb(xx, &ff, gg); };
     LbfgsbResult r = lbfgsb_dense<4>(fg, n, x, l, u, nbd, W);
     *f = r.f; *success = r.success; *nfev = r.nfev; *nit = r.nit; *status = r.status;

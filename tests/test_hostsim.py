@@ -341,6 +341,56 @@ def test_trimmed_sum_by_selection_matches_sort():
             assert abs(got - ref) <= 1e-12 * max(1.0, np.abs(v).sum()), (n, nt, got, ref)
 
 
+def test_results_do_not_depend_on_what_the_workspaces_held():
+    """The optimisers' workspaces are wave-private LDS on the device - whatever the previous workgroup left there.  Every
+    routine that takes one must give the same bits on a workspace of zeros, of 0xFF (NaNs) and of 0x5A: the IRLS rescue
+    (bounded L-BFGS-B), its BFGS variant, the wide rescue, the three shrinkage optimisers (narrow, dense and wide work
+    structs), the trend fit.  (The entry points here used to zero the workspaces themselves - the device did not, and one
+    rescued gene's iterates varied from launch to launch with the LDS contents until lbfgsb_nd zeroed its workspace as scipy
+    does.  That case needs the device's arithmetic: 9 400 random rescues on the host instantiation built with
+    -DDSQ_LBFGSB_NO_ZERO read no unwritten entry, so the test with detection power for it is the GPU one,
+    test_rescued_gene_is_reproducible_from_pass_to_pass; this one guards every host-visible dependence.)"""
+    k = load_kat("hard")    # genes whose IRLS diverges: all of them take the rescue
+    kw = load_kat("p16")    # the LDS / matrix-core templates
+    k4, k8 = load_kat("p4"), load_kat("p8")
+
+    def run_all():
+        out = []
+        b, mu, H, conv, it, fb = hs.irls(k["b_counts"], k["sf"], k["X"], k["b_disp"])
+        assert fb.all()
+        out += [b, mu, conv, it]
+        b2 = hs.irls(k["b_counts"], k["sf"], k["X"], k["b_disp"], optimizer="BFGS")
+        out += [b2[0], b2[3]]
+        # the same hard genes padded to a wide design (columns of noise): the wide kernels' rescue
+        rng = np.random.default_rng(3)
+        Xw = np.column_stack([k["X"]] + [rng.normal(0, 0.1, k["X"].shape[0]) for _ in range(14 - k["X"].shape[1])])
+        res = hs.lfc_fit(k["b_counts"], k["sf"], Xw, k["b_disp"], entry="hs_lfc_fit_wide")
+        out += [res["beta"], res["conv"]]
+        res = hs.lfc_fit(kw["counts"], kw["sf"], kw["X"], kw["map_alpha"], entry="hs_lfc_fit_wide")
+        out += [res["beta"], res["conv"]]
+        sh = hs.shrink(kw["counts"], kw["X"], 1.0 / kw["map_alpha"], np.log(kw["sf"]), 15.0, 0.3, 1)
+        out += [sh[0], sh[2]]
+        for opt in ("L-BFGS-B", "BFGS", "Newton-CG"):
+            sh = hs.shrink(k4["counts"], k4["X"], 1.0 / k4["map_alpha"], np.log(k4["sf"]), 15.0, 0.3, 1, optimizer=opt)
+            out += [sh[0], sh[1], sh[2]]
+        sh = hs.shrink(k8["counts"], k8["X"], 1.0 / k8["map_alpha"], np.log(k8["sf"]), 15.0, 0.3, 2)
+        out += [sh[0], sh[2]]
+        out += [np.asarray(hs.trend_fit(k8["gw_alpha"], k8["normed"].mean(0), 1e-8, 10.0)[0], float)]
+        return out
+
+    try:
+        hs.set_workspace_fill(0x00)
+        ref = run_all()
+        for fill in (0xFF, 0x5A):
+            hs.set_workspace_fill(fill)
+            got = run_all()
+            for i, (a, b) in enumerate(zip(ref, got)):
+                a, b = np.asarray(a), np.asarray(b)
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), (hex(fill), i)
+    finally:
+        hs.set_workspace_fill(0x00)
+
+
 def test_rank_sums_by_selection_over_an_accessor():
     """select_rank_sum (the buffer-less fallback of the bucket pass: cells of any size): sum of the ranks j_lo .. j_hi among
     the active (>= 0) entries == the sorted slice, with inactive markers (zero counts) scattered in, heavy ties, ranges that

@@ -36,7 +36,7 @@ extern "C" {
 
 #define DSQ_ABI_VERSION 5   /* bumped whenever an exported signature changes; dsq_abi_version() returns the library's */
 #define DSQ_MAX_P 48        /* design columns; up to 12 run the register / cell kernels, wider ones the LDS + MFMA path (round 6: 32 -> 48) */
-#define DSQ_SHRINK_MAX_P 32 /* apeGLM shrinkage (dsq_*_lfc_shrink*): up to 12 columns in registers, 13 ... 32 run-time p */
+#define DSQ_SHRINK_MAX_P 48 /* apeGLM shrinkage (dsq_*_lfc_shrink*): up to 12 columns in registers, 13 ... 48 run-time p */
 #define DSQ_BFGS_MAX_P 12   /* optimizer = "BFGS" of the dispersion fit / the IRLS rescue: register kernels only */
 
 typedef struct dsq_ctx dsq_ctx;

@@ -600,7 +600,7 @@ int dsq_dev_lfc_shrink3(dsq_ctx* ctx, const int32_t* d_y, int ldn, const double*
                         int ldx, int N, int G, int P, const double* d_size, double prior_no_shrink_scale,
                         double prior_scale, int shrink_index, double* d_beta, double* d_inv_hessian,
                         uint8_t* d_converged, double* d_ih_entry, int optimizer) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 48 design columns)");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     DSQ_CHECK_ARG(d_ih_entry == nullptr || P <= DSQ_BFGS_MAX_P, "d_ih_entry: designs of at most 12 columns (wider: d_inv_hessian)");
     DSQ_CHECK_ARG(optimizer >= 0 && optimizer <= 2, "optimizer: 0 (L-BFGS-B), 1 (BFGS) or 2 (Newton-CG)");

@@ -548,7 +548,7 @@ int dsq_inf_lfc_shrink_nbinom_glm2(dsq_ctx* ctx, const void* counts, int count_t
                                    const double* design, const double* size, const double* offset, int N, int G,
                                    int P, double prior_no_shrink_scale, double prior_scale, int shrink_index,
                                    double* beta_out, double* inv_hessian_out, uint8_t* converged, int optimizer) {
-    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 32 design columns)");
+    DSQ_CHECK_ARG(P >= 1 && P <= DSQ_SHRINK_MAX_P, "P out of range (apeGLM shrinkage: at most 48 design columns)");
     DSQ_CHECK_ARG(shrink_index >= 0 && shrink_index < P, "shrink_index out of range");
     if (G <= 0) return DSQ_OK;
     const int ldn = pad16(N);

@@ -45,9 +45,11 @@ __global__ __launch_bounds__(kBlock, DSQ_SHRINK_WAVES > 0 ? DSQ_SHRINK_WAVES : 1
     }
 }
 
-// designs of 13 ... 32 columns: run-time p, one gene per 64-thread workgroup (its workspace is 17 / 33 KB of LDS)
+// designs of 13 ... 48 columns: run-time p, one gene per 64-thread workgroup (its workspace is 17 / 33 / 56 KB of LDS)
 // PB: the multiple of 8 the column loops walk (>= p)
-template <int PMAX, int PB = PMAX>
+// COMPACT: the optimiser's matrices in the LDS workspace (lbfgsb_nd) instead of the wavefront's registers (lbfgsb_wave holds a
+// 16 x 16 or 32 x 32 inverse, four / sixteen entries per lane): designs of 33 ... 48 columns (round 6), 55 KB of LDS
+template <int PMAX, int PB = PMAX, bool COMPACT = false>
 __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ y, int ldn,
                                                     const double* __restrict__ offset, const double* __restrict__ Xt,
                                                     int ldx, int N, int G, int p, const double* __restrict__ size,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(64) void k_shrink_wide(const int32_t* __restrict__ 
 #ifdef DSQ_SHRINK_COMPACT
     __shared__ ShrinkWorkWide<PMAX> work;
 #else
-    __shared__ ShrinkWorkWide<PMAX, true> work;
+    __shared__ ShrinkWorkWide<PMAX, !COMPACT> work;
 #endif
     const int g = blockIdx.x;
     if (g >= G) return;
@@ -81,8 +83,16 @@ hipError_t launch_shrink(hipStream_t st, const int32_t* y, int ldn, const double
         return hipGetLastError();
     }
     if (P_ > DSQ_REG_MAX_P) {
-        if (P_ > 32 || ih_entry != nullptr) return hipErrorInvalidValue;  // (the run-time-p kernel writes the whole inverse)
-        if (P_ <= 16)
+        if (P_ > DSQ_SHRINK_MAX_P || ih_entry != nullptr) return hipErrorInvalidValue;  // (the run-time-p kernel writes the whole inverse)
+        if (P_ > 32) {
+            // 56 KB of static LDS per one-wavefront workgroup
+            if (P_ <= 40)
+                hipLaunchKernelGGL((k_shrink_wide<48, 40, true>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_,
+                                   size, sigma0, sigma, shrink_index, beta, invh, conv);
+            else
+                hipLaunchKernelGGL((k_shrink_wide<48, 48, true>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_,
+                                   size, sigma0, sigma, shrink_index, beta, invh, conv);
+        } else if (P_ <= 16)
             hipLaunchKernelGGL((k_shrink_wide<16, 16>), dim3(G), dim3(64), 0, st, y, ldn, offset, Xt, ldx, N, G, P_, size,
                                sigma0, sigma, shrink_index, beta, invh, conv);
         else if (P_ <= 24)

@@ -413,6 +413,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "shrink_mid":  # round 4: apeGLM shrinkage at the widths 5-7 and 9-12
         shrink_mid_cases(ut)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shrink_wider":  # round 6: apeGLM shrinkage for designs of 33 ... 48 columns
+        shrink_wide_cases(ut, (("p40", 2), ("p48", 5)), "kat_shrink_wider.npz", 16)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "shrink_wide":  # round 3: apeGLM shrinkage for designs of 13 ... 32 columns
         shrink_wide_cases(ut)
         return
@@ -522,15 +525,15 @@ def width_cases(ut, gs, pp, di):
         kat_case(name, synth(40, N, X, seed, eff=0.4), X, ut, gs, pp, di)
 
 
-def shrink_wide_cases(ut):
+def shrink_wide_cases(ut, cases=(("p16", 1), ("p24", 3)), out="kat_shrink_wide.npz", g_max=24):
     """utils.nbinomGLM (the unmodified reference, L-BFGS-B as ds.py:407 calls it) on the wide-design KAT inputs:
-    p = 16 (one factor with 16 levels) and p = 24 -> kat_shrink_wide.npz"""
+    p = 16 (one factor with 16 levels) and p = 24 -> kat_shrink_wide.npz; round 6: p = 40, 48 -> kat_shrink_wider.npz"""
     sh = {}
-    for case, sidx in (("p16", 1), ("p24", 3)):
+    for case, sidx in cases:
         k = np.load(os.path.join(HERE, f"kat_{case}.npz"))
         counts, X, sf = k["counts"], k["X"], k["sf"]
         size = 1.0 / np.clip(k["map_alpha"], 1e-8, max(10, counts.shape[0]))
-        G = min(counts.shape[1], 24)
+        G = min(counts.shape[1], g_max)
         for tag, ps in (("a", 1.0), ("b", 0.3)):
             r = [ut.nbinomGLM(X, counts[:, i], size[i], np.log(sf), 15, ps, "L-BFGS-B", sidx) for i in range(G)]
             sh[f"{case}{tag}_beta"] = np.stack([x[0] for x in r])
@@ -538,7 +541,7 @@ def shrink_wide_cases(ut):
             sh[f"{case}{tag}_conv"] = np.array([x[2] for x in r], dtype=bool)
             sh[f"{case}{tag}_scale"] = np.array(ps)
         sh[f"{case}_sidx"], sh[f"{case}_size"], sh[f"{case}_G"] = np.array(sidx), size[:G], np.array(G)
-    np.savez(os.path.join(HERE, "kat_shrink_wide.npz"), **sh)
+    np.savez(os.path.join(HERE, out), **sh)
 
 
 def shrink_mid_cases(ut):

@@ -329,7 +329,7 @@ int hs_mom_wide(const int32_t* y, int ldn, const double* sf, const double* Xt, c
 int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt, int ldx, int N, int G, int P_,
               const double* size, double sigma0, double sigma, int shrink_index, double* beta /*[G][P]*/,
               double* invh /*[G][P][P]*/, uint8_t* conv, int optimizer) {
-    if (P_ < 1 || P_ > 32) return -1;
+    if (P_ < 1 || P_ > 48) return -1;
     if (optimizer != 0) {  // "BFGS" / "Newton-CG" (k_shrink<P, true> on the device)
         if (P_ > DSQ_REG_MAX_P) return -1;
         DSQ_DISPATCH_P(P_, for (int g = 0; g < G; ++g) {
@@ -342,6 +342,20 @@ int hs_shrink(const int32_t* y, int ldn, const double* offset, const double* Xt,
             conv[g] = (uint8_t)shrink_gene<HostWave, P>(A, Wa, b, invh + (size_t)g * P * P, nullptr, optimizer);
             for (int j = 0; j < P; ++j) beta[(size_t)g * P + j] = b[j];
         })
+        return 0;
+    }
+    if (P_ > 32) {  // 33 ... 48 columns (round 6: k_shrink_wide<48, PB, true>)
+        static ShrinkWorkWide<48> Ww;
+        for (int g = 0; g < G; ++g) {
+            ShrinkArgs A;
+            A.y = y + (size_t)g * ldn; A.offset = offset; A.Xt = Xt; A.ldx = ldx; A.N = N;
+            A.size = size[g]; A.sigma0 = sigma0; A.sigma = sigma; A.shrink_index = shrink_index;
+            std::memset(&Ww, g_hs_fill, sizeof(Ww));
+            if (P_ <= 40)
+                conv[g] = (uint8_t)shrink_gene_wide<HostWave, 48, decltype(Ww), 40>(A, P_, Ww, beta + (size_t)g * P_, invh + (size_t)g * P_ * P_);
+            else
+                conv[g] = (uint8_t)shrink_gene_wide<HostWave, 48>(A, P_, Ww, beta + (size_t)g * P_, invh + (size_t)g * P_ * P_);
+        }
         return 0;
     }
     if (P_ > DSQ_REG_MAX_P) {  // 13 ... 32 columns: the run-time-p templates (k_shrink_wide on the device)

@@ -171,16 +171,18 @@ def test_lfc_shrink_rejects_unknown_optimizers_and_wide_designs_with_other_optim
         inf.lfc_shrink_nbinom_glm(*args, "Newton-CG", 1)  # 16 columns: L-BFGS-B only
 
 
-@pytest.mark.parametrize("case", ["p16", "p24"])
+@pytest.mark.parametrize("case", ["p16", "p24", "p40", "p48"])
 def test_lfc_shrink_wide_designs_vs_reference_kats(case):
-    """13 ... 32 design columns (k_shrink_wide: run-time p) against outputs of the unmodified utils.nbinomGLM."""
+    """13 ... 48 design columns (k_shrink_wide: run-time p; 33 ... 48 since round 6, the optimiser's matrices in LDS) against
+    outputs of the unmodified utils.nbinomGLM."""
     import os
 
     from pydeseq2_amd import HipInference
     from tests.helpers import load_kat
 
     inf = HipInference(device=0)
-    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_wide.npz"))
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden",
+                             "kat_shrink_wider.npz" if case in ("p40", "p48") else "kat_shrink_wide.npz"))
     kk = load_kat(case)
     G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
     for tag in "ab":
@@ -192,14 +194,16 @@ def test_lfc_shrink_wide_designs_vs_reference_kats(case):
         assert np.max(np.abs(ih - k[f"{case}{tag}_invh"]) / scale) < 1e-6
 
 
-def test_lfc_shrink_pipeline_wide_design_vs_oracle():
-    """DeseqStats.lfc_shrink's device path on a 14-column design (two factors + nine continuous covariates): the
-    pipeline-level shrinkage (prior scale from the MLE LFCs, k_shrink_wide, shrunken LFC and lfcSE) against the oracle."""
+@pytest.mark.parametrize("kind,G,N", [("mixed14", 160, 120), ("mixed44", 60, 520)])
+def test_lfc_shrink_pipeline_wide_design_vs_oracle(kind, G, N):
+    """DeseqStats.lfc_shrink's device path on a 14-column design (two factors + nine continuous covariates) and on a
+    44-column one (round 6: shrinkage up to 48 columns): the pipeline-level shrinkage (prior scale from the MLE LFCs,
+    k_shrink_wide, shrunken LFC and lfcSE) against the oracle."""
     import pydeseq2_amd
     from pydeseq2_amd import summary as sm
     from tests.test_gpu_parity import _wide_case
 
-    counts, X = _wide_case("mixed14", 160, 120, 41)
+    counts, X = _wide_case(kind, G, N, 41)
     counts[:, 3] = 0
     c = np.zeros(X.shape[1])
     c[1] = 1.0

@@ -498,11 +498,12 @@ def test_apeglm_shrinkage_other_optimizers_match_reference(case, optimizer, tag)
     assert np.max(np.abs(ih - k[f"{case}_{tag}_invh"]) / scale) < (1e-8 if optimizer == "Newton-CG" else 2e-6)
 
 
-@pytest.mark.parametrize("case", ["p16", "p24"])
+@pytest.mark.parametrize("case", ["p16", "p24", "p40", "p48"])
 def test_apeglm_shrinkage_wide_designs_match_reference(case):
-    """Designs of 13 ... 32 columns (shrink_gene_wide: run-time p, Hessian row by row, inverse in the LDS workspace) against
-    outputs of the unmodified utils.nbinomGLM (kat_shrink_wide.npz)."""
-    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_shrink_wide.npz"))
+    """Designs of 13 ... 48 columns (shrink_gene_wide: run-time p, Hessian row by row, inverse in the LDS workspace) against
+    outputs of the unmodified utils.nbinomGLM (kat_shrink_wide.npz; 33 ... 48 columns, round 6: kat_shrink_wider.npz)."""
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden",
+                             "kat_shrink_wider.npz" if case in ("p40", "p48") else "kat_shrink_wide.npz"))
     kk = load_kat(case)
     G, sidx = int(k[f"{case}_G"]), int(k[f"{case}_sidx"])
     for tag in "ab":

@@ -505,6 +505,14 @@ class _TimedComm:
 
 
 def main():
+    # A run that hangs (a rendezvous, a device queue) must end with the Python stacks of all threads on stderr and a non-zero
+    # exit code, not sit until the caller's limit: DSQ_BENCH_WATCHDOG_S seconds (default 40 min; the default run takes ~70 s,
+    # the largest configuration on one GPU a few minutes with its generator; 0 disables).
+    import faulthandler
+
+    wd = float(os.environ.get("DSQ_BENCH_WATCHDOG_S", "2400"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

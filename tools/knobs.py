@@ -60,6 +60,7 @@ KNOBS = {
     "DSQ_PLUGIN_CACHE_VERIFY": ("debug", "off", "on a cache hit re-upload the argument and compare it with the cached device copy byte for byte"),
     "DSQ_HASH_THREADS": ("tuning", "cores / 2, 32 from 64 cores", "host threads of the plug-in path's content digest"),
     "DSQ_BENCH_SHARE_GPU": ("bench", "off", "all ranks on device 0 (multi-process path on a one-GPU box, host-staged transport)"),
+    "DSQ_BENCH_WATCHDOG_S": ("bench", "2400", "seconds after which a bench run that is still going dumps its Python stacks and exits non-zero (0: off)"),
     "DSQ_FORCE_DIST": ("bench", "off", "take the distributed pipeline with one rank"),
     "DSQ_BENCH_NO_PLUGIN": ("bench", "off", "skip the drop-in-path measurement"),
     "DSQ_BENCH_NO_C5_FULL": ("bench", "off", "skip the full-size c5 measurement of the default run"),

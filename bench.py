@@ -468,16 +468,19 @@ def measure_plugin_path(counts, X, ctx, res, with_shrink=True):
                                                                           X.shape[1] - 1))
         return {k: round(v, 3) for k, v in T.items()}
 
-    first = one_pass()    # nothing cached, output layers pageable
-    second = one_pass()   # device cache warm; this fit page-locks the three N x G output buffers (HipInference._layer)
+    first = one_pass()    # nothing cached, output layers pageable (staged, multi-threaded copy-out: csrc pc_download_rows)
+    second = one_pass()   # device cache warm, output layers still pageable
+    third = one_pass()    # this fit page-locks the three N x G output buffers (HipInference._layer)
     repeat = one_pass()   # steady state
     out = {"workload": f"{G} genes x {N} samples, p={X.shape[1]}: HipInference methods on host arrays in dds.py / ds.py call "
-                       "order, fresh host copies per call", "first": first, "second": second, "repeat": repeat,
+                       "order, fresh host copies per call", "first": first, "second": second, "third": third, "repeat": repeat,
            "total_ms": repeat["total_ms"], "total_ms_first": first["total_ms"], "total_ms_second": second["total_ms"],
-           "note": "first: the only fit of a data set (uploads, pageable outputs); second: a caller that comes back - the "
-                   "output layers are page-locked now (3 x hipHostMalloc of N x G x 8 B, ~80 ms each at c3); repeat: every fit "
-                   "after that.  Floor of `repeat` at c3: 1.44 GB of N x G outputs over PCIe (26 ms) + ten digests of 480 MB "
-                   "matrices at the host's memory bandwidth (2.4 ms each) + the kernels (8 ms)"}
+           "total_ms_third": third["total_ms"],
+           "note": "first: the only fit of a data set (uploads, pageable outputs); second: a caller that comes back (device "
+                   "cache warm, outputs still pageable); third: the output layers are page-locked now (3 x hipHostMalloc of "
+                   "N x G x 8 B, ~80 ms each at c3); repeat: every fit after that.  Floor of `repeat` at c3: 1.44 GB of N x G "
+                   "outputs over PCIe (26 ms) + ten digests of 480 MB matrices at the host's memory bandwidth (2.4 ms each) + "
+                   "the kernels (8 ms)"}
     stats = getattr(inf, "cache_stats", None)
     if stats is not None:
         out["cache"] = stats()

@@ -1,4 +1,6 @@
 // dsq_capi_inf.hip — the Inference-level entry points (dsq_inf_*: the drop-in boundary) and their device cache.
+#include <thread>
+
 #include "dsq_capi_internal.h"
 
 #include "dsq_plugin_cache.h"
@@ -228,10 +230,72 @@ int pc_adopt_f64(dsq_ctx* ctx, PcBuf& buf, int N, int G, int ldn) {
     return DSQ_OK;
 }
 
+// G rows of N doubles (device pitch ldn) -> a contiguous G x N host matrix.
+// A page-locked destination (the layers of a caller's later fits, inference.py:_layer) takes one 2-D DMA.  A PAGEABLE one -
+// the layers of the first fits: fresh memory, every page touched for the first time - took 37 ms per 480 MB that way
+// (the runtime stages it through one thread: tools/probes/pin_probe.py).  Here: 32 MiB blocks of rows go by DMA into the two
+// page-locked staging buffers of the upload path, and while the next block is in flight a few host threads copy the
+// previous one to its place - the page faults of first touch spread over the threads.  DSQ_PLUGIN_D2H_THREADS=0: the
+// runtime's own path (A/B switch).
 int pc_download_rows(dsq_ctx* ctx, double* dst, const double* d_src, int ldn, int N, int G) {
-    DSQ_HIP(hipMemcpy2DAsync(dst, (size_t)N * sizeof(double), d_src, (size_t)ldn * sizeof(double),
-                             (size_t)N * sizeof(double), (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
-    plugin_cache(ctx).st.d2h_bytes += (size_t)N * G * sizeof(double);
+    const size_t row = (size_t)N * sizeof(double), total = row * (size_t)G;
+    plugin_cache(ctx).st.d2h_bytes += total;
+    static const int n_threads = [] {
+        const char* e = getenv("DSQ_PLUGIN_D2H_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        const int cap = e ? 128 : 16;
+        return t < 0 ? 0 : (t > cap ? cap : t);
+    }();
+    constexpr size_t kBlock = (size_t)32 << 20;
+    bool pageable = false;
+    if (n_threads > 0 && total >= 4 * kBlock && row <= kBlock) {
+        hipPointerAttribute_t attr;
+        const hipError_t e = hipPointerGetAttributes(&attr, dst);
+        (void)hipGetLastError();  // (an unregistered host pointer is reported as an error: that is the answer)
+        pageable = e != hipSuccess || attr.type == hipMemoryTypeUnregistered;
+    }
+    if (!pageable) {
+        DSQ_HIP(hipMemcpy2DAsync(dst, row, d_src, (size_t)ldn * sizeof(double), row, (size_t)G, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+        return DSQ_OK;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->stage[k]) DSQ_HIP(hipHostMalloc(&ctx->stage[k], kBlock, hipHostMallocDefault));
+        if (!ctx->stage_ev[k]) DSQ_HIP(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    }
+    const size_t rows_per = kBlock / row;
+    auto copy_out = [&](int k, size_t g0, size_t rows) {  // staging buffer k -> rows g0 .. g0 + rows of dst
+        const char* src = (const char*)ctx->stage[k];
+        char* d = (char*)dst + g0 * row;
+        const size_t bytes = rows * row;
+        const size_t per = ((bytes + (size_t)n_threads - 1) / (size_t)n_threads + 4095) & ~(size_t)4095;  // whole pages
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) {
+            const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+            if (lo >= hi) break;
+            th.emplace_back([=] { std::memcpy(d + lo, src + lo, hi - lo); });
+        }
+        for (auto& x : th) x.join();
+    };
+    size_t g0 = 0, prev_g0 = 0, prev_rows = 0;
+    for (int c = 0; g0 < (size_t)G; ++c) {
+        const size_t rows = (size_t)G - g0 < rows_per ? (size_t)G - g0 : rows_per;
+        const int k = c & 1;
+        // (buffer k was copied out two blocks ago, before this DMA is enqueued: the copies below are synchronous)
+        DSQ_HIP(hipMemcpy2DAsync(ctx->stage[k], row, d_src + g0 * (size_t)ldn, (size_t)ldn * sizeof(double), row, rows,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+        DSQ_HIP(hipEventRecord(ctx->stage_ev[k], ctx->stream));
+        if (prev_rows != 0) {  // the previous block has landed (or lands now): copy it out while this one is in flight
+            DSQ_HIP(hipEventSynchronize(ctx->stage_ev[k ^ 1]));
+            copy_out(k ^ 1, prev_g0, prev_rows);
+        }
+        prev_g0 = g0; prev_rows = rows;
+        g0 += rows;
+        if (g0 >= (size_t)G) {
+            DSQ_HIP(hipEventSynchronize(ctx->stage_ev[k]));
+            copy_out(k, prev_g0, prev_rows);
+        }
+    }
     return DSQ_OK;
 }
 

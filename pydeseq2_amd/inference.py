@@ -75,17 +75,18 @@ class HipInference:
         # page-locked buffers that go back to a free list when the caller drops the array (the reference copies them into
         # its own layers and does): a fresh np.empty costs 40 ms of page faults per layer, five times its PCIe transfer.
         self._pinned = _PinnedPool(self.ctx) if pinned_outputs else None
-        self._pageable_first = 3  # layers of one size handed out pageable before the pool starts page-locking (one fit: mu_hat, mu, hat)
+        self._pageable_first = 6  # layers of one size handed out pageable before the pool starts page-locking (two fits: mu_hat, mu, hat each)
 
     def _layer(self, G, N):
         """Host buffer of a G x N output layer (returned to the caller as its N x G transpose view).
 
-        The FIRST layer of a size is pageable, later ones come from the page-locked pool: hipHostMalloc of 480 MB takes 82 ms
-        on the GPU box (tools/probes/pin_probe.py), a copy into fresh pageable memory 37 ms, the DMA into a page-locked
-        buffer 8.5 ms - so one deseq2() through the plug-in (three such layers, each size seen for the first time) does not
-        pay 250 ms for buffers it will never reuse, and a caller that comes back finds them page-locked from its second fit
-        on.  (Page-locking them on a helper thread meanwhile was measured and dropped: it serialises with the main thread's
-        page faults and digests in the kernel - first fit 249 -> 290 ms.)"""
+        The first layers of a size are pageable, later ones come from the page-locked pool: hipHostMalloc of 480 MB takes
+        82 ms on the GPU box (tools/probes/pin_probe.py), the DMA into a page-locked buffer 8.5 ms, a copy into fresh
+        pageable memory 37 ms through the runtime and ~17 ms through the engine's own staged, multi-threaded copy-out (round 6,
+        csrc pc_download_rows) - so the first two deseq2() through the plug-in (three such layers each) do not pay 250 ms for
+        buffers they may never reuse (first fit at c3: 160-225 -> ~105 ms), and a caller that keeps coming back finds them
+        page-locked from its third fit on.  (Page-locking them on a helper thread meanwhile was measured and dropped: it
+        serialises with the main thread's page faults and digests in the kernel - first fit 249 -> 290 ms.)"""
         nbytes = G * N * 8
         if self._pinned is None or nbytes < (1 << 20):
             return np.empty((G, N))

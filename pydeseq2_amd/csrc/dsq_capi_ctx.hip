@@ -396,14 +396,68 @@ int dsq_upload_counts_i32(dsq_ctx* ctx, const void* counts, int count_type, size
     return DSQ_OK;
 }
 
+// Page-locked host memory.  hipHostMalloc of 480 MB (one N x G output layer of the plug-in path at c3) takes 83-107 ms on the
+// GPU box; ordinary memory whose pages a few threads touch first (4-5 ms) and hipHostRegister (1 ms) is page-locked in 6 ms
+// and takes DMA at the same 56 GB/s from the second copy on (the first one 17 instead of 8.4 ms:
+// tools/probes/register_probe2.py).  Large requests go that way; small ones, and a registration that fails (a low
+// RLIMIT_MEMLOCK), take hipHostMalloc.  DSQ_HOST_ALLOC_MALLOC=1: hipHostMalloc always (A/B switch).
+// (which buffers were registered rather than allocated by the runtime: process-wide, because a buffer may outlive the context
+// it was made through - the Python pools give theirs back from finalisers)
+static std::mutex g_host_mu;
+static std::vector<void*> g_host_registered;
+
 int dsq_host_alloc(dsq_ctx* ctx, size_t bytes, void** out) {
     DSQ_CHECK_ARG(out != nullptr, "null output pointer");
-    DSQ_HIP(hipSetDevice(ctx->device));  // (callable from a helper thread: HipInference page-locks its output layers there)
+    DSQ_HIP(hipSetDevice(ctx->device));  // (callable from a helper thread)
+    static const bool always_malloc = getenv("DSQ_HOST_ALLOC_MALLOC") != nullptr;
+    constexpr size_t kMinRegister = (size_t)8 << 20, kPage = 4096, kAlign = (size_t)2 << 20;
+    if (!always_malloc && bytes >= kMinRegister) {
+        void* p = nullptr;
+        const size_t padded = (bytes + kAlign - 1) & ~(kAlign - 1);
+        if (posix_memalign(&p, kAlign, padded) == 0 && p != nullptr) {
+            const int n_threads = 16;
+            std::vector<std::thread> th;
+            const size_t per = ((padded / kPage + n_threads - 1) / n_threads) * kPage;
+            for (int t = 0; t < n_threads; ++t) {
+                const size_t lo = (size_t)t * per, hi = lo + per < padded ? lo + per : padded;
+                if (lo >= hi) break;
+                th.emplace_back([=] { for (size_t o = lo; o < hi; o += kPage) ((volatile char*)p)[o] = 0; });
+            }
+            for (auto& x : th) x.join();
+            const hipError_t e = hipHostRegister(p, padded, hipHostRegisterDefault);
+            if (e == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_host_mu);
+                g_host_registered.push_back(p);
+                *out = p;
+                return DSQ_OK;
+            }
+            (void)hipGetLastError();
+            free(p);
+        }
+    }
     DSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
     return DSQ_OK;
 }
 int dsq_host_free(dsq_ctx* ctx, void* p) {
-    if (p) DSQ_HIP(hipHostFree(p));
+    if (p == nullptr) return DSQ_OK;
+    bool registered = false;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (size_t i = 0; i < g_host_registered.size(); ++i)
+            if (g_host_registered[i] == p) {
+                g_host_registered[i] = g_host_registered.back();
+                g_host_registered.pop_back();
+                registered = true;
+                break;
+            }
+    }
+    if (registered) {
+        (void)hipHostUnregister(p);  // (the context may be gone: no error report through it)
+        (void)hipGetLastError();
+        free(p);
+        return DSQ_OK;
+    }
+    DSQ_HIP(hipHostFree(p));
     return DSQ_OK;
 }
 // asynchronous device -> pinned-host copy on the context's stream (pair with dsq_sync)

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include <atomic>
+#include <mutex>
 
 // every host-side wait of this library is counted (dsq_host_sync_count: bench.py reports host synchronisations per step)
 extern std::atomic<unsigned long long> g_dsq_host_syncs;  // (defined in dsq_capi_ctx.hip)

@@ -57,6 +57,7 @@ KNOBS = {
     "DSQ_UPLOAD_NO_U16": ("A/B", "off", "upload int32 chunks even where the counts fit 16 bits"),
     "DSQ_PLUGIN_CACHE": ("A/B", "1", "0: the plug-in entry points upload every argument on every call"),
     "DSQ_PLUGIN_CACHE_MB": ("tuning", "25 % of HBM", "budget of the plug-in path's device cache"),
+    "DSQ_HOST_ALLOC_MALLOC": ("A/B", "off", "page-locked host buffers from hipHostMalloc instead of touched-and-registered ordinary memory"),
     "DSQ_PLUGIN_D2H_THREADS": ("tuning", "half the cores, <= 16", "host threads copying the plug-in's N x G outputs out of the staging buffers into pageable memory; 0: the runtime's own pageable copy"),
     "DSQ_PLUGIN_CACHE_VERIFY": ("debug", "off", "on a cache hit re-upload the argument and compare it with the cached device copy byte for byte"),
     "DSQ_HASH_THREADS": ("tuning", "cores / 2, 32 from 64 cores", "host threads of the plug-in path's content digest"),
